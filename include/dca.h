@@ -1,0 +1,175 @@
+/*
+ * dca.h — C ABI of libdca_hip.so, the MI355X (gfx950) batched weighted-A* (BWAS)
+ * node-expansion engine for DeepCubeA-style search.
+ *
+ * This header is the drop-in boundary.  Every entry point names the
+ * reference interface it replaces (paths relative to forestagostinelli/DeepCubeA):
+ *
+ *   environments/environment_abstract.py:23-163   Environment API (Python, in-process)
+ *   environments/cube3.py:48-171                  Cube3.next_state/prev_state/expand/is_solved/state_to_nnet_input
+ *   environments/n_puzzle.py:46-231               NPuzzle.*  (same set)
+ *   utils/pytorch_models.py:49-52                 F.one_hot(x.long(), depth).float().view(-1, D*depth)
+ *   cpp/environments.cpp:92-126,222-256           C++ twins (PuzzleN / Cube3 getNextState, isSolved)
+ *   cpp/parallel_weighted_astar.cpp:138-346       the native BWAS loop (argv/stdout/socket boundary, replaced)
+ *   search_methods/astar.py:50-90,232-340         Instance / AStar (python BWAS semantics)
+ *
+ * Conventions
+ *   - plain C, no torch / STL types.  All `const uint8_t*` / `void*` buffers are
+ *     caller-owned DEVICE memory unless the parameter comment says "host".
+ *   - every call takes a hipStream_t (passed as void*) and is stream-ordered and
+ *     asynchronous unless documented otherwise; the library never frees or
+ *     reallocates caller memory.
+ *   - return value: 0 = ok, >0 = hipError_t, <0 = library error (DCA_E_*);
+ *     dca_last_error() returns a thread-local message for the last failure.
+ *   - state rows are row-major uint8: cube3 [n,54] sticker ids 0..53; puzzles
+ *     [n,dim*dim] tile ids 0..dim*dim-1 (0 = blank) — the reference's own numpy layout.
+ */
+#ifndef DCA_H_
+#define DCA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCA_ABI_VERSION 1
+
+/* library error codes (negative; positive values are hipError_t) */
+#define DCA_E_BADARG (-1)
+#define DCA_E_NOMEM (-2)
+#define DCA_E_CAPACITY (-3) /* node pool / closed table / OPEN exhausted */
+#define DCA_E_STATE (-4)    /* call sequence violated (e.g. commit before pop_expand) */
+#define DCA_E_NOTFOUND (-5)
+
+/* environments (utils/env_utils.py:6-28 registry names) */
+#define DCA_ENV_CUBE3 0   /* "cube3": 54 stickers, 12 moves */
+#define DCA_ENV_NPUZZLE 1 /* "puzzle15/24/35/48": dim 4..7, 4 moves U D L R */
+
+/* one-hot element types for the fused encoder (utils/pytorch_models.py:49-52 emits f32) */
+#define DCA_DT_F32 0
+#define DCA_DT_F16 1
+#define DCA_DT_BF16 2
+
+/* BWAS semantics: which reference implementation is reproduced */
+#define DCA_SEM_PY 0  /* search_methods/astar.py: f64 cost, FIFO ties, CLOSED starts empty */
+#define DCA_SEM_CPP 1 /* cpp/parallel_weighted_astar.cpp: f32 cost, root in CLOSED, deferred stop */
+
+/* built-in deterministic heuristics (test / engine-only benchmarking) */
+#define DCA_HEUR_MOD97 0  /* f32( ((sum_i s_i*(7i+3)) mod 97) ) / 50f                        */
+#define DCA_HEUR_KNUTH3 1 /* f32( ((sum_i s_i*(7i+3)) * 2654435761 mod 2^32) / 2^32 * 3 )    */
+#define DCA_HEUR_HASHU01 2 /* f32( 10 + 5 * (hash64(s) >> 11) / 2^53 )                        */
+#define DCA_HEUR_ZERO 3   /* 0 (uniform-cost search; nnet_utils.py:271-272 all_zeros server) */
+
+int dca_abi_version(void);
+const char* dca_last_error(void);
+
+/* ---- move tables (host pointers, static storage) -------------------------------------- */
+/* cube3 gather map: next[i] = cur[perm[a*54+i]]  (≡ cube3.py:183-256 / environments.h:75-105) */
+const uint8_t* dca_cube3_perm_table(void);                 /* [12*54] */
+/* puzzle blank-swap table [dim*dim*4] (≡ n_puzzle.py:174-214 / environments.cpp:4-46) */
+int dca_npuzzle_swap_table(int dim, uint8_t* out /*host [dim*dim*4]*/);
+
+/* ---- a1,a2: single-action move (Cube3._move_np cube3.py:163-171; prev = action^1) ------ */
+int dca_cube3_next_state(const uint8_t* in /*[n,54]*/, int64_t n, int action, uint8_t* out /*[n,54]*/, void* stream);
+int dca_cube3_prev_state(const uint8_t* in, int64_t n, int action, uint8_t* out, void* stream);
+/* a7: NPuzzle._move_np (n_puzzle.py:216-231); blank index recomputed per state like n_puzzle.py:51-53 */
+int dca_npuzzle_next_state(const uint8_t* in /*[n,dim*dim]*/, int64_t n, int dim, int action, uint8_t* out, void* stream);
+int dca_npuzzle_prev_state(const uint8_t* in, int64_t n, int dim, int action, uint8_t* out, void* stream);
+
+/* ---- a3-a6,a9: fused expansion -----------------------------------------------------------
+ * One launch: all children of every parent (Cube3.expand cube3.py:129-161), plus — each
+ * optional, pass NULL to skip — the network input colour index (state_to_nnet_input
+ * cube3.py:77-85: sticker//9), its one-hot encoding (pytorch_models.py:49-52; row = pos*6+colour),
+ * is_solved (cube3.py:71-75) and the 64-bit state hash defined below.
+ * Output order everywhere: child index = parent*num_moves + move.                           */
+int dca_cube3_expand_fused(const uint8_t* parents /*[n,54]*/, int64_t n,
+                           uint8_t* children /*[n,12,54] or NULL*/,
+                           uint8_t* color_idx /*[n*12,54] or NULL*/,
+                           void* onehot /*[n*12,324] of onehot_dtype or NULL*/, int onehot_dtype,
+                           uint8_t* is_solved /*[n*12] or NULL*/,
+                           uint64_t* hash /*[n*12] or NULL*/, void* stream);
+/* puzzles: nnet input = the tiles themselves (n_puzzle.py:84-89); one-hot depth dim*dim */
+int dca_npuzzle_expand_fused(const uint8_t* parents /*[n,D]*/, int64_t n, int dim,
+                             uint8_t* children /*[n,4,D] or NULL*/,
+                             void* onehot /*[n*4,D*D] or NULL*/, int onehot_dtype,
+                             uint8_t* is_solved /*[n*4] or NULL*/,
+                             uint64_t* hash /*[n*4] or NULL*/, void* stream);
+
+/* ---- stand-alone pieces of the same path (used by the Environment mirror) --------------- */
+int dca_is_solved(int env, int dim, const uint8_t* states, int64_t n, uint8_t* out /*[n]*/, void* stream);
+int dca_hash64(const uint8_t* states, int64_t n, int state_dim, uint64_t* out /*[n]*/, void* stream);
+/* cube3: color_idx[n,54] = states//9 ; puzzles: copy */
+int dca_nnet_input(int env, int dim, const uint8_t* states, int64_t n, uint8_t* out, void* stream);
+/* generic one-hot of a [n,D] uint8 index array with depth `depth` -> [n, D*depth] */
+int dca_onehot(const uint8_t* idx, int64_t n, int state_dim, int depth, void* out, int dtype, void* stream);
+/* built-in deterministic heuristics on raw states -> f32 */
+int dca_heuristic_builtin(int heur_id, const uint8_t* states, int64_t n, int state_dim, float* out, void* stream);
+
+/* state hash (a9).  The reference's hash VALUES are process-randomised SipHash (cube3.py:17-21)
+ * or unpinned boost::hash_range (parallel_weighted_astar.cpp:104-111); what is pinned is key
+ * equality.  This library defines, for a D-byte state split in little-endian 8-byte words
+ * w_0..w_{ceil(D/8)-1} (last word zero-padded):
+ *     h = 0x9E3779B97F4A7C15 ^ (D * 0xD6E8FEB86659FD93)
+ *     for k: h ^= w_k; h *= 0xFF51AFD7ED558CCD; h ^= h >> 32
+ *     h ^= h >> 33; h *= 0xC4CEB9FE1A85EC53; h ^= h >> 33
+ * The HIP kernels and the CPU oracle are bit-exact on it.                                    */
+
+/* ---- a10-a13: device-resident BWAS engine ----------------------------------------------
+ * Replaces cpp/parallel_weighted_astar.cpp (argv/stdout/socket) and the Instance/AStar
+ * bookkeeping of search_methods/astar.py:50-90,232-340.  One engine = one search instance
+ * on the current device.  OPEN, CLOSED and the node pool live in HBM; the heuristic is
+ * supplied between the two halves of an iteration:
+ *
+ *     dca_engine_reset(e, root)
+ *     dca_engine_root_commit(e, h_root)                        (PY semantics only)
+ *     loop:  dca_engine_pop_expand(e, &states, &m)  ->  h = heuristic(states[m])
+ *            dca_engine_commit(e, h)
+ *            dca_engine_status(e, &st);  stop when st.done
+ *     dca_engine_solution(e, moves, &len, &path_cost)
+ */
+typedef struct dca_engine dca_engine;
+
+typedef struct dca_status {
+    int32_t done;            /* search finished (goal popped / cpp stop rule hit)            */
+    int32_t failed;          /* capacity exhausted or OPEN ran empty                          */
+    int64_t iterations;      /* completed pop/expand/commit iterations                        */
+    int64_t nodes_generated; /* reference's "# Nodes Gen" (astar.py:168 / cpp:166,266)        */
+    int64_t nodes_expanded;  /* parents popped and expanded                                   */
+    int64_t open_size;
+    int64_t closed_size;
+    int64_t pool_size;       /* node ids handed out                                           */
+    double best_cost;        /* cost of the cheapest solved node popped so far (cpp) / NaN    */
+} dca_status;
+
+int dca_engine_create(dca_engine** out, int env, int dim, double weight, int batch_size,
+                      int64_t max_nodes, int semantics);
+void dca_engine_destroy(dca_engine* e);
+int dca_engine_reset(dca_engine* e, const uint8_t* root /*host [D]*/, void* stream);
+/* PY semantics: cost(root) = w*0 + max(h,0)*!solved (astar.py:244-249). h_root: device f32[1] */
+int dca_engine_root_commit(dca_engine* e, const float* h_root, void* stream);
+/* first half: pop min(B,|OPEN|) by (cost, push order), expand.  *states = device pointer to the
+ * batch's child rows [batch*num_moves, D] (valid until the next pop_expand); *nnet_in = device
+ * pointer to the network input rows (cube3: colour index; puzzles: == states).  Rows beyond the
+ * live child count are zero.  m_capacity = batch*num_moves (the fixed row count, so the
+ * heuristic can run without a host sync); the live count is in dca_engine_status.            */
+int dca_engine_pop_expand(dca_engine* e, const uint8_t** states, const uint8_t** nnet_in,
+                          int64_t* m_capacity, void* stream);
+/* second half: h = device f32[m_capacity] (values for dead rows ignored). clip at 0 is applied
+ * here (nnet_utils.py:193-194 clip_zero=True).                                               */
+int dca_engine_commit(dca_engine* e, const float* h, void* stream);
+/* convenience: both halves with a built-in heuristic, `iters` iterations, no host sync
+ * between them (kernels no-op once done).                                                    */
+int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, void* stream);
+/* synchronises the stream */
+int dca_engine_status(dca_engine* e, dca_status* out, void* stream);
+/* root->goal move list (astar.py:213-229 get_path / cpp:336-341).  synchronises.            */
+int dca_engine_solution(dca_engine* e, int32_t* moves /*host [cap]*/, int cap, int* len, double* path_cost, void* stream);
+/* per-phase HIP-event timings of the last dca_engine_run_builtin (ms); keys in DESIGN.md     */
+int dca_engine_phase_ms(dca_engine* e, float* out /*host [8]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCA_H_ */

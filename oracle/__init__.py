@@ -1,0 +1,4 @@
+"""CPU oracle — TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only.
+"""
