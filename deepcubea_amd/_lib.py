@@ -1,0 +1,213 @@
+"""ctypes binding of libdca_hip.so (the C ABI in include/dca.h).
+
+There is NO CPU fallback: if the shared library is missing, or no HIP device is present when a
+compute entry point is called, this module raises.  PyTorch-ROCm is used only for device memory,
+streams and (elsewhere) the heuristic network.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdca_hip.so")
+
+ENV_CUBE3, ENV_NPUZZLE = 0, 1
+DT_F32, DT_F16, DT_BF16 = 0, 1, 2
+SEM_PY, SEM_CPP = 0, 1
+HEUR_MOD97, HEUR_KNUTH3, HEUR_HASHU01, HEUR_ZERO = 0, 1, 2, 3
+
+_TORCH_DT = {torch.float32: DT_F32, torch.float16: DT_F16, torch.bfloat16: DT_BF16}
+
+# every symbol include/dca.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "dca_abi_version", "dca_last_error", "dca_cube3_perm_table", "dca_npuzzle_swap_table",
+    "dca_cube3_next_state", "dca_cube3_prev_state", "dca_npuzzle_next_state", "dca_npuzzle_prev_state",
+    "dca_cube3_expand_fused", "dca_npuzzle_expand_fused", "dca_is_solved", "dca_hash64", "dca_nnet_input",
+    "dca_onehot", "dca_heuristic_builtin",
+    "dca_engine_create", "dca_engine_destroy", "dca_engine_reset", "dca_engine_root_commit",
+    "dca_engine_pop_expand", "dca_engine_commit", "dca_engine_run_builtin", "dca_engine_status",
+    "dca_engine_solution", "dca_engine_phase_ms",
+]
+
+
+class DcaError(RuntimeError):
+    pass
+
+
+class DcaStatus(C.Structure):
+    _fields_ = [("done", C.c_int32), ("failed", C.c_int32), ("iterations", C.c_int64),
+                ("nodes_generated", C.c_int64), ("nodes_expanded", C.c_int64), ("open_size", C.c_int64),
+                ("closed_size", C.c_int64), ("pool_size", C.c_int64), ("best_cost", C.c_double)]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load libdca_hip.so; raise loudly if it was never built (python __graft_entry__.py builds it)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DcaError("HIP extension missing: %s — build it with `make -C deepcubea_amd/csrc` "
+                           "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.dca_last_error.restype = C.c_char_p
+        _lib.dca_cube3_perm_table.restype = C.POINTER(C.c_uint8)
+        for name in ABI_SYMBOLS:
+            fn = getattr(_lib, name)  # AttributeError here = stale build of libdca_hip.so
+            if name not in ("dca_last_error", "dca_cube3_perm_table", "dca_engine_destroy"):
+                fn.restype = C.c_int
+        _lib.dca_engine_destroy.restype = None
+        if _lib.dca_abi_version() != 1:
+            raise DcaError("libdca_hip.so ABI version mismatch")
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise DcaError("%s failed (rc=%d): %s" % (what or "dca call", rc, lib().dca_last_error().decode()))
+
+
+def require_gpu() -> torch.device:
+    if not torch.cuda.is_available():
+        raise DcaError("no HIP device visible: the deepcubea_amd hot path runs on an MI355X only (no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor required"
+    return C.c_void_p(t.data_ptr())
+
+
+def env_ids(env_name: str):
+    """utils/env_utils.py:6-28 registry names -> (env id, dim, state_dim, num_moves, onehot_depth)."""
+    import math
+    import re
+    name = env_name.lower()
+    if name == "cube3":
+        return ENV_CUBE3, 0, 54, 12, 6
+    m = re.search(r"puzzle(\d+)", name)
+    if m:
+        dim = int(math.sqrt(int(m.group(1)) + 1))
+        if 4 <= dim <= 7:
+            return ENV_NPUZZLE, dim, dim * dim, 4, dim * dim
+    raise ValueError("No known environment %s" % env_name)
+
+
+# ------------------------------------------------------------------------------ tables (host)
+def cube3_perm_table() -> np.ndarray:
+    return np.ctypeslib.as_array(lib().dca_cube3_perm_table(), (12, 54)).copy()
+
+
+def npuzzle_swap_table(dim: int) -> np.ndarray:
+    out = np.zeros((dim * dim, 4), np.uint8)
+    check(lib().dca_npuzzle_swap_table(dim, out.ctypes.data_as(C.c_void_p)), "dca_npuzzle_swap_table")
+    return out
+
+
+# ------------------------------------------------------------------------------ device ops
+def _u8(t: torch.Tensor) -> torch.Tensor:
+    assert t.dtype == torch.uint8 and t.is_cuda
+    return t.contiguous()
+
+
+def next_state(env: int, dim: int, states: torch.Tensor, action: int, prev: bool = False) -> torch.Tensor:
+    states = _u8(states)
+    out = torch.empty_like(states)
+    n = states.shape[0]
+    L = lib()
+    if env == ENV_CUBE3:
+        fn = L.dca_cube3_prev_state if prev else L.dca_cube3_next_state
+        check(fn(ptr(states), C.c_int64(n), int(action), ptr(out), stream_ptr()), "dca_cube3_next_state")
+    else:
+        fn = L.dca_npuzzle_prev_state if prev else L.dca_npuzzle_next_state
+        check(fn(ptr(states), C.c_int64(n), dim, int(action), ptr(out), stream_ptr()), "dca_npuzzle_next_state")
+    return out
+
+
+def expand_fused(env: int, dim: int, parents: torch.Tensor, *, children: bool = True, nnet_in: bool = False,
+                 onehot_dtype: Optional[torch.dtype] = None, solved: bool = True, hashes: bool = True,
+                 out: Optional[dict] = None) -> dict:
+    """One launch of the fused expansion.  Returns a dict of the requested device tensors.
+    `out` may hold preallocated tensors (keys: children, nnet_in, onehot, solved, hash)."""
+    parents = _u8(parents)
+    n, D = parents.shape
+    A = 12 if env == ENV_CUBE3 else 4
+    depth = 6 if env == ENV_CUBE3 else D
+    dev = parents.device
+    out = dict(out) if out else {}
+    if children and "children" not in out:
+        out["children"] = torch.empty((n, A, D), dtype=torch.uint8, device=dev)
+    if nnet_in and env == ENV_CUBE3 and "nnet_in" not in out:
+        out["nnet_in"] = torch.empty((n * A, D), dtype=torch.uint8, device=dev)
+    if onehot_dtype is not None and "onehot" not in out:
+        out["onehot"] = torch.empty((n * A, D * depth), dtype=onehot_dtype, device=dev)
+    if solved and "solved" not in out:
+        out["solved"] = torch.empty((n * A,), dtype=torch.uint8, device=dev)
+    if hashes and "hash" not in out:
+        out["hash"] = torch.empty((n * A,), dtype=torch.int64, device=dev)  # bit pattern of the u64 hash
+    oh = out.get("onehot")
+    ohdt = _TORCH_DT[oh.dtype] if oh is not None else DT_F32
+    L = lib()
+    if env == ENV_CUBE3:
+        check(L.dca_cube3_expand_fused(ptr(parents), C.c_int64(n), ptr(out.get("children")), ptr(out.get("nnet_in")),
+                                       ptr(oh), ohdt, ptr(out.get("solved")), ptr(out.get("hash")), stream_ptr()),
+              "dca_cube3_expand_fused")
+    else:
+        check(L.dca_npuzzle_expand_fused(ptr(parents), C.c_int64(n), dim, ptr(out.get("children")), ptr(oh), ohdt,
+                                         ptr(out.get("solved")), ptr(out.get("hash")), stream_ptr()),
+              "dca_npuzzle_expand_fused")
+        if nnet_in and out.get("children") is not None:
+            out["nnet_in"] = out["children"].view(n * A, D)  # n_puzzle.py:84-89: the tiles themselves
+    return out
+
+
+def is_solved(env: int, dim: int, states: torch.Tensor) -> torch.Tensor:
+    states = _u8(states)
+    out = torch.empty((states.shape[0],), dtype=torch.uint8, device=states.device)
+    check(lib().dca_is_solved(env, dim, ptr(states), C.c_int64(states.shape[0]), ptr(out), stream_ptr()),
+          "dca_is_solved")
+    return out
+
+
+def hash64(states: torch.Tensor) -> torch.Tensor:
+    states = _u8(states)
+    out = torch.empty((states.shape[0],), dtype=torch.int64, device=states.device)
+    check(lib().dca_hash64(ptr(states), C.c_int64(states.shape[0]), states.shape[1], ptr(out), stream_ptr()),
+          "dca_hash64")
+    return out
+
+
+def nnet_input(env: int, dim: int, states: torch.Tensor) -> torch.Tensor:
+    states = _u8(states)
+    out = torch.empty_like(states)
+    check(lib().dca_nnet_input(env, dim, ptr(states), C.c_int64(states.shape[0]), ptr(out), stream_ptr()),
+          "dca_nnet_input")
+    return out
+
+
+def onehot(idx: torch.Tensor, depth: int, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    idx = _u8(idx)
+    n, D = idx.shape
+    out = torch.empty((n, D * depth), dtype=dtype, device=idx.device)
+    check(lib().dca_onehot(ptr(idx), C.c_int64(n), D, depth, ptr(out), _TORCH_DT[dtype], stream_ptr()), "dca_onehot")
+    return out
+
+
+def heuristic_builtin(heur_id: int, states: torch.Tensor) -> torch.Tensor:
+    states = _u8(states)
+    out = torch.empty((states.shape[0],), dtype=torch.float32, device=states.device)
+    check(lib().dca_heuristic_builtin(heur_id, ptr(states), C.c_int64(states.shape[0]), states.shape[1], ptr(out),
+                                      stream_ptr()), "dca_heuristic_builtin")
+    return out

@@ -1,0 +1,36 @@
+"""I/O glue of the path: stdout tee (`utils/data_utils.py:12-23`) and a loader for the reference's
+state pickles, whose class paths are `environments.cube3.Cube3State` / `environments.n_puzzle.NPuzzleState`."""
+import io
+import pickle
+import sys
+
+
+class Logger(object):
+    def __init__(self, filename: str, mode: str = "a"):
+        self.terminal = sys.stdout
+        self.log = open(filename, mode)
+
+    def write(self, message):
+        self.terminal.write(message)
+        self.log.write(message)
+        self.log.flush()
+
+    def flush(self):
+        pass
+
+
+class _RefUnpickler(pickle.Unpickler):
+    _MAP = {
+        ("environments.cube3", "Cube3State"): ("deepcubea_amd.environments.cube3", "Cube3State"),
+        ("environments.n_puzzle", "NPuzzleState"): ("deepcubea_amd.environments.n_puzzle", "NPuzzleState"),
+    }
+
+    def find_class(self, module, name):
+        module, name = self._MAP.get((module, name), (module, name))
+        return super().find_class(module, name)
+
+
+def load_pickle(path: str):
+    """pickle.load that maps the reference's State class paths onto this package's classes."""
+    with open(path, "rb") as f:
+        return _RefUnpickler(io.BufferedReader(f)).load()

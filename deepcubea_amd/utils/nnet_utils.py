@@ -1,0 +1,101 @@
+"""Heuristic service of the BWAS path — mirror of the reference's `utils/nnet_utils.py:122-221`
+(get_device, load_nnet, get_heuristic_fn, load_heuristic_fn).  The queue-based multi-process servers
+of nnet_utils.py:224-311 are replaced by one replica per GPU (the search shards per instance).
+
+Two closures are offered:
+  get_heuristic_fn(...)      reference signature: list of States (or nnet-format arrays) -> np.float64[n]
+  get_heuristic_fn_dev(...)  device-resident: uint8 nnet-input tensor [M,D] (or one-hot rows) -> f32 tensor [M]
+                             — what the HIP engine calls between pop_expand and commit, no host copies.
+"""
+from __future__ import annotations
+
+import os
+import re
+from collections import OrderedDict
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+
+def get_available_gpu_nums() -> List[int]:
+    """nnet_utils.py:201-203: the variable is parsed by the program itself, keep its name."""
+    devices: Optional[str] = os.environ.get('CUDA_VISIBLE_DEVICES')
+    return [int(x) for x in devices.split(',')] if devices else []
+
+
+def get_device() -> Tuple[torch.device, List[int], bool]:
+    """nnet_utils.py:122-130, except that a visible HIP device is used even when
+    CUDA_VISIBLE_DEVICES is unset (ROCm boxes usually set HIP_VISIBLE_DEVICES or nothing)."""
+    devices = get_available_gpu_nums()
+    if torch.cuda.is_available():
+        if not devices:
+            devices = list(range(torch.cuda.device_count()))
+        return torch.device("cuda:0"), devices, True
+    return torch.device("cpu"), devices, False
+
+
+def load_nnet(model_file: str, nnet: nn.Module, device: torch.device = None) -> nn.Module:
+    """nnet_utils.py:134-152: strips the DataParallel 'module.' prefix."""
+    state_dict = torch.load(model_file, map_location=device) if device is not None else torch.load(model_file)
+    nnet.load_state_dict(OrderedDict((re.sub(r'^module\.', '', k), v) for k, v in state_dict.items()))
+    nnet.eval()
+    return nnet
+
+
+def get_heuristic_fn_dev(nnet: nn.Module, clip_zero: bool = False, batch_size: Optional[int] = None,
+                         autocast_dtype: Optional[torch.dtype] = None):
+    """Device closure.  fp32 by default (the 1e-5 parity mode); autocast_dtype=torch.bfloat16 is the
+    explicitly non-parity fast mode."""
+    nnet.eval()
+
+    @torch.no_grad()
+    def heuristic_fn_dev(x: torch.Tensor, is_onehot: bool = False) -> torch.Tensor:
+        n = x.shape[0]
+        step = n if batch_size is None else batch_size
+        outs = []
+        for s in range(0, n, max(step, 1)):
+            xb = x[s:s + step]
+            with torch.autocast("cuda", dtype=autocast_dtype, enabled=autocast_dtype is not None):
+                yb = nnet.forward_onehot(xb) if is_onehot else nnet(xb)
+            outs.append(yb[:, 0].float())
+        y = torch.cat(outs) if len(outs) != 1 else outs[0]
+        return torch.clamp_min(y, 0.0) if clip_zero else y
+
+    return heuristic_fn_dev
+
+
+def get_heuristic_fn(nnet: nn.Module, device: torch.device, env, clip_zero: bool = False,
+                     batch_size: Optional[int] = None):
+    """nnet_utils.py:156-198 (same signature and return type)."""
+    dev_fn = get_heuristic_fn_dev(nnet, clip_zero=False, batch_size=batch_size)
+
+    def heuristic_fn(states: List, is_nnet_format: bool = False) -> np.ndarray:
+        if not is_nnet_format:
+            num_states = len(states)
+            states_nnet = env.state_to_nnet_input(states) if num_states else [np.zeros((0, env.state_dim), np.uint8)]
+        else:
+            states_nnet = states
+            num_states = states[0].shape[0]
+        if num_states == 0:
+            return np.zeros(0)
+        x = torch.from_numpy(np.ascontiguousarray(states_nnet[0], dtype=np.uint8)).to(device)
+        cost_to_go = dev_fn(x).cpu().numpy().astype(np.float64)
+        assert cost_to_go.shape[0] == num_states
+        if clip_zero:
+            cost_to_go = np.maximum(cost_to_go, 0.0)
+        return cost_to_go
+
+    return heuristic_fn
+
+
+def load_heuristic_fn(nnet_dir: str, device: torch.device, on_gpu: bool, nnet: nn.Module, env,
+                      clip_zero: bool = False, gpu_num: int = -1, batch_size: Optional[int] = None):
+    """nnet_utils.py:206-221 (one replica per process; no DataParallel)."""
+    if (gpu_num >= 0) and on_gpu:
+        os.environ['CUDA_VISIBLE_DEVICES'] = str(gpu_num)
+    nnet = load_nnet("%s/model_state_dict.pt" % nnet_dir, nnet, device=device)
+    nnet.eval()
+    nnet.to(device)
+    return get_heuristic_fn(nnet, device, env, clip_zero=clip_zero, batch_size=batch_size)

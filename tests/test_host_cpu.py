@@ -1,0 +1,109 @@
+"""CPU-side tests: host logic of the mirror, ABI surface, network definition.  No GPU needed."""
+import ctypes as C
+import io
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from deepcubea_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "dca.h")).read()
+    declared = sorted(set(re.findall(r"\b(dca_[a-z0-9_]+)\s*\(", hdr)) - {"dca_engine"})
+    assert sorted(_lib.ABI_SYMBOLS) == declared
+    L = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), "libdca_hip.so does not export %s" % name
+    assert _lib.lib().dca_abi_version() == 1
+
+
+def test_host_tables_match_golden(golden):
+    from deepcubea_amd import _lib
+    assert np.array_equal(_lib.cube3_perm_table(), golden["cube3_perm"])
+    for n in (4, 5, 6, 7):
+        assert np.array_equal(_lib.npuzzle_swap_table(n), golden["npuzzle_swap_%d" % n])
+    with pytest.raises(_lib.DcaError):
+        _lib.npuzzle_swap_table(9)
+
+
+def test_env_registry_and_errors():
+    from deepcubea_amd import _lib
+    from deepcubea_amd.utils import env_utils
+    assert _lib.env_ids("cube3") == (0, 0, 54, 12, 6)
+    assert _lib.env_ids("puzzle15") == (1, 4, 16, 4, 16)
+    assert _lib.env_ids("puzzle48") == (1, 7, 49, 4, 49)
+    with pytest.raises(ValueError):
+        _lib.env_ids("sokoban")
+    env = env_utils.get_environment("cube3")
+    assert env.get_num_moves() == 12 and env.moves[0] == "U-1" and env.moves_rev[0] == "U1"
+    assert env_utils.get_environment("puzzle24").dim == 5
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.DcaError):  # no silent CPU fallback
+            env.next_state(env.generate_goal_states(2), 0)
+
+
+def test_resnet_matches_reference_outputs(tiny_resnet, golden):
+    from deepcubea_amd.utils.pytorch_models import ResnetModel, fold_batchnorm
+    from oracle import np_oracle as no
+    torch.set_num_threads(2)
+    m = ResnetModel(54, 6, 64, 32, 2, 1, True)
+    sd = {k[2:]: torch.tensor(tiny_resnet[k]) for k in tiny_resnet.files if k.startswith("w:")}
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict(sd)
+    m.eval()
+    x = torch.tensor(tiny_resnet["x"])
+    with torch.no_grad():
+        y = m(x)[:, 0].numpy()
+        yf = fold_batchnorm(m)(x)[:, 0].numpy()
+        yo = m.forward_onehot(torch.tensor(no.onehot(tiny_resnet["x"], 6)))[:, 0].numpy()
+    # tolerance stated by the north star: 1e-5 (|h| here is O(1))
+    assert np.max(np.abs(y - tiny_resnet["y"])) < 1e-5
+    assert np.max(np.abs(yf - tiny_resnet["y"])) < 1e-5
+    assert np.array_equal(yo, y)
+    # full cube3 architecture with seed-regenerated weights vs the reference's own forward
+    full = ResnetModel(54, 6, 5000, 1000, 4, 1, True)
+    w = no.resnet_det_weights(no.resnet_shapes(54, 6, 5000, 1000, 4), 2024)
+    full.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+    full.eval()
+    with torch.no_grad():
+        yy = full(torch.tensor(golden["cube3_resnet_seed2024_x"]))[:, 0].numpy()
+    ref = golden["cube3_resnet_seed2024_y"]
+    assert np.max(np.abs(yy - ref)) < 1e-5 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_reference_pickles_load_through_the_mirror(tmp_path):
+    """data/*/test/data_0.pkl name environments.cube3.Cube3State with int64 colors."""
+    import sys
+    import types
+    from deepcubea_amd.utils import data_utils
+    # fabricate a pickle with the reference's class paths
+    pkg = types.ModuleType("environments")
+    mod = types.ModuleType("environments.cube3")
+
+    class Cube3State:  # noqa
+        __slots__ = ['colors', 'hash']
+
+        def __init__(self, colors):
+            self.colors = colors
+            self.hash = None
+    Cube3State.__module__ = "environments.cube3"
+    Cube3State.__qualname__ = "Cube3State"
+    mod.Cube3State = Cube3State
+    sys.modules["environments"] = pkg
+    sys.modules["environments.cube3"] = mod
+    try:
+        blob = pickle.dumps({"states": [Cube3State(np.arange(54, dtype=np.int64))]}, protocol=2)
+    finally:
+        del sys.modules["environments"], sys.modules["environments.cube3"]
+    p = tmp_path / "data_0.pkl"
+    p.write_bytes(blob)
+    d = data_utils.load_pickle(str(p))
+    from deepcubea_amd.environments.cube3 import Cube3State as Mine
+    assert isinstance(d["states"][0], Mine) and d["states"][0].colors.dtype == np.uint8
+    assert d["states"][0].colors.tolist() == list(range(54))
