@@ -4,17 +4,20 @@
     python bench.py --gpus N --steps K --warmup W            (N>1: launched under torch.distributed.run)
 
 Workloads:
-  astar   (default)  BASELINE.json configs[2] shape: cube3 weighted A*, w=0.8, batch 20 000, one search
-                     instance per GPU, device-resident engine.  One step = one full BWAS iteration
-                     (pop 20 000 -> expand 240 000 children + is_solved + hash -> heuristic -> cost ->
-                     CLOSED dedup -> push).  `value` uses the built-in hash-derived heuristic
-                     (SURVEY §8d "engine-only"); the same line carries `end_to_end_nnet` = the same loop with
-                     the 14.7M-parameter ResNet heuristic on PyTorch-ROCm (synthetic weights).
-  expand             BASELINE.json configs[1]: fused next_state + one-hot kernel on 1M synthetic cube3
-                     states (one step = one launch over the 1M parents).
+  astar   (default)  BASELINE.json configs[2] geometry — the config the metric "A* nodes expanded/sec on
+                     cube3, batch 20k" is quoted on: cube3 weighted A*, w=0.8, batch 20 000, one search
+                     instance per GPU on the device-resident engine.  One step = one full BWAS iteration:
+                     pop 20 000 by (cost, push order) -> expand 240 000 children (+is_solved, hash, node
+                     fields) -> heuristic -> cost -> CLOSED dedup -> push.  `value` is measured with the
+                     built-in hash-derived heuristic 10+5*u01(hash) (SURVEY §8d "engine-only"); the same JSON
+                     line carries `end_to_end_nnet`: the identical loop with the 14.7M-parameter ResNet
+                     heuristic evaluated on PyTorch-ROCm for all 240 000 children per step (synthetic
+                     weights — the reference's checkpoints are not in the mount), fp32 and bf16.
+  expand             BASELINE.json configs[1]: fused next_state + one-hot(f32) + is_solved + hash kernel on
+                     1M synthetic cube3 states (one step = one launch over the 1M parents).
 
 Multi-GPU: the path shards per search instance — every rank runs its own replica on its own
-scrambles, no collective on the data path; only the timing barrier uses RCCL.  scaling = weak.
+scramble, no collective on the data path; only the timing barrier uses RCCL.  scaling = weak.
 """
 from __future__ import annotations
 
@@ -34,6 +37,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (≈6.3 TB/s a
 # SURVEY §8d algorithmic bytes per cube3 expansion with the fp32 fused one-hot:
 #   54 (parent read) + 12*54 (children u8) + 12*324*4 (one-hot f32) = 16 254 B
 CUBE3_EXPAND_BYTES_F32 = 54 + 12 * 54 + 12 * 324 * 4
+# engine expansion launch (no one-hot), per parent:
+#   54 parent row + 4 id + 12*(54 child row + 54 network-input row + 8 hash + 4 h + 4 g + 4 parent + 1 move + 1 solved)
+CUBE3_ENGINE_EXPAND_BYTES = 54 + 4 + 12 * (54 + 54 + 8 + 4 + 4 + 4 + 1 + 1)
 
 
 def synth_states(n: int, d: int, seed: int = 0) -> np.ndarray:
@@ -41,7 +47,7 @@ def synth_states(n: int, d: int, seed: int = 0) -> np.ndarray:
     return rng.permuted(np.tile(np.arange(d, dtype=np.uint8), (n, 1)), axis=1)
 
 
-def dist_setup(n_gpus: int):
+def dist_setup():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -64,22 +70,160 @@ def barrier(world: int):
     torch.cuda.synchronize()
 
 
-def max_over_ranks(x: float, world: int) -> float:
+def reduce_ranks(x: float, world: int, op: str) -> float:
     if world == 1:
         return x
     import torch.distributed as dist
     t = torch.tensor([x], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
     return float(t.item())
 
 
-def sum_over_ranks(x: float, world: int) -> float:
-    if world == 1:
-        return x
-    import torch.distributed as dist
-    t = torch.tensor([x], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return float(t.item())
+def test_root(rank: int) -> np.ndarray:
+    """Rank r searches scramble r of the shipped cube3 test set (data/cube3/test, kept as a fixture)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden.npz"))
+    return np.ascontiguousarray(g["cube3_test_states"][rank % 1000])
+
+
+# --------------------------------------------------------------------------------------------------
+# workload: astar (configs[2] geometry, engine + heuristic)
+# --------------------------------------------------------------------------------------------------
+def run_astar(args, world, rank):
+    from deepcubea_amd import _lib
+    from deepcubea_amd.search_methods.engine import BwasEngine
+    B, w = args.batch_size, args.weight
+    sem = _lib.SEM_CPP if args.semantics == "cpp" else _lib.SEM_PY
+    hid = _lib.HEUR_HASHU01
+    total_iters = args.warmup + args.steps + args.profile_iters + 16
+    max_nodes = max(1 << 20, total_iters * B * 12 + (1 << 16))
+    eng = BwasEngine("cube3", w, B, max_nodes=max_nodes, semantics=sem)
+    root = test_root(rank)
+    eng.reset(root)
+    if sem == _lib.SEM_PY:
+        eng.root_commit(_lib.heuristic_builtin(hid, torch.from_numpy(root[None].copy()).cuda()))
+    eng.run_builtin(hid, args.warmup, use_graph=not args.no_graph)
+    st0 = eng.status()
+    barrier(world)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    eng.run_builtin(hid, args.steps, use_graph=not args.no_graph)
+    e1.record()
+    barrier(world)
+    wall = time.perf_counter() - t0
+    st1 = eng.status()
+    assert not st1["failed"] and not st1["done"], "benchmark search ended early: %r" % (st1,)
+    expanded = st1["nodes_expanded"] - st0["nodes_expanded"]
+    assert st1["iterations"] - st0["iterations"] == args.steps
+    dev_ms = e0.elapsed_time(e1)
+    wall = reduce_ranks(wall, world, "max")
+    total_exp = reduce_ranks(float(expanded), world, "sum")
+    # per-kernel HIP-event timings of further iterations (same stream, eager, events between kernels)
+    prof = eng.profile_builtin(hid, args.profile_iters) if args.profile_iters > 0 else {}
+    st2 = eng.status()
+    if args.debug:
+        for _ in range(12):
+            eng.run_builtin(hid, 1)
+            print("DEBUG", json.dumps(eng.debug()), file=sys.stderr)
+    res = {
+        "value": total_exp / wall,
+        "ms_per_step": wall / args.steps * 1e3,
+        "config": {"workload": "cube3 BWAS iteration on the device-resident engine, batch %d, weight %.2f, "
+                               "%s semantics, heuristic = built-in 10+5*u01(hash) (engine-only, SURVEY §8d); "
+                               "BASELINE configs[2] geometry" % (B, w, args.semantics),
+                   "batch_size": B, "weight": w, "children_per_step": B * 12, "semantics": args.semantics,
+                   "hipgraph": not args.no_graph, "parallelism": "one search instance per GPU x%d" % world,
+                   "open_size_end": st1["open_size"], "closed_size_end": st1["closed_size"],
+                   "nodes_generated_timed": st1["nodes_generated"] - st0["nodes_generated"],
+                   "device_ms_per_step": dev_ms / args.steps},
+    }
+    if prof:
+        dom = max(prof, key=prof.get)
+        # algorithmic bytes of the dominant kernel per launch (DESIGN.md §4)
+        n_open = 0.5 * (st1["open_size"] + st2["open_size"]) + B
+        alg = {
+            "expand": CUBE3_ENGINE_EXPAND_BYTES * B,
+            "sel_hist": 8.0 * n_open,
+            "sel_collect": 24.0 * n_open,
+            "probe": B * 12 * (8 + 16 + 54 + 54 + 8 + 8),
+            "decide": B * 12 * (16 + 4 + 4 + 4 + 1 + 4 + 8),
+            "commit": B * 12 * (1 + 8 + 12),
+        }
+        ach = alg.get(dom, 0.0) / (prof[dom] * 1e-3) / 1e9 if prof[dom] > 0 else 0.0
+        res["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "achieved": ach, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "bytes_per_launch": alg.get(dom, 0.0), "kernel_ms": prof[dom],
+                           "phase_ms": {k: round(v, 5) for k, v in prof.items()},
+                           "sum_phase_ms": sum(prof.values())}
+    eng.close()
+    del eng
+    torch.cuda.empty_cache()
+    return res
+
+
+def run_astar_nnet(args, world, rank, dtype_name: str):
+    """Same loop, heuristic = ResNet(54*6 -> 5000 -> 1000 -> 4 res blocks -> 1) on PyTorch-ROCm, all
+    240 000 children per step, synthetic weights (numpy PCG64 seed 2024)."""
+    from deepcubea_amd import _lib
+    from deepcubea_amd.search_methods.engine import BwasEngine
+    from deepcubea_amd.utils import nnet_utils
+    from deepcubea_amd.utils.pytorch_models import ResnetModel, fold_batchnorm
+    from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
+    B, w = args.batch_size, args.weight
+    steps, warm = args.nnet_steps, 2
+    model = ResnetModel(54, 6, 5000, 1000, 4, 1, True)
+    load_synthetic_weights(model, 2024)
+    model = fold_batchnorm(model).cuda().eval()
+    ac = torch.bfloat16 if dtype_name == "bf16" else None
+    hfn = nnet_utils.get_heuristic_fn_dev(model, clip_zero=False, batch_size=args.nnet_batch_size, autocast_dtype=ac)
+    eng = BwasEngine("cube3", w, B, max_nodes=max(1 << 20, (steps + warm + 12) * B * 12),
+                     onehot_dtype=torch.float32 if ac is None else torch.bfloat16)
+    root = test_root(rank)
+    eng.reset(root)
+    eng.root_commit(hfn(eng.root_nnet_in()))
+    # fill OPEN past one batch quickly with the cheap heuristic so every timed step is a full batch
+    eng.run_builtin(_lib.HEUR_HASHU01, 6)
+    for _ in range(warm):
+        eng.step(hfn)
+    st0 = eng.status()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.step(hfn)
+    barrier(world)
+    wall = time.perf_counter() - t0
+    st1 = eng.status()
+    expanded = st1["nodes_expanded"] - st0["nodes_expanded"]
+    wall = reduce_ranks(wall, world, "max")
+    total_exp = reduce_ranks(float(expanded), world, "sum")
+    flops = 2.0 * (324 * 5000 + 5000 * 1000 + 8 * 1000 * 1000 + 1000) * (B * 12)
+    eng.close()
+    return {"value": total_exp / wall, "unit": "nodes expanded/s", "ms_per_step": wall / steps * 1e3,
+            "steps": steps, "heuristic_dtype": dtype_name, "weights": "synthetic (numpy PCG64 seed 2024, BN folded)",
+            "heuristic_tflops_per_gpu": flops / (wall / steps) / 1e12,
+            "mfma_peak_tflops": 157.3 if dtype_name == "fp32" else 2500.0}
+
+
+def cpu_baseline_astar(args, seconds_budget: float = 20.0):
+    """The build's C++/OpenMP restatement of cpp/parallel_weighted_astar.cpp (oracle, kind=port) on the same
+    root, batch size, weight and built-in heuristic, for a bounded number of iterations."""
+    from oracle import c_oracle as co
+    root = test_root(0)
+    cores = co.num_threads()
+    sem = co.SEM_CPP if args.semantics == "cpp" else co.SEM_PY
+    iters = 6
+    r = co.astar("cube3", root, args.weight, args.batch_size, sem, heur_builtin_id=2, max_iters=iters,
+                 stop_on_goal=False)
+    per = r["seconds"] / max(r["iterations"], 1)
+    iters2 = int(min(max(seconds_budget / max(per, 1e-3), iters), 60))
+    r = co.astar("cube3", root, args.weight, args.batch_size, sem, heur_builtin_id=2, max_iters=iters2,
+                 stop_on_goal=False)
+    return {"value": r["nodes_expanded"] / r["seconds"], "unit": "nodes expanded/s", "cores": cores, "kind": "port",
+            "sample": "%d BWAS iterations (batch %d, weight %.2f, %s semantics, same root and built-in heuristic) of "
+                      "oracle/dca_oracle.cpp — the C++/OpenMP restatement of cpp/parallel_weighted_astar.cpp "
+                      "(std::priority_queue OPEN, hash-map CLOSED, OpenMP expand); the reference binary itself "
+                      "needs boost and cannot be built here" % (r["iterations"], args.batch_size, args.weight,
+                                                                 args.semantics)}
 
 
 # --------------------------------------------------------------------------------------------------
@@ -112,10 +256,10 @@ def run_expand(args, world, rank):
     barrier(world)
     wall = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    wall = max_over_ranks(wall, world)
-    total_exp = sum_over_ranks(float(n * args.steps), world)
+    wall = reduce_ranks(wall, world, "max")
+    total_exp = reduce_ranks(float(n * args.steps), world, "sum")
     achieved = CUBE3_EXPAND_BYTES_F32 * n / (kern_ms * 1e-3) / 1e9
-    res = {
+    return {
         "value": total_exp / wall,
         "ms_per_step": wall / args.steps * 1e3,
         "config": {"workload": "cube3 fused next_state+one-hot(f32)+is_solved+hash kernel, %d synthetic states "
@@ -125,7 +269,6 @@ def run_expand(args, world, rank):
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "bytes_per_launch": CUBE3_EXPAND_BYTES_F32 * n, "kernel_ms": kern_ms},
     }
-    return res
 
 
 def cpu_baseline_expand(seconds_budget: float = 12.0):
@@ -141,8 +284,7 @@ def cpu_baseline_expand(seconds_budget: float = 12.0):
     t0 = time.perf_counter()
     fn("cube3", S)
     dt = time.perf_counter() - t0
-    reps = max(1, int(seconds_budget / max(dt, 1e-3)))
-    reps = min(reps, 40)
+    reps = min(max(1, int(seconds_budget / max(dt, 1e-3))), 40)
     t0 = time.perf_counter()
     for _ in range(reps):
         fn("cube3", S)
@@ -157,18 +299,27 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="expand", choices=["expand"])
+    ap.add_argument("--workload", default="astar", choices=["astar", "expand"])
+    ap.add_argument("--batch_size", type=int, default=20000)
+    ap.add_argument("--weight", type=float, default=0.8)
+    ap.add_argument("--semantics", default="py", choices=["py", "cpp"])
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--profile-iters", type=int, default=20, help="astar: extra per-kernel-timed iterations")
+    ap.add_argument("--nnet-steps", type=int, default=4, help="astar: timed steps of the ResNet-heuristic leg (0=skip)")
+    ap.add_argument("--nnet_batch_size", type=int, default=60000)
     ap.add_argument("--n", type=int, default=1_000_000, help="expand: synthetic states per launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug", action="store_true")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 20
+        args.steps = 200 if args.workload == "astar" else 20
     if args.warmup is None:
-        args.warmup = 3
-    world, rank, local = dist_setup(args.gpus)
-    res = run_expand(args, world, rank)
+        args.warmup = 10 if args.workload == "astar" else 3
+    world, rank, local = dist_setup()
+    res = run_astar(args, world, rank) if args.workload == "astar" else run_expand(args, world, rank)
     line = {
-        "metric": "A* nodes expanded/sec on cube3",
+        "metric": "A* nodes expanded/sec on cube3, batch 20k" if args.workload == "astar"
+                  else "A* nodes expanded/sec on cube3",
         "value": res["value"],
         "unit": "nodes expanded/s",
         "n_gpus": world,
@@ -178,13 +329,17 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u8",
+        "dtype": "u8" if args.workload == "expand" else "u8 states / f64 cost keys / f32 heuristic",
         "data": "synthetic",
         "config": res["config"],
-        "roofline": res["roofline"],
     }
+    if "roofline" in res:
+        line["roofline"] = res["roofline"]
+    if args.workload == "astar" and args.nnet_steps > 0:
+        line["end_to_end_nnet"] = {"fp32": run_astar_nnet(args, world, rank, "fp32"),
+                                   "bf16": run_astar_nnet(args, world, rank, "bf16")}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline_expand()
+        line["cpu_baseline"] = cpu_baseline_astar(args) if args.workload == "astar" else cpu_baseline_expand()
     if rank == 0:
         print(json.dumps(line))
     if world > 1:

@@ -1,16 +1,1841 @@
-// dca_engine.hip — device-resident BWAS engine (placeholder until the engine lands in the next commit)
+// dca_engine.hip — device-resident batched weighted A* (BWAS) for gfx950 (MI355X).
+//
+// Replaces the reference's two search cores behind one C ABI (include/dca.h):
+//   search_methods/astar.py:50-90,232-340      Instance / AStar.step   (DCA_SEM_PY)
+//   cpp/parallel_weighted_astar.cpp:138-346    parallelWeightedAStar   (DCA_SEM_CPP)
+//
+// Everything the search touches lives in HBM:
+//   node pool   SoA: state[N][D] u8 rows, g[N] i32, parent[N] u32, move[N] u8, solved[N] u8.
+//               A node id is handed to EVERY generated child (id = base + pop_rank*A + move), so
+//               the expansion kernel writes child rows straight to their final place, ids increase
+//               in the reference's push order (astar.py:64-67 heappush_count) and (cost, id) is the
+//               reference's (cost, count) FIFO tie-break.
+//   CLOSED      open-addressing table of 16-byte slots {tag32|rep32, best g, batch list head},
+//               keyed by the 64-bit state hash, verified against the representative node's state
+//               bytes (exact key equality, like State.__eq__ / NodePointerEq).
+//   OPEN        (cost key u64, node id u32) arrays; pop = exact top-B by (cost, id) via radix select.
+//
+// One BWAS iteration = pop -> expand -> heuristic -> dedup -> push, all stream-ordered, no host
+// round trip: counts live in a device control block and every kernel sizes itself from it.
+//
+// Sequential-order dedup, done in parallel: children of one batch that hit the same
+// CLOSED slot are chained through the slot's `head`; child j is kept iff g_j < v0 (the slot's value
+// before the batch) and no earlier chain member has g <= g_j — exactly astar.py:78-90 / cpp:244-265.
+#include <string.h>
+
+#include <new>
+
 #include "dca_common.h"
-using namespace dca;
-extern "C" {
-#define NOT_YET() do { set_error("engine not built yet"); return DCA_E_STATE; } while (0)
-int dca_engine_create(dca_engine**, int, int, double, int, int64_t, int) { NOT_YET(); }
-void dca_engine_destroy(dca_engine*) {}
-int dca_engine_reset(dca_engine*, const uint8_t*, void*) { NOT_YET(); }
-int dca_engine_root_commit(dca_engine*, const float*, void*) { NOT_YET(); }
-int dca_engine_pop_expand(dca_engine*, const uint8_t**, const uint8_t**, int64_t*, void*) { NOT_YET(); }
-int dca_engine_commit(dca_engine*, const float*, void*) { NOT_YET(); }
-int dca_engine_run_builtin(dca_engine*, int, int, void*) { NOT_YET(); }
-int dca_engine_status(dca_engine*, dca_status*, void*) { NOT_YET(); }
-int dca_engine_solution(dca_engine*, int32_t*, int, int*, double*, void*) { NOT_YET(); }
-int dca_engine_phase_ms(dca_engine*, float*) { NOT_YET(); }
+#include "dca_tile.h"
+
+namespace dca {
+
+constexpr int NBIN = 2048;            // radix-select fan-out per level
+constexpr uint32_t NIL = 0xFFFFFFFFu;
+constexpr uint64_t EMPTY = ~0ull;
+constexpr uint32_t GINF = 0xFFFFFFFFu;
+constexpr int kMaxMoves = 4096;
+
+struct Slot {
+    uint64_t entry;  // (hash >> 32) << 32 | representative node id ; EMPTY = unused
+    uint32_t g;      // best path cost recorded for this state (GINF = none yet)
+    uint32_t head;   // node id of the most recently chained child; < batch base = stale
+};
+
+// device control block: every count the kernels need, so nothing is read back by the host
+struct Ctl {
+    int32_t done, failed, stop_after, skip;
+    int64_t iters, gen, expanded, closed_n;
+    uint32_t pool_n;
+    // OPEN is two tiers of (key,id) arrays.  FRONT (buffers 0/1, ping-pong) holds every entry with
+    // key <= T, BACK (buffers 2/3) the rest; pops only ever look at FRONT, so an iteration costs
+    // O(|FRONT| + children), independent of |OPEN|.
+    uint32_t cur_f, cur_b;   // live FRONT buffer (0/1) and live BACK buffer (2/3)
+    uint32_t open_n[4];
+    uint64_t kmin[4], kmax[4];
+    uint64_t T;              // tier threshold key (inclusive upper bound of FRONT)
+    uint32_t refill, r_bstar, spill_bin;
+    uint64_t r_kmin;
+    uint32_t r_shift;
+    // selection
+    uint32_t want, bstar, sel_less, sel_r, cand_n, shift, sel_fill;
+    uint64_t sel_kmin;
+    uint64_t tail_vmin_hi, tail_vmin_lo;
+    uint32_t tail_shift;
+    // batch
+    uint32_t npop, m, base;
+    // goals
+    unsigned long long goal_best;  // PY: min over solved popped of (g << 32 | pop rank)
+    uint32_t goal_id;
+    uint32_t first_solved;  // CPP: smallest pop rank holding a solved node
+    int32_t has_best;
+    float best_cost;
+    uint32_t best_id;
+};
+
+__device__ __forceinline__ uint64_t key_of_cost(double c) {
+    uint64_t b = (uint64_t)__double_as_longlong(c);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);  // order-preserving
 }
+__device__ __forceinline__ double cost_of_key(uint64_t k) {
+    uint64_t b = (k & 0x8000000000000000ull) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+__device__ __forceinline__ uint32_t select_shift(uint64_t kmin, uint64_t kmax) {
+    uint64_t range = kmax - kmin;
+    int bits = range ? 64 - __clzll((long long)range) : 0;
+    return bits > 11 ? (uint32_t)(bits - 11) : 0u;
+}
+__device__ __forceinline__ bool pair_less(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib) {
+    return ka < kb || (ka == kb && ia < ib);
+}
+
+struct Eng {
+    int env, dim, D, A, B, sem, oh_dtype, depth;
+    double w;
+    float wf;
+    uint32_t max_nodes, M, tab_cap, tab_mask;
+    uint8_t* state;
+    int32_t* g;
+    uint32_t* parent;
+    uint8_t* move;
+    uint8_t* solved;
+    Slot* tab;
+    uint64_t* open_key[4];
+    uint32_t* open_id[4];
+    uint32_t f_keep, f_max;  // FRONT hysteresis: refill/spill down to ~f_keep, spill when above f_max
+    uint32_t *hist, *bin_start, *bin_fill, *tail_start;
+    uint64_t* cand_key;
+    uint32_t* cand_id;
+    uint8_t* cand_st;
+    uint64_t *tmp_key, *pop_key, *ord_key, *spl_key;
+    uint32_t *tmp_id, *pop_id, *ord_id, *spl_id, *ord_b, *ord_s, *ord_pb, *bcnt, *bpre;
+    uint64_t *child_hash, *child_key;
+    uint32_t *child_slot, *child_next;
+    uint8_t* child_flags;
+    float* child_h;
+    uint8_t* nnet_in;
+    uint8_t* onehot;
+    uint8_t* root_nnet;
+    int32_t* d_moves;
+    Ctl* ctl;
+};
+
+// ---------------------------------------------------------------------------------------------
+// wave-aggregated append to the live OPEN buffer (+ running min/max of its keys)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void open_append(const Eng& E, Ctl* c, uint32_t buf, bool pred, uint64_t key, uint32_t id) {
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0) return;
+    int lane = threadIdx.x & 63;
+    int leader = __ffsll((long long)mask) - 1;
+    uint32_t cnt = (uint32_t)__popcll(mask);
+    uint32_t basep = 0;
+    // wave min / max of the appended keys
+    uint64_t kmn = pred ? key : ~0ull, kmx = pred ? key : 0ull;
+    for (int o = 32; o > 0; o >>= 1) {
+        uint64_t a = __shfl_xor(kmn, o), b = __shfl_xor(kmx, o);
+        kmn = a < kmn ? a : kmn;
+        kmx = b > kmx ? b : kmx;
+    }
+    if (lane == leader) {
+        basep = atomicAdd(&c->open_n[buf], cnt);
+        atomicMin((unsigned long long*)&c->kmin[buf], (unsigned long long)kmn);
+        atomicMax((unsigned long long*)&c->kmax[buf], (unsigned long long)kmx);
+    }
+    basep = __shfl(basep, leader);
+    if (pred) {
+        uint32_t pos = basep + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (pos < E.max_nodes) {
+            E.open_key[buf][pos] = key;
+            E.open_id[buf][pos] = id;
+        } else {
+            c->failed = 1;
+        }
+    }
+}
+
+// block-aggregated reservation in two output arrays at once: every thread asks for cntA / cntB slots,
+// the block issues ONE atomicAdd per array (same-address atomics saturate near 90 per microsecond on
+// this chip, so per-wave appends would bound a multi-million-entry pass).  sh: 2*NW+2 words of LDS.
+struct Pos2 {
+    uint32_t a, b;
+};
+template <int NT>
+__device__ __forceinline__ Pos2 block_reserve2(uint32_t cntA, uint32_t cntB, uint32_t* ctrA, uint32_t* ctrB,
+                                               uint32_t* sh) {
+    constexpr int NW = NT / 64;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t ia = cntA, ib = cntB;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t va = __shfl_up(ia, o), vb = __shfl_up(ib, o);
+        if (lane >= o) {
+            ia += va;
+            ib += vb;
+        }
+    }
+    if (lane == 63) {
+        sh[wv] = ia;
+        sh[NW + wv] = ib;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t aa = 0, ab = 0;
+        for (int w = 0; w < NW; w++) {
+            uint32_t ta = sh[w], tb = sh[NW + w];
+            sh[w] = aa;
+            sh[NW + w] = ab;
+            aa += ta;
+            ab += tb;
+        }
+        sh[2 * NW] = aa ? atomicAdd(ctrA, aa) : 0u;
+        sh[2 * NW + 1] = ab ? atomicAdd(ctrB, ab) : 0u;
+    }
+    __syncthreads();
+    Pos2 p{sh[2 * NW] + sh[wv] + ia - cntA, sh[2 * NW + 1] + sh[NW + wv] + ib - cntB};
+    __syncthreads();
+    return p;
+}
+
+struct Pos3 {
+    uint32_t a, b, c;
+};
+template <int NT>
+__device__ __forceinline__ Pos3 block_reserve3(uint32_t cntA, uint32_t cntB, uint32_t cntC, uint32_t* ctrA,
+                                               uint32_t* ctrB, uint32_t* ctrC, uint32_t* sh /*3*NW+3*/) {
+    constexpr int NW = NT / 64;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t ia = cntA, ib = cntB, ic = cntC;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t va = __shfl_up(ia, o), vb = __shfl_up(ib, o), vc = __shfl_up(ic, o);
+        if (lane >= o) {
+            ia += va;
+            ib += vb;
+            ic += vc;
+        }
+    }
+    if (lane == 63) {
+        sh[wv] = ia;
+        sh[NW + wv] = ib;
+        sh[2 * NW + wv] = ic;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t aa = 0, ab = 0, ac = 0;
+        for (int w = 0; w < NW; w++) {
+            uint32_t ta = sh[w], tb = sh[NW + w], tc = sh[2 * NW + w];
+            sh[w] = aa;
+            sh[NW + w] = ab;
+            sh[2 * NW + w] = ac;
+            aa += ta;
+            ab += tb;
+            ac += tc;
+        }
+        sh[3 * NW] = aa ? atomicAdd(ctrA, aa) : 0u;
+        sh[3 * NW + 1] = ab ? atomicAdd(ctrB, ab) : 0u;
+        sh[3 * NW + 2] = ac ? atomicAdd(ctrC, ac) : 0u;
+    }
+    __syncthreads();
+    Pos3 p{sh[3 * NW] + sh[wv] + ia - cntA, sh[3 * NW + 1] + sh[NW + wv] + ib - cntB,
+           sh[3 * NW + 2] + sh[2 * NW + wv] + ic - cntC};
+    __syncthreads();
+    return p;
+}
+
+// K-way variant: cnt[k] slots wanted in the array behind ctr[k]; pos[k] receives the first slot
+template <int NT, int K>
+__device__ __forceinline__ void block_reserveK(const uint32_t (&cnt)[K], uint32_t* const (&ctr)[K], uint32_t (&pos)[K],
+                                               uint32_t* sh /*K*NW+K*/) {
+    constexpr int NW = NT / 64;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t inc[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) inc[k] = cnt[k];
+    for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            uint32_t v = __shfl_up(inc[k], o);
+            if (lane >= o) inc[k] += v;
+        }
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < K; k++) sh[k * NW + wv] = inc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        const int k = threadIdx.x;
+        uint32_t acc = 0;
+        for (int w = 0; w < NW; w++) {
+            uint32_t tv = sh[k * NW + w];
+            sh[k * NW + w] = acc;
+            acc += tv;
+        }
+        sh[K * NW + k] = acc ? atomicAdd(ctr[k], acc) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) pos[k] = sh[K * NW + k] + sh[k * NW + wv] + inc[k] - cnt[k];
+    __syncthreads();
+}
+
+// fold a thread's running key range into a buffer's kmin/kmax (one atomic per wave, only if it helps)
+__device__ __forceinline__ void fold_range(Ctl* c, uint32_t buf, uint64_t kmn, uint64_t kmx) {
+    for (int o = 32; o > 0; o >>= 1) {
+        uint64_t a = __shfl_xor(kmn, o), b = __shfl_xor(kmx, o);
+        kmn = a < kmn ? a : kmn;
+        kmx = b > kmx ? b : kmx;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (kmn < c->kmin[buf]) atomicMin((unsigned long long*)&c->kmin[buf], (unsigned long long)kmn);
+        if (kmx > c->kmax[buf]) atomicMax((unsigned long long*)&c->kmax[buf], (unsigned long long)kmx);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// reset / root
+// ---------------------------------------------------------------------------------------------
+__global__ void k_init_table(Slot* tab, uint32_t cap) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t stride = gridDim.x * blockDim.x;
+    for (; i < cap; i += stride) {
+        tab[i].entry = EMPTY;
+        tab[i].g = GINF;
+        tab[i].head = 0;
+    }
+}
+
+__global__ void k_reset(Eng E) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Ctl* c = E.ctl;
+    memset(c, 0, sizeof(Ctl));
+    const uint8_t* s = E.state;  // node 0 = root, already copied in
+    uint64_t h = hash_init(E.D);
+    bool ok = true;
+    for (int k = 0; k < E.D; k += 8) {
+        uint64_t w = 0;
+        for (int j = 0; j < 8 && k + j < E.D; j++) {
+            uint32_t b = s[k + j];
+            uint32_t goal = E.env == DCA_ENV_CUBE3 ? (uint32_t)(k + j) : (uint32_t)((k + j + 1) % E.D);
+            ok &= (b == goal);
+            w |= (uint64_t)b << (8 * j);
+            E.root_nnet[k + j] = (uint8_t)(E.env == DCA_ENV_CUBE3 ? (b * 57u) >> 9 : b);
+        }
+        h = hash_word(h, w);
+    }
+    h = hash_final(h);
+    E.g[0] = 0;
+    E.parent[0] = NIL;
+    E.move[0] = 0xFF;
+    E.solved[0] = ok ? 1 : 0;
+    c->pool_n = 1;
+    c->goal_best = ~0ull;
+    c->first_solved = NIL;
+    for (int b = 0; b < 4; b++) {
+        c->kmin[b] = ~0ull;
+        c->kmax[b] = 0;
+    }
+    c->cur_f = 0;
+    c->cur_b = 2;
+    c->T = ~0ull;  // everything is FRONT until the first spill
+    if (E.sem == DCA_SEM_CPP) {
+        // cpp:160-166: root pushed with cost 0 (h never evaluated), a copy inserted in CLOSED, gen = 1
+        uint32_t slot = (uint32_t)h & E.tab_mask;
+        E.tab[slot].entry = ((h >> 32) << 32) | 0u;
+        E.tab[slot].g = 0;
+        c->closed_n = 1;
+        c->gen = 1;
+        uint64_t key = key_of_cost(0.0);
+        E.open_key[0][0] = key;
+        E.open_id[0][0] = 0;
+        c->open_n[0] = 1;
+        c->kmin[0] = c->kmax[0] = key;
+    }
+}
+
+__global__ void k_root_commit(Eng E, const float* h_root) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Ctl* c = E.ctl;
+    if (E.sem != DCA_SEM_PY || c->open_n[c->cur_f] != 0) return;
+    // astar.py:246-249,196: cost = w*0.0 + max(h,0)*!solved   (float64)
+    double hv = fmax((double)h_root[0], 0.0);
+    double cost = __dadd_rn(__dmul_rn(E.w, 0.0), __dmul_rn(hv, E.solved[0] ? 0.0 : 1.0));
+    uint64_t key = key_of_cost(cost);
+    uint32_t b = c->cur_f;
+    E.open_key[b][0] = key;
+    E.open_id[b][0] = 0;
+    c->open_n[b] = 1;
+    c->kmin[b] = c->kmax[b] = key;
+}
+
+// ---------------------------------------------------------------------------------------------
+// refill: when FRONT holds fewer than one batch, raise T and move the cheapest part of BACK over
+// (rare: amortised over the iterations FRONT then lasts).  Always enqueued; exits early when idle.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool need_refill(const Eng& E, const Ctl* c) {
+    const uint32_t nf = c->open_n[c->cur_f], nb = c->open_n[c->cur_b];
+    return nb != 0 && nf < (uint32_t)E.B;
+}
+
+__global__ __launch_bounds__(256) void k_refill_hist(Eng E) {
+    Ctl* c = E.ctl;
+    if (c->done || !need_refill(E, c)) return;
+    __shared__ uint32_t lh[NBIN];
+    for (int i = threadIdx.x; i < NBIN; i += 256) lh[i] = 0;
+    __syncthreads();
+    const uint32_t b = c->cur_b, n = c->open_n[b];
+    const uint64_t kmin = c->kmin[b];
+    const uint32_t shift = select_shift(kmin, c->kmax[b]);
+    const uint64_t* __restrict__ keys = E.open_key[b];
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        uint64_t f = (keys[i] - kmin) >> shift;
+        atomicAdd(&lh[f < NBIN ? (uint32_t)f : NBIN - 1], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NBIN; i += 256)
+        if (lh[i]) atomicAdd(&E.hist[i], lh[i]);
+}
+
+// exclusive prefix of the 2048 global bins into pre[0..NBIN] (1024 threads, 2 bins each); zeroes hist
+__device__ __forceinline__ void scan_bins(const Eng& E, uint32_t* pre, uint32_t* wsum) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    uint32_t a = E.hist[2 * t], b2 = E.hist[2 * t + 1];
+    E.hist[2 * t] = 0;
+    E.hist[2 * t + 1] = 0;
+    uint32_t s = a + b2, incl = s;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    if (t < 16) {
+        uint32_t v = wsum[t], acc = v;
+        for (int o = 1; o < 16; o <<= 1) {
+            uint32_t u = __shfl_up(acc, o, 16);
+            if (t >= o) acc += u;
+        }
+        wsum[t] = acc - v;  // exclusive wave offsets
+    }
+    __syncthreads();
+    uint32_t excl = incl - s + wsum[wv];
+    pre[2 * t] = excl;
+    pre[2 * t + 1] = excl + a;
+    if (t == 1023) pre[NBIN] = excl + s;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void k_refill_scan(Eng E) {
+    Ctl* c = E.ctl;
+    if (c->done) return;
+    if (!need_refill(E, c)) {
+        if (threadIdx.x == 0) c->refill = 0;
+        return;
+    }
+    __shared__ uint32_t pre[NBIN + 1];
+    __shared__ uint32_t wsum[16];
+    scan_bins(E, pre, wsum);
+    const int t = threadIdx.x;
+    const uint32_t b = c->cur_b, n = c->open_n[b];
+    const uint32_t target = n < E.f_keep ? n : E.f_keep;
+    for (int k = 0; k < 2; k++) {
+        int bin = 2 * t + k;
+        if (pre[bin] < target && target <= pre[bin + 1]) c->r_bstar = (uint32_t)bin;  // whole bins move
+    }
+    __syncthreads();
+    if (t == 0) {
+        const uint64_t kmin = c->kmin[b];
+        const uint32_t shift = select_shift(kmin, c->kmax[b]);
+        c->refill = 1;
+        c->r_kmin = kmin;
+        c->r_shift = shift;
+        // new tier threshold = top key of the last bin that moves (the final bin also absorbs overflow)
+        uint64_t top = (c->r_bstar >= NBIN - 1) ? ~0ull : kmin + (((uint64_t)c->r_bstar + 1) << shift) - 1;
+        if (top < kmin) top = ~0ull;  // wrapped
+        c->T = top;
+        const uint32_t nb = b ^ 1;  // 2 <-> 3
+        c->open_n[nb] = 0;
+        c->kmin[nb] = ~0ull;
+        c->kmax[nb] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_refill_move(Eng E) {
+    Ctl* c = E.ctl;
+    if (c->done || !c->refill) return;
+    __shared__ uint32_t sh[2 * 4 + 2];
+    const uint32_t sb = c->cur_b, db = sb ^ 1, fb = c->cur_f;
+    const uint32_t n = c->open_n[sb];
+    const uint64_t kmin = c->r_kmin;
+    const uint32_t shift = c->r_shift, bstar = c->r_bstar;
+    const uint64_t* __restrict__ keys = E.open_key[sb];
+    const uint32_t* __restrict__ ids = E.open_id[sb];
+    constexpr uint32_t ITEMS = 8, TILE = 256 * ITEMS;
+    uint64_t fmn = ~0ull, fmx = 0, bmn = ~0ull, bmx = 0;
+    const uint32_t ntiles = (n + TILE - 1) / TILE;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint64_t k[ITEMS];
+        uint32_t id[ITEMS];
+        uint32_t tof = 0;  // bit i: item i goes to FRONT; valid mask in high half
+        uint32_t cf = 0, cb = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < ITEMS; i++) {
+            uint32_t idx = tile * TILE + i * 256 + threadIdx.x;
+            bool live = idx < n;
+            k[i] = live ? keys[idx] : 0;
+            id[i] = live ? ids[idx] : 0;
+            uint64_t f = (k[i] - kmin) >> shift;
+            bool front = live && (f < NBIN ? (uint32_t)f : NBIN - 1) <= bstar;
+            tof |= (front ? 1u : 0u) << i;
+            tof |= (live ? 1u : 0u) << (16 + i);
+            cf += front ? 1u : 0u;
+            cb += (live && !front) ? 1u : 0u;
+        }
+        Pos2 p = block_reserve2<256>(cf, cb, &c->open_n[fb], &c->open_n[db], sh);
+#pragma unroll
+        for (uint32_t i = 0; i < ITEMS; i++) {
+            if (!((tof >> (16 + i)) & 1u)) continue;
+            if ((tof >> i) & 1u) {
+                if (p.a < E.max_nodes) {
+                    E.open_key[fb][p.a] = k[i];
+                    E.open_id[fb][p.a] = id[i];
+                }
+                p.a++;
+                fmn = k[i] < fmn ? k[i] : fmn;
+                fmx = k[i] > fmx ? k[i] : fmx;
+            } else {
+                E.open_key[db][p.b] = k[i];
+                E.open_id[db][p.b] = id[i];
+                p.b++;
+                bmn = k[i] < bmn ? k[i] : bmn;
+                bmx = k[i] > bmx ? k[i] : bmx;
+            }
+        }
+    }
+    fold_range(c, fb, fmn, fmx);
+    fold_range(c, db, bmn, bmx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// pop: exact top-B of FRONT by (cost key, node id)
+// ---------------------------------------------------------------------------------------------
+// S1: histogram of (key - kmin) >> shift over FRONT, 2048 bins, LDS-privatised
+__global__ __launch_bounds__(256) void k_sel_hist(Eng E) {
+    Ctl* c = E.ctl;
+    if (c->done) return;
+    __shared__ uint32_t lh[NBIN];
+    for (int i = threadIdx.x; i < NBIN; i += 256) lh[i] = 0;
+    __syncthreads();
+    const uint32_t b = c->cur_f, n = c->open_n[b];
+    const uint64_t kmin = c->kmin[b];
+    const uint32_t shift = select_shift(kmin, c->kmax[b]);
+    const uint64_t* __restrict__ keys = E.open_key[b];
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        uint64_t f = (keys[i] - kmin) >> shift;
+        atomicAdd(&lh[f < NBIN ? (uint32_t)f : NBIN - 1], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NBIN; i += 256)
+        if (lh[i]) atomicAdd(&E.hist[i], lh[i]);
+}
+
+// S2: one workgroup — prefix over the bins, threshold bin, spill decision, per-iteration counter reset
+__global__ __launch_bounds__(1024) void k_sel_scan(Eng E) {
+    Ctl* c = E.ctl;
+    if (c->done) return;
+    __shared__ uint32_t pre[NBIN + 1];
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t s_spill;
+    const int t = threadIdx.x;
+    if (t == 0) {
+        if (c->refill) {  // the refill's destination buffer becomes BACK
+            c->cur_b ^= 1;
+            c->refill = 0;
+        }
+        s_spill = NBIN;  // no spill
+    }
+    E.bin_fill[2 * t] = 0;
+    E.bin_fill[2 * t + 1] = 0;
+    scan_bins(E, pre, wsum);
+    const uint32_t cb = c->cur_f, n = c->open_n[cb];
+    const uint32_t want = n < (uint32_t)E.B ? n : (uint32_t)E.B;
+    // threshold bin: first bin with pre[b] < want <= pre[b+1]
+    for (int k = 0; k < 2; k++) {
+        int bin = 2 * t + k;
+        if (pre[bin] < want && want <= pre[bin + 1]) {
+            c->bstar = (uint32_t)bin;
+            c->sel_less = pre[bin];
+            c->sel_r = want - pre[bin];
+        }
+        // spill: FRONT grew past f_max -> keep the bins that hold the batch plus ~f_keep more
+        if (n > E.f_max) {
+            const uint32_t keepn = want + E.f_keep;
+            if (pre[bin] < keepn && keepn <= pre[bin + 1]) s_spill = (uint32_t)bin;
+        }
+    }
+    E.bin_start[2 * t] = pre[2 * t];
+    E.bin_start[2 * t + 1] = pre[2 * t + 1];
+    __syncthreads();
+    if (t == 0) {
+        E.bin_start[NBIN] = pre[NBIN];
+        const uint64_t kmin = c->kmin[cb];
+        const uint32_t shift = select_shift(kmin, c->kmax[cb]);
+        c->want = want;
+        c->cand_n = 0;
+        c->sel_fill = 0;
+        c->sel_kmin = kmin;
+        c->shift = shift;
+        uint32_t sp = s_spill;
+        if (sp < NBIN - 1) {
+            uint64_t top = kmin + (((uint64_t)sp + 1) << shift) - 1;
+            if (top >= kmin && top < c->T) c->T = top;  else sp = NBIN;
+        } else {
+            sp = NBIN;
+        }
+        c->spill_bin = sp;  // survivors in bins above it move to BACK
+        c->open_n[cb ^ 1] = 0;
+        c->kmin[cb ^ 1] = ~0ull;
+        c->kmax[cb ^ 1] = 0;
+        c->goal_best = ~0ull;
+        c->first_solved = NIL;
+        c->skip = 0;
+        if (want == 0) {  // OPEN ran empty: no solution reachable
+            c->failed = 1;
+            c->done = 1;
+        }
+    }
+}
+
+// S3: scatter FRONT — below the threshold bin: popped (unordered); in it: candidates; above:
+// survivors -> the other FRONT buffer, or BACK when a spill lowered T.  One atomic per array per tile.
+__global__ __launch_bounds__(256) void k_sel_collect(Eng E) {
+    Ctl* c = E.ctl;
+    if (c->done) return;
+    __shared__ uint32_t sh[4 * 4 + 4];
+    const uint32_t b = c->cur_f, nf = b ^ 1, bb = c->cur_b;
+    const uint32_t n = c->open_n[b];
+    const uint64_t kmin = c->sel_kmin;
+    const uint32_t shift = c->shift, bstar = c->bstar, spill = c->spill_bin;
+    const uint64_t* __restrict__ keys = E.open_key[b];
+    const uint32_t* __restrict__ ids = E.open_id[b];
+    constexpr uint32_t ITEMS = 4, TILE = 256 * ITEMS;
+    uint64_t fmn = ~0ull, fmx = 0, bmn = ~0ull, bmx = 0;
+    const uint32_t ntiles = (n + TILE - 1) / TILE;
+    uint32_t* const ctr[4] = {&c->sel_fill, &c->open_n[nf], &c->open_n[bb], &c->cand_n};
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint64_t k[ITEMS];
+        uint32_t id[ITEMS];
+        uint32_t dest = 0;  // 3 bits per item: 0 dead, 1 popped, 2 FRONT', 3 BACK, 4 candidate
+        uint32_t cnt[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (uint32_t i = 0; i < ITEMS; i++) {
+            uint32_t idx = tile * TILE + i * 256 + threadIdx.x;
+            bool live = idx < n;
+            k[i] = live ? keys[idx] : 0;
+            id[i] = live ? ids[idx] : 0;
+            uint64_t f64 = (k[i] - kmin) >> shift;
+            uint32_t f = f64 < NBIN ? (uint32_t)f64 : NBIN - 1;
+            uint32_t d = !live ? 0u : (f < bstar ? 1u : (f == bstar ? 4u : (f > spill ? 3u : 2u)));
+            dest |= d << (3 * i);
+            if (d) cnt[d - 1]++;
+        }
+        uint32_t pos[4];
+        block_reserveK<256, 4>(cnt, ctr, pos, sh);
+#pragma unroll
+        for (uint32_t i = 0; i < ITEMS; i++) {
+            uint32_t d = (dest >> (3 * i)) & 7u;
+            if (d == 1u) {
+                E.tmp_key[pos[0]] = k[i];
+                E.tmp_id[pos[0]] = id[i];
+                pos[0]++;
+            } else if (d == 2u) {
+                E.open_key[nf][pos[1]] = k[i];
+                E.open_id[nf][pos[1]] = id[i];
+                pos[1]++;
+                fmn = k[i] < fmn ? k[i] : fmn;
+                fmx = k[i] > fmx ? k[i] : fmx;
+            } else if (d == 3u) {
+                if (pos[2] < E.max_nodes) {
+                    E.open_key[bb][pos[2]] = k[i];
+                    E.open_id[bb][pos[2]] = id[i];
+                }
+                pos[2]++;
+                bmn = k[i] < bmn ? k[i] : bmn;
+                bmx = k[i] > bmx ? k[i] : bmx;
+            } else if (d == 4u) {
+                E.cand_key[pos[3]] = k[i];
+                E.cand_id[pos[3]] = id[i];
+                E.cand_st[pos[3]] = 0;
+                pos[3]++;
+            }
+        }
+    }
+    fold_range(c, nf, fmn, fmx);
+    fold_range(c, bb, bmn, bmx);
+}
+
+// S4: one workgroup — exact choice of the sel_r smallest (key,id) among the candidates of the
+// threshold bin by adaptive radix refinement on the 96-bit composite; the rest survive.  The chosen
+// ones are written to the tail of the popped list grouped into 2048 sub-bins of their own range, so
+// that S5 only has to rank inside small groups.
+typedef unsigned __int128 u128;
+__device__ __forceinline__ u128 comp_of(uint64_t key, uint32_t id) { return ((u128)key << 32) | (u128)id; }
+__device__ __forceinline__ int clz128(u128 v) {
+    uint64_t hi = (uint64_t)(v >> 64), lo = (uint64_t)v;
+    return hi ? __clzll((long long)hi) : 64 + (lo ? __clzll((long long)lo) : 64);
+}
+
+struct CandShared {
+    uint32_t lh[NBIN];
+    uint32_t pre[NBIN + 1];
+    uint32_t wsum[16];
+    uint64_t red_lo[32], red_hi[32];
+    uint64_t vmin_hi, vmin_lo;
+    uint32_t active, rr, shift, bsel, cnt;
+    uint64_t fk[1024];
+    uint32_t fi[1024], fidx[1024];
+    uint64_t fk2[2048];
+    uint32_t fi2[2048];
+};
+
+// min / max composite over the candidates whose status equals `want_st`; result -> S.vmin_*, S.shift
+__device__ __forceinline__ void cand_range(const Eng& E, CandShared& S, uint32_t n, uint8_t want_st) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    u128 vmin = ~(u128)0, vmax = 0;
+    for (uint32_t i = t; i < n; i += 1024)
+        if (E.cand_st[i] == want_st) {
+            u128 v = comp_of(E.cand_key[i], E.cand_id[i]);
+            vmin = v < vmin ? v : vmin;
+            vmax = v > vmax ? v : vmax;
+        }
+    for (int o = 32; o > 0; o >>= 1) {
+        uint64_t ahi = __shfl_xor((uint64_t)(vmin >> 64), o), alo = __shfl_xor((uint64_t)vmin, o);
+        uint64_t bhi = __shfl_xor((uint64_t)(vmax >> 64), o), blo = __shfl_xor((uint64_t)vmax, o);
+        u128 a = ((u128)ahi << 64) | alo, b = ((u128)bhi << 64) | blo;
+        vmin = a < vmin ? a : vmin;
+        vmax = b > vmax ? b : vmax;
+    }
+    __syncthreads();  // earlier readers of the shared words are done
+    if (lane == 0) {
+        S.red_hi[wv] = (uint64_t)(vmin >> 64);
+        S.red_lo[wv] = (uint64_t)vmin;
+        S.red_hi[16 + wv] = (uint64_t)(vmax >> 64);
+        S.red_lo[16 + wv] = (uint64_t)vmax;
+    }
+    for (int i = t; i < NBIN; i += 1024) S.lh[i] = 0;
+    __syncthreads();
+    if (t == 0) {
+        u128 mn = ~(u128)0, mx = 0;
+        for (int k = 0; k < 16; k++) {
+            u128 a = ((u128)S.red_hi[k] << 64) | S.red_lo[k], b = ((u128)S.red_hi[16 + k] << 64) | S.red_lo[16 + k];
+            mn = a < mn ? a : mn;
+            mx = b > mx ? b : mx;
+        }
+        u128 range = mx >= mn ? mx - mn : 0;
+        int bits = range ? 128 - clz128(range) : 0;
+        S.shift = bits > 11 ? (uint32_t)(bits - 11) : 0u;
+        S.vmin_hi = (uint64_t)(mn >> 64);
+        S.vmin_lo = (uint64_t)mn;
+    }
+    __syncthreads();
+}
+
+// exclusive scan of S.lh into S.pre (1024 threads, 2 bins each)
+__device__ __forceinline__ void cand_scan(CandShared& S) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    uint32_t a = S.lh[2 * t], b2 = S.lh[2 * t + 1], s = a + b2, incl = s;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) S.wsum[wv] = incl;
+    __syncthreads();
+    if (t < 16) {
+        uint32_t v = S.wsum[t], acc = v;
+        for (int o = 1; o < 16; o <<= 1) {
+            uint32_t u = __shfl_up(acc, o, 16);
+            if (t >= o) acc += u;
+        }
+        S.wsum[t] = acc - v;
+    }
+    __syncthreads();
+    uint32_t excl = incl - s + S.wsum[wv];
+    S.pre[2 * t] = excl;
+    S.pre[2 * t + 1] = excl + a;
+    if (t == 1023) S.pre[NBIN] = excl + s;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void k_sel_cand(Eng E) {
+    Ctl* c = E.ctl;
+    if (c->done) return;
+    __shared__ CandShared S;
+    const int t = threadIdx.x;
+    const uint32_t n = c->cand_n;
+    if (t == 0) {
+        S.active = n;
+        S.rr = c->sel_r;
+    }
+    __syncthreads();
+    while (true) {
+        uint32_t active = S.active, rr = S.rr;
+        if (rr == 0 || rr == active) {  // take none / take all of what is still undecided
+            for (uint32_t i = t; i < n; i += 1024)
+                if (E.cand_st[i] == 0) E.cand_st[i] = rr ? 1 : 2;
+            break;
+        }
+        if (active <= 1024) {  // final: all-pairs rank in LDS
+            if (t == 0) S.cnt = 0;
+            __syncthreads();
+            for (uint32_t i = t; i < n; i += 1024)
+                if (E.cand_st[i] == 0) {
+                    uint32_t p = atomicAdd(&S.cnt, 1u);
+                    S.fk[p] = E.cand_key[i];
+                    S.fi[p] = E.cand_id[i];
+                    S.fidx[p] = i;
+                }
+            __syncthreads();
+            if ((uint32_t)t < active) {
+                uint32_t rank = 0;
+                uint64_t k0 = S.fk[t];
+                uint32_t i0 = S.fi[t];
+                for (uint32_t j = 0; j < active; j++) rank += pair_less(S.fk[j], S.fi[j], k0, i0) ? 1u : 0u;
+                E.cand_st[S.fidx[t]] = rank < rr ? 1 : 2;
+            }
+            break;
+        }
+        // ---- one refinement level on the undecided set
+        cand_range(E, S, n, 0);
+        const u128 base = ((u128)S.vmin_hi << 64) | S.vmin_lo;
+        const uint32_t sh = S.shift;
+        for (uint32_t i = t; i < n; i += 1024)
+            if (E.cand_st[i] == 0) {
+                uint32_t f = (uint32_t)((comp_of(E.cand_key[i], E.cand_id[i]) - base) >> sh);
+                atomicAdd(&S.lh[f], 1u);
+            }
+        __syncthreads();
+        cand_scan(S);
+        for (int k = 0; k < 2; k++) {
+            int bin = 2 * t + k;
+            if (S.pre[bin] < rr && rr <= S.pre[bin + 1]) S.bsel = (uint32_t)bin;
+        }
+        __syncthreads();
+        const uint32_t bsel = S.bsel;
+        for (uint32_t i = t; i < n; i += 1024)
+            if (E.cand_st[i] == 0) {
+                uint32_t f = (uint32_t)((comp_of(E.cand_key[i], E.cand_id[i]) - base) >> sh);
+                if (f < bsel)
+                    E.cand_st[i] = 1;
+                else if (f > bsel)
+                    E.cand_st[i] = 2;
+            }
+        __syncthreads();
+        if (t == 0) {
+            S.rr = rr - S.pre[bsel];
+            S.active = S.pre[bsel + 1] - S.pre[bsel];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    // ---- emit: chosen -> tail of the (still unordered) popped list, the rest -> FRONT'
+    const uint32_t out0 = c->sel_less;
+    const uint32_t nb = c->cur_f ^ 1;
+    if (t == 0) S.cnt = 0;
+    __syncthreads();
+    {
+        const uint32_t total = ((n + 1023) / 1024) * 1024;
+        for (uint32_t i = t; i < total; i += 1024) {
+            bool live = i < n;
+            uint8_t st = live ? E.cand_st[i] : 0;
+            uint64_t key = live ? E.cand_key[i] : 0;
+            uint32_t id = live ? E.cand_id[i] : 0;
+            if (live && st == 1) {
+                uint32_t p = out0 + atomicAdd(&S.cnt, 1u);
+                E.tmp_key[p] = key;
+                E.tmp_id[p] = id;
+            }
+            open_append(E, c, nb, live && st == 2, key, id);
+        }
+    }
+    __syncthreads();
+
+    // ---- order the popped list by (key, id), step 1: 2048 sampled entries are bitonic-sorted here and
+    // become the splitters of a sample sort whose bucket/scatter/rank passes run chip-wide (k_ord_*).
+    // Works for any key distribution (ids make the composite unique), unlike fixed-width bins.
+    const uint32_t want = c->want;
+    uint64_t* sk = S.fk2;
+    uint32_t* si = S.fi2;
+    const bool small = want <= 2048;
+    for (uint32_t j = t; j < 2048; j += 1024) {
+        uint32_t idx = small ? j : (uint32_t)(((uint64_t)j * want) >> 11);
+        bool ok = idx < want;
+        sk[j] = ok ? E.tmp_key[idx] : ~0ull;
+        si[j] = ok ? E.tmp_id[idx] : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    for (uint32_t k2 = 2; k2 <= 2048; k2 <<= 1)
+        for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            uint32_t i = ((t / j2) * 2 * j2) + (t % j2), l = i + j2;
+            bool up = (i & k2) == 0;
+            uint64_t ka = sk[i], kb = sk[l];
+            uint32_t ia = si[i], ib = si[l];
+            bool gt = pair_less(kb, ib, ka, ia);
+            if (gt == up) {
+                sk[i] = kb;
+                si[i] = ib;
+                sk[l] = ka;
+                si[l] = ia;
+            }
+            __syncthreads();
+        }
+    for (uint32_t j = t; j < 2048; j += 1024) {
+        E.spl_key[j] = sk[j];
+        E.spl_id[j] = si[j];
+    }
+    for (uint32_t j = t; j < 2049; j += 1024) E.bcnt[j] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sample sort of the popped list (2049 buckets delimited by the sorted sample)
+// ---------------------------------------------------------------------------------------------
+struct OrdShared {
+    uint64_t sk[2048];
+    uint32_t si[2048];
+};
+__device__ __forceinline__ void ord_load_splitters(const Eng& E, OrdShared& S) {
+    for (uint32_t j = threadIdx.x; j < 2048; j += blockDim.x) {
+        S.sk[j] = E.spl_key[j];
+        S.si[j] = E.spl_id[j];
+    }
+    __syncthreads();
+}
+// bucket = number of splitters < (k,id)  (0..2048)
+__device__ __forceinline__ uint32_t ord_bucket(const OrdShared& S, uint64_t k, uint32_t id) {
+    uint32_t lo = 0, hi = 2048;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (pair_less(S.sk[mid], S.si[mid], k, id))
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// O1: bucket of every popped entry + its arrival slot inside the bucket
+__global__ __launch_bounds__(256) void k_ord_count(Eng E) {
+    Ctl* c = E.ctl;
+    if (c->done) return;
+    const uint32_t want = c->want;
+    if (blockIdx.x * 256 >= want) return;
+    __shared__ OrdShared S;
+    ord_load_splitters(E, S);
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= want) return;
+    const uint32_t b = ord_bucket(S, E.tmp_key[e], E.tmp_id[e]);
+    E.ord_b[e] = b;
+    E.ord_s[e] = atomicAdd(&E.bcnt[b], 1u);
+}
+
+// exclusive prefix of bcnt[0..2048] into LDS pre[0..2049] (256 threads)
+__device__ __forceinline__ void ord_prefix(const Eng& E, uint32_t* pre, uint32_t* wsum) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    uint32_t v[8], s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        v[k] = E.bcnt[8 * t + k];
+        s += v[k];
+    }
+    uint32_t incl = s;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t u = __shfl_up(incl, o);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wv; w++) woff += wsum[w];
+    uint32_t run = incl - s + woff;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        pre[8 * t + k] = run;
+        run += v[k];
+    }
+    if (t == 255) {
+        pre[2048] = run;
+        pre[2049] = run + E.bcnt[2048];
+    }
+    __syncthreads();
+}
+
+// O2: scatter bucket-contiguously
+__global__ __launch_bounds__(256) void k_ord_scatter(Eng E) {
+    Ctl* c = E.ctl;
+    if (c->done) return;
+    const uint32_t want = c->want;
+    if (blockIdx.x * 256 >= want) return;
+    __shared__ uint32_t pre[2050];
+    __shared__ uint32_t wsum[4];
+    ord_prefix(E, pre, wsum);
+    if (blockIdx.x == 0)
+        for (uint32_t j = threadIdx.x; j < 2050; j += 256) E.bpre[j] = pre[j];
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= want) return;
+    const uint32_t b = E.ord_b[e];
+    const uint32_t p = pre[b] + E.ord_s[e];
+    E.ord_key[p] = E.tmp_key[e];
+    E.ord_id[p] = E.tmp_id[e];
+    E.ord_pb[p] = b;
+}
+
+// O3: rank inside the bucket -> final pop order; note solved pops
+__global__ __launch_bounds__(256) void k_ord_rank(Eng E) {
+    Ctl* c = E.ctl;
+    if (c->done) return;
+    const uint32_t want = c->want;
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= want) return;
+    const uint64_t k = E.ord_key[e];
+    const uint32_t id = E.ord_id[e];
+    const uint32_t b = E.ord_pb[e];
+    const uint32_t s0 = E.bpre[b], e0 = E.bpre[b + 1];
+    uint32_t rank = s0;
+    for (uint32_t j = s0; j < e0; j++) rank += pair_less(E.ord_key[j], E.ord_id[j], k, id) ? 1u : 0u;
+    E.pop_key[rank] = k;
+    E.pop_id[rank] = id;
+    if (E.solved[id]) {
+        if (E.sem == DCA_SEM_PY)
+            atomicMin(&c->goal_best, ((unsigned long long)(uint32_t)E.g[id] << 32) | rank);
+        else
+            atomicMin(&c->first_solved, rank);
+    }
+}
+
+// S6: single thread — fix the batch geometry, goal bookkeeping, swap OPEN buffers
+__global__ void k_post_pop(Eng E) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Ctl* c = E.ctl;
+    if (c->done) return;
+    const uint32_t want = c->want;
+    uint32_t npop = want;
+    if (E.sem == DCA_SEM_PY) {
+        // astar.py:73,421: any solved node among the popped ends the search after this iteration;
+        // answer = solved popped node of smallest path cost, first in pop order on ties (327-333)
+        if (c->goal_best != ~0ull) {
+            c->stop_after = 1;
+            c->goal_id = E.pop_id[(uint32_t)(c->goal_best & 0xFFFFFFFFull)];
+        }
+    } else {
+        // cpp:185-208
+        const uint32_t fs = c->first_solved;
+        const int prev = c->has_best;
+        if (fs != NIL) {
+            npop = fs + 1;  // break at the first solved node popped
+            float cst = (float)cost_of_key(E.pop_key[fs]);
+            if (E.B == 1) {
+                c->best_id = E.pop_id[fs];
+                c->best_cost = cst;
+                c->has_best = 1;
+                c->stop_after = 1;
+            } else if (!c->has_best || c->best_cost > cst) {
+                c->best_id = E.pop_id[fs];
+                c->best_cost = cst;
+                c->has_best = 1;
+            }
+        }
+        if (prev && (float)cost_of_key(E.pop_key[0]) >= c->best_cost) c->stop_after = 1;
+    }
+    const uint32_t base = (c->pool_n + 15u) & ~15u;  // 16-aligned ids => 16-byte aligned child rows for every D
+    const uint64_t m = (uint64_t)npop * (uint64_t)E.A;
+    if ((uint64_t)base + m > (uint64_t)E.max_nodes) {
+        c->failed = 1;
+        c->done = 1;
+        return;
+    }
+    c->npop = npop;
+    c->m = (uint32_t)m;
+    c->base = base;
+    c->pool_n = base + (uint32_t)m;
+    c->gen += (int64_t)m;
+    c->expanded += npop;
+    c->cur_f ^= 1;  // the survivors' buffer becomes FRONT; un-popped entries and cheap children are appended to it
+}
+
+// ---------------------------------------------------------------------------------------------
+// expand: gather the popped parents by id, write children rows + node fields + hash/solved/heuristic
+// ---------------------------------------------------------------------------------------------
+template <int ENV, int DIM, int OH>
+__global__ __launch_bounds__(kThreads) void k_expand(Eng E, int heur_id) {
+    using EV = EnvT<ENV, DIM>;
+    using TL = Tile<ENV, DIM>;
+    Ctl* c = E.ctl;
+    if (c->done) return;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* lpar = smem;
+    uint8_t* ltab = smem + TL::PAR_BYTES;
+    const uint32_t npop = c->npop, want = c->want, base = c->base;
+    const uint32_t r0 = blockIdx.x * kTileParents;
+    if (E.sem == DCA_SEM_CPP && r0 + kTileParents > npop) {
+        // cpp:203 `break`: entries selected after the first solved node were never popped — put them back
+        uint32_t r = r0 + threadIdx.x;
+        bool back = threadIdx.x < kTileParents && r >= npop && r < want;
+        open_append(E, c, c->cur_f, back, back ? E.pop_key[r] : 0, back ? E.pop_id[r] : 0);
+    }
+    if (r0 >= npop) return;
+    const uint32_t np = min((uint32_t)kTileParents, npop - r0);
+    for (uint32_t idx = threadIdx.x; idx < np * EV::D; idx += kThreads) {
+        uint32_t r = idx / EV::D, i = idx - r * EV::D;
+        lpar[idx] = E.state[(size_t)E.pop_id[r0 + r] * EV::D + i];
+    }
+    if constexpr (ENV == DCA_ENV_CUBE3) stage_tables<ENV, DIM>(ltab, lpar, np);
+    __syncthreads();
+    if constexpr (ENV != DCA_ENV_CUBE3) {
+        stage_tables<ENV, DIM>(ltab, lpar, np);
+        __syncthreads();
+    }
+    TL t{lpar, ltab};
+    const uint32_t nchild = np * EV::A;
+    const uint32_t j0 = r0 * EV::A;  // first child index of the tile within the batch
+
+    // per child: hash, is_solved, node fields, built-in heuristic
+    for (uint32_t cc = threadIdx.x; cc < nchild; cc += kThreads) {
+        uint32_t r = cc / EV::A, a = cc - r * EV::A;
+        uint64_t h = hash_init(EV::D), sum = 0;
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < EV::D; k += 8) {
+            uint64_t w = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (k + j < EV::D) {
+                    uint32_t b = t.child_byte(r, a, k + j);
+                    uint32_t goal = ENV == DCA_ENV_CUBE3 ? (uint32_t)(k + j) : (uint32_t)((k + j + 1) % EV::D);
+                    ok &= (b == goal);
+                    w |= (uint64_t)b << (8 * j);
+                    sum += (uint64_t)b * (uint64_t)(7 * (k + j) + 3);
+                }
+            }
+            h = hash_word(h, w);
+        }
+        h = hash_final(h);
+        const uint32_t j = j0 + cc, id = base + j, pid = E.pop_id[r0 + r];
+        E.child_hash[j] = h;
+        E.g[id] = E.g[pid] + 1;  // path cost + unit transition cost (astar.py:125-126 / cpp:219)
+        E.parent[id] = pid;
+        E.move[id] = (uint8_t)a;
+        E.solved[id] = ok ? 1 : 0;
+        if (heur_id >= 0) E.child_h[j] = heur_from(heur_id, sum, h);
+    }
+
+    // child rows -> node pool (final place), network-input rows -> batch buffer; 16 B per lane
+    {
+        const uint32_t tb = nchild * EV::D;
+        uint8_t* gpool = E.state + ((size_t)base + j0) * EV::D;
+        uint8_t* gnn = E.nnet_in + (size_t)j0 * EV::D;
+        const uint32_t nch = (tb + 15) >> 4;
+        for (uint32_t q = threadIdx.x; q < nch; q += kThreads) {
+            uint32_t b0 = q << 4;
+            uint32_t cch = b0 / EV::D, i = b0 - cch * EV::D;
+            uint32_t r = cch / EV::A, a = cch - r * EV::A;
+            uint32_t w[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                uint32_t b = (b0 + k < tb) ? t.child_byte(r, a, i) : 0u;
+                w[k >> 2] |= b << (8 * (k & 3));
+                if constexpr (ENV == DCA_ENV_CUBE3) v[k >> 2] |= ((b * 57u) >> 9) << (8 * (k & 3));
+                if (++i == EV::D) {
+                    i = 0;
+                    if (++a == EV::A) {
+                        a = 0;
+                        ++r;
+                    }
+                }
+            }
+            if (b0 + 16 <= tb) {
+                store16(gpool + b0, w, true);
+                store16(gnn + b0, ENV == DCA_ENV_CUBE3 ? v : w, true);
+            } else {
+                for (uint32_t k = 0; b0 + k < tb; k++) {
+                    gpool[b0 + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+                    gnn[b0 + k] = (uint8_t)((ENV == DCA_ENV_CUBE3 ? v : w)[k >> 2] >> (8 * (k & 3)));
+                }
+            }
+        }
+    }
+
+    // optional one-hot rows of the batch (pytorch_models.py:49-52) for the heuristic network
+    if constexpr (OH != 0) {
+        constexpr uint32_t ROW = EV::D * EV::DEPTH;
+        constexpr uint32_t EPC = 16 / OH;
+        const uint32_t te = nchild * ROW;
+        const uint32_t one16 = E.oh_dtype == DCA_DT_F16 ? 0x3C00u : 0x3F80u;
+        uint8_t* goh = E.onehot + (size_t)j0 * ROW * OH;
+        const uint32_t nch = (te + EPC - 1) / EPC;
+        for (uint32_t q = threadIdx.x; q < nch; q += kThreads) {
+            uint32_t e0 = q * EPC;
+            uint32_t cch = e0 / ROW, e = e0 - cch * ROW;
+            uint32_t pos = e / EV::DEPTH, col = e - pos * EV::DEPTH;
+            uint32_t r = cch / EV::A, a = cch - r * EV::A;
+            uint32_t nb = t.nnet_byte(r, a, pos);
+            uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t k = 0; k < EPC; k++) {
+                bool hot = (nb == col) && (e0 + k < te);
+                if constexpr (OH == 4)
+                    w[k] = hot ? 0x3F800000u : 0u;
+                else
+                    w[k >> 1] |= (hot ? one16 : 0u) << (16 * (k & 1));
+                if (++col == EV::DEPTH) {
+                    col = 0;
+                    if (++pos == EV::D) {
+                        pos = 0;
+                        if (++a == EV::A) {
+                            a = 0;
+                            ++r;
+                        }
+                    }
+                    nb = t.nnet_byte(r, a, pos);
+                }
+            }
+            uint8_t* dst = goh + (size_t)e0 * OH;
+            if (e0 + EPC <= te) {
+                store16(dst, w, true);
+            } else {
+                for (uint32_t k = 0; e0 + k < te; k++) {
+                    if constexpr (OH == 4)
+                        reinterpret_cast<uint32_t*>(dst)[k] = w[k];
+                    else
+                        reinterpret_cast<uint16_t*>(dst)[k] = (uint16_t)(w[k >> 1] >> (16 * (k & 1)));
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dedup A: find-or-insert the CLOSED slot of every child, chain the child to it
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_probe(Eng E) {
+    Ctl* c = E.ctl;
+    if (c->done) return;
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t m = c->m, base = c->base;
+    bool inserted = false;
+    if (j < m) {
+        const uint32_t id = base + j;
+        const uint64_t h = E.child_hash[j];
+        const uint64_t tag = h >> 32;
+        const uint8_t* mine = E.state + (size_t)id * E.D;
+        const bool even = (E.D & 1) == 0;  // even row length => rows start on 2-byte boundaries
+        uint32_t slot = (uint32_t)h & E.tab_mask;
+        for (uint32_t probes = 0;; probes++) {
+            uint64_t e = __hip_atomic_load(&E.tab[slot].entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (e == EMPTY) {
+                uint64_t old = atomicCAS((unsigned long long*)&E.tab[slot].entry, (unsigned long long)EMPTY,
+                                         (unsigned long long)((tag << 32) | id));
+                if (old == EMPTY) {
+                    inserted = true;
+                    break;
+                }
+                e = old;
+            }
+            if ((e >> 32) == tag) {
+                // exact key equality against the representative's state bytes (State.__eq__, cube3.py:23-24)
+                const uint8_t* rep = E.state + (size_t)(uint32_t)e * E.D;
+                bool eq = true;
+                if (even) {
+                    const uint16_t* a = reinterpret_cast<const uint16_t*>(rep);
+                    const uint16_t* b = reinterpret_cast<const uint16_t*>(mine);
+                    for (int k = 0; k < (E.D >> 1); k++) eq &= (a[k] == b[k]);
+                } else {
+                    for (int k = 0; k < E.D; k++) eq &= (rep[k] == mine[k]);
+                }
+                if (eq) break;
+            }
+            slot = (slot + 1) & E.tab_mask;
+            if (probes > E.tab_mask) {  // table full (cannot happen while pool <= cap/2)
+                c->failed = 1;
+                break;
+            }
+        }
+        uint32_t old_head = atomicExch(&E.tab[slot].head, id);
+        E.child_next[j] = old_head >= base ? old_head - base : NIL;
+        E.child_slot[j] = slot;
+    }
+    unsigned long long mk = __ballot(inserted);
+    if (mk && (threadIdx.x & 63) == (__ffsll((long long)mk) - 1))
+        atomicAdd((unsigned long long*)&c->closed_n, (unsigned long long)__popcll(mk));
+}
+
+// dedup B: keep decision in sequential order + cost
+constexpr uint8_t F_KEEP = 1, F_MIN = 2;
+__global__ __launch_bounds__(256) void k_decide(Eng E) {
+    Ctl* c = E.ctl;
+    if (c->done) return;
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t m = c->m, base = c->base;
+    if (j >= m) return;
+    const uint32_t id = base + j;
+    const uint32_t slot = E.child_slot[j];
+    const uint32_t v0 = E.tab[slot].g;
+    const uint32_t gj = (uint32_t)E.g[id];
+    bool dominated = false;
+    uint32_t gmin = GINF, pmin = NIL, first = j;
+    for (uint32_t k = E.tab[slot].head - base; k != NIL; k = E.child_next[k]) {
+        uint32_t gk = (uint32_t)E.g[base + k];
+        dominated |= (k < j && gk <= gj);
+        if (gk < gmin || (gk == gmin && k < pmin)) {
+            gmin = gk;
+            pmin = k;
+        }
+        first = k < first ? k : first;
+    }
+    const bool keep = (gj < v0) && !dominated;  // astar.py:81-88 / cpp:247-265 in sequential order
+    E.child_flags[j] = (keep ? F_KEEP : 0) | (j == pmin ? F_MIN : 0);
+    if (j == first) {
+        // a state first seen in this batch is represented by its sequentially-first child (the node
+        // the reference inserts, cpp:250) whichever lane won the CAS
+        uint64_t e = E.tab[slot].entry;
+        if ((uint32_t)e >= base && (uint32_t)e != id) E.tab[slot].entry = (e & 0xFFFFFFFF00000000ull) | id;
+    }
+    const float hv = fmaxf(E.child_h[j], 0.0f);  // clip_zero (nnet_utils.py:193-194)
+    const bool ns = E.solved[id] == 0;
+    double cost;
+    if (E.sem == DCA_SEM_PY) {
+        // astar.py:196  weights*path_costs + heuristics*logical_not(is_solved), float64, two roundings
+        cost = __dadd_rn(__dmul_rn(E.w, (double)gj), __dmul_rn((double)hv, ns ? 1.0 : 0.0));
+    } else {
+        // cpp:298  values[i]*(!isSolved) + depthPenalty*((float) depth), float32
+        cost = (double)__fadd_rn(__fmul_rn(hv, ns ? 1.0f : 0.0f), __fmul_rn(E.wf, (float)gj));
+    }
+    E.child_key[j] = key_of_cost(cost);
+}
+
+// dedup C: record the new best g per state, push the kept children (FRONT if key <= T, else BACK)
+__global__ __launch_bounds__(1024) void k_commit(Eng E) {
+    Ctl* c = E.ctl;
+    if (c->done) return;
+    __shared__ uint32_t sh[2 * 16 + 2];
+    const uint32_t m = c->m, base = c->base;
+    const uint32_t fb = c->cur_f, bb = c->cur_b;
+    const uint64_t T = c->T;
+    const uint32_t j = blockIdx.x * 1024 + threadIdx.x;
+    if (blockIdx.x * 1024 >= m) return;
+    const bool live = j < m;
+    const uint8_t fl = live ? E.child_flags[j] : 0;
+    const bool keep = (fl & F_KEEP) != 0;
+    const uint32_t id = base + j;
+    if (keep && (fl & F_MIN)) {
+        const uint32_t slot = E.child_slot[j];
+        const uint32_t gj = (uint32_t)E.g[id];
+        E.tab[slot].g = gj;  // one writer per slot: the first occurrence of the batch minimum
+        if (E.sem == DCA_SEM_CPP) {
+            // cpp:254-257: a shallower duplicate rewrites the CLOSED node's depth/parent/move in place
+            uint32_t rep = (uint32_t)E.tab[slot].entry;
+            if (rep != id) {
+                E.g[rep] = (int32_t)gj;
+                E.parent[rep] = E.parent[id];
+                E.move[rep] = E.move[id];
+            }
+        }
+    }
+    const uint64_t key = keep ? E.child_key[j] : 0;
+    const bool tof = keep && key <= T, tob = keep && key > T;
+    Pos2 p = block_reserve2<1024>(tof ? 1u : 0u, tob ? 1u : 0u, &c->open_n[fb], &c->open_n[bb], sh);
+    if (tof) {
+        if (p.a < E.max_nodes) {
+            E.open_key[fb][p.a] = key;
+            E.open_id[fb][p.a] = id;
+        } else {
+            c->failed = 1;
+        }
+    } else if (tob) {
+        if (p.b < E.max_nodes) {
+            E.open_key[bb][p.b] = key;
+            E.open_id[bb][p.b] = id;
+        } else {
+            c->failed = 1;
+        }
+    }
+    fold_range(c, fb, tof ? key : ~0ull, tof ? key : 0ull);
+    fold_range(c, bb, tob ? key : ~0ull, tob ? key : 0ull);
+}
+
+__global__ void k_end_iter(Eng E) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Ctl* c = E.ctl;
+    if (c->done) return;
+    c->iters += 1;
+    if (c->stop_after || c->failed) c->done = 1;
+}
+
+__global__ void k_solution(Eng E, int32_t* out /*[0]=len, [1..]=moves root->goal*/, double* path_cost) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Ctl* c = E.ctl;
+    out[0] = -1;
+    *path_cost = 0.0;
+    uint32_t n;
+    if (E.sem == DCA_SEM_PY) {
+        if (c->goal_best == ~0ull && !(c->done && c->stop_after)) return;
+        n = c->goal_id;
+        *path_cost = (double)E.g[n];  // astar.py:229 node.path_cost
+    } else {
+        if (!c->has_best) return;
+        n = c->best_id;
+    }
+    int len = 0;
+    // astar.py:218-223 walks parents to the root; cpp:337-341 walks while depth > 0
+    while ((E.sem == DCA_SEM_PY ? E.parent[n] != NIL : E.g[n] > 0) && len < kMaxMoves - 1) {
+        out[1 + len++] = E.move[n];
+        n = E.parent[n];
+    }
+    for (int i = 0; i < len / 2; i++) {
+        int32_t tmp = out[1 + i];
+        out[1 + i] = out[len - i];
+        out[len - i] = tmp;
+    }
+    out[0] = len;
+    if (E.sem == DCA_SEM_CPP) *path_cost = (double)len;  // astar.py:554 sum of unit transition costs
+}
+
+}  // namespace dca
+
+using namespace dca;
+
+struct dca_engine {
+    Eng E;
+    Ctl* h_ctl;  // pinned
+    int32_t* h_moves;
+    double* d_cost;
+    double* h_cost;
+    int phase;  // 0 idle, 1 between pop_expand and commit
+    hipGraph_t graph;
+    hipGraphExec_t graph_exec;
+    int graph_heur;
+    void* allocs[48];
+    int nalloc;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(dca_engine* e, T** p, size_t count) {
+    void* q = nullptr;
+    hipError_t err = hipMalloc(&q, count * sizeof(T) + 256);
+    if (err != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(err));
+        return DCA_E_NOMEM;
+    }
+    e->allocs[e->nalloc++] = q;
+    *p = reinterpret_cast<T*>(q);
+    return 0;
+}
+
+template <int ENV, int DIM>
+int launch_expand_env(const Eng& E, int heur_id, hipStream_t s) {
+    using TL = Tile<ENV, DIM>;
+    dim3 g((E.B + kTileParents - 1) / kTileParents), b(kThreads);
+    if (E.onehot == nullptr)
+        hipLaunchKernelGGL((k_expand<ENV, DIM, 0>), g, b, TL::LDS_BYTES, s, E, heur_id);
+    else if (E.oh_dtype == DCA_DT_F32)
+        hipLaunchKernelGGL((k_expand<ENV, DIM, 4>), g, b, TL::LDS_BYTES, s, E, heur_id);
+    else
+        hipLaunchKernelGGL((k_expand<ENV, DIM, 2>), g, b, TL::LDS_BYTES, s, E, heur_id);
+    return launch_check("k_expand");
+}
+
+int launch_expand(const Eng& E, int heur_id, hipStream_t s) {
+    if (E.env == DCA_ENV_CUBE3) return launch_expand_env<DCA_ENV_CUBE3, 0>(E, heur_id, s);
+    switch (E.dim) {
+        case 4: return launch_expand_env<DCA_ENV_NPUZZLE, 4>(E, heur_id, s);
+        case 5: return launch_expand_env<DCA_ENV_NPUZZLE, 5>(E, heur_id, s);
+        case 6: return launch_expand_env<DCA_ENV_NPUZZLE, 6>(E, heur_id, s);
+        case 7: return launch_expand_env<DCA_ENV_NPUZZLE, 7>(E, heur_id, s);
+    }
+    return DCA_E_BADARG;
+}
+
+constexpr int kScanBlocks = 1024;
+
+int enqueue_first_half(dca_engine* e, int heur_id, hipStream_t s) {
+    const Eng& E = e->E;
+    hipLaunchKernelGGL(k_refill_hist, dim3(kScanBlocks), dim3(256), 0, s, E);
+    hipLaunchKernelGGL(k_refill_scan, dim3(1), dim3(1024), 0, s, E);
+    hipLaunchKernelGGL(k_refill_move, dim3(kScanBlocks), dim3(256), 0, s, E);
+    hipLaunchKernelGGL(k_sel_hist, dim3(kScanBlocks), dim3(256), 0, s, E);
+    hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(1024), 0, s, E);
+    hipLaunchKernelGGL(k_sel_collect, dim3(kScanBlocks), dim3(256), 0, s, E);
+    hipLaunchKernelGGL(k_sel_cand, dim3(1), dim3(1024), 0, s, E);
+    hipLaunchKernelGGL(k_ord_count, dim3((E.B + 255) / 256), dim3(256), 0, s, E);
+    hipLaunchKernelGGL(k_ord_scatter, dim3((E.B + 255) / 256), dim3(256), 0, s, E);
+    hipLaunchKernelGGL(k_ord_rank, dim3((E.B + 255) / 256), dim3(256), 0, s, E);
+    hipLaunchKernelGGL(k_post_pop, dim3(1), dim3(64), 0, s, E);
+    if (int rc = launch_check("select kernels")) return rc;
+    return launch_expand(E, heur_id, s);
+}
+
+int enqueue_second_half(dca_engine* e, hipStream_t s) {
+    const Eng& E = e->E;
+    const unsigned gb = (E.M + 255) / 256;
+    hipLaunchKernelGGL(k_probe, dim3(gb), dim3(256), 0, s, E);
+    hipLaunchKernelGGL(k_decide, dim3(gb), dim3(256), 0, s, E);
+    hipLaunchKernelGGL(k_commit, dim3((E.M + 1023) / 1024), dim3(1024), 0, s, E);
+    hipLaunchKernelGGL(k_end_iter, dim3(1), dim3(64), 0, s, E);
+    return launch_check("dedup kernels");
+}
+
+}  // namespace
+
+extern "C" {
+
+int dca_engine_create(dca_engine** out, int env, int dim, double weight, int batch_size, int64_t max_nodes,
+                      int semantics, int onehot_dtype) {
+    DCA_ARG(out != nullptr);
+    *out = nullptr;
+    DCA_ARG(env == DCA_ENV_CUBE3 || (env == DCA_ENV_NPUZZLE && dim >= 4 && dim <= 7));
+    DCA_ARG(batch_size >= 1 && batch_size <= (1 << 22));
+    DCA_ARG(semantics == DCA_SEM_PY || semantics == DCA_SEM_CPP);
+    DCA_ARG(onehot_dtype >= -1 && onehot_dtype <= DCA_DT_BF16);
+    DCA_ARG(weight >= 0.0);
+    const int A = env == DCA_ENV_CUBE3 ? 12 : 4;
+    const int D = env == DCA_ENV_CUBE3 ? 54 : dim * dim;
+    const int64_t Mll = (int64_t)batch_size * A;
+    DCA_ARG(max_nodes >= Mll + 16 && max_nodes <= 0x7FFFFF00ll);
+    dca_engine* e = new (std::nothrow) dca_engine();
+    if (!e) return DCA_E_NOMEM;
+    memset(e, 0, sizeof(*e));
+    Eng& E = e->E;
+    E.env = env;
+    E.dim = dim;
+    E.D = D;
+    E.A = A;
+    E.B = batch_size;
+    E.sem = semantics;
+    E.oh_dtype = onehot_dtype;
+    E.depth = env == DCA_ENV_CUBE3 ? 6 : D;
+    E.w = weight;
+    E.wf = (float)weight;  // cpp:353 (float) atof(argv[2])
+    E.max_nodes = (uint32_t)max_nodes;
+    E.M = (uint32_t)Mll;
+    E.f_keep = (uint32_t)(32 * batch_size > 65536 ? 32 * batch_size : 65536);
+    E.f_max = 3 * E.f_keep;
+    uint64_t cap = 1024;
+    while (cap < 2ull * (uint64_t)max_nodes) cap <<= 1;
+    E.tab_cap = (uint32_t)cap;
+    E.tab_mask = (uint32_t)(cap - 1);
+    if (cap > 0x80000000ull) {
+        delete e;
+        set_error("max_nodes too large for a 32-bit slot index");
+        return DCA_E_BADARG;
+    }
+    int rc = 0;
+    const size_t N = (size_t)max_nodes, M = (size_t)Mll, Bz = (size_t)batch_size;
+#define ALLOC(field, count) \
+    if (!rc) rc = dev_alloc(e, &E.field, (count))
+    ALLOC(state, N * D + 64);
+    ALLOC(g, N);
+    ALLOC(parent, N);
+    ALLOC(move, N);
+    ALLOC(solved, N);
+    ALLOC(tab, (size_t)cap);
+    for (int b = 0; b < 4; b++) {
+        ALLOC(open_key[b], N);
+        ALLOC(open_id[b], N);
+    }
+    ALLOC(hist, NBIN);
+    ALLOC(bin_start, NBIN + 1);
+    ALLOC(bin_fill, NBIN);
+    ALLOC(tail_start, NBIN + 1);
+    ALLOC(cand_key, N);
+    ALLOC(cand_id, N);
+    ALLOC(cand_st, N);
+    ALLOC(tmp_key, Bz);
+    ALLOC(pop_key, Bz);
+    ALLOC(tmp_id, Bz);
+    ALLOC(pop_id, Bz);
+    ALLOC(ord_key, Bz);
+    ALLOC(ord_id, Bz);
+    ALLOC(ord_b, Bz);
+    ALLOC(ord_s, Bz);
+    ALLOC(ord_pb, Bz);
+    ALLOC(spl_key, 2048);
+    ALLOC(spl_id, 2048);
+    ALLOC(bcnt, 2056);
+    ALLOC(bpre, 2056);
+    ALLOC(child_hash, M);
+    ALLOC(child_key, M);
+    ALLOC(child_slot, M);
+    ALLOC(child_next, M);
+    ALLOC(child_flags, M);
+    ALLOC(child_h, M);
+    ALLOC(nnet_in, M * D + 64);
+    ALLOC(root_nnet, 64);
+    ALLOC(d_moves, kMaxMoves);
+    ALLOC(ctl, 1);
+    if (!rc && onehot_dtype >= 0) {
+        size_t esz = onehot_dtype == DCA_DT_F32 ? 4 : 2;
+        ALLOC(onehot, M * D * E.depth * esz + 64);
+    }
+    if (!rc) rc = dev_alloc(e, &e->d_cost, 1);
+#undef ALLOC
+    if (!rc) {
+        hipError_t err = hipHostMalloc((void**)&e->h_ctl, sizeof(Ctl) + kMaxMoves * sizeof(int32_t) + 512);
+        if (err != hipSuccess) rc = hip_fail(err, "hipHostMalloc");
+    }
+    if (rc) {
+        dca_engine_destroy(e);
+        return rc;
+    }
+    e->h_moves = reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(e->h_ctl) + ((sizeof(Ctl) + 15) & ~15ul));
+    e->h_cost = reinterpret_cast<double*>(e->h_moves + kMaxMoves);
+    (void)hipMemset(E.nnet_in, 0, M * D);
+    (void)hipMemset(E.hist, 0, NBIN * sizeof(uint32_t));
+    (void)hipMemset(E.bin_fill, 0, NBIN * sizeof(uint32_t));
+    (void)hipMemset(E.ctl, 0, sizeof(Ctl));
+    *out = e;
+    return 0;
+}
+
+void dca_engine_destroy(dca_engine* e) {
+    if (!e) return;
+    if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
+    if (e->graph) (void)hipGraphDestroy(e->graph);
+    for (int i = 0; i < e->nalloc; i++) (void)hipFree(e->allocs[i]);
+    if (e->h_ctl) (void)hipHostFree(e->h_ctl);
+    delete e;
+}
+
+int dca_engine_reset(dca_engine* e, const uint8_t* root, void* stream) {
+    DCA_ARG(e != nullptr && root != nullptr);
+    hipStream_t s = (hipStream_t)stream;
+    Eng& E = e->E;
+    for (int i = 0; i < E.D; i++) DCA_ARG(root[i] < (E.env == DCA_ENV_CUBE3 ? 54 : E.D));
+    // the root row must outlive this call: stage it in the pinned block
+    uint8_t* stage = reinterpret_cast<uint8_t*>(e->h_cost + 1);
+    memcpy(stage, root, (size_t)E.D);
+    DCA_HIP(hipMemcpyAsync(E.state, stage, (size_t)E.D, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_init_table, dim3(4096), dim3(256), 0, s, E.tab, E.tab_cap);
+    hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, s, E);
+    e->phase = 0;
+    return launch_check("k_reset");
+}
+
+int dca_engine_root_commit(dca_engine* e, const float* h_root, void* stream) {
+    DCA_ARG(e != nullptr);
+    if (e->E.sem != DCA_SEM_PY) return 0;
+    DCA_ARG(h_root != nullptr);
+    hipLaunchKernelGGL(k_root_commit, dim3(1), dim3(64), 0, (hipStream_t)stream, e->E, h_root);
+    return launch_check("k_root_commit");
+}
+
+int dca_engine_root_nnet_in(dca_engine* e, const uint8_t** nnet_in) {
+    DCA_ARG(e != nullptr && nnet_in != nullptr);
+    *nnet_in = e->E.root_nnet;
+    return 0;
+}
+
+int dca_engine_pop_expand(dca_engine* e, const uint8_t** nnet_in, const void** onehot, int64_t* m_capacity,
+                          void* stream) {
+    DCA_ARG(e != nullptr);
+    if (e->phase != 0) {
+        set_error("dca_engine_pop_expand called twice without dca_engine_commit");
+        return DCA_E_STATE;
+    }
+    if (int rc = enqueue_first_half(e, -1, (hipStream_t)stream)) return rc;
+    if (nnet_in) *nnet_in = e->E.nnet_in;
+    if (onehot) *onehot = e->E.onehot;
+    if (m_capacity) *m_capacity = e->E.M;
+    e->phase = 1;
+    return 0;
+}
+
+int dca_engine_commit(dca_engine* e, const float* h, void* stream) {
+    DCA_ARG(e != nullptr && h != nullptr);
+    if (e->phase != 1) {
+        set_error("dca_engine_commit without a preceding dca_engine_pop_expand");
+        return DCA_E_STATE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    DCA_HIP(hipMemcpyAsync(e->E.child_h, h, (size_t)e->E.M * sizeof(float), hipMemcpyDeviceToDevice, s));
+    e->phase = 0;
+    return enqueue_second_half(e, s);
+}
+
+int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph, void* stream) {
+    DCA_ARG(e != nullptr && heur_id >= 0 && heur_id <= DCA_HEUR_ZERO && iters >= 0);
+    if (e->phase != 0) {
+        set_error("dca_engine_run_builtin between pop_expand and commit");
+        return DCA_E_STATE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (!use_graph) {
+        for (int i = 0; i < iters; i++) {
+            if (int rc = enqueue_first_half(e, heur_id, s)) return rc;
+            if (int rc = enqueue_second_half(e, s)) return rc;
+        }
+        return 0;
+    }
+    if (e->graph_exec == nullptr || e->graph_heur != heur_id) {
+        if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
+        if (e->graph) (void)hipGraphDestroy(e->graph);
+        e->graph_exec = nullptr;
+        e->graph = nullptr;
+        hipStream_t cs;
+        DCA_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        hipError_t err = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+        int rc = 0;
+        if (err == hipSuccess) {
+            rc = enqueue_first_half(e, heur_id, cs);
+            if (!rc) rc = enqueue_second_half(e, cs);
+            err = hipStreamEndCapture(cs, &e->graph);
+        }
+        (void)hipStreamDestroy(cs);
+        if (err != hipSuccess) return hip_fail(err, "hipStream capture");
+        if (rc) return rc;
+        DCA_HIP(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
+        e->graph_heur = heur_id;
+    }
+    for (int i = 0; i < iters; i++) DCA_HIP(hipGraphLaunch(e->graph_exec, s));
+    return 0;
+}
+
+int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, float* ms_out, void* stream) {
+    // one hipEvent between every pair of kernels of an iteration (eager launches on `stream`);
+    // ms_out[k] = summed milliseconds of phase k over `iters` iterations.  Phases:
+    // 0 refill(3 kernels) 1 sel_hist 2 sel_scan 3 sel_collect 4 sel_cand 5 order(3 kernels) 6 post_pop
+    // 7 expand 8 probe 9 decide 10 commit 11 end_iter
+    DCA_ARG(e != nullptr && ms_out != nullptr && heur_id >= 0 && heur_id <= DCA_HEUR_ZERO && iters >= 0);
+    if (e->phase != 0) {
+        set_error("dca_engine_profile_builtin between pop_expand and commit");
+        return DCA_E_STATE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const Eng& E = e->E;
+    constexpr int NP = 12;
+    hipEvent_t ev[NP + 1];
+    for (int k = 0; k <= NP; k++) DCA_HIP(hipEventCreate(&ev[k]));
+    for (int k = 0; k < 16; k++) ms_out[k] = 0.f;
+    const unsigned gb = (E.M + 255) / 256;
+    int rc = 0;
+    for (int it = 0; it < iters && !rc; it++) {
+        int k = 0;
+        (void)hipEventRecord(ev[k++], s);
+        hipLaunchKernelGGL(k_refill_hist, dim3(kScanBlocks), dim3(256), 0, s, E);
+        hipLaunchKernelGGL(k_refill_scan, dim3(1), dim3(1024), 0, s, E);
+        hipLaunchKernelGGL(k_refill_move, dim3(kScanBlocks), dim3(256), 0, s, E);
+        (void)hipEventRecord(ev[k++], s);
+        hipLaunchKernelGGL(k_sel_hist, dim3(kScanBlocks), dim3(256), 0, s, E);
+        (void)hipEventRecord(ev[k++], s);
+        hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(1024), 0, s, E);
+        (void)hipEventRecord(ev[k++], s);
+        hipLaunchKernelGGL(k_sel_collect, dim3(kScanBlocks), dim3(256), 0, s, E);
+        (void)hipEventRecord(ev[k++], s);
+        hipLaunchKernelGGL(k_sel_cand, dim3(1), dim3(1024), 0, s, E);
+        (void)hipEventRecord(ev[k++], s);
+        hipLaunchKernelGGL(k_ord_count, dim3((E.B + 255) / 256), dim3(256), 0, s, E);
+        hipLaunchKernelGGL(k_ord_scatter, dim3((E.B + 255) / 256), dim3(256), 0, s, E);
+        hipLaunchKernelGGL(k_ord_rank, dim3((E.B + 255) / 256), dim3(256), 0, s, E);
+        (void)hipEventRecord(ev[k++], s);
+        hipLaunchKernelGGL(k_post_pop, dim3(1), dim3(64), 0, s, E);
+        (void)hipEventRecord(ev[k++], s);
+        rc = launch_expand(E, heur_id, s);
+        (void)hipEventRecord(ev[k++], s);
+        hipLaunchKernelGGL(k_probe, dim3(gb), dim3(256), 0, s, E);
+        (void)hipEventRecord(ev[k++], s);
+        hipLaunchKernelGGL(k_decide, dim3(gb), dim3(256), 0, s, E);
+        (void)hipEventRecord(ev[k++], s);
+        hipLaunchKernelGGL(k_commit, dim3((E.M + 1023) / 1024), dim3(1024), 0, s, E);
+        (void)hipEventRecord(ev[k++], s);
+        hipLaunchKernelGGL(k_end_iter, dim3(1), dim3(64), 0, s, E);
+        (void)hipEventRecord(ev[k++], s);
+        if (!rc) rc = launch_check("profiled iteration");
+        if (hipStreamSynchronize(s) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipStreamSynchronize");
+        for (int p = 0; p < NP && !rc; p++) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[p], ev[p + 1]);
+            ms_out[p] += ms;
+        }
+    }
+    for (int k = 0; k <= NP; k++) (void)hipEventDestroy(ev[k]);
+    return rc;
+}
+
+int dca_engine_status(dca_engine* e, dca_status* out, void* stream) {
+    DCA_ARG(e != nullptr && out != nullptr);
+    hipStream_t s = (hipStream_t)stream;
+    DCA_HIP(hipMemcpyAsync(e->h_ctl, e->E.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s));
+    DCA_HIP(hipStreamSynchronize(s));
+    const Ctl& c = *e->h_ctl;
+    out->done = c.done;
+    out->failed = c.failed;
+    out->iterations = c.iters;
+    out->nodes_generated = c.gen;
+    out->nodes_expanded = c.expanded;
+    out->open_size = (int64_t)c.open_n[c.cur_f] + (int64_t)c.open_n[c.cur_b];
+    out->closed_size = c.closed_n;
+    out->pool_size = c.pool_n;
+    out->best_cost = c.has_best ? (double)c.best_cost : __builtin_nan("");
+    return 0;
+}
+
+int dca_engine_debug(dca_engine* e, double* out, void* stream) {
+    DCA_ARG(e != nullptr && out != nullptr);
+    hipStream_t s = (hipStream_t)stream;
+    DCA_HIP(hipMemcpyAsync(e->h_ctl, e->E.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s));
+    DCA_HIP(hipStreamSynchronize(s));
+    const Ctl& c = *e->h_ctl;
+    auto cost = [](uint64_t k) {
+        uint64_t b = (k & 0x8000000000000000ull) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+        double d;
+        memcpy(&d, &b, 8);
+        return d;
+    };
+    out[0] = c.open_n[c.cur_f];
+    out[1] = c.open_n[c.cur_b];
+    out[2] = cost(c.kmin[c.cur_f]);
+    out[3] = cost(c.kmax[c.cur_f]);
+    out[4] = cost(c.kmin[c.cur_b]);
+    out[5] = cost(c.kmax[c.cur_b]);
+    out[6] = cost(c.T);
+    out[7] = c.want;
+    out[8] = c.bstar;
+    out[9] = c.sel_less;
+    out[10] = c.sel_r;
+    out[11] = c.cand_n;
+    out[12] = c.shift;
+    out[13] = c.spill_bin;
+    out[14] = c.npop;
+    out[15] = c.m;
+    return 0;
+}
+
+int dca_engine_last_children(dca_engine* e, const uint8_t** states, int64_t* m_live, void* stream) {
+    DCA_ARG(e != nullptr && states != nullptr && m_live != nullptr);
+    hipStream_t s = (hipStream_t)stream;
+    DCA_HIP(hipMemcpyAsync(e->h_ctl, e->E.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s));
+    DCA_HIP(hipStreamSynchronize(s));
+    *states = e->E.state + (size_t)e->h_ctl->base * e->E.D;
+    *m_live = e->h_ctl->m;
+    return 0;
+}
+
+int dca_engine_solution(dca_engine* e, int32_t* moves, int cap, int* len, double* path_cost, void* stream) {
+    DCA_ARG(e != nullptr && len != nullptr && cap >= 0 && (cap == 0 || moves != nullptr));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_solution, dim3(1), dim3(64), 0, s, e->E, e->E.d_moves, e->d_cost);
+    if (int rc = launch_check("k_solution")) return rc;
+    DCA_HIP(hipMemcpyAsync(e->h_moves, e->E.d_moves, kMaxMoves * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    DCA_HIP(hipMemcpyAsync(e->h_cost, e->d_cost, sizeof(double), hipMemcpyDeviceToHost, s));
+    DCA_HIP(hipStreamSynchronize(s));
+    int n = e->h_moves[0];
+    if (n < 0) {
+        set_error("no solution recorded (search not finished)");
+        return DCA_E_NOTFOUND;
+    }
+    *len = n;
+    if (path_cost) *path_cost = *e->h_cost;
+    for (int i = 0; i < n && i < cap; i++) moves[i] = e->h_moves[1 + i];
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,197 @@
+"""Host handle of the device-resident BWAS engine (libdca_hip.so, `dca_engine_*`).
+
+Mirrors the surface of the reference's `AStar` (search_methods/astar.py:232-340) for ONE instance:
+`step(heuristic)`, `has_found_goal()`, solution / node-count accessors — but all state (OPEN, CLOSED,
+node pool) stays in HBM and a step enqueues kernels without reading anything back.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+_OH = {None: -1, torch.float32: _lib.DT_F32, torch.float16: _lib.DT_F16, torch.bfloat16: _lib.DT_BF16}
+
+
+class BwasEngine:
+    """One search instance on the current HIP device.
+
+    semantics: _lib.SEM_PY reproduces search_methods/astar.py node for node; _lib.SEM_CPP reproduces
+    cpp/parallel_weighted_astar.cpp (ties between equal float32 costs are broken by push order, where the
+    reference's std::priority_queue order is unspecified — SURVEY §3.3)."""
+
+    def __init__(self, env_name: str, weight: float, batch_size: int, max_nodes: int = 1 << 24,
+                 semantics: int = _lib.SEM_PY, onehot_dtype: Optional[torch.dtype] = None):
+        _lib.require_gpu()
+        self.env_id, self.dim, self.state_dim, self.num_moves, self.depth = _lib.env_ids(env_name)
+        self.batch_size = int(batch_size)
+        self.weight = float(weight)
+        self.semantics = semantics
+        self.onehot_dtype = onehot_dtype
+        self.m_capacity = self.batch_size * self.num_moves
+        self._h = C.c_void_p(0)
+        _lib.check(_lib.lib().dca_engine_create(C.byref(self._h), self.env_id, self.dim, C.c_double(self.weight),
+                                                self.batch_size, C.c_int64(int(max_nodes)), semantics,
+                                                _OH[onehot_dtype]), "dca_engine_create")
+        self._zero_h = torch.zeros(1, dtype=torch.float32, device="cuda")
+
+    def close(self):
+        if self._h:
+            _lib.lib().dca_engine_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- search control ---------------------------------------------------------------------
+    def reset(self, root: np.ndarray) -> None:
+        r = np.ascontiguousarray(root, dtype=np.uint8)
+        assert r.shape == (self.state_dim,)
+        _lib.check(_lib.lib().dca_engine_reset(self._h, r.ctypes.data_as(C.c_void_p), _lib.stream_ptr()),
+                   "dca_engine_reset")
+
+    def root_nnet_in(self) -> torch.Tensor:
+        p = C.c_void_p(0)
+        _lib.check(_lib.lib().dca_engine_root_nnet_in(self._h, C.byref(p)), "dca_engine_root_nnet_in")
+        return _wrap_u8(p.value, (1, self.state_dim))
+
+    def root_commit(self, h_root: torch.Tensor) -> None:
+        h_root = h_root.to(torch.float32).contiguous()
+        _lib.check(_lib.lib().dca_engine_root_commit(self._h, _lib.ptr(h_root), _lib.stream_ptr()),
+                   "dca_engine_root_commit")
+
+    def pop_expand(self) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """-> (nnet_in [M,D] uint8 view, onehot [M, D*depth] view or None), M = batch*num_moves fixed."""
+        pn, po, m = C.c_void_p(0), C.c_void_p(0), C.c_int64(0)
+        _lib.check(_lib.lib().dca_engine_pop_expand(self._h, C.byref(pn), C.byref(po), C.byref(m),
+                                                    _lib.stream_ptr()), "dca_engine_pop_expand")
+        nn = _wrap_u8(pn.value, (m.value, self.state_dim))
+        oh = None
+        if po.value:
+            oh = _wrap(po.value, (m.value, self.state_dim * self.depth), self.onehot_dtype)
+        return nn, oh
+
+    def commit(self, h: torch.Tensor) -> None:
+        assert h.is_cuda and h.dtype == torch.float32 and h.numel() == self.m_capacity and h.is_contiguous()
+        _lib.check(_lib.lib().dca_engine_commit(self._h, _lib.ptr(h), _lib.stream_ptr()), "dca_engine_commit")
+
+    def step(self, heuristic_fn_dev: Callable[[torch.Tensor], torch.Tensor]) -> None:
+        """One BWAS iteration (AStar.step, astar.py:256-317) with a device heuristic closure."""
+        nn, oh = self.pop_expand()
+        h = heuristic_fn_dev(oh, True) if oh is not None else heuristic_fn_dev(nn)
+        self.commit(h.to(torch.float32).contiguous())
+
+    def run_builtin(self, heur_id: int, iters: int, use_graph: bool = False) -> None:
+        _lib.check(_lib.lib().dca_engine_run_builtin(self._h, heur_id, int(iters), int(use_graph),
+                                                     _lib.stream_ptr()), "dca_engine_run_builtin")
+
+    PHASES = ["refill", "sel_hist", "sel_scan", "sel_collect", "sel_cand", "order", "post_pop", "expand", "probe",
+              "decide", "commit", "end_iter"]
+
+    def profile_builtin(self, heur_id: int, iters: int) -> dict:
+        """Per-kernel HIP-event timings (ms per iteration) of `iters` eager iterations."""
+        ms = (C.c_float * 16)()
+        _lib.check(_lib.lib().dca_engine_profile_builtin(self._h, heur_id, int(iters), ms, _lib.stream_ptr()),
+                   "dca_engine_profile_builtin")
+        return {name: ms[k] / max(iters, 1) for k, name in enumerate(self.PHASES)}
+
+    def debug(self) -> dict:
+        out = (C.c_double * 16)()
+        _lib.check(_lib.lib().dca_engine_debug(self._h, out, _lib.stream_ptr()), "dca_engine_debug")
+        names = ["front_n", "back_n", "front_cmin", "front_cmax", "back_cmin", "back_cmax", "T", "want", "bstar",
+                 "sel_less", "sel_r", "cand_n", "shift", "spill_bin", "npop", "m"]
+        return dict(zip(names, list(out)))
+
+    def status(self) -> dict:
+        st = _lib.DcaStatus()
+        _lib.check(_lib.lib().dca_engine_status(self._h, C.byref(st), _lib.stream_ptr()), "dca_engine_status")
+        return {k: getattr(st, k) for k, _ in _lib.DcaStatus._fields_}
+
+    def last_children(self) -> torch.Tensor:
+        p, m = C.c_void_p(0), C.c_int64(0)
+        _lib.check(_lib.lib().dca_engine_last_children(self._h, C.byref(p), C.byref(m), _lib.stream_ptr()),
+                   "dca_engine_last_children")
+        return _wrap_u8(p.value, (m.value, self.state_dim))
+
+    def solution(self) -> Tuple[List[int], float]:
+        moves = np.zeros(4096, np.int32)
+        n, pc = C.c_int(0), C.c_double(0)
+        _lib.check(_lib.lib().dca_engine_solution(self._h, moves.ctypes.data_as(C.c_void_p), moves.size, C.byref(n),
+                                                  C.byref(pc), _lib.stream_ptr()), "dca_engine_solution")
+        return moves[:n.value].tolist(), float(pc.value)
+
+    # ---- convenience drivers -----------------------------------------------------------------
+    def solve_builtin(self, root: np.ndarray, heur_id: int, max_iters: int = 1 << 30, chunk: int = 16,
+                      use_graph: bool = False) -> dict:
+        """Full search with a built-in heuristic; the host only looks at the done flag every `chunk`
+        iterations (iterations after `done` are device-side no-ops, so node counts stay exact)."""
+        self.reset(root)
+        if self.semantics == _lib.SEM_PY:
+            h0 = _lib.heuristic_builtin(heur_id, torch.from_numpy(np.ascontiguousarray(root, np.uint8)[None]).cuda())
+            self.root_commit(h0)
+        it = 0
+        while it < max_iters:
+            n = min(chunk, max_iters - it)
+            self.run_builtin(heur_id, n, use_graph)
+            it += n
+            st = self.status()
+            if st["done"]:
+                break
+        return self._result()
+
+    def solve(self, root: np.ndarray, heuristic_fn_dev, max_iters: int = 1 << 30) -> dict:
+        """Full search with a device heuristic closure (e.g. nnet_utils.get_heuristic_fn_dev)."""
+        self.reset(root)
+        if self.semantics == _lib.SEM_PY:
+            self.root_commit(heuristic_fn_dev(self.root_nnet_in()).to(torch.float32))
+        for _ in range(max_iters):
+            self.step(heuristic_fn_dev)
+            if self.status()["done"]:
+                break
+        return self._result()
+
+    def _result(self) -> dict:
+        st = self.status()
+        res = dict(st)
+        res["solved"] = bool(st["done"] and not st["failed"])
+        if res["solved"]:
+            res["moves"], res["path_cost"] = self.solution()
+        else:
+            res["moves"], res["path_cost"] = None, float("nan")
+        return res
+
+
+def _wrap(ptr: int, shape, dtype: torch.dtype) -> torch.Tensor:
+    """Zero-copy torch view of library-owned device memory (valid until the next pop_expand)."""
+    esz = torch.empty(0, dtype=dtype).element_size()
+    n = int(np.prod(shape))
+
+    class _Cai:
+        __cuda_array_interface__ = {"shape": (n * esz,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+    t = torch.as_tensor(_Cai(), device="cuda")
+    return t.view(dtype).view(*shape)
+
+
+def _wrap_u8(ptr: int, shape) -> torch.Tensor:
+    return _wrap(ptr, shape, torch.uint8)
+
+
+def smoke_check() -> None:
+    """Used by __graft_entry__.smoke(): a short device-resident solve checked against the oracle."""
+    from oracle import c_oracle as co
+    root = np.arange(54, dtype=np.uint8)[None]
+    for a in (0, 5, 7, 2):
+        root = co.next_state("cube3", root, a)
+    eng = BwasEngine("cube3", 0.8, 50, max_nodes=1 << 16)
+    res = eng.solve_builtin(root[0], _lib.HEUR_MOD97)
+    ref = co.astar("cube3", root[0], 0.8, 50, co.SEM_PY, heur_builtin_id=0)
+    assert res["solved"] and res["moves"] == ref["moves"], (res, ref)
+    assert res["nodes_generated"] == ref["nodes_generated"] and res["iterations"] == ref["iterations"]
+    eng.close()

@@ -124,7 +124,7 @@ int dca_heuristic_builtin(int heur_id, const uint8_t* states, int64_t n, int sta
  *
  *     dca_engine_reset(e, root)
  *     dca_engine_root_commit(e, h_root)                        (PY semantics only)
- *     loop:  dca_engine_pop_expand(e, &states, &m)  ->  h = heuristic(states[m])
+ *     loop:  dca_engine_pop_expand(e, &nnet_in, &onehot, &m)  ->  h = heuristic(nnet_in[m])
  *            dca_engine_commit(e, h)
  *            dca_engine_status(e, &st);  stop when st.done
  *     dca_engine_solution(e, moves, &len, &path_cost)
@@ -143,31 +143,45 @@ typedef struct dca_status {
     double best_cost;        /* cost of the cheapest solved node popped so far (cpp) / NaN    */
 } dca_status;
 
+/* onehot_dtype: DCA_DT_* to have pop_expand also emit the one-hot rows of the batch's children
+ * (fused into the expansion launch), or -1 for none.  max_nodes bounds the node pool (one id per
+ * generated child), the CLOSED table (2x, power of two) and OPEN.                                 */
 int dca_engine_create(dca_engine** out, int env, int dim, double weight, int batch_size,
-                      int64_t max_nodes, int semantics);
+                      int64_t max_nodes, int semantics, int onehot_dtype);
 void dca_engine_destroy(dca_engine* e);
 int dca_engine_reset(dca_engine* e, const uint8_t* root /*host [D]*/, void* stream);
-/* PY semantics: cost(root) = w*0 + max(h,0)*!solved (astar.py:244-249). h_root: device f32[1] */
+/* PY semantics: cost(root) = w*0 + max(h,0)*!solved (astar.py:244-249). h_root: device f32[1].
+ * CPP semantics never evaluates the root (cpp:160) — the call is then a no-op.                    */
 int dca_engine_root_commit(dca_engine* e, const float* h_root, void* stream);
-/* first half: pop min(B,|OPEN|) by (cost, push order), expand.  *states = device pointer to the
- * batch's child rows [batch*num_moves, D] (valid until the next pop_expand); *nnet_in = device
- * pointer to the network input rows (cube3: colour index; puzzles: == states).  Rows beyond the
- * live child count are zero.  m_capacity = batch*num_moves (the fixed row count, so the
- * heuristic can run without a host sync); the live count is in dca_engine_status.            */
-int dca_engine_pop_expand(dca_engine* e, const uint8_t** states, const uint8_t** nnet_in,
+/* network-input row of the root (device [D]; cube3: colour index), valid after reset            */
+int dca_engine_root_nnet_in(dca_engine* e, const uint8_t** nnet_in);
+/* first half: pop min(B,|OPEN|) by (cost, push order), expand.  *nnet_in = device pointer to the
+ * network-input rows [batch*num_moves, D] of the batch's children (cube3: colour index; puzzles:
+ * the tiles), child index = pop_rank*num_moves + move; *onehot = their one-hot rows
+ * [batch*num_moves, D*depth] (NULL unless enabled at create).  Both buffers have the FIXED row
+ * count m_capacity = batch*num_moves so the heuristic can be enqueued without a host sync; rows
+ * past the live child count hold stale but valid rows and their heuristic values are ignored.     */
+int dca_engine_pop_expand(dca_engine* e, const uint8_t** nnet_in, const void** onehot,
                           int64_t* m_capacity, void* stream);
-/* second half: h = device f32[m_capacity] (values for dead rows ignored). clip at 0 is applied
- * here (nnet_utils.py:193-194 clip_zero=True).                                               */
+/* second half: h = device f32[m_capacity].  max(h,0) is applied here (nnet_utils.py:193-194
+ * clip_zero=True): cost, CLOSED dedup, push.                                                      */
 int dca_engine_commit(dca_engine* e, const float* h, void* stream);
-/* convenience: both halves with a built-in heuristic, `iters` iterations, no host sync
- * between them (kernels no-op once done).                                                    */
-int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, void* stream);
+/* both halves with a built-in heuristic (evaluated inside the expansion launch), `iters`
+ * iterations enqueued without any host sync (kernels no-op once the search is done).
+ * use_graph != 0 replays one captured hipGraph per iteration instead of eager launches.           */
+int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph, void* stream);
+/* like run_builtin (eager) but with a hipEvent between every pair of kernels; ms_out (host float[16])
+ * receives the summed milliseconds per phase: 0 refill 1 sel_hist 2 sel_scan 3 sel_collect 4 sel_cand
+ * 5 order 6 post_pop 7 expand 8 probe 9 decide 10 commit 11 end_iter.  Synchronises every iteration. */
+int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, float* ms_out /*host [16]*/, void* stream);
 /* synchronises the stream */
 int dca_engine_status(dca_engine* e, dca_status* out, void* stream);
-/* root->goal move list (astar.py:213-229 get_path / cpp:336-341).  synchronises.            */
+/* internals of the last iteration for diagnostics (host double[16]; layout in dca_engine.hip); synchronises */
+int dca_engine_debug(dca_engine* e, double* out /*host [16]*/, void* stream);
+/* child rows of the last pop_expand straight from the node pool (device [m_live, D]); synchronises */
+int dca_engine_last_children(dca_engine* e, const uint8_t** states, int64_t* m_live, void* stream);
+/* root->goal move list (astar.py:213-229 get_path / cpp:336-341).  synchronises.                 */
 int dca_engine_solution(dca_engine* e, int32_t* moves /*host [cap]*/, int cap, int* len, double* path_cost, void* stream);
-/* per-phase HIP-event timings of the last dca_engine_run_builtin (ms); keys in DESIGN.md     */
-int dca_engine_phase_ms(dca_engine* e, float* out /*host [8]*/);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,225 @@
+"""GPU parity tests of the device-resident BWAS engine against (a) traces of the reference's own python
+AStar (tests/golden, made by importing the reference) and (b) the C++ oracle restating both reference
+semantics.  Integer work: node counts, per-iteration |OPEN| / |CLOSED|, move lists are compared exactly."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from deepcubea_amd import _lib
+    _lib.require_gpu()
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def co():
+    from oracle import c_oracle
+    return c_oracle
+
+
+def scramble(co, env, moves):
+    if env == "cube3":
+        s = np.arange(54, dtype=np.uint8)[None]
+    else:
+        n = {"puzzle15": 4, "puzzle24": 5, "puzzle35": 6, "puzzle48": 7}[env]
+        s = np.concatenate((np.arange(1, n * n), [0])).astype(np.uint8)[None]
+    for a in moves:
+        s = co.next_state(env, s, a)
+    return s[0]
+
+
+def run_traced(L, eng, root, hid, max_iters=100000):
+    """Step the engine one iteration at a time, reading the status after each (tests only)."""
+    eng.reset(root)
+    if eng.semantics == L.SEM_PY:
+        eng.root_commit(L.heuristic_builtin(hid, torch.from_numpy(root[None].copy()).cuda()))
+    trace = []
+    for _ in range(max_iters):
+        eng.run_builtin(hid, 1)
+        st = eng.status()
+        trace.append((st["open_size"], st["closed_size"], st["nodes_generated"]))
+        if st["done"]:
+            break
+    res = eng._result()
+    res["trace"] = np.array(trace, np.int64)
+    return res
+
+
+def test_py_semantics_vs_reference_traces(L, golden):
+    from deepcubea_amd.search_methods.engine import BwasEngine
+    for key in [str(k) for k in golden["astar_py_cases"]]:
+        env = "cube3" if "cube3" in key else "puzzle15"
+        root = golden[key + "_root"]
+        w, B, hid = golden[key + "_cfg"]
+        trace = golden[key + "_trace"]
+        pc, nn = golden[key + "_result"]
+        eng = BwasEngine(env, float(w), int(B), max_nodes=max(1 << 16, int(nn) + 4 * int(B) * 12 + 64))
+        res = run_traced(L, eng, root, int(hid))
+        assert res["solved"], key
+        assert res["moves"] == golden[key + "_moves"].tolist(), key
+        assert res["path_cost"] == pc and res["nodes_generated"] == int(nn), key
+        assert res["iterations"] == len(trace), key
+        assert np.array_equal(res["trace"], trace), key
+        eng.close()
+
+
+PY_CASES = [
+    ("cube3", [3, 8, 1, 10, 6, 4, 11], 0.6, 1000, 1),
+    ("cube3", [3, 8, 1, 10, 6], 0.8, 64, 0),      # mod97: many exact cost ties
+    ("cube3", [2, 9, 4], 1.0, 5000, 3),            # zero heuristic: uniform-cost search, massive ties
+    ("cube3", [7, 0, 11, 5], 0.5, 1, 1),           # batch 1
+    ("puzzle15", [1, 3, 1, 1, 3, 0, 2, 0, 3, 1, 1, 2], 0.8, 33, 1),
+    ("puzzle24", [1, 1, 3, 3, 0, 2, 1, 3], 0.7, 100, 0),
+    ("puzzle35", [1, 3, 1, 3, 0, 1, 2, 3, 1], 0.6, 50, 1),
+    ("puzzle48", [1, 1, 3, 1, 3, 3, 0, 2, 1, 3, 0, 0], 0.6, 64, 1),
+]
+
+
+@pytest.mark.parametrize("env,scr,w,B,hid", PY_CASES)
+def test_py_semantics_vs_oracle(L, co, env, scr, w, B, hid):
+    from deepcubea_amd.search_methods.engine import BwasEngine
+    root = scramble(co, env, scr)
+    ref = co.astar(env, root, w, B, co.SEM_PY, heur_builtin_id=hid, trace_cap=200000)
+    assert ref["solved"]
+    eng = BwasEngine(env, w, B, max_nodes=max(1 << 16, ref["nodes_generated"] + 4 * B * 12 + 64))
+    res = run_traced(L, eng, root, hid)
+    assert res["moves"] == ref["moves"]
+    assert res["nodes_generated"] == ref["nodes_generated"] and res["iterations"] == ref["iterations"]
+    assert res["nodes_expanded"] == ref["nodes_expanded"]
+    assert np.array_equal(res["trace"], ref["trace"])
+    # un-traced run (no host sync inside chunks) gives the same answer, eager and graph
+    for graph in (False, True):
+        r2 = eng.solve_builtin(root, hid, chunk=7, use_graph=graph)
+        assert r2["moves"] == ref["moves"] and r2["nodes_generated"] == ref["nodes_generated"]
+        assert r2["iterations"] == ref["iterations"]
+    eng.close()
+
+
+CPP_CASES = [
+    ("cube3", [0, 5, 7, 2], 0.8, 50, 1),
+    ("cube3", [11, 2, 6, 9, 0, 5], 0.8, 200, 1),
+    ("cube3", [3, 8, 1, 10, 6, 4], 0.6, 1000, 1),
+    ("cube3", [7, 0, 11, 5], 0.5, 1, 1),
+    ("puzzle15", [1, 3, 1, 1, 3, 0, 2, 0, 3, 1], 0.8, 100, 1),
+    ("puzzle48", [1, 1, 3, 1, 3, 3, 0, 2, 1, 3, 0, 0], 0.6, 64, 1),
+]
+
+
+@pytest.mark.parametrize("env,scr,w,B,hid", CPP_CASES)
+def test_cpp_semantics_vs_oracle(L, co, env, scr, w, B, hid):
+    """KNUTH3 heuristic: float32 cost ties are rare, so the reference's heap tie order does not matter
+    and node counts / iteration counts / traces must agree exactly."""
+    from deepcubea_amd.search_methods.engine import BwasEngine
+    root = scramble(co, env, scr)
+    ref = co.astar(env, root, w, B, co.SEM_CPP, heur_builtin_id=hid, trace_cap=200000)
+    assert ref["solved"]
+    eng = BwasEngine(env, w, B, max_nodes=max(1 << 16, ref["nodes_generated"] + 4 * B * 12 + 64), semantics=L.SEM_CPP)
+    res = run_traced(L, eng, root, hid)
+    assert res["solved"]
+    assert len(res["moves"]) == len(ref["moves"]) and res["path_cost"] == ref["path_cost"]
+    same = res["nodes_generated"] == ref["nodes_generated"]
+    if env != "puzzle48":  # SURVEY: puzzle48 row differs by two expansions from heap tie order
+        assert same and res["moves"] == ref["moves"] and res["iterations"] == ref["iterations"]
+        # nodes generated per iteration must agree exactly; |OPEN| / |CLOSED| may drift by a few entries
+        # where equal float32 costs are popped in a different order than libstdc++'s heap
+        assert np.array_equal(res["trace"][:, 2], ref["trace"][:, 2])
+        rel = np.abs(res["trace"][:, :2] - ref["trace"][:, :2]) / np.maximum(ref["trace"][:, :2], 1)
+        assert rel.max() < 1e-2, rel.max()
+    # the move list always solves the state
+    s = root[None].copy()
+    for a in res["moves"]:
+        s = co.next_state(env, s, a)
+    assert co.is_solved(env, s)[0]
+    eng.close()
+
+
+def test_cpp_known_answers_from_reference_binary(L, co):
+    """SURVEY Appendix A rows recorded from the reference binary."""
+    from deepcubea_amd.search_methods.engine import BwasEngine
+    rows = [("cube3", [0, 5, 7, 2], 0.8, 50, [3, 6, 4, 1], 3241, 8),
+            ("cube3", [11, 2, 6, 9, 0, 5], 0.8, 200, [4, 1, 8, 7, 3, 10], 5360737, 2237),
+            ("puzzle15", [1, 3, 1, 1, 3, 0, 2, 0, 3, 1], 0.8, 100, [0, 2, 1, 3, 1, 2, 0, 0, 2, 0], 9445, 29)]
+    for env, scr, w, B, soln, nodes, iters in rows:
+        eng = BwasEngine(env, w, B, max_nodes=nodes + 8 * B * 12 + 64, semantics=L.SEM_CPP)
+        res = eng.solve_builtin(scramble(co, env, scr), L.HEUR_KNUTH3, chunk=64)
+        assert res["moves"] == soln and res["nodes_generated"] == nodes and res["iterations"] == iters
+        eng.close()
+
+
+def test_external_heuristic_split_matches_builtin(L, co):
+    """pop_expand -> heuristic on the device -> commit gives the same search as the fused built-in path,
+    and the batch buffers (network input, one-hot) hold exactly the children rows."""
+    from deepcubea_amd.search_methods.engine import BwasEngine
+    from oracle import np_oracle as no
+    root = scramble(co, "cube3", [3, 8, 1, 10, 6])
+    ref = co.astar("cube3", root, 0.8, 64, co.SEM_PY, heur_builtin_id=1, trace_cap=10000)
+    eng = BwasEngine("cube3", 0.8, 64, max_nodes=1 << 18, onehot_dtype=torch.float32)
+    eng.reset(root)
+    assert np.array_equal(eng.root_nnet_in().cpu().numpy()[0], root // 9)
+    eng.root_commit(L.heuristic_builtin(1, torch.from_numpy(root[None].copy()).cuda()))
+    it = 0
+    while True:
+        nn, oh = eng.pop_expand()
+        ch = eng.last_children()
+        m = ch.shape[0]
+        h = torch.zeros(eng.m_capacity, dtype=torch.float32, device="cuda")
+        h[:m] = L.heuristic_builtin(1, ch.contiguous())
+        if it < 3:
+            chn = ch.cpu().numpy()
+            assert np.array_equal(nn[:m].cpu().numpy(), chn // 9)
+            assert np.array_equal(oh[:m].cpu().numpy(), no.onehot(chn // 9, 6))
+        with pytest.raises(L.DcaError):
+            eng.pop_expand()  # DCA_E_STATE: commit missing
+        eng.commit(h)
+        it += 1
+        if eng.status()["done"]:
+            break
+    res = eng._result()
+    assert res["moves"] == ref["moves"] and res["nodes_generated"] == ref["nodes_generated"]
+    assert res["iterations"] == ref["iterations"]
+    with pytest.raises(L.DcaError):
+        eng.commit(torch.zeros(eng.m_capacity, dtype=torch.float32, device="cuda"))
+    eng.close()
+
+
+def test_solved_root_and_capacity_failure(L, co):
+    from deepcubea_amd.search_methods.engine import BwasEngine
+    goal = np.arange(54, dtype=np.uint8)
+    eng = BwasEngine("cube3", 0.8, 10, max_nodes=1 << 12)
+    res = eng.solve_builtin(goal, 0)
+    assert res["solved"] and res["moves"] == [] and res["path_cost"] == 0.0 and res["nodes_generated"] == 12
+    # pool too small for a deep search: the engine must stop with failed=1, not corrupt memory
+    root = scramble(co, "cube3", [3, 8, 1, 10, 6, 4, 11, 2, 9, 0])
+    res = eng.solve_builtin(root, 2, max_iters=200)
+    assert res["failed"] and not res["solved"]
+    eng.close()
+    with pytest.raises(L.DcaError):
+        BwasEngine("cube3", 0.8, 100, max_nodes=100)  # max_nodes < one batch of children
+
+
+def test_engine_full_size_batch_properties(L, co):
+    """BASELINE configs[2] geometry (batch 20 000, w 0.8): counters stay consistent over a long run and the
+    first iterations agree with the oracle (which is too slow to follow the whole run)."""
+    from deepcubea_amd.search_methods.engine import BwasEngine
+    root = scramble(co, "cube3", [3, 8, 1, 10, 6, 4, 11, 2, 9, 0, 7, 5, 1, 3, 10, 8, 6, 2])
+    iters = 12
+    ref = co.astar("cube3", root, 0.8, 20000, co.SEM_PY, heur_builtin_id=2, max_iters=iters, trace_cap=iters)
+    eng = BwasEngine("cube3", 0.8, 20000, max_nodes=1 << 23)
+    eng.reset(root)
+    eng.root_commit(L.heuristic_builtin(2, torch.from_numpy(root[None].copy()).cuda()))
+    tr = []
+    for _ in range(iters):
+        eng.run_builtin(2, 1)
+        st = eng.status()
+        tr.append((st["open_size"], st["closed_size"], st["nodes_generated"]))
+    assert np.array_equal(np.array(tr), ref["trace"])
+    eng.run_builtin(2, 8, use_graph=True)
+    st = eng.status()
+    assert st["iterations"] == iters + 8 and not st["failed"]
+    assert st["nodes_generated"] == st["nodes_expanded"] * 12
+    assert st["open_size"] + st["nodes_expanded"] <= st["nodes_generated"] + 1
+    eng.close()
