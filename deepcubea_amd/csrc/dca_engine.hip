@@ -42,35 +42,49 @@ struct Slot {
     uint32_t head;   // node id of the most recently chained child; < batch base = stale
 };
 
-// device control block: every count the kernels need, so nothing is read back by the host
+// device control block: every count the kernels need, so nothing is read back by the host.
+// Words that take atomics from many workgroups each sit on their own 128-byte line: same-address (and
+// same-line) atomics retire at ~90 per microsecond on this chip, and they would otherwise also stall
+// every wave that merely reads the per-iteration parameters next to them.
+struct alignas(128) Cnt {
+    uint32_t v;
+    uint32_t pad[31];
+};
+struct alignas(128) Rng {
+    uint64_t kmin, kmax;
+    uint64_t pad[14];
+};
 struct Ctl {
+    // ---- read-mostly parameters, written by single-thread / single-workgroup kernels ----------
     int32_t done, failed, stop_after, skip;
-    int64_t iters, gen, expanded, closed_n;
+    int64_t iters, gen, expanded;
     uint32_t pool_n;
     // OPEN is two tiers of (key,id) arrays.  FRONT (buffers 0/1, ping-pong) holds every entry with
-    // key <= T, BACK (buffers 2/3) the rest; pops only ever look at FRONT, so an iteration costs
+    // key <= T, BACK (buffer 2) the rest; pops only ever look at FRONT, so an iteration costs
     // O(|FRONT| + children), independent of |OPEN|.
-    uint32_t cur_f, cur_b;   // live FRONT buffer (0/1) and live BACK buffer (2/3)
-    uint32_t open_n[4];
-    uint64_t kmin[4], kmax[4];
-    uint64_t T;              // tier threshold key (inclusive upper bound of FRONT)
+    uint32_t cur_f, cur_b;  // live FRONT buffer (0/1) and the BACK buffer (2)
+    uint64_t T;             // tier threshold key (inclusive upper bound of FRONT)
     uint32_t refill, r_bstar, spill_bin;
     uint64_t r_kmin;
     uint32_t r_shift;
     // selection
-    uint32_t want, bstar, sel_less, sel_r, cand_n, shift, sel_fill;
+    uint32_t want, bstar, sel_less, sel_r, shift;
+    uint32_t superset, n_ord;  // superset: the whole threshold bin is ordered too and the overshoot goes back to FRONT
+    uint32_t nb2;              // number of ordering buckets this iteration
     uint64_t sel_kmin;
-    uint64_t tail_vmin_hi, tail_vmin_lo;
-    uint32_t tail_shift;
     // batch
     uint32_t npop, m, base;
     // goals
-    unsigned long long goal_best;  // PY: min over solved popped of (g << 32 | pop rank)
     uint32_t goal_id;
-    uint32_t first_solved;  // CPP: smallest pop rank holding a solved node
     int32_t has_best;
     float best_cost;
     uint32_t best_id;
+    // ---- hot words -----------------------------------------------------------------------------
+    Cnt open_n[3];   // physical entries per OPEN buffer
+    Cnt cand_n, sel_fill, closed_n, back_dead, ticket_a, ticket_b;
+    Rng rng[3];      // running key range per OPEN buffer
+    alignas(128) unsigned long long goal_best;  // PY: min over solved popped of (g << 32 | pop rank)
+    alignas(128) uint32_t first_solved;         // CPP: smallest pop rank holding a solved node
 };
 
 __device__ __forceinline__ uint64_t key_of_cost(double c) {
@@ -103,7 +117,7 @@ struct Eng {
     Slot* tab;
     uint64_t* open_key[4];
     uint32_t* open_id[4];
-    uint32_t f_keep, f_max;  // FRONT hysteresis: refill/spill down to ~f_keep, spill when above f_max
+    uint32_t f_keep, f_max, ord_cap;  // FRONT hysteresis: refill/spill down to ~f_keep, spill when above f_max
     uint32_t *hist, *bin_start, *bin_fill, *tail_start;
     uint64_t* cand_key;
     uint32_t* cand_id;
@@ -139,9 +153,9 @@ __device__ __forceinline__ void open_append(const Eng& E, Ctl* c, uint32_t buf, 
         kmx = b > kmx ? b : kmx;
     }
     if (lane == leader) {
-        basep = atomicAdd(&c->open_n[buf], cnt);
-        atomicMin((unsigned long long*)&c->kmin[buf], (unsigned long long)kmn);
-        atomicMax((unsigned long long*)&c->kmax[buf], (unsigned long long)kmx);
+        basep = atomicAdd(&c->open_n[buf].v, cnt);
+        atomicMin((unsigned long long*)&c->rng[buf].kmin, (unsigned long long)kmn);
+        atomicMax((unsigned long long*)&c->rng[buf].kmax, (unsigned long long)kmx);
     }
     basep = __shfl(basep, leader);
     if (pred) {
@@ -287,8 +301,8 @@ __device__ __forceinline__ void fold_range(Ctl* c, uint32_t buf, uint64_t kmn, u
         kmx = b > kmx ? b : kmx;
     }
     if ((threadIdx.x & 63) == 0) {
-        if (kmn < c->kmin[buf]) atomicMin((unsigned long long*)&c->kmin[buf], (unsigned long long)kmn);
-        if (kmx > c->kmax[buf]) atomicMax((unsigned long long*)&c->kmax[buf], (unsigned long long)kmx);
+        if (kmn < c->rng[buf].kmin) atomicMin((unsigned long long*)&c->rng[buf].kmin, (unsigned long long)kmn);
+        if (kmx > c->rng[buf].kmax) atomicMax((unsigned long long*)&c->rng[buf].kmax, (unsigned long long)kmx);
     }
 }
 
@@ -332,8 +346,8 @@ __global__ void k_reset(Eng E) {
     c->goal_best = ~0ull;
     c->first_solved = NIL;
     for (int b = 0; b < 4; b++) {
-        c->kmin[b] = ~0ull;
-        c->kmax[b] = 0;
+        c->rng[b].kmin = ~0ull;
+        c->rng[b].kmax = 0;
     }
     c->cur_f = 0;
     c->cur_b = 2;
@@ -343,20 +357,20 @@ __global__ void k_reset(Eng E) {
         uint32_t slot = (uint32_t)h & E.tab_mask;
         E.tab[slot].entry = ((h >> 32) << 32) | 0u;
         E.tab[slot].g = 0;
-        c->closed_n = 1;
+        c->closed_n.v = 1;
         c->gen = 1;
         uint64_t key = key_of_cost(0.0);
         E.open_key[0][0] = key;
         E.open_id[0][0] = 0;
-        c->open_n[0] = 1;
-        c->kmin[0] = c->kmax[0] = key;
+        c->open_n[0].v = 1;
+        c->rng[0].kmin = c->rng[0].kmax = key;
     }
 }
 
 __global__ void k_root_commit(Eng E, const float* h_root) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Ctl* c = E.ctl;
-    if (E.sem != DCA_SEM_PY || c->open_n[c->cur_f] != 0) return;
+    if (E.sem != DCA_SEM_PY || c->open_n[c->cur_f].v != 0) return;
     // astar.py:246-249,196: cost = w*0.0 + max(h,0)*!solved   (float64)
     double hv = fmax((double)h_root[0], 0.0);
     double cost = __dadd_rn(__dmul_rn(E.w, 0.0), __dmul_rn(hv, E.solved[0] ? 0.0 : 1.0));
@@ -364,8 +378,8 @@ __global__ void k_root_commit(Eng E, const float* h_root) {
     uint32_t b = c->cur_f;
     E.open_key[b][0] = key;
     E.open_id[b][0] = 0;
-    c->open_n[b] = 1;
-    c->kmin[b] = c->kmax[b] = key;
+    c->open_n[b].v = 1;
+    c->rng[b].kmin = c->rng[b].kmax = key;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -373,9 +387,9 @@ __global__ void k_root_commit(Eng E, const float* h_root) {
 // (rare: amortised over the iterations FRONT then lasts).  Always enqueued; exits early when idle.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool need_refill(const Eng& E, const Ctl* c) {
-    const uint32_t nf = c->open_n[c->cur_f], nb = c->open_n[c->cur_b];
-    return nb != 0 && nf < (uint32_t)E.B;
+    return c->open_n[c->cur_b].v != c->back_dead.v && c->open_n[c->cur_f].v < (uint32_t)E.B;
 }
+constexpr uint64_t DEAD = ~0ull;  // tombstone key of a BACK entry that moved to FRONT
 
 __global__ __launch_bounds__(256) void k_refill_hist(Eng E) {
     Ctl* c = E.ctl;
@@ -383,12 +397,14 @@ __global__ __launch_bounds__(256) void k_refill_hist(Eng E) {
     __shared__ uint32_t lh[NBIN];
     for (int i = threadIdx.x; i < NBIN; i += 256) lh[i] = 0;
     __syncthreads();
-    const uint32_t b = c->cur_b, n = c->open_n[b];
-    const uint64_t kmin = c->kmin[b];
-    const uint32_t shift = select_shift(kmin, c->kmax[b]);
+    const uint32_t b = c->cur_b, n = c->open_n[b].v;
+    const uint64_t kmin = c->rng[b].kmin;
+    const uint32_t shift = select_shift(kmin, c->rng[b].kmax);
     const uint64_t* __restrict__ keys = E.open_key[b];
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        uint64_t f = (keys[i] - kmin) >> shift;
+        uint64_t k = keys[i];
+        if (k == DEAD) continue;
+        uint64_t f = (k - kmin) >> shift;
         atomicAdd(&lh[f < NBIN ? (uint32_t)f : NBIN - 1], 1u);
     }
     __syncthreads();
@@ -436,7 +452,7 @@ __global__ __launch_bounds__(1024) void k_refill_scan(Eng E) {
     __shared__ uint32_t wsum[16];
     scan_bins(E, pre, wsum);
     const int t = threadIdx.x;
-    const uint32_t b = c->cur_b, n = c->open_n[b];
+    const uint32_t b = c->cur_b, n = c->open_n[b].v - c->back_dead.v;
     const uint32_t target = n < E.f_keep ? n : E.f_keep;
     for (int k = 0; k < 2; k++) {
         int bin = 2 * t + k;
@@ -444,8 +460,8 @@ __global__ __launch_bounds__(1024) void k_refill_scan(Eng E) {
     }
     __syncthreads();
     if (t == 0) {
-        const uint64_t kmin = c->kmin[b];
-        const uint32_t shift = select_shift(kmin, c->kmax[b]);
+        const uint64_t kmin = c->rng[b].kmin;
+        const uint32_t shift = select_shift(kmin, c->rng[b].kmax);
         c->refill = 1;
         c->r_kmin = kmin;
         c->r_shift = shift;
@@ -453,67 +469,58 @@ __global__ __launch_bounds__(1024) void k_refill_scan(Eng E) {
         uint64_t top = (c->r_bstar >= NBIN - 1) ? ~0ull : kmin + (((uint64_t)c->r_bstar + 1) << shift) - 1;
         if (top < kmin) top = ~0ull;  // wrapped
         c->T = top;
-        const uint32_t nb = b ^ 1;  // 2 <-> 3
-        c->open_n[nb] = 0;
-        c->kmin[nb] = ~0ull;
-        c->kmax[nb] = 0;
+        if (top != ~0ull) c->rng[b].kmin = top + 1;  // everything at or below `top` leaves BACK
     }
 }
 
+// moved entries are appended to FRONT and tombstoned in place: BACK is never compacted (its dead
+// entries are only the ones that moved, a small fraction of what keeps arriving)
 __global__ __launch_bounds__(256) void k_refill_move(Eng E) {
     Ctl* c = E.ctl;
     if (c->done || !c->refill) return;
     __shared__ uint32_t sh[2 * 4 + 2];
-    const uint32_t sb = c->cur_b, db = sb ^ 1, fb = c->cur_f;
-    const uint32_t n = c->open_n[sb];
+    const uint32_t sb = c->cur_b, fb = c->cur_f;
+    const uint32_t n = c->open_n[sb].v;
     const uint64_t kmin = c->r_kmin;
     const uint32_t shift = c->r_shift, bstar = c->r_bstar;
-    const uint64_t* __restrict__ keys = E.open_key[sb];
+    uint64_t* __restrict__ keys = E.open_key[sb];
     const uint32_t* __restrict__ ids = E.open_id[sb];
     constexpr uint32_t ITEMS = 8, TILE = 256 * ITEMS;
-    uint64_t fmn = ~0ull, fmx = 0, bmn = ~0ull, bmx = 0;
+    uint64_t fmn = ~0ull, fmx = 0;
+    uint32_t moved = 0;
     const uint32_t ntiles = (n + TILE - 1) / TILE;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint64_t k[ITEMS];
-        uint32_t id[ITEMS];
-        uint32_t tof = 0;  // bit i: item i goes to FRONT; valid mask in high half
-        uint32_t cf = 0, cb = 0;
+        uint32_t tof = 0, cf = 0;
 #pragma unroll
         for (uint32_t i = 0; i < ITEMS; i++) {
             uint32_t idx = tile * TILE + i * 256 + threadIdx.x;
             bool live = idx < n;
-            k[i] = live ? keys[idx] : 0;
-            id[i] = live ? ids[idx] : 0;
+            k[i] = live ? keys[idx] : DEAD;
             uint64_t f = (k[i] - kmin) >> shift;
-            bool front = live && (f < NBIN ? (uint32_t)f : NBIN - 1) <= bstar;
+            bool front = k[i] != DEAD && (f < NBIN ? (uint32_t)f : NBIN - 1) <= bstar;
             tof |= (front ? 1u : 0u) << i;
-            tof |= (live ? 1u : 0u) << (16 + i);
             cf += front ? 1u : 0u;
-            cb += (live && !front) ? 1u : 0u;
         }
-        Pos2 p = block_reserve2<256>(cf, cb, &c->open_n[fb], &c->open_n[db], sh);
+        Pos2 p = block_reserve2<256>(cf, 0u, &c->open_n[fb].v, &c->open_n[fb].v, sh);
 #pragma unroll
         for (uint32_t i = 0; i < ITEMS; i++) {
-            if (!((tof >> (16 + i)) & 1u)) continue;
-            if ((tof >> i) & 1u) {
-                if (p.a < E.max_nodes) {
-                    E.open_key[fb][p.a] = k[i];
-                    E.open_id[fb][p.a] = id[i];
-                }
-                p.a++;
-                fmn = k[i] < fmn ? k[i] : fmn;
-                fmx = k[i] > fmx ? k[i] : fmx;
-            } else {
-                E.open_key[db][p.b] = k[i];
-                E.open_id[db][p.b] = id[i];
-                p.b++;
-                bmn = k[i] < bmn ? k[i] : bmn;
-                bmx = k[i] > bmx ? k[i] : bmx;
+            if (!((tof >> i) & 1u)) continue;
+            uint32_t idx = tile * TILE + i * 256 + threadIdx.x;
+            if (p.a < E.max_nodes) {
+                E.open_key[fb][p.a] = k[i];
+                E.open_id[fb][p.a] = ids[idx];
             }
+            keys[idx] = DEAD;
+            p.a++;
+            moved++;
+            fmn = k[i] < fmn ? k[i] : fmn;
+            fmx = k[i] > fmx ? k[i] : fmx;
         }
     }
     fold_range(c, fb, fmn, fmx);
-    fold_range(c, db, bmn, bmx);
+    for (int o = 32; o > 0; o >>= 1) moved += __shfl_xor(moved, o);
+    if ((threadIdx.x & 63) == 0 && moved) atomicAdd(&c->back_dead.v, moved);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -526,9 +533,9 @@ __global__ __launch_bounds__(256) void k_sel_hist(Eng E) {
     __shared__ uint32_t lh[NBIN];
     for (int i = threadIdx.x; i < NBIN; i += 256) lh[i] = 0;
     __syncthreads();
-    const uint32_t b = c->cur_f, n = c->open_n[b];
-    const uint64_t kmin = c->kmin[b];
-    const uint32_t shift = select_shift(kmin, c->kmax[b]);
+    const uint32_t b = c->cur_f, n = c->open_n[b].v;
+    const uint64_t kmin = c->rng[b].kmin;
+    const uint32_t shift = select_shift(kmin, c->rng[b].kmax);
     const uint64_t* __restrict__ keys = E.open_key[b];
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         uint64_t f = (keys[i] - kmin) >> shift;
@@ -548,16 +555,13 @@ __global__ __launch_bounds__(1024) void k_sel_scan(Eng E) {
     __shared__ uint32_t s_spill;
     const int t = threadIdx.x;
     if (t == 0) {
-        if (c->refill) {  // the refill's destination buffer becomes BACK
-            c->cur_b ^= 1;
-            c->refill = 0;
-        }
+        c->refill = 0;
         s_spill = NBIN;  // no spill
     }
     E.bin_fill[2 * t] = 0;
     E.bin_fill[2 * t + 1] = 0;
     scan_bins(E, pre, wsum);
-    const uint32_t cb = c->cur_f, n = c->open_n[cb];
+    const uint32_t cb = c->cur_f, n = c->open_n[cb].v;
     const uint32_t want = n < (uint32_t)E.B ? n : (uint32_t)E.B;
     // threshold bin: first bin with pre[b] < want <= pre[b+1]
     for (int k = 0; k < 2; k++) {
@@ -566,6 +570,12 @@ __global__ __launch_bounds__(1024) void k_sel_scan(Eng E) {
             c->bstar = (uint32_t)bin;
             c->sel_less = pre[bin];
             c->sel_r = want - pre[bin];
+            // normal case: order the whole threshold bin with the batch and hand the overshoot back to
+            // FRONT (k_ord_rank); only a bin too big for the ordering buffers takes the exact
+            // candidate-refinement path (k_sel_cand)
+            const bool sup = pre[bin + 1] <= E.ord_cap;
+            c->superset = sup ? 1u : 0u;
+            c->n_ord = sup ? pre[bin + 1] : want;
         }
         // spill: FRONT grew past f_max -> keep the bins that hold the batch plus ~f_keep more
         if (n > E.f_max) {
@@ -578,11 +588,11 @@ __global__ __launch_bounds__(1024) void k_sel_scan(Eng E) {
     __syncthreads();
     if (t == 0) {
         E.bin_start[NBIN] = pre[NBIN];
-        const uint64_t kmin = c->kmin[cb];
-        const uint32_t shift = select_shift(kmin, c->kmax[cb]);
+        const uint64_t kmin = c->rng[cb].kmin;
+        const uint32_t shift = select_shift(kmin, c->rng[cb].kmax);
         c->want = want;
-        c->cand_n = 0;
-        c->sel_fill = 0;
+        c->cand_n.v = 0;
+        c->sel_fill.v = 0;
         c->sel_kmin = kmin;
         c->shift = shift;
         uint32_t sp = s_spill;
@@ -593,9 +603,9 @@ __global__ __launch_bounds__(1024) void k_sel_scan(Eng E) {
             sp = NBIN;
         }
         c->spill_bin = sp;  // survivors in bins above it move to BACK
-        c->open_n[cb ^ 1] = 0;
-        c->kmin[cb ^ 1] = ~0ull;
-        c->kmax[cb ^ 1] = 0;
+        c->open_n[cb ^ 1].v = 0;
+        c->rng[cb ^ 1].kmin = ~0ull;
+        c->rng[cb ^ 1].kmax = 0;
         c->goal_best = ~0ull;
         c->first_solved = NIL;
         c->skip = 0;
@@ -613,15 +623,16 @@ __global__ __launch_bounds__(256) void k_sel_collect(Eng E) {
     if (c->done) return;
     __shared__ uint32_t sh[4 * 4 + 4];
     const uint32_t b = c->cur_f, nf = b ^ 1, bb = c->cur_b;
-    const uint32_t n = c->open_n[b];
+    const uint32_t n = c->open_n[b].v;
     const uint64_t kmin = c->sel_kmin;
     const uint32_t shift = c->shift, bstar = c->bstar, spill = c->spill_bin;
+    const uint32_t candd = c->superset ? 1u : 4u;  // where the threshold bin goes
     const uint64_t* __restrict__ keys = E.open_key[b];
     const uint32_t* __restrict__ ids = E.open_id[b];
-    constexpr uint32_t ITEMS = 4, TILE = 256 * ITEMS;
+    constexpr uint32_t ITEMS = 8, TILE = 256 * ITEMS;
     uint64_t fmn = ~0ull, fmx = 0, bmn = ~0ull, bmx = 0;
     const uint32_t ntiles = (n + TILE - 1) / TILE;
-    uint32_t* const ctr[4] = {&c->sel_fill, &c->open_n[nf], &c->open_n[bb], &c->cand_n};
+    uint32_t* const ctr[4] = {&c->sel_fill.v, &c->open_n[nf].v, &c->open_n[bb].v, &c->cand_n.v};
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint64_t k[ITEMS];
         uint32_t id[ITEMS];
@@ -635,7 +646,7 @@ __global__ __launch_bounds__(256) void k_sel_collect(Eng E) {
             id[i] = live ? ids[idx] : 0;
             uint64_t f64 = (k[i] - kmin) >> shift;
             uint32_t f = f64 < NBIN ? (uint32_t)f64 : NBIN - 1;
-            uint32_t d = !live ? 0u : (f < bstar ? 1u : (f == bstar ? 4u : (f > spill ? 3u : 2u)));
+            uint32_t d = !live ? 0u : (f < bstar ? 1u : (f == bstar ? candd : (f > spill ? 3u : 2u)));
             dest |= d << (3 * i);
             if (d) cnt[d - 1]++;
         }
@@ -771,13 +782,13 @@ __global__ __launch_bounds__(1024) void k_sel_cand(Eng E) {
     if (c->done) return;
     __shared__ CandShared S;
     const int t = threadIdx.x;
-    const uint32_t n = c->cand_n;
+    const uint32_t n = c->superset ? 0u : c->cand_n.v;
     if (t == 0) {
         S.active = n;
-        S.rr = c->sel_r;
+        S.rr = n ? c->sel_r : 0u;
     }
     __syncthreads();
-    while (true) {
+    while (n != 0) {
         uint32_t active = S.active, rr = S.rr;
         if (rr == 0 || rr == active) {  // take none / take all of what is still undecided
             for (uint32_t i = t; i < n; i += 1024)
@@ -862,7 +873,7 @@ __global__ __launch_bounds__(1024) void k_sel_cand(Eng E) {
     // ---- order the popped list by (key, id), step 1: 2048 sampled entries are bitonic-sorted here and
     // become the splitters of a sample sort whose bucket/scatter/rank passes run chip-wide (k_ord_*).
     // Works for any key distribution (ids make the composite unique), unlike fixed-width bins.
-    const uint32_t want = c->want;
+    const uint32_t want = c->n_ord;  // entries to order (batch, or batch + rest of the threshold bin)
     uint64_t* sk = S.fk2;
     uint32_t* si = S.fi2;
     const bool small = want <= 2048;
@@ -926,7 +937,7 @@ __device__ __forceinline__ uint32_t ord_bucket(const OrdShared& S, uint64_t k, u
 __global__ __launch_bounds__(256) void k_ord_count(Eng E) {
     Ctl* c = E.ctl;
     if (c->done) return;
-    const uint32_t want = c->want;
+    const uint32_t want = c->n_ord;
     if (blockIdx.x * 256 >= want) return;
     __shared__ OrdShared S;
     ord_load_splitters(E, S);
@@ -972,7 +983,7 @@ __device__ __forceinline__ void ord_prefix(const Eng& E, uint32_t* pre, uint32_t
 __global__ __launch_bounds__(256) void k_ord_scatter(Eng E) {
     Ctl* c = E.ctl;
     if (c->done) return;
-    const uint32_t want = c->want;
+    const uint32_t want = c->n_ord;
     if (blockIdx.x * 256 >= want) return;
     __shared__ uint32_t pre[2050];
     __shared__ uint32_t wsum[4];
@@ -988,27 +999,35 @@ __global__ __launch_bounds__(256) void k_ord_scatter(Eng E) {
     E.ord_pb[p] = b;
 }
 
-// O3: rank inside the bucket -> final pop order; note solved pops
+// O3: rank inside the bucket -> final pop order; entries ranked past the batch return to FRONT'
 __global__ __launch_bounds__(256) void k_ord_rank(Eng E) {
     Ctl* c = E.ctl;
     if (c->done) return;
-    const uint32_t want = c->want;
+    const uint32_t n_ord = c->n_ord, want = c->want;
+    if (blockIdx.x * 256 >= n_ord) return;
     const uint32_t e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= want) return;
-    const uint64_t k = E.ord_key[e];
-    const uint32_t id = E.ord_id[e];
-    const uint32_t b = E.ord_pb[e];
-    const uint32_t s0 = E.bpre[b], e0 = E.bpre[b + 1];
-    uint32_t rank = s0;
-    for (uint32_t j = s0; j < e0; j++) rank += pair_less(E.ord_key[j], E.ord_id[j], k, id) ? 1u : 0u;
-    E.pop_key[rank] = k;
-    E.pop_id[rank] = id;
-    if (E.solved[id]) {
-        if (E.sem == DCA_SEM_PY)
-            atomicMin(&c->goal_best, ((unsigned long long)(uint32_t)E.g[id] << 32) | rank);
-        else
-            atomicMin(&c->first_solved, rank);
+    const bool live = e < n_ord;
+    uint64_t k = 0;
+    uint32_t id = 0, rank = 0;
+    if (live) {
+        k = E.ord_key[e];
+        id = E.ord_id[e];
+        const uint32_t b = E.ord_pb[e];
+        const uint32_t s0 = E.bpre[b], e0 = E.bpre[b + 1];
+        rank = s0;
+        for (uint32_t j = s0; j < e0; j++) rank += pair_less(E.ord_key[j], E.ord_id[j], k, id) ? 1u : 0u;
+        if (rank < want) {
+            E.pop_key[rank] = k;
+            E.pop_id[rank] = id;
+            if (E.solved[id]) {
+                if (E.sem == DCA_SEM_PY)
+                    atomicMin(&c->goal_best, ((unsigned long long)(uint32_t)E.g[id] << 32) | rank);
+                else
+                    atomicMin(&c->first_solved, rank);
+            }
+        }
     }
+    open_append(E, c, c->cur_f ^ 1, live && rank >= want, k, id);
 }
 
 // S6: single thread — fix the batch geometry, goal bookkeeping, swap OPEN buffers
@@ -1083,9 +1102,38 @@ __global__ __launch_bounds__(kThreads) void k_expand(Eng E, int heur_id) {
     }
     if (r0 >= npop) return;
     const uint32_t np = min((uint32_t)kTileParents, npop - r0);
-    for (uint32_t idx = threadIdx.x; idx < np * EV::D; idx += kThreads) {
-        uint32_t r = idx / EV::D, i = idx - r * EV::D;
-        lpar[idx] = E.state[(size_t)E.pop_id[r0 + r] * EV::D + i];
+    {
+        // gather the popped rows by node id.  One lane per (parent, 4-byte word): 16 lanes cover a row, so
+        // a 256-thread block fetches 16 rows per round and the 4 rounds are issued back to back.
+        constexpr int WPR = (EV::D + 3) / 4;  // words per row (<= 14)
+        static_assert(WPR <= 16, "row wider than 64 bytes");
+        const uint32_t w = threadIdx.x & 15, rr = threadIdx.x >> 4;
+        uint32_t val[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t r = rr + 16 * k;
+            val[k] = 0;
+            if (r < np && w < WPR) {
+                const uint8_t* row = E.state + (size_t)E.pop_id[r0 + r] * EV::D;
+                // rows start at id*D: read byte-wise only where a word would cross the row end
+                if (4 * w + 4 <= EV::D) {
+                    uint32_t v;
+                    __builtin_memcpy(&v, row + 4 * w, 4);
+                    val[k] = v;
+                } else {
+                    for (int b = 0; 4 * w + b < EV::D; b++) val[k] |= (uint32_t)row[4 * w + b] << (8 * b);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t r = rr + 16 * k;
+            if (r < np && w < WPR) {
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                    if (4 * w + b < EV::D) lpar[r * EV::D + 4 * w + b] = (uint8_t)(val[k] >> (8 * b));
+            }
+        }
     }
     if constexpr (ENV == DCA_ENV_CUBE3) stage_tables<ENV, DIM>(ltab, lpar, np);
     __syncthreads();
@@ -1215,60 +1263,86 @@ __global__ __launch_bounds__(kThreads) void k_expand(Eng E, int heur_id) {
 // ---------------------------------------------------------------------------------------------
 // dedup A: find-or-insert the CLOSED slot of every child, chain the child to it
 // ---------------------------------------------------------------------------------------------
+constexpr uint8_t F_KEEP = 1, F_MIN = 2, F_NEW = 4;
+template <int D>
 __global__ __launch_bounds__(256) void k_probe(Eng E) {
     Ctl* c = E.ctl;
     if (c->done) return;
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
     const uint32_t m = c->m, base = c->base;
-    bool inserted = false;
-    if (j < m) {
-        const uint32_t id = base + j;
-        const uint64_t h = E.child_hash[j];
-        const uint64_t tag = h >> 32;
-        const uint8_t* mine = E.state + (size_t)id * E.D;
-        const bool even = (E.D & 1) == 0;  // even row length => rows start on 2-byte boundaries
-        uint32_t slot = (uint32_t)h & E.tab_mask;
-        for (uint32_t probes = 0;; probes++) {
-            uint64_t e = __hip_atomic_load(&E.tab[slot].entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (e == EMPTY) {
-                uint64_t old = atomicCAS((unsigned long long*)&E.tab[slot].entry, (unsigned long long)EMPTY,
-                                         (unsigned long long)((tag << 32) | id));
-                if (old == EMPTY) {
-                    inserted = true;
-                    break;
-                }
-                e = old;
-            }
-            if ((e >> 32) == tag) {
-                // exact key equality against the representative's state bytes (State.__eq__, cube3.py:23-24)
-                const uint8_t* rep = E.state + (size_t)(uint32_t)e * E.D;
-                bool eq = true;
-                if (even) {
-                    const uint16_t* a = reinterpret_cast<const uint16_t*>(rep);
-                    const uint16_t* b = reinterpret_cast<const uint16_t*>(mine);
-                    for (int k = 0; k < (E.D >> 1); k++) eq &= (a[k] == b[k]);
-                } else {
-                    for (int k = 0; k < E.D; k++) eq &= (rep[k] == mine[k]);
-                }
-                if (eq) break;
-            }
-            slot = (slot + 1) & E.tab_mask;
-            if (probes > E.tab_mask) {  // table full (cannot happen while pool <= cap/2)
-                c->failed = 1;
-                break;
+    if (j >= m) return;
+    constexpr int NW = (D + 3) / 4;
+    const uint32_t id = base + j;
+    const uint64_t h = E.child_hash[j];
+    const uint64_t tag = h >> 32;
+    // this child's row, as words (the row was written by k_expand; the tail word is masked)
+    uint32_t mine[NW];
+    {
+        const uint8_t* row = E.state + (size_t)id * D;
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            if (4 * k + 4 <= D) {
+                __builtin_memcpy(&mine[k], row + 4 * k, 4);
+            } else {
+                mine[k] = 0;
+                for (int b = 0; 4 * k + b < D; b++) mine[k] |= (uint32_t)row[4 * k + b] << (8 * b);
             }
         }
-        uint32_t old_head = atomicExch(&E.tab[slot].head, id);
-        E.child_next[j] = old_head >= base ? old_head - base : NIL;
-        E.child_slot[j] = slot;
     }
-    unsigned long long mk = __ballot(inserted);
-    if (mk && (threadIdx.x & 63) == (__ffsll((long long)mk) - 1))
-        atomicAdd((unsigned long long*)&c->closed_n, (unsigned long long)__popcll(mk));
+    bool inserted = false;
+    uint32_t slot = (uint32_t)h & E.tab_mask;
+    for (uint32_t probes = 0;; probes++) {
+        uint64_t e = __hip_atomic_load(&E.tab[slot].entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e == EMPTY) {
+            uint64_t old = atomicCAS((unsigned long long*)&E.tab[slot].entry, (unsigned long long)EMPTY,
+                                     (unsigned long long)((tag << 32) | id));
+            if (old == EMPTY) {
+                inserted = true;
+                break;
+            }
+            e = old;
+        }
+        if ((e >> 32) == tag) {
+            // exact key equality against the representative's state bytes (State.__eq__, cube3.py:23-24)
+            const uint8_t* rep = E.state + (size_t)(uint32_t)e * D;
+            uint32_t diff = 0;
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                uint32_t v;
+                if (4 * k + 4 <= D) {
+                    __builtin_memcpy(&v, rep + 4 * k, 4);
+                } else {
+                    v = 0;
+                    for (int b = 0; 4 * k + b < D; b++) v |= (uint32_t)rep[4 * k + b] << (8 * b);
+                }
+                diff |= v ^ mine[k];
+            }
+            if (diff == 0) break;
+        }
+        slot = (slot + 1) & E.tab_mask;
+        if (probes > E.tab_mask) {  // table full (cannot happen while pool <= cap/2)
+            c->failed = 1;
+            break;
+        }
+    }
+    uint32_t old_head = atomicExch(&E.tab[slot].head, id);
+    E.child_next[j] = old_head >= base ? old_head - base : NIL;
+    E.child_slot[j] = slot;
+    E.child_flags[j] = inserted ? F_NEW : 0;  // counted in k_commit (one atomic per block there)
+}
+
+static void launch_probe(const Eng& E, hipStream_t s) {
+    const dim3 g((E.M + 255) / 256), b(256);
+    switch (E.D) {
+        case 54: hipLaunchKernelGGL(k_probe<54>, g, b, 0, s, E); break;
+        case 16: hipLaunchKernelGGL(k_probe<16>, g, b, 0, s, E); break;
+        case 25: hipLaunchKernelGGL(k_probe<25>, g, b, 0, s, E); break;
+        case 36: hipLaunchKernelGGL(k_probe<36>, g, b, 0, s, E); break;
+        default: hipLaunchKernelGGL(k_probe<49>, g, b, 0, s, E); break;
+    }
 }
 
 // dedup B: keep decision in sequential order + cost
-constexpr uint8_t F_KEEP = 1, F_MIN = 2;
 __global__ __launch_bounds__(256) void k_decide(Eng E) {
     Ctl* c = E.ctl;
     if (c->done) return;
@@ -1291,7 +1365,7 @@ __global__ __launch_bounds__(256) void k_decide(Eng E) {
         first = k < first ? k : first;
     }
     const bool keep = (gj < v0) && !dominated;  // astar.py:81-88 / cpp:247-265 in sequential order
-    E.child_flags[j] = (keep ? F_KEEP : 0) | (j == pmin ? F_MIN : 0);
+    E.child_flags[j] = (E.child_flags[j] & F_NEW) | (keep ? F_KEEP : 0) | (j == pmin ? F_MIN : 0);
     if (j == first) {
         // a state first seen in this batch is represented by its sequentially-first child (the node
         // the reference inserts, cpp:250) whichever lane won the CAS
@@ -1311,16 +1385,32 @@ __global__ __launch_bounds__(256) void k_decide(Eng E) {
     E.child_key[j] = key_of_cost(cost);
 }
 
+// the last workgroup of k_commit to finish closes the iteration (astar.py:317 step_num += 1)
+__device__ __forceinline__ void commit_ticket(Ctl* c) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = atomicAdd(&c->ticket_a.v, 1u);
+        if (t == gridDim.x - 1) {
+            c->ticket_a.v = 0;
+            c->iters += 1;
+            if (c->stop_after || c->failed) c->done = 1;
+        }
+    }
+}
+
 // dedup C: record the new best g per state, push the kept children (FRONT if key <= T, else BACK)
 __global__ __launch_bounds__(1024) void k_commit(Eng E) {
     Ctl* c = E.ctl;
     if (c->done) return;
-    __shared__ uint32_t sh[2 * 16 + 2];
+    __shared__ uint32_t sh[3 * 16 + 3];
     const uint32_t m = c->m, base = c->base;
     const uint32_t fb = c->cur_f, bb = c->cur_b;
     const uint64_t T = c->T;
     const uint32_t j = blockIdx.x * 1024 + threadIdx.x;
-    if (blockIdx.x * 1024 >= m) return;
+    if (blockIdx.x * 1024 >= m) {
+        commit_ticket(c);
+        return;
+    }
     const bool live = j < m;
     const uint8_t fl = live ? E.child_flags[j] : 0;
     const bool keep = (fl & F_KEEP) != 0;
@@ -1341,24 +1431,28 @@ __global__ __launch_bounds__(1024) void k_commit(Eng E) {
     }
     const uint64_t key = keep ? E.child_key[j] : 0;
     const bool tof = keep && key <= T, tob = keep && key > T;
-    Pos2 p = block_reserve2<1024>(tof ? 1u : 0u, tob ? 1u : 0u, &c->open_n[fb], &c->open_n[bb], sh);
+    const uint32_t cnt[3] = {tof ? 1u : 0u, tob ? 1u : 0u, (fl & F_NEW) ? 1u : 0u};
+    uint32_t* const ctr[3] = {&c->open_n[fb].v, &c->open_n[bb].v, &c->closed_n.v};
+    uint32_t pos[3];
+    block_reserveK<1024, 3>(cnt, ctr, pos, sh);
     if (tof) {
-        if (p.a < E.max_nodes) {
-            E.open_key[fb][p.a] = key;
-            E.open_id[fb][p.a] = id;
+        if (pos[0] < E.max_nodes) {
+            E.open_key[fb][pos[0]] = key;
+            E.open_id[fb][pos[0]] = id;
         } else {
             c->failed = 1;
         }
     } else if (tob) {
-        if (p.b < E.max_nodes) {
-            E.open_key[bb][p.b] = key;
-            E.open_id[bb][p.b] = id;
+        if (pos[1] < E.max_nodes) {
+            E.open_key[bb][pos[1]] = key;
+            E.open_id[bb][pos[1]] = id;
         } else {
             c->failed = 1;
         }
     }
     fold_range(c, fb, tof ? key : ~0ull, tof ? key : 0ull);
     fold_range(c, bb, tob ? key : ~0ull, tob ? key : 0ull);
+    commit_ticket(c);
 }
 
 __global__ void k_end_iter(Eng E) {
@@ -1455,7 +1549,7 @@ int launch_expand(const Eng& E, int heur_id, hipStream_t s) {
     return DCA_E_BADARG;
 }
 
-constexpr int kScanBlocks = 1024;
+constexpr int kScanBlocks = 256;  // persistent-style grids: few fat blocks, cheap to launch when they early-exit
 
 int enqueue_first_half(dca_engine* e, int heur_id, hipStream_t s) {
     const Eng& E = e->E;
@@ -1466,9 +1560,9 @@ int enqueue_first_half(dca_engine* e, int heur_id, hipStream_t s) {
     hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(1024), 0, s, E);
     hipLaunchKernelGGL(k_sel_collect, dim3(kScanBlocks), dim3(256), 0, s, E);
     hipLaunchKernelGGL(k_sel_cand, dim3(1), dim3(1024), 0, s, E);
-    hipLaunchKernelGGL(k_ord_count, dim3((E.B + 255) / 256), dim3(256), 0, s, E);
-    hipLaunchKernelGGL(k_ord_scatter, dim3((E.B + 255) / 256), dim3(256), 0, s, E);
-    hipLaunchKernelGGL(k_ord_rank, dim3((E.B + 255) / 256), dim3(256), 0, s, E);
+    hipLaunchKernelGGL(k_ord_count, dim3((E.ord_cap + 255) / 256), dim3(256), 0, s, E);
+    hipLaunchKernelGGL(k_ord_scatter, dim3((E.ord_cap + 255) / 256), dim3(256), 0, s, E);
+    hipLaunchKernelGGL(k_ord_rank, dim3((E.ord_cap + 255) / 256), dim3(256), 0, s, E);
     hipLaunchKernelGGL(k_post_pop, dim3(1), dim3(64), 0, s, E);
     if (int rc = launch_check("select kernels")) return rc;
     return launch_expand(E, heur_id, s);
@@ -1477,10 +1571,9 @@ int enqueue_first_half(dca_engine* e, int heur_id, hipStream_t s) {
 int enqueue_second_half(dca_engine* e, hipStream_t s) {
     const Eng& E = e->E;
     const unsigned gb = (E.M + 255) / 256;
-    hipLaunchKernelGGL(k_probe, dim3(gb), dim3(256), 0, s, E);
+    launch_probe(E, s);
     hipLaunchKernelGGL(k_decide, dim3(gb), dim3(256), 0, s, E);
     hipLaunchKernelGGL(k_commit, dim3((E.M + 1023) / 1024), dim3(1024), 0, s, E);
-    hipLaunchKernelGGL(k_end_iter, dim3(1), dim3(64), 0, s, E);
     return launch_check("dedup kernels");
 }
 
@@ -1517,6 +1610,7 @@ int dca_engine_create(dca_engine** out, int env, int dim, double weight, int bat
     E.wf = (float)weight;  // cpp:353 (float) atof(argv[2])
     E.max_nodes = (uint32_t)max_nodes;
     E.M = (uint32_t)Mll;
+    E.ord_cap = (uint32_t)(2 * batch_size + 131072);
     E.f_keep = (uint32_t)(32 * batch_size > 65536 ? 32 * batch_size : 65536);
     E.f_max = 3 * E.f_keep;
     uint64_t cap = 1024;
@@ -1529,7 +1623,7 @@ int dca_engine_create(dca_engine** out, int env, int dim, double weight, int bat
         return DCA_E_BADARG;
     }
     int rc = 0;
-    const size_t N = (size_t)max_nodes, M = (size_t)Mll, Bz = (size_t)batch_size;
+    const size_t N = (size_t)max_nodes, M = (size_t)Mll, Bz = (size_t)(2 * batch_size + 131072);
 #define ALLOC(field, count) \
     if (!rc) rc = dev_alloc(e, &E.field, (count))
     ALLOC(state, N * D + 64);
@@ -1538,7 +1632,7 @@ int dca_engine_create(dca_engine** out, int env, int dim, double weight, int bat
     ALLOC(move, N);
     ALLOC(solved, N);
     ALLOC(tab, (size_t)cap);
-    for (int b = 0; b < 4; b++) {
+    for (int b = 0; b < 3; b++) {  // FRONT ping-pong (0/1) + BACK (2)
         ALLOC(open_key[b], N);
         ALLOC(open_id[b], N);
     }
@@ -1703,7 +1797,7 @@ int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, float* ms_
     // one hipEvent between every pair of kernels of an iteration (eager launches on `stream`);
     // ms_out[k] = summed milliseconds of phase k over `iters` iterations.  Phases:
     // 0 refill(3 kernels) 1 sel_hist 2 sel_scan 3 sel_collect 4 sel_cand 5 order(3 kernels) 6 post_pop
-    // 7 expand 8 probe 9 decide 10 commit 11 end_iter
+    // 7 expand 8 probe 9 decide 10 commit
     DCA_ARG(e != nullptr && ms_out != nullptr && heur_id >= 0 && heur_id <= DCA_HEUR_ZERO && iters >= 0);
     if (e->phase != 0) {
         set_error("dca_engine_profile_builtin between pop_expand and commit");
@@ -1711,7 +1805,7 @@ int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, float* ms_
     }
     hipStream_t s = (hipStream_t)stream;
     const Eng& E = e->E;
-    constexpr int NP = 12;
+    constexpr int NP = 11;
     hipEvent_t ev[NP + 1];
     for (int k = 0; k <= NP; k++) DCA_HIP(hipEventCreate(&ev[k]));
     for (int k = 0; k < 16; k++) ms_out[k] = 0.f;
@@ -1732,21 +1826,19 @@ int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, float* ms_
         (void)hipEventRecord(ev[k++], s);
         hipLaunchKernelGGL(k_sel_cand, dim3(1), dim3(1024), 0, s, E);
         (void)hipEventRecord(ev[k++], s);
-        hipLaunchKernelGGL(k_ord_count, dim3((E.B + 255) / 256), dim3(256), 0, s, E);
-        hipLaunchKernelGGL(k_ord_scatter, dim3((E.B + 255) / 256), dim3(256), 0, s, E);
-        hipLaunchKernelGGL(k_ord_rank, dim3((E.B + 255) / 256), dim3(256), 0, s, E);
+        hipLaunchKernelGGL(k_ord_count, dim3((E.ord_cap + 255) / 256), dim3(256), 0, s, E);
+        hipLaunchKernelGGL(k_ord_scatter, dim3((E.ord_cap + 255) / 256), dim3(256), 0, s, E);
+        hipLaunchKernelGGL(k_ord_rank, dim3((E.ord_cap + 255) / 256), dim3(256), 0, s, E);
         (void)hipEventRecord(ev[k++], s);
         hipLaunchKernelGGL(k_post_pop, dim3(1), dim3(64), 0, s, E);
         (void)hipEventRecord(ev[k++], s);
         rc = launch_expand(E, heur_id, s);
         (void)hipEventRecord(ev[k++], s);
-        hipLaunchKernelGGL(k_probe, dim3(gb), dim3(256), 0, s, E);
+        launch_probe(E, s);
         (void)hipEventRecord(ev[k++], s);
         hipLaunchKernelGGL(k_decide, dim3(gb), dim3(256), 0, s, E);
         (void)hipEventRecord(ev[k++], s);
         hipLaunchKernelGGL(k_commit, dim3((E.M + 1023) / 1024), dim3(1024), 0, s, E);
-        (void)hipEventRecord(ev[k++], s);
-        hipLaunchKernelGGL(k_end_iter, dim3(1), dim3(64), 0, s, E);
         (void)hipEventRecord(ev[k++], s);
         if (!rc) rc = launch_check("profiled iteration");
         if (hipStreamSynchronize(s) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipStreamSynchronize");
@@ -1771,8 +1863,8 @@ int dca_engine_status(dca_engine* e, dca_status* out, void* stream) {
     out->iterations = c.iters;
     out->nodes_generated = c.gen;
     out->nodes_expanded = c.expanded;
-    out->open_size = (int64_t)c.open_n[c.cur_f] + (int64_t)c.open_n[c.cur_b];
-    out->closed_size = c.closed_n;
+    out->open_size = (int64_t)c.open_n[c.cur_f].v + (int64_t)c.open_n[c.cur_b].v - (int64_t)c.back_dead.v;
+    out->closed_size = c.closed_n.v;
     out->pool_size = c.pool_n;
     out->best_cost = c.has_best ? (double)c.best_cost : __builtin_nan("");
     return 0;
@@ -1790,18 +1882,18 @@ int dca_engine_debug(dca_engine* e, double* out, void* stream) {
         memcpy(&d, &b, 8);
         return d;
     };
-    out[0] = c.open_n[c.cur_f];
-    out[1] = c.open_n[c.cur_b];
-    out[2] = cost(c.kmin[c.cur_f]);
-    out[3] = cost(c.kmax[c.cur_f]);
-    out[4] = cost(c.kmin[c.cur_b]);
-    out[5] = cost(c.kmax[c.cur_b]);
+    out[0] = c.open_n[c.cur_f].v;
+    out[1] = (double)c.open_n[c.cur_b].v - (double)c.back_dead.v;
+    out[2] = cost(c.rng[c.cur_f].kmin);
+    out[3] = cost(c.rng[c.cur_f].kmax);
+    out[4] = cost(c.rng[c.cur_b].kmin);
+    out[5] = cost(c.rng[c.cur_b].kmax);
     out[6] = cost(c.T);
     out[7] = c.want;
     out[8] = c.bstar;
     out[9] = c.sel_less;
     out[10] = c.sel_r;
-    out[11] = c.cand_n;
+    out[11] = c.cand_n.v;
     out[12] = c.shift;
     out[13] = c.spill_bin;
     out[14] = c.npop;

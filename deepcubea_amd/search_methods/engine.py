@@ -93,7 +93,7 @@ class BwasEngine:
                                                      _lib.stream_ptr()), "dca_engine_run_builtin")
 
     PHASES = ["refill", "sel_hist", "sel_scan", "sel_collect", "sel_cand", "order", "post_pop", "expand", "probe",
-              "decide", "commit", "end_iter"]
+              "decide", "commit"]
 
     def profile_builtin(self, heur_id: int, iters: int) -> dict:
         """Per-kernel HIP-event timings (ms per iteration) of `iters` eager iterations."""

@@ -172,7 +172,7 @@ int dca_engine_commit(dca_engine* e, const float* h, void* stream);
 int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph, void* stream);
 /* like run_builtin (eager) but with a hipEvent between every pair of kernels; ms_out (host float[16])
  * receives the summed milliseconds per phase: 0 refill 1 sel_hist 2 sel_scan 3 sel_collect 4 sel_cand
- * 5 order 6 post_pop 7 expand 8 probe 9 decide 10 commit 11 end_iter.  Synchronises every iteration. */
+ * 5 order 6 post_pop 7 expand 8 probe 9 decide 10 commit.  Synchronises every iteration.              */
 int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, float* ms_out /*host [16]*/, void* stream);
 /* synchronises the stream */
 int dca_engine_status(dca_engine* e, dca_status* out, void* stream);
