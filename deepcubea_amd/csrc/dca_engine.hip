@@ -118,7 +118,9 @@ struct Eng {
     uint64_t* open_key[4];
     uint32_t* open_id[4];
     uint32_t f_keep, f_max, ord_cap;  // FRONT hysteresis: refill/spill down to ~f_keep, spill when above f_max
-    uint32_t *hist, *bin_start, *bin_fill, *tail_start;
+    uint32_t *hist, *sub_base;
+    uint8_t* sub_lg;
+    uint32_t nb2_cap;
     uint64_t* cand_key;
     uint32_t* cand_id;
     uint8_t* cand_st;
@@ -558,8 +560,6 @@ __global__ __launch_bounds__(1024) void k_sel_scan(Eng E) {
         c->refill = 0;
         s_spill = NBIN;  // no spill
     }
-    E.bin_fill[2 * t] = 0;
-    E.bin_fill[2 * t + 1] = 0;
     scan_bins(E, pre, wsum);
     const uint32_t cb = c->cur_f, n = c->open_n[cb].v;
     const uint32_t want = n < (uint32_t)E.B ? n : (uint32_t)E.B;
@@ -583,11 +583,57 @@ __global__ __launch_bounds__(1024) void k_sel_scan(Eng E) {
             if (pre[bin] < keepn && keepn <= pre[bin + 1]) s_spill = (uint32_t)bin;
         }
     }
-    E.bin_start[2 * t] = pre[2 * t];
-    E.bin_start[2 * t + 1] = pre[2 * t + 1];
+    __syncthreads();
+    {
+        // ordering layout: coarse bin f <= bstar is cut into 2^lg uniform sub-bins (~8 entries each; inside
+        // one coarse bin the keys are close to uniform, whatever the global distribution looks like), so
+        // bucket(key) is pure arithmetic and k_ord_rank only ever ranks inside a handful of entries
+        const uint32_t bstar = c->bstar;
+        const uint32_t shiftv = select_shift(c->rng[cb].kmin, c->rng[cb].kmax);
+        __shared__ uint32_t nsub[NBIN];
+        __shared__ uint32_t wsum2[16];
+        uint32_t lgv[2], ns[2];
+        for (int k = 0; k < 2; k++) {
+            const uint32_t bin = 2 * t + k;
+            const uint32_t cnt = pre[bin + 1] - pre[bin];
+            uint32_t lg = 0;
+            while ((8u << lg) < cnt && lg < 20) lg++;
+            if (lg > shiftv) lg = shiftv;  // cannot cut finer than one key unit
+            lgv[k] = lg;
+            ns[k] = bin <= bstar ? (1u << lg) : 0u;
+        }
+        // exclusive scan of ns over the bins
+        const int lane = t & 63, wv = t >> 6;
+        uint32_t ssum = ns[0] + ns[1], incl = ssum;
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wsum2[wv] = incl;
+        __syncthreads();
+        if (t < 16) {
+            uint32_t v = wsum2[t], acc = v;
+            for (int o = 1; o < 16; o <<= 1) {
+                uint32_t u = __shfl_up(acc, o, 16);
+                if (t >= o) acc += u;
+            }
+            wsum2[t] = acc - v;
+        }
+        __syncthreads();
+        const uint32_t excl = incl - ssum + wsum2[wv];
+        E.sub_base[2 * t] = excl;
+        E.sub_base[2 * t + 1] = excl + ns[0];
+        E.sub_lg[2 * t] = (uint8_t)lgv[0];
+        E.sub_lg[2 * t + 1] = (uint8_t)lgv[1];
+        if (t == 1023) c->nb2 = excl + ssum;
+        (void)nsub;
+    }
     __syncthreads();
     if (t == 0) {
-        E.bin_start[NBIN] = pre[NBIN];
+        if (c->superset && c->nb2 > E.nb2_cap) {  // cannot happen with ~8 entries per sub-bin; stay exact anyway
+            c->superset = 0;
+            c->n_ord = want;
+        }
         const uint64_t kmin = c->rng[cb].kmin;
         const uint32_t shift = select_shift(kmin, c->rng[cb].kmax);
         c->want = want;
@@ -780,9 +826,10 @@ __device__ __forceinline__ void cand_scan(CandShared& S) {
 __global__ __launch_bounds__(1024) void k_sel_cand(Eng E) {
     Ctl* c = E.ctl;
     if (c->done) return;
+    if (c->superset) return;  // normal case: nothing to refine, ordering buckets are arithmetic
     __shared__ CandShared S;
     const int t = threadIdx.x;
-    const uint32_t n = c->superset ? 0u : c->cand_n.v;
+    const uint32_t n = c->cand_n.v;
     if (t == 0) {
         S.active = n;
         S.rr = n ? c->sel_r : 0u;
@@ -903,7 +950,7 @@ __global__ __launch_bounds__(1024) void k_sel_cand(Eng E) {
         E.spl_key[j] = sk[j];
         E.spl_id[j] = si[j];
     }
-    for (uint32_t j = t; j < 2049; j += 1024) E.bcnt[j] = 0;
+    if (t == 0) c->nb2 = 2049;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -939,67 +986,86 @@ __global__ __launch_bounds__(256) void k_ord_count(Eng E) {
     if (c->done) return;
     const uint32_t want = c->n_ord;
     if (blockIdx.x * 256 >= want) return;
-    __shared__ OrdShared S;
-    ord_load_splitters(E, S);
     const uint32_t e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= want) return;
-    const uint32_t b = ord_bucket(S, E.tmp_key[e], E.tmp_id[e]);
+    uint32_t b;
+    if (c->superset) {
+        if (e >= want) return;
+        const uint64_t key = E.tmp_key[e];
+        const uint32_t shift = c->shift;
+        const uint64_t off = key - c->sel_kmin;
+        uint64_t f64 = off >> shift;
+        const uint32_t f = f64 < NBIN ? (uint32_t)f64 : NBIN - 1;
+        const uint32_t lg = E.sub_lg[f];
+        uint64_t sub = (off - ((uint64_t)f << shift)) >> (shift - lg);
+        const uint32_t smax = (1u << lg) - 1u;
+        b = E.sub_base[f] + (sub < smax ? (uint32_t)sub : smax);
+    } else {
+        __shared__ OrdShared S;
+        ord_load_splitters(E, S);
+        if (e >= want) return;
+        b = ord_bucket(S, E.tmp_key[e], E.tmp_id[e]);
+    }
     E.ord_b[e] = b;
     E.ord_s[e] = atomicAdd(&E.bcnt[b], 1u);
 }
 
-// exclusive prefix of bcnt[0..2048] into LDS pre[0..2049] (256 threads)
-__device__ __forceinline__ void ord_prefix(const Eng& E, uint32_t* pre, uint32_t* wsum) {
+// O2: one workgroup — exclusive prefix of the bucket counts (and reset them for the next iteration)
+__global__ __launch_bounds__(1024) void k_ord_scan(Eng E) {
+    Ctl* c = E.ctl;
+    if (c->done) return;
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t s_carry;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    uint32_t v[8], s = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        v[k] = E.bcnt[8 * t + k];
-        s += v[k];
-    }
-    uint32_t incl = s;
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t u = __shfl_up(incl, o);
-        if (lane >= o) incl += u;
-    }
-    if (lane == 63) wsum[wv] = incl;
+    const uint32_t nb = c->nb2;
+    if (t == 0) s_carry = 0;
     __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < wv; w++) woff += wsum[w];
-    uint32_t run = incl - s + woff;
+    for (uint32_t base = 0; base < nb; base += 4096) {
+        uint32_t v[4], s4 = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        pre[8 * t + k] = run;
-        run += v[k];
+        for (int k = 0; k < 4; k++) {
+            uint32_t i = base + 4 * t + k;
+            v[k] = i < nb ? E.bcnt[i] : 0u;
+            if (i < nb) E.bcnt[i] = 0;
+            s4 += v[k];
+        }
+        uint32_t incl = s4;
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t u = __shfl_up(incl, o);
+            if (lane >= o) incl += u;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        uint32_t woff = s_carry;
+        for (int w = 0; w < wv; w++) woff += wsum[w];
+        uint32_t run = incl - s4 + woff;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t i = base + 4 * t + k;
+            if (i < nb) E.bpre[i] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (t == 1023) s_carry = run;
+        __syncthreads();
     }
-    if (t == 255) {
-        pre[2048] = run;
-        pre[2049] = run + E.bcnt[2048];
-    }
-    __syncthreads();
+    if (t == 0) E.bpre[nb] = s_carry;
 }
 
-// O2: scatter bucket-contiguously
+// O3: scatter bucket-contiguously
 __global__ __launch_bounds__(256) void k_ord_scatter(Eng E) {
     Ctl* c = E.ctl;
     if (c->done) return;
     const uint32_t want = c->n_ord;
-    if (blockIdx.x * 256 >= want) return;
-    __shared__ uint32_t pre[2050];
-    __shared__ uint32_t wsum[4];
-    ord_prefix(E, pre, wsum);
-    if (blockIdx.x == 0)
-        for (uint32_t j = threadIdx.x; j < 2050; j += 256) E.bpre[j] = pre[j];
     const uint32_t e = blockIdx.x * 256 + threadIdx.x;
     if (e >= want) return;
     const uint32_t b = E.ord_b[e];
-    const uint32_t p = pre[b] + E.ord_s[e];
+    const uint32_t p = E.bpre[b] + E.ord_s[e];
     E.ord_key[p] = E.tmp_key[e];
     E.ord_id[p] = E.tmp_id[e];
     E.ord_pb[p] = b;
 }
 
-// O3: rank inside the bucket -> final pop order; entries ranked past the batch return to FRONT'
+// O4: rank inside the bucket -> final pop order; entries ranked past the batch return to FRONT'
 __global__ __launch_bounds__(256) void k_ord_rank(Eng E) {
     Ctl* c = E.ctl;
     if (c->done) return;
@@ -1083,10 +1149,12 @@ __global__ void k_post_pop(Eng E) {
 // ---------------------------------------------------------------------------------------------
 // expand: gather the popped parents by id, write children rows + node fields + hash/solved/heuristic
 // ---------------------------------------------------------------------------------------------
+constexpr int kEngTile = 16;  // parents per workgroup: a 20 000-parent batch then fills the chip (1250 workgroups)
 template <int ENV, int DIM, int OH>
 __global__ __launch_bounds__(kThreads) void k_expand(Eng E, int heur_id) {
     using EV = EnvT<ENV, DIM>;
-    using TL = Tile<ENV, DIM>;
+    using TL = Tile<ENV, DIM, kEngTile>;
+    constexpr int kTileParents = kEngTile;  // shadows the stand-alone kernels' 64
     Ctl* c = E.ctl;
     if (c->done) return;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1107,32 +1175,19 @@ __global__ __launch_bounds__(kThreads) void k_expand(Eng E, int heur_id) {
         // a 256-thread block fetches 16 rows per round and the 4 rounds are issued back to back.
         constexpr int WPR = (EV::D + 3) / 4;  // words per row (<= 14)
         static_assert(WPR <= 16, "row wider than 64 bytes");
-        const uint32_t w = threadIdx.x & 15, rr = threadIdx.x >> 4;
-        uint32_t val[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t r = rr + 16 * k;
-            val[k] = 0;
-            if (r < np && w < WPR) {
-                const uint8_t* row = E.state + (size_t)E.pop_id[r0 + r] * EV::D;
-                // rows start at id*D: read byte-wise only where a word would cross the row end
-                if (4 * w + 4 <= EV::D) {
-                    uint32_t v;
-                    __builtin_memcpy(&v, row + 4 * w, 4);
-                    val[k] = v;
-                } else {
-                    for (int b = 0; 4 * w + b < EV::D; b++) val[k] |= (uint32_t)row[4 * w + b] << (8 * b);
-                }
+        const uint32_t w = threadIdx.x & 15, r = threadIdx.x >> 4;  // 16 lanes per row, 16 rows
+        if (r < np && w < WPR) {
+            const uint8_t* row = E.state + (size_t)E.pop_id[r0 + r] * EV::D;
+            uint32_t v = 0;
+            // rows start at id*D: read byte-wise only where a word would cross the row end
+            if (4 * w + 4 <= EV::D) {
+                __builtin_memcpy(&v, row + 4 * w, 4);
+            } else {
+                for (int b = 0; 4 * w + b < EV::D; b++) v |= (uint32_t)row[4 * w + b] << (8 * b);
             }
-        }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t r = rr + 16 * k;
-            if (r < np && w < WPR) {
-#pragma unroll
-                for (int b = 0; b < 4; b++)
-                    if (4 * w + b < EV::D) lpar[r * EV::D + 4 * w + b] = (uint8_t)(val[k] >> (8 * b));
-            }
+            for (int b = 0; b < 4; b++)
+                if (4 * w + b < EV::D) lpar[r * EV::D + 4 * w + b] = (uint8_t)(v >> (8 * b));
         }
     }
     if constexpr (ENV == DCA_ENV_CUBE3) stage_tables<ENV, DIM>(ltab, lpar, np);
@@ -1527,8 +1582,8 @@ int dev_alloc(dca_engine* e, T** p, size_t count) {
 
 template <int ENV, int DIM>
 int launch_expand_env(const Eng& E, int heur_id, hipStream_t s) {
-    using TL = Tile<ENV, DIM>;
-    dim3 g((E.B + kTileParents - 1) / kTileParents), b(kThreads);
+    using TL = Tile<ENV, DIM, kEngTile>;
+    dim3 g((E.B + kEngTile - 1) / kEngTile), b(kThreads);
     if (E.onehot == nullptr)
         hipLaunchKernelGGL((k_expand<ENV, DIM, 0>), g, b, TL::LDS_BYTES, s, E, heur_id);
     else if (E.oh_dtype == DCA_DT_F32)
@@ -1561,6 +1616,7 @@ int enqueue_first_half(dca_engine* e, int heur_id, hipStream_t s) {
     hipLaunchKernelGGL(k_sel_collect, dim3(kScanBlocks), dim3(256), 0, s, E);
     hipLaunchKernelGGL(k_sel_cand, dim3(1), dim3(1024), 0, s, E);
     hipLaunchKernelGGL(k_ord_count, dim3((E.ord_cap + 255) / 256), dim3(256), 0, s, E);
+    hipLaunchKernelGGL(k_ord_scan, dim3(1), dim3(1024), 0, s, E);
     hipLaunchKernelGGL(k_ord_scatter, dim3((E.ord_cap + 255) / 256), dim3(256), 0, s, E);
     hipLaunchKernelGGL(k_ord_rank, dim3((E.ord_cap + 255) / 256), dim3(256), 0, s, E);
     hipLaunchKernelGGL(k_post_pop, dim3(1), dim3(64), 0, s, E);
@@ -1637,9 +1693,8 @@ int dca_engine_create(dca_engine** out, int env, int dim, double weight, int bat
         ALLOC(open_id[b], N);
     }
     ALLOC(hist, NBIN);
-    ALLOC(bin_start, NBIN + 1);
-    ALLOC(bin_fill, NBIN);
-    ALLOC(tail_start, NBIN + 1);
+    ALLOC(sub_base, NBIN);
+    ALLOC(sub_lg, NBIN);
     ALLOC(cand_key, N);
     ALLOC(cand_id, N);
     ALLOC(cand_st, N);
@@ -1654,8 +1709,9 @@ int dca_engine_create(dca_engine** out, int env, int dim, double weight, int bat
     ALLOC(ord_pb, Bz);
     ALLOC(spl_key, 2048);
     ALLOC(spl_id, 2048);
-    ALLOC(bcnt, 2056);
-    ALLOC(bpre, 2056);
+    E.nb2_cap = (uint32_t)(Bz / 2 + 4096);
+    ALLOC(bcnt, E.nb2_cap + 8);
+    ALLOC(bpre, E.nb2_cap + 8);
     ALLOC(child_hash, M);
     ALLOC(child_key, M);
     ALLOC(child_slot, M);
@@ -1684,7 +1740,7 @@ int dca_engine_create(dca_engine** out, int env, int dim, double weight, int bat
     e->h_cost = reinterpret_cast<double*>(e->h_moves + kMaxMoves);
     (void)hipMemset(E.nnet_in, 0, M * D);
     (void)hipMemset(E.hist, 0, NBIN * sizeof(uint32_t));
-    (void)hipMemset(E.bin_fill, 0, NBIN * sizeof(uint32_t));
+    (void)hipMemset(E.bcnt, 0, (E.nb2_cap + 8) * sizeof(uint32_t));
     (void)hipMemset(E.ctl, 0, sizeof(Ctl));
     *out = e;
     return 0;
@@ -1827,7 +1883,8 @@ int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, float* ms_
         hipLaunchKernelGGL(k_sel_cand, dim3(1), dim3(1024), 0, s, E);
         (void)hipEventRecord(ev[k++], s);
         hipLaunchKernelGGL(k_ord_count, dim3((E.ord_cap + 255) / 256), dim3(256), 0, s, E);
-        hipLaunchKernelGGL(k_ord_scatter, dim3((E.ord_cap + 255) / 256), dim3(256), 0, s, E);
+        hipLaunchKernelGGL(k_ord_scan, dim3(1), dim3(1024), 0, s, E);
+    hipLaunchKernelGGL(k_ord_scatter, dim3((E.ord_cap + 255) / 256), dim3(256), 0, s, E);
         hipLaunchKernelGGL(k_ord_rank, dim3((E.ord_cap + 255) / 256), dim3(256), 0, s, E);
         (void)hipEventRecord(ev[k++], s);
         hipLaunchKernelGGL(k_post_pop, dim3(1), dim3(64), 0, s, E);

@@ -20,12 +20,12 @@ struct EnvT<DCA_ENV_NPUZZLE, DIM> {
 };
 
 // LDS view of one parent tile + its move tables
-template <int ENV, int DIM>
+template <int ENV, int DIM, int TP = kTileParents>
 struct Tile {
     using E = EnvT<ENV, DIM>;
-    static constexpr int PAR_BYTES = ((kTileParents * E::D + 15) / 16) * 16;
-    static constexpr int TAB_BYTES = ENV == DCA_ENV_CUBE3 ? ((12 * 54 + 15) / 16) * 16 : kTileParents * 8;
-    static constexpr int LDS_BYTES = PAR_BYTES + TAB_BYTES + 16;
+    static constexpr int PAR_BYTES = ((TP * E::D + 15) / 16) * 16;
+    static constexpr int TAB_BYTES = ENV == DCA_ENV_CUBE3 ? ((12 * 54 + 15) / 16) * 16 : TP * 8;
+    static constexpr int LDS_BYTES = PAR_BYTES + TAB_BYTES + 16 + 256;  // slack: the last one-hot lane may peek one row past the tile
 
     const uint8_t* par;  // [64][D]
     const uint8_t* tab;  // cube3: perm[12*54]; puzzle: per parent {z, s0, s1, s2, s3, pad..} (8 B)
