@@ -388,8 +388,13 @@ __global__ void k_root_commit(Eng E, const float* h_root) {
 // refill: when FRONT holds fewer than one batch, raise T and move the cheapest part of BACK over
 // (rare: amortised over the iterations FRONT then lasts).  Always enqueued; exits early when idle.
 // ---------------------------------------------------------------------------------------------
+// The refill kernels are only enqueued every kRefillPeriod-th iteration (they cost a few microseconds
+// even when idle), so they top FRONT up early enough to last until the next check: an iteration
+// removes at most B entries from FRONT.
+constexpr int kRefillPeriod = 8;
 __device__ __forceinline__ bool need_refill(const Eng& E, const Ctl* c) {
-    return c->open_n[c->cur_b].v != c->back_dead.v && c->open_n[c->cur_f].v < (uint32_t)E.B;
+    return c->open_n[c->cur_b].v != c->back_dead.v &&
+           c->open_n[c->cur_f].v < (uint32_t)(kRefillPeriod + 1) * (uint32_t)E.B;
 }
 constexpr uint64_t DEAD = ~0ull;  // tombstone key of a BACK entry that moved to FRONT
 
@@ -1558,9 +1563,10 @@ struct dca_engine {
     double* d_cost;
     double* h_cost;
     int phase;  // 0 idle, 1 between pop_expand and commit
-    hipGraph_t graph;
-    hipGraphExec_t graph_exec;
+    hipGraph_t graph[2];          // [0] iteration without / [1] with the refill check
+    hipGraphExec_t graph_exec[2];
     int graph_heur;
+    long host_iter;               // iterations enqueued since reset (drives the refill cadence)
     void* allocs[48];
     int nalloc;
 };
@@ -1606,11 +1612,13 @@ int launch_expand(const Eng& E, int heur_id, hipStream_t s) {
 
 constexpr int kScanBlocks = 256;  // persistent-style grids: few fat blocks, cheap to launch when they early-exit
 
-int enqueue_first_half(dca_engine* e, int heur_id, hipStream_t s) {
+int enqueue_first_half(dca_engine* e, int heur_id, bool with_refill, hipStream_t s) {
     const Eng& E = e->E;
-    hipLaunchKernelGGL(k_refill_hist, dim3(kScanBlocks), dim3(256), 0, s, E);
-    hipLaunchKernelGGL(k_refill_scan, dim3(1), dim3(1024), 0, s, E);
-    hipLaunchKernelGGL(k_refill_move, dim3(kScanBlocks), dim3(256), 0, s, E);
+    if (with_refill) {
+        hipLaunchKernelGGL(k_refill_hist, dim3(kScanBlocks), dim3(256), 0, s, E);
+        hipLaunchKernelGGL(k_refill_scan, dim3(1), dim3(1024), 0, s, E);
+        hipLaunchKernelGGL(k_refill_move, dim3(kScanBlocks), dim3(256), 0, s, E);
+    }
     hipLaunchKernelGGL(k_sel_hist, dim3(kScanBlocks), dim3(256), 0, s, E);
     hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(1024), 0, s, E);
     hipLaunchKernelGGL(k_sel_collect, dim3(kScanBlocks), dim3(256), 0, s, E);
@@ -1748,8 +1756,10 @@ int dca_engine_create(dca_engine** out, int env, int dim, double weight, int bat
 
 void dca_engine_destroy(dca_engine* e) {
     if (!e) return;
-    if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
-    if (e->graph) (void)hipGraphDestroy(e->graph);
+    for (int g = 0; g < 2; g++) {
+        if (e->graph_exec[g]) (void)hipGraphExecDestroy(e->graph_exec[g]);
+        if (e->graph[g]) (void)hipGraphDestroy(e->graph[g]);
+    }
     for (int i = 0; i < e->nalloc; i++) (void)hipFree(e->allocs[i]);
     if (e->h_ctl) (void)hipHostFree(e->h_ctl);
     delete e;
@@ -1767,6 +1777,7 @@ int dca_engine_reset(dca_engine* e, const uint8_t* root, void* stream) {
     hipLaunchKernelGGL(k_init_table, dim3(4096), dim3(256), 0, s, E.tab, E.tab_cap);
     hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, s, E);
     e->phase = 0;
+    e->host_iter = 0;
     return launch_check("k_reset");
 }
 
@@ -1791,7 +1802,7 @@ int dca_engine_pop_expand(dca_engine* e, const uint8_t** nnet_in, const void** o
         set_error("dca_engine_pop_expand called twice without dca_engine_commit");
         return DCA_E_STATE;
     }
-    if (int rc = enqueue_first_half(e, -1, (hipStream_t)stream)) return rc;
+    if (int rc = enqueue_first_half(e, -1, (e->host_iter++ % kRefillPeriod) == 0, (hipStream_t)stream)) return rc;
     if (nnet_in) *nnet_in = e->E.nnet_in;
     if (onehot) *onehot = e->E.onehot;
     if (m_capacity) *m_capacity = e->E.M;
@@ -1820,32 +1831,35 @@ int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph,
     hipStream_t s = (hipStream_t)stream;
     if (!use_graph) {
         for (int i = 0; i < iters; i++) {
-            if (int rc = enqueue_first_half(e, heur_id, s)) return rc;
+            if (int rc = enqueue_first_half(e, heur_id, (e->host_iter++ % kRefillPeriod) == 0, s)) return rc;
             if (int rc = enqueue_second_half(e, s)) return rc;
         }
         return 0;
     }
-    if (e->graph_exec == nullptr || e->graph_heur != heur_id) {
-        if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
-        if (e->graph) (void)hipGraphDestroy(e->graph);
-        e->graph_exec = nullptr;
-        e->graph = nullptr;
-        hipStream_t cs;
-        DCA_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-        hipError_t err = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
-        int rc = 0;
-        if (err == hipSuccess) {
-            rc = enqueue_first_half(e, heur_id, cs);
-            if (!rc) rc = enqueue_second_half(e, cs);
-            err = hipStreamEndCapture(cs, &e->graph);
+    if (e->graph_exec[0] == nullptr || e->graph_heur != heur_id) {
+        for (int g = 0; g < 2; g++) {
+            if (e->graph_exec[g]) (void)hipGraphExecDestroy(e->graph_exec[g]);
+            if (e->graph[g]) (void)hipGraphDestroy(e->graph[g]);
+            e->graph_exec[g] = nullptr;
+            e->graph[g] = nullptr;
+            hipStream_t cs;
+            DCA_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            hipError_t err = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+            int rc = 0;
+            if (err == hipSuccess) {
+                rc = enqueue_first_half(e, heur_id, g == 1, cs);
+                if (!rc) rc = enqueue_second_half(e, cs);
+                err = hipStreamEndCapture(cs, &e->graph[g]);
+            }
+            (void)hipStreamDestroy(cs);
+            if (err != hipSuccess) return hip_fail(err, "hipStream capture");
+            if (rc) return rc;
+            DCA_HIP(hipGraphInstantiate(&e->graph_exec[g], e->graph[g], nullptr, nullptr, 0));
         }
-        (void)hipStreamDestroy(cs);
-        if (err != hipSuccess) return hip_fail(err, "hipStream capture");
-        if (rc) return rc;
-        DCA_HIP(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
         e->graph_heur = heur_id;
     }
-    for (int i = 0; i < iters; i++) DCA_HIP(hipGraphLaunch(e->graph_exec, s));
+    for (int i = 0; i < iters; i++)
+        DCA_HIP(hipGraphLaunch(e->graph_exec[(e->host_iter++ % kRefillPeriod) == 0 ? 1 : 0], s));
     return 0;
 }
 
@@ -1870,9 +1884,11 @@ int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, float* ms_
     for (int it = 0; it < iters && !rc; it++) {
         int k = 0;
         (void)hipEventRecord(ev[k++], s);
-        hipLaunchKernelGGL(k_refill_hist, dim3(kScanBlocks), dim3(256), 0, s, E);
-        hipLaunchKernelGGL(k_refill_scan, dim3(1), dim3(1024), 0, s, E);
-        hipLaunchKernelGGL(k_refill_move, dim3(kScanBlocks), dim3(256), 0, s, E);
+        if ((e->host_iter++ % kRefillPeriod) == 0) {
+            hipLaunchKernelGGL(k_refill_hist, dim3(kScanBlocks), dim3(256), 0, s, E);
+            hipLaunchKernelGGL(k_refill_scan, dim3(1), dim3(1024), 0, s, E);
+            hipLaunchKernelGGL(k_refill_move, dim3(kScanBlocks), dim3(256), 0, s, E);
+        }
         (void)hipEventRecord(ev[k++], s);
         hipLaunchKernelGGL(k_sel_hist, dim3(kScanBlocks), dim3(256), 0, s, E);
         (void)hipEventRecord(ev[k++], s);

@@ -1,0 +1,159 @@
+"""Batched weighted A* (BWAS) command line — the `--language hip` driver.
+
+Mirror of the reference CLI `search_methods/astar.py:343-397` (same flags incl. argparse prefix matching such
+as `--model` for `--model_dir`, same `results.pkl` keys, same per-state log line, same `--start_idx`
+semantics) with the search itself running on the device-resident engine (libdca_hip.so):
+
+    python -m deepcubea_amd.search_methods.astar --states data/cube3/test/data_0.pkl \
+        --model_dir saved_models/cube3/current/ --env cube3 --weight 0.6 --batch_size 10000 \
+        --results_dir results/cube3/ --language hip --nnet_batch_size 10000
+
+Multi-GPU: launch under `python -m torch.distributed.run --nproc-per-node N ...`; test scrambles are sharded
+per instance (state i -> rank i mod N), every rank holds a replica of the heuristic network and
+its own OPEN/CLOSED/node pool, and rank 0 merges the results in state order.  No collective on the data path.
+
+`bwas_hip(args, env, states)` has the signature and return value of the reference's `bwas_python` /
+`bwas_cpp` (astar.py:400-568) so it drops into the `--language` switch at astar.py:385-390.
+"""
+from __future__ import annotations
+
+import os
+import pickle
+import sys
+import time
+from argparse import ArgumentParser
+from typing import Any, Dict, List, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..utils import data_utils, env_utils, nnet_utils, search_utils
+from . import sharding
+from .engine import BwasEngine
+
+
+def _load_heuristic(args, env):
+    """Device heuristic closure.  `--model_dir synthetic:SEED` builds the environment's network with
+    deterministic synthetic weights (the reference checkpoints are not redistributable here)."""
+    device, devices, on_gpu = nnet_utils.get_device()
+    print("device: %s, devices: %s, on_gpu: %s" % (device, devices, on_gpu))
+    if not on_gpu:
+        raise _lib.DcaError("--language hip needs an MI355X: no HIP device visible")
+    nnet = env.get_nnet_model()
+    if str(args.model_dir).startswith("synthetic:"):
+        from ..utils.synthetic_weights import load_synthetic_weights
+        load_synthetic_weights(nnet, int(str(args.model_dir).split(":", 1)[1]))
+        nnet.eval()
+    else:
+        nnet = nnet_utils.load_nnet("%s/model_state_dict.pt" % args.model_dir, nnet, device=device)
+    nnet.to(device)
+    if getattr(args, "fold_bn", False):
+        from ..utils.pytorch_models import fold_batchnorm
+        nnet = fold_batchnorm(nnet).to(device)
+    ac = {"fp32": None, "bf16": torch.bfloat16, "fp16": torch.float16}[getattr(args, "nnet_dtype", "fp32")]
+    return nnet_utils.get_heuristic_fn_dev(nnet, clip_zero=False, batch_size=args.nnet_batch_size, autocast_dtype=ac)
+
+
+def bwas_hip(args, env, states: List) -> Tuple[List[List[int]], List[List], List[float], List[int]]:
+    """astar.py:400-454 (bwas_python) with the engine in place of AStar.  Returns
+    (solns, paths, times, num_nodes_gen) for `states`, in order."""
+    heuristic_fn = _load_heuristic(args, env)
+    sem = _lib.SEM_CPP if getattr(args, "semantics", "py") == "cpp" else _lib.SEM_PY
+    oh = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[getattr(args, "nnet_dtype", "fp32")]
+    eng = BwasEngine(args.env, args.weight, args.batch_size, max_nodes=int(getattr(args, "max_nodes", 1 << 26)),
+                     semantics=sem, onehot_dtype=oh)
+    world, rank = sharding.world_info()
+    mine = sharding.shard_indices(len(states), world, rank)
+    local: Dict[int, Tuple[List[int], List, float, int]] = {}
+    for state_idx in mine:
+        state = states[state_idx]
+        start_time = time.time()
+        root = np.ascontiguousarray(env._get_arr(state), dtype=np.uint8)
+        res = eng.solve(root, heuristic_fn)
+        if not res["solved"]:
+            raise _lib.DcaError("state %d: search stopped without a solution (%s) — raise --max_nodes"
+                                % (state_idx, "node pool exhausted" if res["failed"] else "OPEN empty"))
+        soln: List[int] = res["moves"]
+        path_cost: float = res["path_cost"]
+        num_nodes_gen_idx: int = int(res["nodes_generated"])
+        # path of states along the solution (astar.py:213-229 get_path / 534-546 replay)
+        path = [state]
+        cur = state
+        for move in soln:
+            cur = env.next_state([cur], move)[0][0]
+            path.append(cur)
+        solve_time = time.time() - start_time
+        assert search_utils.is_valid_soln(state, soln, env)  # astar.py:443
+        local[state_idx] = (soln, path, solve_time, num_nodes_gen_idx)
+        print("State: %i, SolnCost: %.2f, # Moves: %i, "
+              "# Nodes Gen: %s, Time: %.2f" % (state_idx, path_cost, len(soln), format(num_nodes_gen_idx, ","),
+                                               solve_time))
+    eng.close()
+    merged = sharding.gather_results(local, len(states), world, rank)
+    if merged is None:  # non-zero ranks
+        return [], [], [], []
+    solns = [merged[i][0] for i in range(len(states))]
+    paths = [merged[i][1] for i in range(len(states))]
+    times = [merged[i][2] for i in range(len(states))]
+    num_nodes_gen = [merged[i][3] for i in range(len(states))]
+    return solns, paths, times, num_nodes_gen
+
+
+def build_parser() -> ArgumentParser:
+    parser = ArgumentParser()
+    # reference flags (astar.py:346-362)
+    parser.add_argument('--states', type=str, required=True, help="File containing states to solve")
+    parser.add_argument('--model_dir', type=str, required=True, help="Directory of nnet model, or synthetic:SEED")
+    parser.add_argument('--env', type=str, required=True, help="Environment: cube3, puzzle15, puzzle24, ...")
+    parser.add_argument('--batch_size', type=int, default=1, help="Batch size for BWAS")
+    parser.add_argument('--weight', type=float, default=1.0, help="Weight of path cost")
+    parser.add_argument('--language', type=str, default="hip", help="hip (the MI355X engine)")
+    parser.add_argument('--results_dir', type=str, required=True, help="Directory to save results")
+    parser.add_argument('--start_idx', type=int, default=0, help="")
+    parser.add_argument('--nnet_batch_size', type=int, default=None,
+                        help="How many states the network evaluates at a time (memory only; results unchanged)")
+    parser.add_argument('--verbose', action='store_true', default=False, help="Set for verbose")
+    parser.add_argument('--debug', action='store_true', default=False, help="Set when debugging")
+    # engine options
+    parser.add_argument('--semantics', type=str, default="py", choices=["py", "cpp"],
+                        help="which reference search core to reproduce (astar.py vs parallel_weighted_astar.cpp)")
+    parser.add_argument('--max_nodes', type=int, default=1 << 26, help="node pool capacity (ids per search)")
+    parser.add_argument('--nnet_dtype', type=str, default="fp32", choices=["fp32", "bf16", "fp16"],
+                        help="fp32 = parity mode (1e-5); bf16/fp16 = faster, NOT parity")
+    parser.add_argument('--fold_bn', action='store_true', default=False, help="fold BatchNorm into the Linears")
+    return parser
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    world, rank = sharding.init_from_env()
+    if rank == 0 and not os.path.exists(args.results_dir):
+        os.makedirs(args.results_dir, exist_ok=True)
+    results_file: str = "%s/results.pkl" % args.results_dir
+    output_file: str = "%s/output.txt" % args.results_dir
+    if not args.debug and rank == 0:
+        sys.stdout = data_utils.Logger(output_file, "w")
+
+    input_data = data_utils.load_pickle(args.states)
+    states = input_data['states'][args.start_idx:]
+    env = env_utils.get_environment(args.env)
+
+    results: Dict[str, Any] = dict()
+    results["states"] = states
+    if args.language == "hip":
+        solns, paths, times, num_nodes_gen = bwas_hip(args, env, states)
+    else:
+        # astar.py:390 — the python / cpp cores are the reference's own; this package only ships hip
+        raise ValueError("Unknown language %s" % args.language)
+    if rank == 0:
+        results["solutions"] = solns
+        results["paths"] = paths
+        results["times"] = times
+        results["num_nodes_generated"] = num_nodes_gen
+        pickle.dump(results, open(results_file, "wb"), protocol=-1)
+    sharding.finalize()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,66 @@
+"""Per-instance sharding of test scrambles across ranks: replicas only, no data-path
+collective.  The reference's only hook is `--start_idx` (astar.py:354,376); here state i goes to rank
+i mod world and rank 0 merges the per-state results in state order.
+
+Under `torch.distributed.run` the ranks rendezvous with gloo (CPU objects are all that is exchanged:
+move lists, times, node counts); a single process needs no process group at all.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+
+def world_info() -> Tuple[int, int]:
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
+def init_from_env() -> Tuple[int, int]:
+    """Initialise from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run).  One GPU per rank."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+        if not dist.is_initialized():
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    return world, rank
+
+
+def shard_indices(n: int, world: int, rank: int) -> List[int]:
+    """Instance i -> rank i mod world (round robin keeps the expensive scrambles spread out)."""
+    return list(range(rank, n, world))
+
+
+def gather_results(local: Dict[int, tuple], n: int, world: int, rank: int) -> Optional[Dict[int, tuple]]:
+    """Merge per-rank {state index: result} dicts on rank 0 (None elsewhere)."""
+    if world == 1:
+        assert sorted(local) == list(range(n))
+        return local
+    import torch.distributed as dist
+    bucket = [None] * world if rank == 0 else None
+    dist.gather_object(local, bucket, dst=0)
+    if rank != 0:
+        return None
+    merged: Dict[int, tuple] = {}
+    for part in bucket:
+        for k, v in part.items():
+            assert k not in merged, "state %d solved twice" % k
+            merged[k] = v
+    assert sorted(merged) == list(range(n)), "missing states after merge"
+    return merged
+
+
+def finalize() -> None:
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()

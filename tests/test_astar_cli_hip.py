@@ -1,0 +1,140 @@
+"""GPU end-to-end tests of the `--language hip` driver and of the heuristic service on PyTorch-ROCm."""
+import os
+import pickle
+import re
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_pickle(path, arrays):
+    """A states pickle with the REFERENCE's class path (environments.cube3.Cube3State, int64 colors)."""
+    pkg, mod = types.ModuleType("environments"), types.ModuleType("environments.cube3")
+
+    class Cube3State:  # noqa
+        __slots__ = ['colors', 'hash']
+
+        def __init__(self, colors):
+            self.colors = colors
+            self.hash = None
+    Cube3State.__module__, Cube3State.__qualname__ = "environments.cube3", "Cube3State"
+    mod.Cube3State = Cube3State
+    sys.modules["environments"], sys.modules["environments.cube3"] = pkg, mod
+    try:
+        blob = pickle.dumps({"states": [Cube3State(a.astype(np.int64)) for a in arrays]}, protocol=2)
+    finally:
+        del sys.modules["environments"], sys.modules["environments.cube3"]
+    open(path, "wb").write(blob)
+
+
+def test_heuristic_forward_matches_reference_within_1e5(golden, tiny_resnet):
+    """north star: heuristic values within 1e-5 of the reference (fp32 both sides)."""
+    from deepcubea_amd.utils.pytorch_models import ResnetModel, fold_batchnorm
+    from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
+    from deepcubea_amd.utils import nnet_utils
+    from deepcubea_amd import _lib
+    m = ResnetModel(54, 6, 64, 32, 2, 1, True)
+    m.load_state_dict({k[2:]: torch.tensor(tiny_resnet[k]) for k in tiny_resnet.files if k.startswith("w:")})
+    m = m.cuda().eval()
+    x = torch.tensor(tiny_resnet["x"]).cuda()
+    hfn = nnet_utils.get_heuristic_fn_dev(m, batch_size=100)
+    y = hfn(x).cpu().numpy()
+    assert np.max(np.abs(y - tiny_resnet["y"])) < 1e-5
+    yo = hfn(_lib.onehot(x, 6, torch.float32), True).cpu().numpy()
+    assert np.array_equal(yo, y)
+    full = ResnetModel(54, 6, 5000, 1000, 4, 1, True)
+    load_synthetic_weights(full, 2024)
+    full = full.cuda().eval()
+    ref = golden["cube3_resnet_seed2024_y"]
+    with torch.no_grad():
+        yy = full(torch.tensor(golden["cube3_resnet_seed2024_x"]).cuda())[:, 0].cpu().numpy()
+        yf = fold_batchnorm(full)(torch.tensor(golden["cube3_resnet_seed2024_x"]).cuda())[:, 0].cpu().numpy()
+    tol = 1e-5 * max(1.0, float(np.abs(ref).max()))
+    assert np.max(np.abs(yy - ref)) < tol and np.max(np.abs(yf - ref)) < tol
+    # reference-signature closure (lists of State objects -> float64)
+    from deepcubea_amd.utils import env_utils
+    env = env_utils.get_environment("cube3")
+    states = env.np_to_states(golden["cube3_synth64_in"][:16])
+    h = nnet_utils.get_heuristic_fn(full, torch.device("cuda"), env, clip_zero=True, batch_size=7)(states)
+    assert h.dtype == np.float64 and h.shape == (16,) and (h >= 0).all()
+
+
+def test_cli_end_to_end(tmp_path, capsys):
+    from deepcubea_amd.search_methods import astar
+    from deepcubea_amd.utils import env_utils, nnet_utils
+    from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
+    from oracle import c_oracle as co
+    scr = [[0, 5, 7], [1, 3, 8, 10], [], [4, 9]]
+    roots = []
+    for mv in scr:
+        s = np.arange(54, dtype=np.uint8)[None]
+        for a in mv:
+            s = co.next_state("cube3", s, a)
+        roots.append(s[0])
+    spath = str(tmp_path / "states.pkl")
+    _ref_pickle(spath, roots)
+    rdir = str(tmp_path / "res")
+    B, w = 60, 0.8
+    astar.main(["--states", spath, "--model", "synthetic:11", "--env", "cube3", "--weight", str(w), "--batch_size",
+                str(B), "--results_dir", rdir, "--language", "hip", "--nnet_batch_size", "1000", "--max_nodes",
+                str(1 << 20)])
+    sys.stdout = sys.__stdout__
+    res = pickle.load(open(os.path.join(rdir, "results.pkl"), "rb"))
+    assert sorted(res.keys()) == ["num_nodes_generated", "paths", "solutions", "states", "times"]  # astar.py:382-397
+    log = open(os.path.join(rdir, "output.txt")).read()
+    lines = re.findall(r"State: (\d+), SolnCost: ([\d.]+), # Moves: (\d+), # Nodes Gen: ([\d,]+), Time: ([\d.]+)", log)
+    assert len(lines) == 4  # astar.py:449-452 line format
+    env = env_utils.get_environment("cube3")
+    # same search with the CPU oracle driven by the SAME device heuristic (padded to the engine's row count)
+    nnet = env.get_nnet_model()
+    load_synthetic_weights(nnet, 11)
+    nnet = nnet.cuda().eval()
+    hfn = nnet_utils.get_heuristic_fn_dev(nnet, batch_size=1000)
+    M = B * 12
+
+    def heur(states):
+        x = torch.zeros((max(M, len(states)), 54), dtype=torch.uint8, device="cuda")
+        x[:len(states)] = torch.from_numpy(np.ascontiguousarray(states // 9)).cuda()
+        return hfn(x)[:len(states)].cpu().numpy()
+
+    for i, root in enumerate(roots):
+        soln = res["solutions"][i]
+        s = root[None].copy()
+        for a in soln:
+            s = co.next_state("cube3", s, a)
+        assert co.is_solved("cube3", s)[0]
+        assert len(res["paths"][i]) == len(soln) + 1
+        assert int(lines[i][2]) == len(soln) and int(lines[i][3].replace(",", "")) == res["num_nodes_generated"][i]
+        ref = co.astar("cube3", root, w, B, co.SEM_PY, heur_fn=heur)
+        assert len(soln) == len(ref["moves"])
+        assert res["num_nodes_generated"][i] == ref["nodes_generated"], (i, res["num_nodes_generated"][i], ref)
+
+
+def test_nnet_bf16_mode_still_solves(tmp_path):
+    """bf16 heuristic = explicitly non-parity mode: only validity of the solution is asserted."""
+    from deepcubea_amd import _lib
+    from deepcubea_amd.search_methods.engine import BwasEngine
+    from deepcubea_amd.utils import nnet_utils
+    from deepcubea_amd.utils.pytorch_models import ResnetModel, fold_batchnorm
+    from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
+    from oracle import c_oracle as co
+    m = ResnetModel(54, 6, 5000, 1000, 4, 1, True)
+    load_synthetic_weights(m, 3)
+    m = fold_batchnorm(m).cuda().eval()
+    hfn = nnet_utils.get_heuristic_fn_dev(m, autocast_dtype=torch.bfloat16)
+    s = np.arange(54, dtype=np.uint8)[None]
+    for a in [2, 7, 9, 4]:
+        s = co.next_state("cube3", s, a)
+    eng = BwasEngine("cube3", 0.8, 200, max_nodes=1 << 21, onehot_dtype=torch.bfloat16)
+    res = eng.solve(s[0], hfn, max_iters=3000)
+    assert res["solved"]
+    t = s.copy()
+    for a in res["moves"]:
+        t = co.next_state("cube3", t, a)
+    assert co.is_solved("cube3", t)[0]
+    eng.close()

@@ -1,0 +1,82 @@
+"""world_size-2 gloo test (CPU) of the N>1 path: per-instance sharding + merge on rank 0.  The solver is the
+CPU oracle here (tests may use it); on the GPU box the same code path is driven by bwas_hip."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from deepcubea_amd.search_methods import sharding
+    from oracle import c_oracle as co
+    w, r = sharding.init_from_env()
+    assert (w, r) == (world, rank)
+    roots = []
+    scr = [[0, 5, 7, 2], [1, 3, 8], [4, 9, 1], [6], [], [11, 2, 6], [3, 3]]
+    for mv in scr:
+        s = np.arange(54, dtype=np.uint8)[None]
+        for a in mv:
+            s = co.next_state("cube3", s, a)
+        roots.append(s[0])
+    mine = sharding.shard_indices(len(roots), w, r)
+    assert mine == list(range(rank, len(roots), world))
+    local = {}
+    for i in mine:
+        res = co.astar("cube3", roots[i], 0.8, 50, co.SEM_PY, heur_builtin_id=1)
+        local[i] = (res["moves"], None, 0.0, res["nodes_generated"])
+    merged = sharding.gather_results(local, len(roots), w, r)
+    if r == 0:
+        assert sorted(merged) == list(range(len(roots)))
+        np.save(out_path, np.array([merged[i][3] for i in range(len(roots))], np.int64))
+        for i, mv in enumerate(scr):
+            s = roots[i][None].copy()
+            for a in merged[i][0]:
+                s = co.next_state("cube3", s, a)
+            assert co.is_solved("cube3", s)[0]
+    else:
+        assert merged is None
+    sharding.finalize()
+
+
+def test_two_rank_sharding_and_merge(tmp_path):
+    from oracle import c_oracle as co
+    co.lib()  # build once before forking workers
+    out = str(tmp_path / "nodes.npy")
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    nodes2 = np.load(out)
+    # single-process path gives the same merged answer
+    from deepcubea_amd.search_methods import sharding
+    assert sharding.shard_indices(7, 1, 0) == list(range(7))
+    assert sharding.gather_results({i: (None,) for i in range(3)}, 3, 1, 0) == {i: (None,) for i in range(3)}
+    assert nodes2.shape == (7,) and nodes2[4] == 12  # solved root: one expansion
+
+
+def test_cli_rejects_other_languages(tmp_path):
+    import pickle
+    import pytest
+    from deepcubea_amd.search_methods import astar
+    p = tmp_path / "s.pkl"
+    pickle.dump({"states": []}, open(p, "wb"))
+    # argparse prefix matching like the reference's train.sh (`--model` for `--model_dir`)
+    args = astar.build_parser().parse_args(["--states", str(p), "--model", "synthetic:1", "--env", "cube3",
+                                            "--results_dir", str(tmp_path / "r")])
+    assert args.model_dir == "synthetic:1" and args.language == "hip" and args.batch_size == 1 and args.weight == 1.0
+    with pytest.raises(ValueError, match="Unknown language python"):
+        astar.main(["--states", str(p), "--model_dir", "x", "--env", "cube3", "--results_dir", str(tmp_path / "r"),
+                    "--language", "python", "--debug"])
