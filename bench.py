@@ -47,7 +47,12 @@ def synth_states(n: int, d: int, seed: int = 0) -> np.ndarray:
     return rng.permuted(np.tile(np.arange(d, dtype=np.uint8), (n, 1)), axis=1)
 
 
-def dist_setup():
+_BACKEND = "nccl"
+
+
+def dist_setup(backend: str = "nccl"):
+    global _BACKEND
+    _BACKEND = backend
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -55,8 +60,9 @@ def dist_setup():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # one rank per GPU (nccl = RCCL); gloo lets several ranks share a device for smoke tests
+        torch.cuda.set_device(local if backend == "nccl" else local % torch.cuda.device_count())
+        dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     return world, rank, local
@@ -74,7 +80,7 @@ def reduce_ranks(x: float, world: int, op: str) -> float:
     if world == 1:
         return x
     import torch.distributed as dist
-    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    t = torch.tensor([x], dtype=torch.float64, device="cuda" if _BACKEND == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
     return float(t.item())
 
@@ -121,6 +127,7 @@ def run_astar(args, world, rank):
     # per-kernel HIP-event timings of further iterations (same stream, eager, events between kernels)
     prof = eng.profile_builtin(hid, args.profile_iters) if args.profile_iters > 0 else {}
     st2 = eng.status()
+    dbg = eng.debug()
     if args.debug:
         for _ in range(12):
             eng.run_builtin(hid, 1)
@@ -140,11 +147,11 @@ def run_astar(args, world, rank):
     if prof:
         dom = max(prof, key=prof.get)
         # algorithmic bytes of the dominant kernel per launch
-        n_open = 0.5 * (st1["open_size"] + st2["open_size"]) + B
+        n_front = dbg["front_n"] + B  # FRONT tier at the last profiled iteration (pops only scan FRONT)
         alg = {
             "expand": CUBE3_ENGINE_EXPAND_BYTES * B,
-            "sel_hist": 8.0 * n_open,
-            "sel_collect": 24.0 * n_open,
+            "sel_hist": 8.0 * n_front,
+            "sel_collect": 24.0 * n_front,
             "probe": B * 12 * (8 + 16 + 54 + 54 + 8 + 8),
             "decide": B * 12 * (16 + 4 + 4 + 4 + 1 + 4 + 8),
             "commit": B * 12 * (1 + 8 + 12),
@@ -158,7 +165,49 @@ def run_astar(args, world, rank):
     eng.close()
     del eng
     torch.cuda.empty_cache()
+    if args.concurrent > 1:
+        res["concurrent_instances"] = run_astar_concurrent(args, world, rank, sem, hid)
     return res
+
+
+def run_astar_concurrent(args, world, rank, sem, hid):
+    """k independent search instances per GPU, one HIP stream each (finer per-instance sharding: a batch-20 000
+    iteration is latency-bound and leaves most of the chip idle, so instances overlap).  Reported next to the
+    single-instance `value`, never instead of it."""
+    from deepcubea_amd import _lib
+    from deepcubea_amd.search_methods.engine import BwasEngine
+    k, B, w = args.concurrent, args.batch_size, args.weight
+    steps, warm = args.steps, args.warmup
+    engs, streams = [], [torch.cuda.Stream() for _ in range(k)]
+    for i in range(k):
+        e = BwasEngine("cube3", w, B, max_nodes=max(1 << 20, (steps + warm + 8) * B * 12 + (1 << 16)), semantics=sem)
+        root = test_root(rank * k + i)
+        with torch.cuda.stream(streams[i]):
+            e.reset(root)
+            if sem == _lib.SEM_PY:
+                e.root_commit(_lib.heuristic_builtin(hid, torch.from_numpy(root[None].copy()).cuda()))
+            e.run_builtin(hid, warm, use_graph=not args.no_graph)
+        engs.append(e)
+    st0 = [e.status() for e in engs]
+    barrier(world)
+    t0 = time.perf_counter()
+    chunk = 10  # interleave the enqueues so every stream always has work
+    for c0 in range(0, steps, chunk):
+        for i in range(k):
+            with torch.cuda.stream(streams[i]):
+                engs[i].run_builtin(hid, min(chunk, steps - c0), use_graph=not args.no_graph)
+    barrier(world)
+    wall = time.perf_counter() - t0
+    st1 = [e.status() for e in engs]
+    expanded = sum(b["nodes_expanded"] - a["nodes_expanded"] for a, b in zip(st0, st1))
+    assert all(not s["failed"] and not s["done"] for s in st1)
+    wall = reduce_ranks(wall, world, "max")
+    total = reduce_ranks(float(expanded), world, "sum")
+    for e in engs:
+        e.close()
+    torch.cuda.empty_cache()
+    return {"instances_per_gpu": k, "value": total / wall, "unit": "nodes expanded/s",
+            "ms_per_step_per_instance": wall / steps * 1e3}
 
 
 def run_astar_nnet(args, world, rank, dtype_name: str):
@@ -308,6 +357,8 @@ def main():
     ap.add_argument("--nnet-steps", type=int, default=4, help="astar: timed steps of the ResNet-heuristic leg (0=skip)")
     ap.add_argument("--nnet_batch_size", type=int, default=60000)
     ap.add_argument("--n", type=int, default=1_000_000, help="expand: synthetic states per launch")
+    ap.add_argument("--concurrent", type=int, default=4, help="astar: also time k concurrent instances per GPU (0/1 = skip)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug", action="store_true")
     args = ap.parse_args()
@@ -315,7 +366,7 @@ def main():
         args.steps = 200 if args.workload == "astar" else 20
     if args.warmup is None:
         args.warmup = 10 if args.workload == "astar" else 3
-    world, rank, local = dist_setup()
+    world, rank, local = dist_setup(args.dist_backend)
     res = run_astar(args, world, rank) if args.workload == "astar" else run_expand(args, world, rank)
     line = {
         "metric": "A* nodes expanded/sec on cube3, batch 20k" if args.workload == "astar"
@@ -335,6 +386,8 @@ def main():
     }
     if "roofline" in res:
         line["roofline"] = res["roofline"]
+    if "concurrent_instances" in res:
+        line["concurrent_instances"] = res["concurrent_instances"]
     if args.workload == "astar" and args.nnet_steps > 0:
         line["end_to_end_nnet"] = {"fp32": run_astar_nnet(args, world, rank, "fp32"),
                                    "bf16": run_astar_nnet(args, world, rank, "bf16")}
