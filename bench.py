@@ -276,6 +276,54 @@ def cpu_baseline_astar(args, seconds_budget: float = 20.0):
 
 
 # --------------------------------------------------------------------------------------------------
+# workload: avi (configs[4]'s update step)
+# --------------------------------------------------------------------------------------------------
+def run_avi(args, world, rank):
+    """One step = the AVI update of `--n` cube3 training states on this GPU: random reverse walks from the goal
+    (0..30 moves), expansion, ResNet heuristic on all 12 children, Bellman backup (1 GBFS step, eps 0) — the
+    data-generation half of ctg_approx/avi.py:do_update.  value = training states produced per second."""
+    from deepcubea_amd.updaters.updater import Updater
+    from deepcubea_amd.utils import env_utils, nnet_utils
+    from deepcubea_amd.utils.pytorch_models import fold_batchnorm
+    from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
+    env = env_utils.get_environment("cube3")
+    model = env.get_nnet_model()
+    load_synthetic_weights(model, 2024)
+    model = fold_batchnorm(model).cuda().eval()
+    ac = torch.bfloat16 if args.nnet_dtype == "bf16" else None
+    hfn = nnet_utils.get_heuristic_fn_dev(model, clip_zero=False, batch_size=args.nnet_batch_size, autocast_dtype=ac)
+    n = args.n if args.n != 1_000_000 else 200_000
+    oh = torch.bfloat16 if ac is not None else torch.float32
+
+    def step(i):
+        upd = Updater(env, n * world, 30, hfn, 1, update_batch_size=100_000, seed=1000 + i, onehot_dtype=oh)
+        return upd.update_dev()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier(world)
+    t0 = time.perf_counter()
+    tot = 0
+    for i in range(args.steps):
+        sn, out, sv = step(100 + i)
+        tot += sn.shape[0]
+    barrier(world)
+    wall = reduce_ranks(time.perf_counter() - t0, world, "max")
+    total = reduce_ranks(float(tot), world, "sum")
+    flops = 2.0 * 14_621_000 * 12 * (tot / args.steps)
+    return {
+        "value": total / wall, "ms_per_step": wall / args.steps * 1e3,
+        "config": {"workload": "cube3 AVI update step (BASELINE configs[4] / avi.py:do_update): generate %d states "
+                               "(back_max 30) -> expand -> ResNet heuristic on 12 children -> Bellman backup; %s "
+                               "heuristic, synthetic weights" % (n, args.nnet_dtype),
+                   "states_per_step_per_gpu": n, "back_max": 30, "gbfs_steps": 1, "nnet_dtype": args.nnet_dtype,
+                   "parallelism": "state shards per GPU x%d" % world,
+                   "heuristic_tflops_per_gpu": flops / (wall / args.steps) / 1e12,
+                   "reference_published": "1.55e5 states/s on 3 GPUs + 30 CPU procs (saved_models/cube3/output.txt)"},
+    }
+
+
+# --------------------------------------------------------------------------------------------------
 # workload: expand (configs[1])
 # --------------------------------------------------------------------------------------------------
 def run_expand(args, world, rank):
@@ -348,7 +396,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="astar", choices=["astar", "expand"])
+    ap.add_argument("--workload", default="astar", choices=["astar", "expand", "avi"])
+    ap.add_argument("--nnet_dtype", default="fp32", choices=["fp32", "bf16"], help="avi: heuristic precision")
     ap.add_argument("--batch_size", type=int, default=20000)
     ap.add_argument("--weight", type=float, default=0.8)
     ap.add_argument("--semantics", default="py", choices=["py", "cpp"])
@@ -363,16 +412,16 @@ def main():
     ap.add_argument("--debug", action="store_true")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 200 if args.workload == "astar" else 20
+        args.steps = {"astar": 200, "expand": 20, "avi": 3}[args.workload]
     if args.warmup is None:
-        args.warmup = 10 if args.workload == "astar" else 3
+        args.warmup = {"astar": 10, "expand": 3, "avi": 1}[args.workload]
     world, rank, local = dist_setup(args.dist_backend)
-    res = run_astar(args, world, rank) if args.workload == "astar" else run_expand(args, world, rank)
+    res = {"astar": run_astar, "expand": run_expand, "avi": run_avi}[args.workload](args, world, rank)
     line = {
-        "metric": "A* nodes expanded/sec on cube3, batch 20k" if args.workload == "astar"
-                  else "A* nodes expanded/sec on cube3",
+        "metric": {"astar": "A* nodes expanded/sec on cube3, batch 20k", "expand": "A* nodes expanded/sec on cube3",
+                   "avi": "AVI update-step training states generated/sec on cube3"}[args.workload],
         "value": res["value"],
-        "unit": "nodes expanded/s",
+        "unit": "states/s" if args.workload == "avi" else "nodes expanded/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
@@ -391,7 +440,7 @@ def main():
     if args.workload == "astar" and args.nnet_steps > 0:
         line["end_to_end_nnet"] = {"fp32": run_astar_nnet(args, world, rank, "fp32"),
                                    "bf16": run_astar_nnet(args, world, rank, "bf16")}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "avi":
         line["cpu_baseline"] = cpu_baseline_astar(args) if args.workload == "astar" else cpu_baseline_expand()
     if rank == 0:
         print(json.dumps(line))

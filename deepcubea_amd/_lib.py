@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "dca_abi_version", "dca_last_error", "dca_cube3_perm_table", "dca_npuzzle_swap_table",
     "dca_cube3_next_state", "dca_cube3_prev_state", "dca_npuzzle_next_state", "dca_npuzzle_prev_state",
     "dca_cube3_expand_fused", "dca_npuzzle_expand_fused", "dca_is_solved", "dca_hash64", "dca_nnet_input",
-    "dca_onehot", "dca_heuristic_builtin",
+    "dca_onehot", "dca_heuristic_builtin", "dca_generate_states", "dca_bellman_backup",
     "dca_engine_create", "dca_engine_destroy", "dca_engine_reset", "dca_engine_root_commit",
     "dca_engine_root_nnet_in", "dca_engine_pop_expand", "dca_engine_commit", "dca_engine_run_builtin",
     "dca_engine_profile_builtin", "dca_engine_debug", "dca_engine_status", "dca_engine_last_children", "dca_engine_solution",
@@ -211,3 +211,29 @@ def heuristic_builtin(heur_id: int, states: torch.Tensor) -> torch.Tensor:
     check(lib().dca_heuristic_builtin(heur_id, ptr(states), C.c_int64(states.shape[0]), states.shape[1], ptr(out),
                                       stream_ptr()), "dca_heuristic_builtin")
     return out
+
+
+def generate_states(env: int, dim: int, n: int, back_lo: int, back_hi: int, seed: int, index0: int = 0,
+                    want_moves: bool = False):
+    """Device random reverse walks from the goal -> (states [n,D] u8, num_back [n] i32, moves [n,back_hi] i8|None)."""
+    dev = require_gpu()
+    D = 54 if env == ENV_CUBE3 else dim * dim
+    states = torch.empty((n, D), dtype=torch.uint8, device=dev)
+    nb = torch.empty((n,), dtype=torch.int32, device=dev)
+    mv = torch.full((n, max(back_hi, 1)), -1, dtype=torch.int8, device=dev) if want_moves else None
+    check(lib().dca_generate_states(env, dim, C.c_int64(n), int(back_lo), int(back_hi), C.c_uint64(seed & (2**64 - 1)),
+                                    C.c_int64(index0), ptr(states), ptr(nb), ptr(mv), max(back_hi, 1), stream_ptr()),
+          "dca_generate_states")
+    return states, nb, mv
+
+
+def bellman_backup(h_children: torch.Tensor, solved_parent: Optional[torch.Tensor], num_moves: int,
+                   clip_zero: bool = True):
+    """-> (ctg_backup f32 [n], argmin i32 [n])  (search_utils.py:16-32, gbfs.py:108)."""
+    h = h_children.to(torch.float32).contiguous()
+    n = h.numel() // num_moves
+    ctg = torch.empty((n,), dtype=torch.float32, device=h.device)
+    am = torch.empty((n,), dtype=torch.int32, device=h.device)
+    check(lib().dca_bellman_backup(ptr(h), ptr(solved_parent), C.c_int64(n), int(num_moves), int(clip_zero), ptr(ctg),
+                                   ptr(am), stream_ptr()), "dca_bellman_backup")
+    return ctg, am

@@ -111,23 +111,15 @@ class Environment(ABC):
         tc = np.ones((n, A))
         return states_exp, [tc[i] for i in range(n)]
 
-    def generate_states(self, num_states: int, backwards_range: Tuple[int, int]) -> Tuple[List[State], List[int]]:
-        """environment_abstract.py:88-125 (cube3.py:96-127, n_puzzle.py:100-134): start from the goal and
-        take `k_i ~ U{lo..hi}` reverse moves.  Device-resident random walk: at step t every state with
-        t < k_i takes an independent uniformly random reverse move (the reference draws one move per
-        randomly chosen subset; the per-state marginal is the same uniform walk)."""
+    def generate_states(self, num_states: int, backwards_range: Tuple[int, int], seed: int = None) -> Tuple[List[State], List[int]]:
+        """environment_abstract.py:88-125 (cube3.py:96-127, n_puzzle.py:100-134): start from the goal and take
+        `k_i ~ U{lo..hi}` reverse moves.  One launch of the device random-walk kernel (`dca_generate_states`): every
+        state takes its own independent uniformly random reverse moves (the reference draws one move per randomly
+        chosen subset; the per-state marginal is the same uniform walk)."""
         assert num_states > 0
         assert backwards_range[0] >= 0
         assert self.fixed_actions, "Environments without fixed actions must implement their own method"
-        A = self.get_num_moves()
-        scramble_nums = np.random.randint(backwards_range[0], backwards_range[1] + 1, size=num_states)
-        cur = self.to_device(self.generate_goal_states(num_states, np_format=True))
-        k = torch.from_numpy(scramble_nums).to(cur.device)
-        for t in range(int(scramble_nums.max()) if num_states else 0):
-            mv = torch.randint(0, A, (num_states,), device=cur.device)
-            live = k > t
-            for a in range(A):
-                idx = torch.nonzero(live & (mv == a)).flatten()
-                if idx.numel():
-                    cur[idx] = self.prev_state_dev(cur[idx], a)
-        return self.np_to_states(cur.cpu().numpy()), scramble_nums.tolist()
+        if seed is None:
+            seed = int(np.random.randint(0, 2 ** 31 - 1))
+        st, nb, _ = _lib.generate_states(self._env_id, self._dim, num_states, backwards_range[0], backwards_range[1], seed)
+        return self.np_to_states(st.cpu().numpy()), nb.cpu().numpy().tolist()

@@ -1,0 +1,144 @@
+"""Approximate-value-iteration UPDATE STEP on the device (BASELINE configs[4]).
+
+Mirror of the data-generation half of the reference's training loop — `ctg_approx/avi.py:129-159` (do_update),
+`updaters/updater.py:11-33,57-165` (gbfs_update, update_runner, Updater), `search_methods/gbfs.py:43-120`,
+`utils/search_utils.py:16-32` (bellman) — with the 30 CPU worker processes and the heuristic queues replaced by
+one replica per GPU: states are generated, expanded, evaluated and backed up without leaving HBM.
+
+    updater = Updater(env, num_states, back_max, heuristic_fn_dev, num_steps, "GBFS", eps_max=0.0)
+    states_nnet, ctg, is_solved = updater.update()      # same triple as updater.py:116-123
+
+Scope note: this is only the update step (targets for the cost-to-go network); the training step itself
+(`nnet_utils.train_nnet`) is out of scope.  ASTAR updates (updater.py:36-54) are not provided.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..search_methods import sharding
+
+
+def bellman_dev(env, states: torch.Tensor, heuristic_fn_dev: Callable, onehot_dtype=None):
+    """search_utils.bellman (search_utils.py:16-32) on device.
+    -> (ctg_backup f32 [n], argmin i32 [n], children u8 [n,A,D])."""
+    A = env.get_num_moves()
+    out = env.expand_dev(states, children=True, nnet_in=(onehot_dtype is None), onehot_dtype=onehot_dtype, solved=False,
+                         hashes=False)
+    h = heuristic_fn_dev(out["onehot"], True) if onehot_dtype is not None else heuristic_fn_dev(out["nnet_in"])
+    ctg, am = _lib.bellman_backup(h, env.is_solved_dev(states), A, clip_zero=True)  # avi.py:213 clip_zero=True
+    return ctg, am, out["children"]
+
+
+def gbfs_update_dev(states: torch.Tensor, env, num_steps: int, heuristic_fn_dev: Callable, eps_max: float = 0.0,
+                    generator: Optional[torch.Generator] = None, onehot_dtype=None,
+                    rand_child: Optional[Callable[[int, int], torch.Tensor]] = None):
+    """updater.py:11-33 gbfs_update with GBFS.step (gbfs.py:43-120) for all instances at once.
+    -> (states_update u8 [T,D], cost_to_go f32 [T], is_solved bool [n]) in the reference's instance-major order.
+    `rand_child(k, A)` may override the random-child draw (tests stub it, like np.random.choice)."""
+    n, D = states.shape
+    A = env.get_num_moves()
+    dev = states.device
+    cur = states.clone()
+    solved = torch.zeros(n, dtype=torch.bool, device=dev)
+    eps = torch.rand(n, device=dev, generator=generator) * eps_max  # updater.py:12
+    traj_states: List[torch.Tensor] = []
+    traj_ctg: List[torch.Tensor] = []
+    traj_inst: List[torch.Tensor] = []
+    hist: List[Tuple[torch.Tensor, torch.Tensor]] = []  # (instance idx, state rows) per recorded step, for seen-checks
+    arange = torch.arange(n, device=dev)
+    for _ in range(num_steps):
+        uns = arange[~solved]
+        if uns.numel():  # _record_solved (gbfs.py:67-84)
+            sv = env.is_solved_dev(cur[uns]).bool()
+            idx = uns[sv]
+            if idx.numel():
+                traj_states.append(cur[idx].clone())
+                traj_ctg.append(torch.zeros(idx.numel(), dtype=torch.float32, device=dev))
+                traj_inst.append(idx)
+                solved[idx] = True
+        uns = arange[~solved]
+        if uns.numel() == 0:
+            continue
+        st = cur[uns].contiguous()  # _move (gbfs.py:86-120)
+        ctg, am, children = bellman_dev(env, st, heuristic_fn_dev, onehot_dtype)
+        traj_states.append(st)
+        traj_ctg.append(ctg)
+        traj_inst.append(uns)
+        hist.append((uns, st))
+        k = uns.numel()
+        rows = torch.arange(k, device=dev)
+        nxt = children[rows, am.long()]
+        # seen_states (gbfs.py:110-111): every state this instance already put on its trajectory
+        seen = torch.zeros(k, dtype=torch.bool, device=dev)
+        pos = torch.full((n,), -1, dtype=torch.long, device=dev)
+        pos[uns] = rows
+        for h_idx, h_st in hist:
+            p = pos[h_idx]
+            ok = p >= 0
+            if ok.any():
+                eq = (h_st[ok] == nxt[p[ok]]).all(dim=1)
+                seen[p[ok]] |= eq
+        rnd = torch.rand(k, device=dev, generator=generator) < eps[uns]
+        pick_rand = rnd | seen
+        if pick_rand.any():
+            kk = int(pick_rand.sum())
+            ridx = rand_child(kk, A) if rand_child is not None else torch.randint(0, A, (kk,), device=dev,
+                                                                                   generator=generator)
+            nxt[pick_rand] = children[rows[pick_rand], ridx.to(dev).long()]
+        cur[uns] = nxt
+    if not traj_states:
+        return (torch.zeros((0, D), dtype=torch.uint8, device=dev), torch.zeros(0, dtype=torch.float32, device=dev),
+                solved)
+    su = torch.cat(traj_states)
+    cg = torch.cat(traj_ctg)
+    inst = torch.cat(traj_inst)
+    order = torch.sort(inst, stable=True).indices  # instance-major, steps in order (misc_utils.flatten(trajs))
+    return su[order], cg[order], solved
+
+
+class Updater:
+    """Drop-in for updaters/updater.py:84-165: same constructor meaning and `update()` triple, but
+    `heur_fn_i_q / heur_fn_o_qs` become a device heuristic closure and the worker processes become ranks:
+    every rank generates and backs up its share (split_evenly) of `num_states` on its own GPU."""
+
+    def __init__(self, env, num_states: int, back_max: int, heuristic_fn_dev: Callable, num_steps: int,
+                 update_method: str = "GBFS", update_batch_size: int = 1_000_000, eps_max: float = 0.0, seed: int = 0,
+                 onehot_dtype=None):
+        if update_method.upper() != "GBFS":
+            raise ValueError("Unknown update method %s" % update_method)  # updater.py:73 (ASTAR not provided)
+        self.env, self.num_states, self.back_max = env, int(num_states), int(back_max)
+        self.hfn, self.num_steps, self.eps_max = heuristic_fn_dev, int(num_steps), float(eps_max)
+        self.batch, self.seed, self.onehot_dtype = int(update_batch_size), int(seed), onehot_dtype
+        self.world, self.rank = sharding.world_info()
+        per = [self.num_states // self.world + (1 if r < self.num_states % self.world else 0) for r in range(self.world)]
+        self.local_n = per[self.rank]  # misc_utils.split_evenly (misc_utils.py:29-36)
+        self.index0 = sum(per[:self.rank])
+
+    def update_dev(self):
+        """This rank's shard, on device: (states_nnet u8 [T,D], ctg f32 [T,1], is_solved bool [local_n])."""
+        env = self.env
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(self.seed * 1000003 + self.rank)
+        sn, cg, sv = [], [], []
+        start = 0
+        while start < self.local_n:
+            m = min(self.batch, self.local_n - start)
+            states, _, _ = _lib.generate_states(env._env_id, env._dim, m, 0, self.back_max, self.seed,
+                                                self.index0 + start)  # updater.py:66 env.generate_states(n,(0,back_max))
+            su, ctg, solved = gbfs_update_dev(states, env, self.num_steps, self.hfn, self.eps_max, gen,
+                                              self.onehot_dtype)
+            sn.append(_lib.nnet_input(env._env_id, env._dim, su))  # updater.py:75 state_to_nnet_input
+            cg.append(ctg)
+            sv.append(solved)
+            start += m
+        return torch.cat(sn), torch.cat(cg)[:, None], torch.cat(sv)
+
+    def update(self):
+        """updater.py:116-123: (states_update_nnet: List[np.ndarray], output_update [T,1], is_solved) for THIS rank's
+        shard (a trainer on the same rank consumes it; no collective is needed for the update itself)."""
+        sn, out, sv = self.update_dev()
+        return [sn.cpu().numpy()], out.cpu().numpy(), sv.cpu().numpy()

@@ -107,6 +107,20 @@ int dca_onehot(const uint8_t* idx, int64_t n, int state_dim, int depth, void* ou
 /* built-in deterministic heuristics on raw states -> f32 */
 int dca_heuristic_builtin(int heur_id, const uint8_t* states, int64_t n, int state_dim, float* out, void* stream);
 
+/* ---- (f)-1: approximate-value-iteration update step (ctg_approx/avi.py:129-159 do_update) -----------
+ * generate_states (cube3.py:96-127 / n_puzzle.py:100-134): state i = goal after k_i ~ U{back_lo..back_hi}
+ * uniformly random REVERSE moves; counter-based RNG keyed by (seed, index0 + i, step) so shards are
+ * reproducible and independent.  out_num_back[n] / out_moves[n, moves_stride] (the forward move undone at
+ * each step, -as taken-) are optional (NULL).                                                        */
+int dca_generate_states(int env, int dim, int64_t n, int back_lo, int back_hi, uint64_t seed, int64_t index0,
+                        uint8_t* out_states /*[n,D]*/, int32_t* out_num_back, int8_t* out_moves, int moves_stride,
+                        void* stream);
+/* search_utils.bellman (search_utils.py:16-32) after the children were expanded and evaluated:
+ * ctg_backup[i] = solved_parent[i] ? 0 : min_a(1 + h[i*A+a]) (max(h,0) first when clip_zero),
+ * argmin[i] = first a attaining it (gbfs.py:108 np.argmin).  Either output may be NULL.            */
+int dca_bellman_backup(const float* h_children /*[n*A]*/, const uint8_t* solved_parent /*[n] or NULL*/, int64_t n,
+                       int num_moves, int clip_zero, float* ctg_backup /*[n]*/, int32_t* argmin /*[n]*/, void* stream);
+
 /* state hash (a9).  The reference's hash VALUES are process-randomised SipHash (cube3.py:17-21)
  * or unpinned boost::hash_range (parallel_weighted_astar.cpp:104-111); what is pinned is key
  * equality.  This library defines, for a D-byte state split in little-endian 8-byte words

@@ -313,6 +313,72 @@ def main():
         cases.append(key)
     golden["astar_py_cases"] = np.array(cases)
 
+    # ------------------------------------------------- AVI update step
+    # reference updaters/updater.py:gbfs_update + search_utils.bellman with a deterministic heuristic, eps_max = 0.
+    # A revisited state triggers a random move (gbfs.py:112-116): np.random.choice is stubbed to return child 0
+    # while the fixture is recorded, so the seen-state logic itself is pinned deterministically.
+    from updaters.updater import gbfs_update
+    from utils import search_utils
+
+    def upd_case(env, mk_state, get_arr, roots, heur, steps):
+        def hfn(states, is_nnet_format=False):
+            arr = np.stack([get_arr(s) for s in states]).astype(np.uint8)
+            return np.maximum(heur(arr).astype(np.float64), 0.0)
+        outs = []
+        real_choice = np.random.choice
+        calls = [0]
+
+        def stub_choice(n, *a, **k):  # the RNG source is stubbed (not the reference): "random child" := child 0
+            calls[0] += 1
+            return 0
+        np.random.choice = stub_choice
+        try:
+            for sd in (1, 2):
+                np.random.seed(sd)
+                su, ctg, solved = gbfs_update([mk_state(r.copy()) for r in roots], env, steps, hfn, 0.0)
+                outs.append((np.stack([get_arr(s) for s in su]).astype(np.uint8), np.asarray(ctg, np.float64),
+                             np.asarray(solved, bool)))
+        finally:
+            np.random.choice = real_choice
+        assert all(np.array_equal(a, b) for a, b in zip(outs[0], outs[1]))
+        print("   (random-child draws stubbed to child 0: %d per run)" % (calls[0] // 2))
+        return outs[0]
+
+    rng = np.random.default_rng(99)
+    # cube3: 96 states, 0..4 random moves from the goal (some are solved / get solved within the steps)
+    roots = []
+    for i in range(96):
+        st = Cube3State(c3.goal_colors.copy())
+        for a in rng.integers(0, 12, size=int(rng.integers(0, 5))):
+            st = c3.next_state([st], int(a))[0][0]
+        roots.append(st.colors.astype(np.uint8))
+    roots = np.stack(roots)
+    golden["avi_cube3_roots"] = roots
+    for steps in (1, 3):
+        su, ctg, sv = upd_case(c3, c3mk, c3get, roots, heur_knuth3, steps)
+        golden["avi_cube3_steps%d_states" % steps] = su
+        golden["avi_cube3_steps%d_ctg" % steps] = ctg
+        golden["avi_cube3_steps%d_solved" % steps] = sv
+        print("avi cube3 steps", steps, su.shape, ctg[:4], sv.sum())
+    # bellman alone (search_utils.py:16-32) on the synthetic states
+    hfn64 = lambda sts, is_nnet_format=False: np.maximum(  # noqa: E731
+        heur_mod97(np.stack([s.colors for s in sts]).astype(np.uint8)).astype(np.float64), 0.0)
+    bk, _, _ = search_utils.bellman([Cube3State(x.copy()) for x in S[:64]], hfn64, c3)
+    golden["avi_cube3_bellman_synth64_mod97"] = np.asarray(bk, np.float64)
+    # puzzle15
+    proots = []
+    for i in range(64):
+        st = NPuzzleState(p15e.goal_tiles.copy())
+        for a in rng.integers(0, 4, size=int(rng.integers(0, 6))):
+            st = p15e.next_state([st], int(a))[0][0]
+        proots.append(st.tiles.astype(np.uint8))
+    proots = np.stack(proots)
+    golden["avi_puzzle15_roots"] = proots
+    su, ctg, sv = upd_case(p15e, pmk, pget, proots, heur_knuth3, 2)
+    golden["avi_puzzle15_steps2_states"] = su
+    golden["avi_puzzle15_steps2_ctg"] = ctg
+    golden["avi_puzzle15_steps2_solved"] = sv
+
     np.savez_compressed(os.path.join(OUT, "golden.npz"), **golden)
     print("wrote", os.path.join(OUT, "golden.npz"), "with", len(golden), "arrays")
 

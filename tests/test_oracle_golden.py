@@ -285,3 +285,19 @@ def test_astar_cpp_puzzle48_known_answer():
     assert r["moves"] == [1, 2, 1, 3, 0, 2, 1, 2, 0, 2, 0, 0]
     # SURVEY: binary 345 897 / survey restatement 345 889 (heap tie order); same libstdc++ heap here
     assert r["nodes_generated"] in (345897, 345889)
+
+
+# ------------------------------------------------------------------ AVI update step ((f)-1)
+def test_avi_update_restatement_vs_reference(golden):
+    kn = lambda s: no.heur_builtin(1, s)  # noqa: E731
+    for steps in (1, 3):
+        su, ctg, sv = no.gbfs_update("cube3", golden["avi_cube3_roots"], steps, kn)
+        assert np.array_equal(su, golden["avi_cube3_steps%d_states" % steps])
+        assert np.array_equal(ctg, golden["avi_cube3_steps%d_ctg" % steps])
+        assert np.array_equal(sv, golden["avi_cube3_steps%d_solved" % steps])
+    su, ctg, sv = no.gbfs_update("puzzle15", golden["avi_puzzle15_roots"], 2, kn)
+    assert np.array_equal(su, golden["avi_puzzle15_steps2_states"])
+    assert np.array_equal(ctg, golden["avi_puzzle15_steps2_ctg"])
+    assert np.array_equal(sv, golden["avi_puzzle15_steps2_solved"])
+    bk, _, _ = no.bellman("cube3", golden["cube3_synth64_in"], lambda s: no.heur_builtin(0, s))
+    assert np.array_equal(bk, golden["avi_cube3_bellman_synth64_mod97"])
