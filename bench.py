@@ -85,6 +85,15 @@ def reduce_ranks(x: float, world: int, op: str) -> float:
     return float(t.item())
 
 
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch measured separately with rocprofv3 PMC passes (profiles/pmc_traffic.json), or None."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        return d.get(kernel)
+    except (OSError, ValueError):
+        return None
+
+
 def test_root(rank: int) -> np.ndarray:
     """Rank r searches scramble r of the shipped cube3 test set (data/cube3/test, kept as a fixture)."""
     g = np.load(os.path.join(ROOT, "tests", "golden", "golden.npz"))
@@ -158,7 +167,7 @@ def run_astar(args, world, rank):
         }
         ach = alg.get(dom, 0.0) / (prof[dom] * 1e-3) / 1e9 if prof[dom] > 0 else 0.0
         res["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "achieved": ach, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("k_" + dom),
                            "bytes_per_launch": alg.get(dom, 0.0), "kernel_ms": prof[dom],
                            "phase_ms": {k: round(v, 5) for k, v in prof.items()},
                            "sum_phase_ms": sum(prof.values())}
@@ -363,7 +372,8 @@ def run_expand(args, world, rank):
                                "(BASELINE configs[1])" % n, "states": n, "moves": 12, "onehot": "f32",
                    "parallelism": "replica-per-gpu x%d" % world},
         "roofline": {"bound": "hbm", "kernel": "expand_fused_kernel<cube3,f32>", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic("expand_fused_kernel<cube3,f32>") if n == 1_000_000 else None,
                      "bytes_per_launch": CUBE3_EXPAND_BYTES_F32 * n, "kernel_ms": kern_ms},
     }
 
