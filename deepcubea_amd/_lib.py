@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libdca_hip.so")
 ENV_CUBE3, ENV_NPUZZLE = 0, 1
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 SEM_PY, SEM_CPP = 0, 1
-HEUR_MOD97, HEUR_KNUTH3, HEUR_HASHU01, HEUR_ZERO = 0, 1, 2, 3
+HEUR_MOD97, HEUR_KNUTH3, HEUR_HASHU01, HEUR_ZERO, HEUR_MANHATTAN = 0, 1, 2, 3, 4
 
 _TORCH_DT = {torch.float32: DT_F32, torch.float16: DT_F16, torch.bfloat16: DT_BF16}
 

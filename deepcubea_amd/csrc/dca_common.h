@@ -75,8 +75,17 @@ __host__ __device__ inline uint64_t hash_final(uint64_t h) {
     return h;
 }
 
-// built-in heuristics (include/dca.h DCA_HEUR_*); `sum` = sum_i s_i*(7i+3), `h` = state hash
-__host__ __device__ inline float heur_from(int id, uint64_t sum, uint64_t h) {
+// Manhattan distance contribution of tile `t` sitting at position `pos` of a dim x dim sliding puzzle
+// (goal position of tile t is t-1; the blank does not count)
+__host__ __device__ inline uint32_t manhattan_term(int dim, uint32_t pos, uint32_t t) {
+    if (t == 0) return 0;
+    int g = (int)t - 1;
+    int dr = (int)(pos / dim) - g / dim, dc = (int)(pos % dim) - g % dim;
+    return (uint32_t)((dr < 0 ? -dr : dr) + (dc < 0 ? -dc : dc));
+}
+
+// built-in heuristics (include/dca.h DCA_HEUR_*); `sum` = sum_i s_i*(7i+3), `h` = state hash, `manh` = Manhattan distance
+__host__ __device__ inline float heur_from(int id, uint64_t sum, uint64_t h, uint32_t manh = 0) {
     switch (id) {
         case DCA_HEUR_MOD97: return (float)(sum % 97) / 50.0f;
         case DCA_HEUR_KNUTH3: {
@@ -84,6 +93,7 @@ __host__ __device__ inline float heur_from(int id, uint64_t sum, uint64_t h) {
             return (float)((double)x / 4294967296.0 * 3.0);
         }
         case DCA_HEUR_HASHU01: return (float)(10.0 + 5.0 * ((double)(h >> 11) / 9007199254740992.0));
+        case DCA_HEUR_MANHATTAN: return (float)manh;
         default: return 0.0f;
     }
 }

@@ -1209,6 +1209,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(Eng E, int heur_id) {
     for (uint32_t cc = threadIdx.x; cc < nchild; cc += kThreads) {
         uint32_t r = cc / EV::A, a = cc - r * EV::A;
         uint64_t h = hash_init(EV::D), sum = 0;
+        uint32_t manh = 0;
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < EV::D; k += 8) {
@@ -1221,6 +1222,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(Eng E, int heur_id) {
                     ok &= (b == goal);
                     w |= (uint64_t)b << (8 * j);
                     sum += (uint64_t)b * (uint64_t)(7 * (k + j) + 3);
+                    if constexpr (ENV == DCA_ENV_NPUZZLE) manh += manhattan_term(DIM, (uint32_t)(k + j), b);
                 }
             }
             h = hash_word(h, w);
@@ -1232,7 +1234,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(Eng E, int heur_id) {
         E.parent[id] = pid;
         E.move[id] = (uint8_t)a;
         E.solved[id] = ok ? 1 : 0;
-        if (heur_id >= 0) E.child_h[j] = heur_from(heur_id, sum, h);
+        if (heur_id >= 0) E.child_h[j] = heur_from(heur_id, sum, h, manh);
     }
 
     // child rows -> node pool (final place), network-input rows -> batch buffer; 16 B per lane
@@ -1823,7 +1825,7 @@ int dca_engine_commit(dca_engine* e, const float* h, void* stream) {
 }
 
 int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph, void* stream) {
-    DCA_ARG(e != nullptr && heur_id >= 0 && heur_id <= DCA_HEUR_ZERO && iters >= 0);
+    DCA_ARG(e != nullptr && heur_id >= 0 && heur_id <= DCA_HEUR_MANHATTAN && iters >= 0);
     if (e->phase != 0) {
         set_error("dca_engine_run_builtin between pop_expand and commit");
         return DCA_E_STATE;
@@ -1868,7 +1870,7 @@ int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, float* ms_
     // ms_out[k] = summed milliseconds of phase k over `iters` iterations.  Phases:
     // 0 refill(3 kernels) 1 sel_hist 2 sel_scan 3 sel_collect 4 sel_cand 5 order(3 kernels) 6 post_pop
     // 7 expand 8 probe 9 decide 10 commit
-    DCA_ARG(e != nullptr && ms_out != nullptr && heur_id >= 0 && heur_id <= DCA_HEUR_ZERO && iters >= 0);
+    DCA_ARG(e != nullptr && ms_out != nullptr && heur_id >= 0 && heur_id <= DCA_HEUR_MANHATTAN && iters >= 0);
     if (e->phase != 0) {
         set_error("dca_engine_profile_builtin between pop_expand and commit");
         return DCA_E_STATE;

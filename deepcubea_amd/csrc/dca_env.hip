@@ -234,6 +234,8 @@ __global__ void state_scan_kernel(int env, const uint8_t* __restrict__ st, int64
     if (i >= n) return;
     const uint8_t* s = st + i * D;
     uint64_t h = hash_init(D), sum = 0;
+    uint32_t manh = 0;
+    const int pdim = D == 16 ? 4 : D == 25 ? 5 : D == 36 ? 6 : D == 49 ? 7 : 0;  // sliding-puzzle side (0: cube3)
     bool ok = true;
     for (int k = 0; k < D; k += 8) {
         uint64_t w = 0;
@@ -243,13 +245,14 @@ __global__ void state_scan_kernel(int env, const uint8_t* __restrict__ st, int64
             ok &= (b == goal);
             w |= (uint64_t)b << (8 * j);
             sum += (uint64_t)b * (uint64_t)(7 * (k + j) + 3);
+            if (pdim) manh += manhattan_term(pdim, (uint32_t)(k + j), b);
         }
         h = hash_word(h, w);
     }
     h = hash_final(h);
     if (solved) solved[i] = ok ? 1 : 0;
     if (hash) hash[i] = h;
-    if (heur) heur[i] = heur_from(heur_id, sum, h);
+    if (heur) heur[i] = heur_from(heur_id, sum, h, manh);
 }
 
 __global__ void nnet_input_kernel(int env, const uint8_t* __restrict__ st, int64_t nbytes, uint8_t* __restrict__ out) {
@@ -422,7 +425,7 @@ int dca_hash64(const uint8_t* states, int64_t n, int state_dim, uint64_t* out, v
     return launch_check("state_scan_kernel");
 }
 int dca_heuristic_builtin(int heur_id, const uint8_t* states, int64_t n, int state_dim, float* out, void* stream) {
-    DCA_ARG(heur_id >= 0 && heur_id <= DCA_HEUR_ZERO && n >= 0 && state_dim > 0 && state_dim <= 64);
+    DCA_ARG(heur_id >= 0 && heur_id <= DCA_HEUR_MANHATTAN && n >= 0 && state_dim > 0 && state_dim <= 64);
     DCA_ARG(n == 0 || (states && out));
     if (n == 0) return 0;
     hipLaunchKernelGGL(state_scan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,

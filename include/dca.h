@@ -61,6 +61,7 @@ extern "C" {
 #define DCA_HEUR_KNUTH3 1 /* f32( ((sum_i s_i*(7i+3)) * 2654435761 mod 2^32) / 2^32 * 3 )    */
 #define DCA_HEUR_HASHU01 2 /* f32( 10 + 5 * (hash64(s) >> 11) / 2^53 )                        */
 #define DCA_HEUR_ZERO 3   /* 0 (uniform-cost search; nnet_utils.py:271-272 all_zeros server) */
+#define DCA_HEUR_MANHATTAN 4 /* puzzles: sum over tiles of |row-row*|+|col-col*| (admissible, consistent); cube3: 0 */
 
 int dca_abi_version(void);
 const char* dca_last_error(void);

@@ -167,6 +167,17 @@ inline float heur_builtin(int id, const uint8_t* s, int D) {
         }
         case 2:
             return (float)(10.0 + 5.0 * ((double)(hash64(s, D) >> 11) / 9007199254740992.0));
+        case 4: {  // DCA_HEUR_MANHATTAN (puzzles; 0 for cube3)
+            int dim = D == 16 ? 4 : D == 25 ? 5 : D == 36 ? 6 : D == 49 ? 7 : 0, m = 0;
+            if (!dim) return 0.0f;
+            for (int p = 0; p < D; p++) {
+                int t = s[p];
+                if (t == 0) continue;
+                int g = t - 1;
+                m += std::abs(p / dim - g / dim) + std::abs(p % dim - g % dim);
+            }
+            return (float)m;
+        }
         default:
             return 0.0f;
     }
