@@ -107,3 +107,30 @@ def test_reference_pickles_load_through_the_mirror(tmp_path):
     from deepcubea_amd.environments.cube3 import Cube3State as Mine
     assert isinstance(d["states"][0], Mine) and d["states"][0].colors.dtype == np.uint8
     assert d["states"][0].colors.tolist() == list(range(54))
+
+
+def test_compare_solutions_report(tmp_path, golden, capsys):
+    """§8(f)-3: statistics of scripts/compare_solutions.py + the reader of published output.txt logs."""
+    from deepcubea_amd.utils import compare_solutions as cs
+    lens, nodes, times = golden["published_cube3_len"], golden["published_cube3_nodes"], golden["published_cube3_time"]
+    log = tmp_path / "output.txt"
+    with open(log, "w") as f:
+        f.write("device: cuda:0, devices: [0], on_gpu: True\n")
+        for i in range(len(lens)):
+            f.write("State: %i, SolnCost: %.2f, # Moves: %i, # Nodes Gen: %s, Time: %.2f\n"
+                    % (i, lens[i], lens[i], format(int(nodes[i]), ","), times[i]))
+    pub = cs.load_results(str(log))
+    assert np.array_equal(pub["lens"], lens) and np.array_equal(pub["num_nodes_generated"], nodes)
+    s = cs.summarize(pub)
+    assert abs(s["Lengths"]["mean"] - 21.349) < 1e-3 and s["Lengths"]["min"] == 16 and s["Lengths"]["max"] == 24
+    assert abs(s["Nodes Generated"]["mean"] - 8185993) < 1  # BASELINE.md section 1
+    import pickle
+    opt = golden["cube3_test_opt_len"]
+    p1 = tmp_path / "opt.pkl"
+    pickle.dump({"states": [None] * 1000, "solutions": [[0] * int(k) for k in opt], "times": [1.0] * 1000,
+                 "num_nodes_generated": [10.0] * 1000}, open(p1, "wb"))
+    c = cs.compare(cs.load_results(str(p1)), pub)
+    assert abs(c["pct_equal"] - 65.0) < 0.05 and c["length_diff"]["max"] == 4  # 65.0 % optimal, +2/+4 otherwise
+    cs.main(["--soln1", str(p1), "--soln2", str(log)])
+    out = capsys.readouterr().out
+    assert "1000 states" in out and "65.00% soln2 equal to soln1" in out and "-Nodes/Sec-" in out
