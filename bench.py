@@ -154,7 +154,10 @@ def run_astar(args, world, rank):
                    "device_ms_per_step": dev_ms / args.steps},
     }
     if prof:
-        dom = max(prof, key=prof.get)
+        # "refill" and "order" are groups of 3-4 kernels timed together; the dominant KERNEL is picked among the
+        # single-kernel phases (rocprofv3 per-kernel averages in profiles/ agree: k_probe)
+        single = {k: v for k, v in prof.items() if k not in ("refill", "order")}
+        dom = max(single, key=single.get)
         # algorithmic bytes of the dominant kernel per launch
         n_front = dbg["front_n"] + B  # FRONT tier at the last profiled iteration (pops only scan FRONT)
         alg = {

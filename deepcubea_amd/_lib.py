@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "dca_onehot", "dca_heuristic_builtin", "dca_generate_states", "dca_bellman_backup",
     "dca_engine_create", "dca_engine_destroy", "dca_engine_reset", "dca_engine_root_commit",
     "dca_engine_root_nnet_in", "dca_engine_pop_expand", "dca_engine_commit", "dca_engine_run_builtin",
-    "dca_engine_profile_builtin", "dca_engine_debug", "dca_engine_status", "dca_engine_last_children", "dca_engine_solution",
+    "dca_engine_profile_builtin", "dca_engine_set_tiers", "dca_engine_debug", "dca_engine_status", "dca_engine_last_children", "dca_engine_solution",
 ]
 
 

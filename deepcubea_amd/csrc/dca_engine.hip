@@ -64,7 +64,7 @@ struct Ctl {
     // O(|FRONT| + children), independent of |OPEN|.
     uint32_t cur_f, cur_b;  // live FRONT buffer (0/1) and the BACK buffer (2)
     uint64_t T;             // tier threshold key (inclusive upper bound of FRONT)
-    uint32_t refill, r_bstar, spill_bin;
+    uint32_t refill, compact, r_bstar, spill_bin;
     uint64_t r_kmin;
     uint32_t r_shift;
     // selection
@@ -80,9 +80,9 @@ struct Ctl {
     float best_cost;
     uint32_t best_id;
     // ---- hot words -----------------------------------------------------------------------------
-    Cnt open_n[3];   // physical entries per OPEN buffer
+    Cnt open_n[4];   // physical entries per OPEN buffer (0/1 FRONT ping-pong, 2/3 BACK + its compaction target)
     Cnt cand_n, sel_fill, closed_n, back_dead, ticket_a, ticket_b;
-    Rng rng[3];      // running key range per OPEN buffer
+    Rng rng[4];      // running key range per OPEN buffer
     alignas(128) unsigned long long goal_best;  // PY: min over solved popped of (g << 32 | pop rank)
     alignas(128) uint32_t first_solved;         // CPP: smallest pop rank holding a solved node
 };
@@ -392,6 +392,11 @@ __global__ void k_root_commit(Eng E, const float* h_root) {
 // even when idle), so they top FRONT up early enough to last until the next check: an iteration
 // removes at most B entries from FRONT.
 constexpr int kRefillPeriod = 8;
+// what a refill / spill must leave in FRONT so that it cannot run short before the next refill check
+__device__ __forceinline__ uint32_t front_keep(const Eng& E) {
+    const uint32_t floor_ = (uint32_t)(kRefillPeriod + 1) * (uint32_t)E.B;
+    return E.f_keep > floor_ ? E.f_keep : floor_;
+}
 __device__ __forceinline__ bool need_refill(const Eng& E, const Ctl* c) {
     return c->open_n[c->cur_b].v != c->back_dead.v &&
            c->open_n[c->cur_f].v < (uint32_t)(kRefillPeriod + 1) * (uint32_t)E.B;
@@ -460,7 +465,7 @@ __global__ __launch_bounds__(1024) void k_refill_scan(Eng E) {
     scan_bins(E, pre, wsum);
     const int t = threadIdx.x;
     const uint32_t b = c->cur_b, n = c->open_n[b].v - c->back_dead.v;
-    const uint32_t target = n < E.f_keep ? n : E.f_keep;
+    const uint32_t target = n < front_keep(E) ? n : front_keep(E);
     for (int k = 0; k < 2; k++) {
         int bin = 2 * t + k;
         if (pre[bin] < target && target <= pre[bin + 1]) c->r_bstar = (uint32_t)bin;  // whole bins move
@@ -477,6 +482,15 @@ __global__ __launch_bounds__(1024) void k_refill_scan(Eng E) {
         if (top < kmin) top = ~0ull;  // wrapped
         c->T = top;
         if (top != ~0ull) c->rng[b].kmin = top + 1;  // everything at or below `top` leaves BACK
+        // BACK is append-only with tombstones; squeeze them out once they outnumber the live entries
+        // (entries can re-enter BACK through spills, so its physical size is not bounded by the pool)
+        const uint32_t phys = c->open_n[b].v, dead = c->back_dead.v;
+        c->compact = ((dead > phys / 2 && phys > 4096) || (dead != 0 && phys > (E.max_nodes / 8) * 7)) ? 1u : 0u;
+        if (c->compact) {
+            c->open_n[b ^ 1].v = 0;
+            c->rng[b ^ 1].kmin = c->rng[b].kmin;
+            c->rng[b ^ 1].kmax = c->rng[b].kmax;
+        }
     }
 }
 
@@ -486,7 +500,8 @@ __global__ __launch_bounds__(256) void k_refill_move(Eng E) {
     Ctl* c = E.ctl;
     if (c->done || !c->refill) return;
     __shared__ uint32_t sh[2 * 4 + 2];
-    const uint32_t sb = c->cur_b, fb = c->cur_f;
+    const uint32_t sb = c->cur_b, fb = c->cur_f, db = sb ^ 1;  // BACK buffers are 2 and 3
+    const bool compact = c->compact != 0;  // also squeeze the tombstones out into the other BACK buffer
     const uint32_t n = c->open_n[sb].v;
     const uint64_t kmin = c->r_kmin;
     const uint32_t shift = c->r_shift, bstar = c->r_bstar;
@@ -498,36 +513,46 @@ __global__ __launch_bounds__(256) void k_refill_move(Eng E) {
     const uint32_t ntiles = (n + TILE - 1) / TILE;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint64_t k[ITEMS];
-        uint32_t tof = 0, cf = 0;
+        uint32_t tof = 0, stay = 0, cf = 0, cs = 0;
 #pragma unroll
         for (uint32_t i = 0; i < ITEMS; i++) {
             uint32_t idx = tile * TILE + i * 256 + threadIdx.x;
             bool live = idx < n;
             k[i] = live ? keys[idx] : DEAD;
             uint64_t f = (k[i] - kmin) >> shift;
-            bool front = k[i] != DEAD && (f < NBIN ? (uint32_t)f : NBIN - 1) <= bstar;
+            bool alive = k[i] != DEAD;
+            bool front = alive && (f < NBIN ? (uint32_t)f : NBIN - 1) <= bstar;
             tof |= (front ? 1u : 0u) << i;
+            stay |= ((alive && !front && compact) ? 1u : 0u) << i;
             cf += front ? 1u : 0u;
+            cs += (alive && !front && compact) ? 1u : 0u;
         }
-        Pos2 p = block_reserve2<256>(cf, 0u, &c->open_n[fb].v, &c->open_n[fb].v, sh);
+        Pos2 p = block_reserve2<256>(cf, cs, &c->open_n[fb].v, &c->open_n[db].v, sh);
 #pragma unroll
         for (uint32_t i = 0; i < ITEMS; i++) {
-            if (!((tof >> i) & 1u)) continue;
             uint32_t idx = tile * TILE + i * 256 + threadIdx.x;
-            if (p.a < E.max_nodes) {
-                E.open_key[fb][p.a] = k[i];
-                E.open_id[fb][p.a] = ids[idx];
+            if ((tof >> i) & 1u) {
+                if (p.a < E.max_nodes) {
+                    E.open_key[fb][p.a] = k[i];
+                    E.open_id[fb][p.a] = ids[idx];
+                }
+                if (!compact) keys[idx] = DEAD;
+                p.a++;
+                moved++;
+                fmn = k[i] < fmn ? k[i] : fmn;
+                fmx = k[i] > fmx ? k[i] : fmx;
+            } else if ((stay >> i) & 1u) {
+                E.open_key[db][p.b] = k[i];
+                E.open_id[db][p.b] = ids[idx];
+                p.b++;
             }
-            keys[idx] = DEAD;
-            p.a++;
-            moved++;
-            fmn = k[i] < fmn ? k[i] : fmn;
-            fmx = k[i] > fmx ? k[i] : fmx;
         }
     }
     fold_range(c, fb, fmn, fmx);
-    for (int o = 32; o > 0; o >>= 1) moved += __shfl_xor(moved, o);
-    if ((threadIdx.x & 63) == 0 && moved) atomicAdd(&c->back_dead.v, moved);
+    if (!compact) {
+        for (int o = 32; o > 0; o >>= 1) moved += __shfl_xor(moved, o);
+        if ((threadIdx.x & 63) == 0 && moved) atomicAdd(&c->back_dead.v, moved);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -562,6 +587,11 @@ __global__ __launch_bounds__(1024) void k_sel_scan(Eng E) {
     __shared__ uint32_t s_spill;
     const int t = threadIdx.x;
     if (t == 0) {
+        if (c->refill && c->compact) {  // the compacted copy becomes BACK
+            c->cur_b ^= 1;
+            c->back_dead.v = 0;
+            c->compact = 0;
+        }
         c->refill = 0;
         s_spill = NBIN;  // no spill
     }
@@ -584,7 +614,7 @@ __global__ __launch_bounds__(1024) void k_sel_scan(Eng E) {
         }
         // spill: FRONT grew past f_max -> keep the bins that hold the batch plus ~f_keep more
         if (n > E.f_max) {
-            const uint32_t keepn = want + E.f_keep;
+            const uint32_t keepn = want + front_keep(E);
             if (pre[bin] < keepn && keepn <= pre[bin + 1]) s_spill = (uint32_t)bin;
         }
     }
@@ -1698,7 +1728,7 @@ int dca_engine_create(dca_engine** out, int env, int dim, double weight, int bat
     ALLOC(move, N);
     ALLOC(solved, N);
     ALLOC(tab, (size_t)cap);
-    for (int b = 0; b < 3; b++) {  // FRONT ping-pong (0/1) + BACK (2)
+    for (int b = 0; b < 4; b++) {  // FRONT ping-pong (0/1) + BACK and its compaction target (2/3)
         ALLOC(open_key[b], N);
         ALLOC(open_id[b], N);
     }
@@ -1942,6 +1972,20 @@ int dca_engine_status(dca_engine* e, dca_status* out, void* stream) {
     out->closed_size = c.closed_n.v;
     out->pool_size = c.pool_n;
     out->best_cost = c.has_best ? (double)c.best_cost : __builtin_nan("");
+    return 0;
+}
+
+int dca_engine_set_tiers(dca_engine* e, int64_t front_keep, int64_t front_max) {
+    // test / tuning hook: FRONT hysteresis in entries (defaults 32*B and 96*B).  Search results never depend on it.
+    DCA_ARG(e != nullptr && front_keep >= 1 && front_max >= front_keep && front_max < (1ll << 31));
+    e->E.f_keep = (uint32_t)front_keep;
+    e->E.f_max = (uint32_t)front_max;
+    for (int g = 0; g < 2; g++) {  // captured graphs hold the old values
+        if (e->graph_exec[g]) (void)hipGraphExecDestroy(e->graph_exec[g]);
+        if (e->graph[g]) (void)hipGraphDestroy(e->graph[g]);
+        e->graph_exec[g] = nullptr;
+        e->graph[g] = nullptr;
+    }
     return 0;
 }
 

@@ -102,6 +102,11 @@ class BwasEngine:
                    "dca_engine_profile_builtin")
         return {name: ms[k] / max(iters, 1) for k, name in enumerate(self.PHASES)}
 
+    def set_tiers(self, front_keep: int, front_max: int) -> None:
+        """Override the FRONT-tier hysteresis (tests use tiny values to force constant refills / spills)."""
+        _lib.check(_lib.lib().dca_engine_set_tiers(self._h, C.c_int64(front_keep), C.c_int64(front_max)),
+                   "dca_engine_set_tiers")
+
     def debug(self) -> dict:
         out = (C.c_double * 16)()
         _lib.check(_lib.lib().dca_engine_debug(self._h, out, _lib.stream_ptr()), "dca_engine_debug")

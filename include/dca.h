@@ -191,6 +191,8 @@ int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph,
 int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, float* ms_out /*host [16]*/, void* stream);
 /* synchronises the stream */
 int dca_engine_status(dca_engine* e, dca_status* out, void* stream);
+/* test / tuning hook: FRONT-tier hysteresis in entries (defaults 32*B / 96*B); results never depend on it */
+int dca_engine_set_tiers(dca_engine* e, int64_t front_keep, int64_t front_max);
 /* internals of the last iteration for diagnostics (host double[16]; layout in dca_engine.hip); synchronises */
 int dca_engine_debug(dca_engine* e, double* out /*host [16]*/, void* stream);
 /* child rows of the last pop_expand straight from the node pool (device [m_live, D]); synchronises */

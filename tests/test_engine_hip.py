@@ -223,3 +223,28 @@ def test_engine_full_size_batch_properties(L, co):
     assert st["nodes_generated"] == st["nodes_expanded"] * 12
     assert st["open_size"] + st["nodes_expanded"] <= st["nodes_generated"] + 1
     eng.close()
+
+
+@pytest.mark.parametrize("keep,fmax", [(1, 1), (40, 100), (500, 2000)])
+def test_tier_thrash_keeps_exactness(L, co, keep, fmax):
+    """FRONT/BACK tiering must never change the search: with absurdly small tier sizes every iteration refills from
+    BACK and spills back, and the per-iteration traces still match the oracle exactly (PY and CPP semantics)."""
+    from deepcubea_amd.search_methods.engine import BwasEngine
+    for env, scr, w, B, hid, sem in [("cube3", [3, 8, 1, 10, 6, 4], 0.6, 100, 1, 0), ("cube3", [3, 8, 1, 10, 6], 0.8, 64, 0, 0),
+                                     ("puzzle15", [1, 3, 1, 1, 3, 0, 2, 0, 3, 1, 1, 2], 0.8, 33, 1, 0),
+                                     ("cube3", [11, 2, 6, 9, 0], 0.8, 50, 1, 1)]:
+        root = scramble(co, env, scr)
+        ref = co.astar(env, root, w, B, sem, heur_builtin_id=hid, trace_cap=200000)
+        eng = BwasEngine(env, w, B, max_nodes=max(1 << 16, 2 * ref["nodes_generated"] + 4 * B * 12 + 64), semantics=sem)
+        eng.set_tiers(keep, fmax)
+        res = run_traced(L, eng, root, hid)
+        assert not res["failed"], (env, scr, sem, res, eng.debug())
+        assert res["moves"] == ref["moves"] and res["nodes_generated"] == ref["nodes_generated"]
+        assert res["iterations"] == ref["iterations"]
+        if sem == 0 or hid == 1:
+            assert np.array_equal(res["trace"][:, 2], ref["trace"][:, 2])
+        if sem == 0:
+            assert np.array_equal(res["trace"], ref["trace"])
+        r2 = eng.solve_builtin(root, hid, chunk=5, use_graph=True)
+        assert r2["moves"] == ref["moves"] and r2["nodes_generated"] == ref["nodes_generated"]
+        eng.close()
