@@ -31,6 +31,7 @@
 namespace dca {
 
 constexpr int NBIN = 2048;            // radix-select fan-out per level
+constexpr int kScanBlocks = 256;      // grid of the OPEN scans: few fat blocks (cheap when they early-exit)
 constexpr uint32_t NIL = 0xFFFFFFFFu;
 constexpr uint64_t EMPTY = ~0ull;
 constexpr uint32_t GINF = 0xFFFFFFFFu;
@@ -119,6 +120,7 @@ struct Eng {
     uint32_t* open_id[4];
     uint32_t f_keep, f_max, ord_cap;  // FRONT hysteresis: refill/spill down to ~f_keep, spill when above f_max
     uint32_t *hist, *sub_base;
+    uint64_t* part;  // [4][kScanBlocks] per-block key ranges of k_sel_collect (survivor min/max, spill min/max)
     uint8_t* sub_lg;
     uint32_t nb2_cap;
     uint64_t* cand_key;
@@ -569,9 +571,21 @@ __global__ __launch_bounds__(256) void k_sel_hist(Eng E) {
     const uint64_t kmin = c->rng[b].kmin;
     const uint32_t shift = select_shift(kmin, c->rng[b].kmax);
     const uint64_t* __restrict__ keys = E.open_key[b];
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        uint64_t f = (keys[i] - kmin) >> shift;
-        atomicAdd(&lh[f < NBIN ? (uint32_t)f : NBIN - 1], 1u);
+    const uint32_t stride = gridDim.x * 256;
+    for (uint32_t i0 = blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        uint64_t k[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {  // 4 loads in flight per lane
+            ok[u] = i0 + u * stride < n;
+            k[u] = ok[u] ? keys[i0 + u * stride] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (!ok[u]) continue;
+            uint64_t f = (k[u] - kmin) >> shift;
+            atomicAdd(&lh[f < NBIN ? (uint32_t)f : NBIN - 1], 1u);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < NBIN; i += 256)
@@ -762,8 +776,29 @@ __global__ __launch_bounds__(256) void k_sel_collect(Eng E) {
             }
         }
     }
-    fold_range(c, nf, fmn, fmx);
-    fold_range(c, bb, bmn, bmx);
+    // key ranges: reduced per block into E.part and folded into the control block by k_ord_scan (one thread) —
+    // a thousand waves doing atomicMin/Max on two words cost as much as the whole scatter
+    {
+        __shared__ uint64_t red[4][4];
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        uint64_t v[4] = {fmn, fmx, bmn, bmx};
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint64_t u = __shfl_xor(v[q], o);
+                v[q] = (q & 1) ? (u > v[q] ? u : v[q]) : (u < v[q] ? u : v[q]);
+            }
+        }
+        if (lane == 0)
+            for (int q = 0; q < 4; q++) red[q][wv] = v[q];
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            const int q = threadIdx.x;
+            uint64_t r = red[q][0];
+            for (int w = 1; w < 4; w++) r = (q & 1) ? (red[q][w] > r ? red[q][w] : r) : (red[q][w] < r ? red[q][w] : r);
+            E.part[q * kScanBlocks + blockIdx.x] = r;
+        }
+    }
 }
 
 // S4: one workgroup — exact choice of the sel_r smallest (key,id) among the candidates of the
@@ -1084,6 +1119,36 @@ __global__ __launch_bounds__(1024) void k_ord_scan(Eng E) {
         __syncthreads();
     }
     if (t == 0) E.bpre[nb] = s_carry;
+    // fold k_sel_collect's per-block key ranges (survivors -> the new FRONT buffer, spills -> BACK)
+    {
+        __shared__ uint64_t red[4][16];
+        uint64_t v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = t < kScanBlocks ? E.part[q * kScanBlocks + t] : ((q & 1) ? 0ull : ~0ull);
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint64_t u = __shfl_xor(v[q], o);
+                v[q] = (q & 1) ? (u > v[q] ? u : v[q]) : (u < v[q] ? u : v[q]);
+            }
+        }
+        if (lane == 0)
+            for (int q = 0; q < 4; q++) red[q][wv] = v[q];
+        __syncthreads();
+        if (t == 0) {
+            uint64_t r[4];
+            for (int q = 0; q < 4; q++) {
+                r[q] = red[q][0];
+                for (int w = 1; w < 16; w++)
+                    r[q] = (q & 1) ? (red[q][w] > r[q] ? red[q][w] : r[q]) : (red[q][w] < r[q] ? red[q][w] : r[q]);
+            }
+            const uint32_t rb = c->cur_f ^ 1, bb = c->cur_b;
+            if (r[0] < c->rng[rb].kmin) c->rng[rb].kmin = r[0];
+            if (r[1] > c->rng[rb].kmax) c->rng[rb].kmax = r[1];
+            if (r[2] < c->rng[bb].kmin) c->rng[bb].kmin = r[2];
+            if (r[3] > c->rng[bb].kmax) c->rng[bb].kmax = r[3];
+        }
+    }
 }
 
 // O3: scatter bucket-contiguously
@@ -1642,7 +1707,6 @@ int launch_expand(const Eng& E, int heur_id, hipStream_t s) {
     return DCA_E_BADARG;
 }
 
-constexpr int kScanBlocks = 256;  // persistent-style grids: few fat blocks, cheap to launch when they early-exit
 
 int enqueue_first_half(dca_engine* e, int heur_id, bool with_refill, hipStream_t s) {
     const Eng& E = e->E;
@@ -1734,6 +1798,7 @@ int dca_engine_create(dca_engine** out, int env, int dim, double weight, int bat
     }
     ALLOC(hist, NBIN);
     ALLOC(sub_base, NBIN);
+    ALLOC(part, 4 * 1024);
     ALLOC(sub_lg, NBIN);
     ALLOC(cand_key, N);
     ALLOC(cand_id, N);
