@@ -94,10 +94,11 @@ def pmc_traffic(kernel: str):
         return None
 
 
-def test_root(rank: int) -> np.ndarray:
-    """Rank r searches scramble r of the shipped cube3 test set (data/cube3/test, kept as a fixture)."""
+def test_root(rank: int, env: str = "cube3") -> np.ndarray:
+    """Rank r searches scramble r of the shipped test set of `env` (data/<env>/test, kept as a fixture)."""
     g = np.load(os.path.join(ROOT, "tests", "golden", "golden.npz"))
-    return np.ascontiguousarray(g["cube3_test_states"][rank % 1000])
+    st = g[env + "_test_states"]
+    return np.ascontiguousarray(st[rank % st.shape[0]])
 
 
 # --------------------------------------------------------------------------------------------------
@@ -111,8 +112,10 @@ def run_astar(args, world, rank):
     hid = _lib.HEUR_HASHU01
     total_iters = args.warmup + args.steps + args.profile_iters + 16
     max_nodes = max(1 << 20, total_iters * B * 12 + (1 << 16))
-    eng = BwasEngine("cube3", w, B, max_nodes=max_nodes, semantics=sem)
-    root = test_root(rank)
+    A = 12 if args.env == "cube3" else 4
+    max_nodes = max(1 << 20, total_iters * B * A + (1 << 16))
+    eng = BwasEngine(args.env, w, B, max_nodes=max_nodes, semantics=sem)
+    root = test_root(rank, args.env)
     eng.reset(root)
     if sem == _lib.SEM_PY:
         eng.root_commit(_lib.heuristic_builtin(hid, torch.from_numpy(root[None].copy()).cuda()))
@@ -144,10 +147,10 @@ def run_astar(args, world, rank):
     res = {
         "value": total_exp / wall,
         "ms_per_step": wall / args.steps * 1e3,
-        "config": {"workload": "cube3 BWAS iteration on the device-resident engine, batch %d, weight %.2f, "
+        "config": {"workload": "%s BWAS iteration on the device-resident engine, batch %d, weight %.2f, "
                                "%s semantics, heuristic = built-in 10+5*u01(hash) (engine-only, SURVEY §8d); "
-                               "BASELINE configs[2] geometry" % (B, w, args.semantics),
-                   "batch_size": B, "weight": w, "children_per_step": B * 12, "semantics": args.semantics,
+                               "BASELINE configs[2] geometry" % (args.env, B, w, args.semantics),
+                   "env": args.env, "batch_size": B, "weight": w, "children_per_step": B * A, "semantics": args.semantics,
                    "hipgraph": not args.no_graph, "parallelism": "one search instance per GPU x%d" % world,
                    "open_size_end": st1["open_size"], "closed_size_end": st1["closed_size"],
                    "nodes_generated_timed": st1["nodes_generated"] - st0["nodes_generated"],
@@ -160,24 +163,26 @@ def run_astar(args, world, rank):
         dom = max(single, key=single.get)
         # algorithmic bytes of the dominant kernel per launch
         n_front = dbg["front_n"] + B  # FRONT tier at the last profiled iteration (pops only scan FRONT)
+        Dn = 54 if args.env == "cube3" else {"puzzle15": 16, "puzzle24": 25, "puzzle35": 36, "puzzle48": 49}[args.env]
         alg = {
-            "expand": CUBE3_ENGINE_EXPAND_BYTES * B,
+            "expand": (Dn + 4 + A * (2 * Dn + 22)) * B,
             "sel_hist": 8.0 * n_front,
             "sel_collect": 24.0 * n_front,
-            "probe": B * 12 * (8 + 16 + 54 + 54 + 8 + 8),
-            "decide": B * 12 * (16 + 4 + 4 + 4 + 1 + 4 + 8),
-            "commit": B * 12 * (1 + 8 + 12),
+            "probe": B * A * (8 + 16 + 2 * Dn + 8 + 8),
+            "decide": B * A * (16 + 4 + 4 + 4 + 1 + 4 + 8),
+            "commit": B * A * (1 + 8 + 12),
         }
         ach = alg.get(dom, 0.0) / (prof[dom] * 1e-3) / 1e9 if prof[dom] > 0 else 0.0
         res["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "achieved": ach, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("k_" + dom),
+                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": pmc_traffic("k_" + dom) if args.env == "cube3" and B == 20000 else None,
                            "bytes_per_launch": alg.get(dom, 0.0), "kernel_ms": prof[dom],
                            "phase_ms": {k: round(v, 5) for k, v in prof.items()},
                            "sum_phase_ms": sum(prof.values())}
     eng.close()
     del eng
     torch.cuda.empty_cache()
-    if args.concurrent > 1:
+    if args.concurrent > 1 and args.env == "cube3":
         res["concurrent_instances"] = run_astar_concurrent(args, world, rank, sem, hid)
     return res
 
@@ -411,6 +416,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="astar", choices=["astar", "expand", "avi"])
     ap.add_argument("--nnet_dtype", default="fp32", choices=["fp32", "bf16"], help="avi: heuristic precision")
+    ap.add_argument("--env", default="cube3", choices=["cube3", "puzzle15", "puzzle24", "puzzle35", "puzzle48"],
+                    help="astar: environment of the engine-only leg (nnet / concurrency legs are cube3)")
     ap.add_argument("--batch_size", type=int, default=20000)
     ap.add_argument("--weight", type=float, default=0.8)
     ap.add_argument("--semantics", default="py", choices=["py", "cpp"])
@@ -431,7 +438,7 @@ def main():
     world, rank, local = dist_setup(args.dist_backend)
     res = {"astar": run_astar, "expand": run_expand, "avi": run_avi}[args.workload](args, world, rank)
     line = {
-        "metric": {"astar": "A* nodes expanded/sec on cube3, batch 20k", "expand": "A* nodes expanded/sec on cube3",
+        "metric": {"astar": "A* nodes expanded/sec on %s, batch 20k" % args.env, "expand": "A* nodes expanded/sec on cube3",
                    "avi": "AVI update-step training states generated/sec on cube3"}[args.workload],
         "value": res["value"],
         "unit": "states/s" if args.workload == "avi" else "nodes expanded/s",
@@ -450,11 +457,14 @@ def main():
         line["roofline"] = res["roofline"]
     if "concurrent_instances" in res:
         line["concurrent_instances"] = res["concurrent_instances"]
-    if args.workload == "astar" and args.nnet_steps > 0:
+    if args.workload == "astar" and args.nnet_steps > 0 and args.env == "cube3":
         line["end_to_end_nnet"] = {"fp32": run_astar_nnet(args, world, rank, "fp32"),
                                    "bf16": run_astar_nnet(args, world, rank, "bf16")}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "avi":
-        line["cpu_baseline"] = cpu_baseline_astar(args) if args.workload == "astar" else cpu_baseline_expand()
+        if args.workload == "expand":
+            line["cpu_baseline"] = cpu_baseline_expand()
+        elif args.env == "cube3":
+            line["cpu_baseline"] = cpu_baseline_astar(args)
     if rank == 0:
         print(json.dumps(line))
     if world > 1:
