@@ -1,16 +1,17 @@
-"""Environment registry for the path (reference `utils/env_utils.py:6-28`): cube3 and puzzle15/24/35/48.
-Environments outside the hot-path scope (lightsout, sokoban) are not provided."""
-import math
+"""Environment registry of the path (names as in the reference's `utils/env_utils.py:6-28`): `cube3` and
+`puzzle<N>` for N in {15, 24, 35, 48}.  Environments outside the hot-path scope (lightsout, sokoban) are not built."""
 import re
+
+_PUZZLE_DIMS = {15: 4, 24: 5, 35: 6, 48: 7}
 
 
 def get_environment(env_name: str):
-    name = env_name.lower()
-    m = re.search(r"puzzle(\d+)", name)
-    if name == 'cube3':
+    key = env_name.strip().lower()
+    if key == "cube3":
         from ..environments.cube3 import Cube3
         return Cube3()
-    if m is not None:
+    found = re.fullmatch(r".*puzzle(\d+).*", key)
+    if found and int(found.group(1)) in _PUZZLE_DIMS:
         from ..environments.n_puzzle import NPuzzle
-        return NPuzzle(int(math.sqrt(int(m.group(1)) + 1)))
+        return NPuzzle(_PUZZLE_DIMS[int(found.group(1))])
     raise ValueError('No known environment %s' % env_name)
