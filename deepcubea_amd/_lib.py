@@ -29,8 +29,10 @@ ABI_SYMBOLS = [
     "dca_cube3_next_state", "dca_cube3_prev_state", "dca_npuzzle_next_state", "dca_npuzzle_prev_state",
     "dca_cube3_expand_fused", "dca_npuzzle_expand_fused", "dca_is_solved", "dca_hash64", "dca_nnet_input",
     "dca_onehot", "dca_heuristic_builtin", "dca_generate_states", "dca_bellman_backup",
-    "dca_engine_create", "dca_engine_destroy", "dca_engine_reset", "dca_engine_root_commit",
-    "dca_engine_root_nnet_in", "dca_engine_pop_expand", "dca_engine_commit", "dca_engine_run_builtin",
+    "dca_engine_create", "dca_engine_create_multi", "dca_engine_num_instances", "dca_engine_destroy",
+    "dca_engine_reset", "dca_engine_reset_instance", "dca_engine_root_commit", "dca_engine_root_commit_instance",
+    "dca_engine_root_nnet_in", "dca_engine_root_nnet_in_instance", "dca_engine_status_instance",
+    "dca_engine_solution_instance", "dca_engine_pop_expand", "dca_engine_commit", "dca_engine_run_builtin",
     "dca_engine_profile_builtin", "dca_engine_set_tiers", "dca_engine_debug", "dca_engine_status", "dca_engine_last_children", "dca_engine_solution",
 ]
 

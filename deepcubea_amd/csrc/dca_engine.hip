@@ -405,7 +405,8 @@ __device__ __forceinline__ bool need_refill(const Eng& E, const Ctl* c) {
 }
 constexpr uint64_t DEAD = ~0ull;  // tombstone key of a BACK entry that moved to FRONT
 
-__global__ __launch_bounds__(256) void k_refill_hist(Eng E) {
+__global__ __launch_bounds__(256) void k_refill_hist(const Eng* __restrict__ engs) {
+    const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done || !need_refill(E, c)) return;
     __shared__ uint32_t lh[NBIN];
@@ -455,7 +456,8 @@ __device__ __forceinline__ void scan_bins(const Eng& E, uint32_t* pre, uint32_t*
     __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void k_refill_scan(Eng E) {
+__global__ __launch_bounds__(1024) void k_refill_scan(const Eng* __restrict__ engs) {
+    const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
     if (!need_refill(E, c)) {
@@ -498,7 +500,8 @@ __global__ __launch_bounds__(1024) void k_refill_scan(Eng E) {
 
 // moved entries are appended to FRONT and tombstoned in place: BACK is never compacted (its dead
 // entries are only the ones that moved, a small fraction of what keeps arriving)
-__global__ __launch_bounds__(256) void k_refill_move(Eng E) {
+__global__ __launch_bounds__(256) void k_refill_move(const Eng* __restrict__ engs) {
+    const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done || !c->refill) return;
     __shared__ uint32_t sh[2 * 4 + 2];
@@ -561,7 +564,8 @@ __global__ __launch_bounds__(256) void k_refill_move(Eng E) {
 // pop: exact top-B of FRONT by (cost key, node id)
 // ---------------------------------------------------------------------------------------------
 // S1: histogram of (key - kmin) >> shift over FRONT, 2048 bins, LDS-privatised
-__global__ __launch_bounds__(256) void k_sel_hist(Eng E) {
+__global__ __launch_bounds__(256) void k_sel_hist(const Eng* __restrict__ engs) {
+    const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
     __shared__ uint32_t lh[NBIN];
@@ -593,7 +597,8 @@ __global__ __launch_bounds__(256) void k_sel_hist(Eng E) {
 }
 
 // S2: one workgroup — prefix over the bins, threshold bin, spill decision, per-iteration counter reset
-__global__ __launch_bounds__(1024) void k_sel_scan(Eng E) {
+__global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs) {
+    const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
     __shared__ uint32_t pre[NBIN + 1];
@@ -713,7 +718,8 @@ __global__ __launch_bounds__(1024) void k_sel_scan(Eng E) {
 
 // S3: scatter FRONT — below the threshold bin: popped (unordered); in it: candidates; above:
 // survivors -> the other FRONT buffer, or BACK when a spill lowered T.  One atomic per array per tile.
-__global__ __launch_bounds__(256) void k_sel_collect(Eng E) {
+__global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ engs) {
+    const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
     __shared__ uint32_t sh[4 * 4 + 4];
@@ -893,7 +899,8 @@ __device__ __forceinline__ void cand_scan(CandShared& S) {
     __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void k_sel_cand(Eng E) {
+__global__ __launch_bounds__(1024) void k_sel_cand(const Eng* __restrict__ engs) {
+    const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
     if (c->superset) return;  // normal case: nothing to refine, ordering buckets are arithmetic
@@ -1051,7 +1058,8 @@ __device__ __forceinline__ uint32_t ord_bucket(const OrdShared& S, uint64_t k, u
 }
 
 // O1: bucket of every popped entry + its arrival slot inside the bucket
-__global__ __launch_bounds__(256) void k_ord_count(Eng E) {
+__global__ __launch_bounds__(256) void k_ord_count(const Eng* __restrict__ engs) {
+    const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
     const uint32_t want = c->n_ord;
@@ -1080,7 +1088,8 @@ __global__ __launch_bounds__(256) void k_ord_count(Eng E) {
 }
 
 // O2: one workgroup — exclusive prefix of the bucket counts (and reset them for the next iteration)
-__global__ __launch_bounds__(1024) void k_ord_scan(Eng E) {
+__global__ __launch_bounds__(1024) void k_ord_scan(const Eng* __restrict__ engs) {
+    const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
     __shared__ uint32_t wsum[16];
@@ -1152,7 +1161,8 @@ __global__ __launch_bounds__(1024) void k_ord_scan(Eng E) {
 }
 
 // O3: scatter bucket-contiguously
-__global__ __launch_bounds__(256) void k_ord_scatter(Eng E) {
+__global__ __launch_bounds__(256) void k_ord_scatter(const Eng* __restrict__ engs) {
+    const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
     const uint32_t want = c->n_ord;
@@ -1166,7 +1176,8 @@ __global__ __launch_bounds__(256) void k_ord_scatter(Eng E) {
 }
 
 // O4: rank inside the bucket -> final pop order; entries ranked past the batch return to FRONT'
-__global__ __launch_bounds__(256) void k_ord_rank(Eng E) {
+__global__ __launch_bounds__(256) void k_ord_rank(const Eng* __restrict__ engs) {
+    const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
     const uint32_t n_ord = c->n_ord, want = c->want;
@@ -1197,8 +1208,9 @@ __global__ __launch_bounds__(256) void k_ord_rank(Eng E) {
 }
 
 // S6: single thread — fix the batch geometry, goal bookkeeping, swap OPEN buffers
-__global__ void k_post_pop(Eng E) {
+__global__ void k_post_pop(const Eng* __restrict__ engs) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
     const uint32_t want = c->want;
@@ -1251,7 +1263,8 @@ __global__ void k_post_pop(Eng E) {
 // ---------------------------------------------------------------------------------------------
 constexpr int kEngTile = 16;  // parents per workgroup: a 20 000-parent batch then fills the chip (1250 workgroups)
 template <int ENV, int DIM, int OH>
-__global__ __launch_bounds__(kThreads) void k_expand(Eng E, int heur_id) {
+__global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ engs, int heur_id) {
+    const Eng& E = engs[blockIdx.y];
     using EV = EnvT<ENV, DIM>;
     using TL = Tile<ENV, DIM, kEngTile>;
     constexpr int kTileParents = kEngTile;  // shadows the stand-alone kernels' 64
@@ -1422,7 +1435,8 @@ __global__ __launch_bounds__(kThreads) void k_expand(Eng E, int heur_id) {
 // ---------------------------------------------------------------------------------------------
 constexpr uint8_t F_KEEP = 1, F_MIN = 2, F_NEW = 4;
 template <int D>
-__global__ __launch_bounds__(256) void k_probe(Eng E) {
+__global__ __launch_bounds__(256) void k_probe(const Eng* __restrict__ engs) {
+    const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
@@ -1488,19 +1502,9 @@ __global__ __launch_bounds__(256) void k_probe(Eng E) {
     E.child_flags[j] = inserted ? F_NEW : 0;  // counted in k_commit (one atomic per block there)
 }
 
-static void launch_probe(const Eng& E, hipStream_t s) {
-    const dim3 g((E.M + 255) / 256), b(256);
-    switch (E.D) {
-        case 54: hipLaunchKernelGGL(k_probe<54>, g, b, 0, s, E); break;
-        case 16: hipLaunchKernelGGL(k_probe<16>, g, b, 0, s, E); break;
-        case 25: hipLaunchKernelGGL(k_probe<25>, g, b, 0, s, E); break;
-        case 36: hipLaunchKernelGGL(k_probe<36>, g, b, 0, s, E); break;
-        default: hipLaunchKernelGGL(k_probe<49>, g, b, 0, s, E); break;
-    }
-}
-
 // dedup B: keep decision in sequential order + cost
-__global__ __launch_bounds__(256) void k_decide(Eng E) {
+__global__ __launch_bounds__(256) void k_decide(const Eng* __restrict__ engs) {
+    const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
@@ -1556,7 +1560,8 @@ __device__ __forceinline__ void commit_ticket(Ctl* c) {
 }
 
 // dedup C: record the new best g per state, push the kept children (FRONT if key <= T, else BACK)
-__global__ __launch_bounds__(1024) void k_commit(Eng E) {
+__global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs) {
+    const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
     __shared__ uint32_t sh[3 * 16 + 3];
@@ -1612,14 +1617,6 @@ __global__ __launch_bounds__(1024) void k_commit(Eng E) {
     commit_ticket(c);
 }
 
-__global__ void k_end_iter(Eng E) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    Ctl* c = E.ctl;
-    if (c->done) return;
-    c->iters += 1;
-    if (c->stop_after || c->failed) c->done = 1;
-}
-
 __global__ void k_solution(Eng E, int32_t* out /*[0]=len, [1..]=moves root->goal*/, double* path_cost) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Ctl* c = E.ctl;
@@ -1649,22 +1646,36 @@ __global__ void k_solution(Eng E, int32_t* out /*[0]=len, [1..]=moves root->goal
     if (E.sem == DCA_SEM_CPP) *path_cost = (double)len;  // astar.py:554 sum of unit transition costs
 }
 
+
 }  // namespace dca
 
 using namespace dca;
 
+// ---------------------------------------------------------------------------------------------
+// host side.  One dca_engine = K independent search instances of the same geometry that share every launch
+// (grid.y = instance): a batch-20 000 iteration is launch/latency bound, so stepping K scrambles together costs little
+// more than stepping one (the reference's AStar also steps a list of instances together, astar.py:232-317).
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxInstances = 64;
+
 struct dca_engine {
-    Eng E;
-    Ctl* h_ctl;  // pinned
+    int K;
+    Eng E[kMaxInstances];  // host copies; E[i].ctl etc. are device pointers
+    Eng* d_engs;           // device copy of E[0..K)
+    uint8_t* nnet_all;     // [K*M, D]   network-input rows of all instances, contiguous
+    uint8_t* onehot_all;   // [K*M, D*depth] or null
+    float* h_all;          // [K*M]
+    Ctl* h_ctl;            // pinned
     int32_t* h_moves;
     double* d_cost;
     double* h_cost;
-    int phase;  // 0 idle, 1 between pop_expand and commit
-    hipGraph_t graph[2];          // [0] iteration without / [1] with the refill check
+    uint8_t* h_stage;
+    int phase;             // 0 idle, 1 between pop_expand and commit
+    hipGraph_t graph[2];   // [0] iteration without / [1] with the refill check
     hipGraphExec_t graph_exec[2];
     int graph_heur;
-    long host_iter;               // iterations enqueued since reset (drives the refill cadence)
-    void* allocs[48];
+    long host_iter;        // iterations enqueued since the last reset of instance 0 (drives the refill cadence)
+    void* allocs[kMaxInstances * 48 + 16];
     int nalloc;
 };
 
@@ -1683,66 +1694,139 @@ int dev_alloc(dca_engine* e, T** p, size_t count) {
     return 0;
 }
 
+constexpr int kScanGrid = kScanBlocks;
+
+inline dim3 gxy(unsigned x, const dca_engine* e) { return dim3(x, (unsigned)e->K); }
+
 template <int ENV, int DIM>
-int launch_expand_env(const Eng& E, int heur_id, hipStream_t s) {
+int launch_expand_env(const dca_engine* e, int heur_id, hipStream_t s) {
     using TL = Tile<ENV, DIM, kEngTile>;
-    dim3 g((E.B + kEngTile - 1) / kEngTile), b(kThreads);
+    const Eng& E = e->E[0];
+    dim3 g = gxy((E.B + kEngTile - 1) / kEngTile, e), b(kThreads);
     if (E.onehot == nullptr)
-        hipLaunchKernelGGL((k_expand<ENV, DIM, 0>), g, b, TL::LDS_BYTES, s, E, heur_id);
+        hipLaunchKernelGGL((k_expand<ENV, DIM, 0>), g, b, TL::LDS_BYTES, s, e->d_engs, heur_id);
     else if (E.oh_dtype == DCA_DT_F32)
-        hipLaunchKernelGGL((k_expand<ENV, DIM, 4>), g, b, TL::LDS_BYTES, s, E, heur_id);
+        hipLaunchKernelGGL((k_expand<ENV, DIM, 4>), g, b, TL::LDS_BYTES, s, e->d_engs, heur_id);
     else
-        hipLaunchKernelGGL((k_expand<ENV, DIM, 2>), g, b, TL::LDS_BYTES, s, E, heur_id);
+        hipLaunchKernelGGL((k_expand<ENV, DIM, 2>), g, b, TL::LDS_BYTES, s, e->d_engs, heur_id);
     return launch_check("k_expand");
 }
 
-int launch_expand(const Eng& E, int heur_id, hipStream_t s) {
-    if (E.env == DCA_ENV_CUBE3) return launch_expand_env<DCA_ENV_CUBE3, 0>(E, heur_id, s);
+int launch_expand(const dca_engine* e, int heur_id, hipStream_t s) {
+    const Eng& E = e->E[0];
+    if (E.env == DCA_ENV_CUBE3) return launch_expand_env<DCA_ENV_CUBE3, 0>(e, heur_id, s);
     switch (E.dim) {
-        case 4: return launch_expand_env<DCA_ENV_NPUZZLE, 4>(E, heur_id, s);
-        case 5: return launch_expand_env<DCA_ENV_NPUZZLE, 5>(E, heur_id, s);
-        case 6: return launch_expand_env<DCA_ENV_NPUZZLE, 6>(E, heur_id, s);
-        case 7: return launch_expand_env<DCA_ENV_NPUZZLE, 7>(E, heur_id, s);
+        case 4: return launch_expand_env<DCA_ENV_NPUZZLE, 4>(e, heur_id, s);
+        case 5: return launch_expand_env<DCA_ENV_NPUZZLE, 5>(e, heur_id, s);
+        case 6: return launch_expand_env<DCA_ENV_NPUZZLE, 6>(e, heur_id, s);
+        case 7: return launch_expand_env<DCA_ENV_NPUZZLE, 7>(e, heur_id, s);
     }
     return DCA_E_BADARG;
 }
 
-
-int enqueue_first_half(dca_engine* e, int heur_id, bool with_refill, hipStream_t s) {
-    const Eng& E = e->E;
-    if (with_refill) {
-        hipLaunchKernelGGL(k_refill_hist, dim3(kScanBlocks), dim3(256), 0, s, E);
-        hipLaunchKernelGGL(k_refill_scan, dim3(1), dim3(1024), 0, s, E);
-        hipLaunchKernelGGL(k_refill_move, dim3(kScanBlocks), dim3(256), 0, s, E);
+void launch_probe(const dca_engine* e, hipStream_t s) {
+    const Eng& E = e->E[0];
+    const dim3 g = gxy((E.M + 255) / 256, e), b(256);
+    switch (E.D) {
+        case 54: hipLaunchKernelGGL(k_probe<54>, g, b, 0, s, e->d_engs); break;
+        case 16: hipLaunchKernelGGL(k_probe<16>, g, b, 0, s, e->d_engs); break;
+        case 25: hipLaunchKernelGGL(k_probe<25>, g, b, 0, s, e->d_engs); break;
+        case 36: hipLaunchKernelGGL(k_probe<36>, g, b, 0, s, e->d_engs); break;
+        default: hipLaunchKernelGGL(k_probe<49>, g, b, 0, s, e->d_engs); break;
     }
-    hipLaunchKernelGGL(k_sel_hist, dim3(kScanBlocks), dim3(256), 0, s, E);
-    hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(1024), 0, s, E);
-    hipLaunchKernelGGL(k_sel_collect, dim3(kScanBlocks), dim3(256), 0, s, E);
-    hipLaunchKernelGGL(k_sel_cand, dim3(1), dim3(1024), 0, s, E);
-    hipLaunchKernelGGL(k_ord_count, dim3((E.ord_cap + 255) / 256), dim3(256), 0, s, E);
-    hipLaunchKernelGGL(k_ord_scan, dim3(1), dim3(1024), 0, s, E);
-    hipLaunchKernelGGL(k_ord_scatter, dim3((E.ord_cap + 255) / 256), dim3(256), 0, s, E);
-    hipLaunchKernelGGL(k_ord_rank, dim3((E.ord_cap + 255) / 256), dim3(256), 0, s, E);
-    hipLaunchKernelGGL(k_post_pop, dim3(1), dim3(64), 0, s, E);
-    if (int rc = launch_check("select kernels")) return rc;
-    return launch_expand(E, heur_id, s);
 }
 
-int enqueue_second_half(dca_engine* e, hipStream_t s) {
-    const Eng& E = e->E;
-    const unsigned gb = (E.M + 255) / 256;
-    launch_probe(E, s);
-    hipLaunchKernelGGL(k_decide, dim3(gb), dim3(256), 0, s, E);
-    hipLaunchKernelGGL(k_commit, dim3((E.M + 1023) / 1024), dim3(1024), 0, s, E);
+// phase boundaries for the per-kernel profile: an event is recorded before phase p when ev != nullptr
+struct Marks {
+    hipEvent_t* ev;
+    int k;
+    hipStream_t s;
+    void mark() {
+        if (ev) (void)hipEventRecord(ev[k++], s);
+    }
+};
+
+int enqueue_first_half(dca_engine* e, int heur_id, bool with_refill, hipStream_t s, Marks* mk = nullptr) {
+    const Eng& E = e->E[0];
+    const Eng* d = e->d_engs;
+    const unsigned ordg = (E.ord_cap + 255) / 256;
+    Marks none{nullptr, 0, s};
+    Marks& m = mk ? *mk : none;
+    m.mark();  // 0 refill
+    if (with_refill) {
+        hipLaunchKernelGGL(k_refill_hist, gxy(kScanGrid, e), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(k_refill_scan, gxy(1, e), dim3(1024), 0, s, d);
+        hipLaunchKernelGGL(k_refill_move, gxy(kScanGrid, e), dim3(256), 0, s, d);
+    }
+    m.mark();  // 1 sel_hist
+    hipLaunchKernelGGL(k_sel_hist, gxy(kScanGrid, e), dim3(256), 0, s, d);
+    m.mark();  // 2 sel_scan
+    hipLaunchKernelGGL(k_sel_scan, gxy(1, e), dim3(1024), 0, s, d);
+    m.mark();  // 3 sel_collect
+    hipLaunchKernelGGL(k_sel_collect, gxy(kScanGrid, e), dim3(256), 0, s, d);
+    m.mark();  // 4 sel_cand
+    hipLaunchKernelGGL(k_sel_cand, gxy(1, e), dim3(1024), 0, s, d);
+    m.mark();  // 5 order
+    hipLaunchKernelGGL(k_ord_count, gxy(ordg, e), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(k_ord_scan, gxy(1, e), dim3(1024), 0, s, d);
+    hipLaunchKernelGGL(k_ord_scatter, gxy(ordg, e), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(k_ord_rank, gxy(ordg, e), dim3(256), 0, s, d);
+    m.mark();  // 6 post_pop
+    hipLaunchKernelGGL(k_post_pop, gxy(1, e), dim3(64), 0, s, d);
+    if (int rc = launch_check("select kernels")) return rc;
+    m.mark();  // 7 expand
+    return launch_expand(e, heur_id, s);
+}
+
+int enqueue_second_half(dca_engine* e, hipStream_t s, Marks* mk = nullptr) {
+    const Eng& E = e->E[0];
+    Marks none{nullptr, 0, s};
+    Marks& m = mk ? *mk : none;
+    m.mark();  // 8 probe
+    launch_probe(e, s);
+    m.mark();  // 9 decide
+    hipLaunchKernelGGL(k_decide, gxy((E.M + 255) / 256, e), dim3(256), 0, s, e->d_engs);
+    m.mark();  // 10 commit
+    hipLaunchKernelGGL(k_commit, gxy((E.M + 1023) / 1024, e), dim3(1024), 0, s, e->d_engs);
+    m.mark();  // end
     return launch_check("dedup kernels");
 }
+
+void drop_graphs(dca_engine* e) {
+    for (int g = 0; g < 2; g++) {
+        if (e->graph_exec[g]) (void)hipGraphExecDestroy(e->graph_exec[g]);
+        if (e->graph[g]) (void)hipGraphDestroy(e->graph[g]);
+        e->graph_exec[g] = nullptr;
+        e->graph[g] = nullptr;
+    }
+}
+
+int upload_engs(dca_engine* e) {
+    DCA_HIP(hipMemcpy(e->d_engs, e->E, sizeof(Eng) * (size_t)e->K, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int fetch_ctl(dca_engine* e, int inst, hipStream_t s) {
+    DCA_HIP(hipMemcpyAsync(e->h_ctl, e->E[inst].ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s));
+    DCA_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+#define DCA_INST(e, i)                                                        \
+    do {                                                                      \
+        DCA_ARG((e) != nullptr);                                              \
+        if ((i) < 0 || (i) >= (e)->K) {                                       \
+            set_error("instance %d out of range (engine has %d)", (i), (e)->K); \
+            return DCA_E_BADARG;                                              \
+        }                                                                     \
+    } while (0)
 
 }  // namespace
 
 extern "C" {
 
-int dca_engine_create(dca_engine** out, int env, int dim, double weight, int batch_size, int64_t max_nodes,
-                      int semantics, int onehot_dtype) {
+int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, int batch_size, int64_t max_nodes,
+                            int semantics, int onehot_dtype, int num_instances) {
     DCA_ARG(out != nullptr);
     *out = nullptr;
     DCA_ARG(env == DCA_ENV_CUBE3 || (env == DCA_ENV_NPUZZLE && dim >= 4 && dim <= 7));
@@ -1750,89 +1834,101 @@ int dca_engine_create(dca_engine** out, int env, int dim, double weight, int bat
     DCA_ARG(semantics == DCA_SEM_PY || semantics == DCA_SEM_CPP);
     DCA_ARG(onehot_dtype >= -1 && onehot_dtype <= DCA_DT_BF16);
     DCA_ARG(weight >= 0.0);
+    DCA_ARG(num_instances >= 1 && num_instances <= kMaxInstances);
     const int A = env == DCA_ENV_CUBE3 ? 12 : 4;
     const int D = env == DCA_ENV_CUBE3 ? 54 : dim * dim;
+    const int depth = env == DCA_ENV_CUBE3 ? 6 : D;
     const int64_t Mll = (int64_t)batch_size * A;
     DCA_ARG(max_nodes >= Mll + 16 && max_nodes <= 0x7FFFFF00ll);
-    dca_engine* e = new (std::nothrow) dca_engine();
-    if (!e) return DCA_E_NOMEM;
-    memset(e, 0, sizeof(*e));
-    Eng& E = e->E;
-    E.env = env;
-    E.dim = dim;
-    E.D = D;
-    E.A = A;
-    E.B = batch_size;
-    E.sem = semantics;
-    E.oh_dtype = onehot_dtype;
-    E.depth = env == DCA_ENV_CUBE3 ? 6 : D;
-    E.w = weight;
-    E.wf = (float)weight;  // cpp:353 (float) atof(argv[2])
-    E.max_nodes = (uint32_t)max_nodes;
-    E.M = (uint32_t)Mll;
-    E.ord_cap = (uint32_t)(2 * batch_size + 131072);
-    E.f_keep = (uint32_t)(32 * batch_size > 65536 ? 32 * batch_size : 65536);
-    E.f_max = 3 * E.f_keep;
     uint64_t cap = 1024;
     while (cap < 2ull * (uint64_t)max_nodes) cap <<= 1;
-    E.tab_cap = (uint32_t)cap;
-    E.tab_mask = (uint32_t)(cap - 1);
     if (cap > 0x80000000ull) {
-        delete e;
         set_error("max_nodes too large for a 32-bit slot index");
         return DCA_E_BADARG;
     }
-    int rc = 0;
+    dca_engine* e = new (std::nothrow) dca_engine();
+    if (!e) return DCA_E_NOMEM;
+    memset(e, 0, sizeof(*e));
+    e->K = num_instances;
+    const size_t K = (size_t)num_instances;
     const size_t N = (size_t)max_nodes, M = (size_t)Mll, Bz = (size_t)(2 * batch_size + 131072);
+    int rc = 0;
+    // batch buffers shared by all instances (contiguous, so one heuristic call serves every instance)
+    rc = dev_alloc(e, &e->nnet_all, K * M * D + 64);
+    if (!rc) rc = dev_alloc(e, &e->h_all, K * M);
+    if (!rc && onehot_dtype >= 0) rc = dev_alloc(e, &e->onehot_all, K * M * D * depth * (onehot_dtype == DCA_DT_F32 ? 4 : 2) + 64);
+    if (!rc) rc = dev_alloc(e, &e->d_engs, K);
+    if (!rc) rc = dev_alloc(e, &e->d_cost, 1);
+    for (size_t i = 0; i < K && !rc; i++) {
+        Eng& E = e->E[i];
+        E.env = env;
+        E.dim = dim;
+        E.D = D;
+        E.A = A;
+        E.B = batch_size;
+        E.sem = semantics;
+        E.oh_dtype = onehot_dtype;
+        E.depth = depth;
+        E.w = weight;
+        E.wf = (float)weight;  // cpp:353 (float) atof(argv[2])
+        E.max_nodes = (uint32_t)max_nodes;
+        E.M = (uint32_t)Mll;
+        E.ord_cap = (uint32_t)Bz;
+        E.f_keep = (uint32_t)(32 * batch_size > 65536 ? 32 * batch_size : 65536);
+        E.f_max = 3 * E.f_keep;
+        E.tab_cap = (uint32_t)cap;
+        E.tab_mask = (uint32_t)(cap - 1);
+        E.nb2_cap = (uint32_t)(Bz / 2 + 4096);
+        E.nnet_in = e->nnet_all + i * M * D;
+        E.child_h = e->h_all + i * M;
+        E.onehot = e->onehot_all ? e->onehot_all + i * M * D * depth * (onehot_dtype == DCA_DT_F32 ? 4 : 2) : nullptr;
 #define ALLOC(field, count) \
     if (!rc) rc = dev_alloc(e, &E.field, (count))
-    ALLOC(state, N * D + 64);
-    ALLOC(g, N);
-    ALLOC(parent, N);
-    ALLOC(move, N);
-    ALLOC(solved, N);
-    ALLOC(tab, (size_t)cap);
-    for (int b = 0; b < 4; b++) {  // FRONT ping-pong (0/1) + BACK and its compaction target (2/3)
-        ALLOC(open_key[b], N);
-        ALLOC(open_id[b], N);
-    }
-    ALLOC(hist, NBIN);
-    ALLOC(sub_base, NBIN);
-    ALLOC(part, 4 * 1024);
-    ALLOC(sub_lg, NBIN);
-    ALLOC(cand_key, N);
-    ALLOC(cand_id, N);
-    ALLOC(cand_st, N);
-    ALLOC(tmp_key, Bz);
-    ALLOC(pop_key, Bz);
-    ALLOC(tmp_id, Bz);
-    ALLOC(pop_id, Bz);
-    ALLOC(ord_key, Bz);
-    ALLOC(ord_id, Bz);
-    ALLOC(ord_b, Bz);
-    ALLOC(ord_s, Bz);
-    ALLOC(ord_pb, Bz);
-    ALLOC(spl_key, 2048);
-    ALLOC(spl_id, 2048);
-    E.nb2_cap = (uint32_t)(Bz / 2 + 4096);
-    ALLOC(bcnt, E.nb2_cap + 8);
-    ALLOC(bpre, E.nb2_cap + 8);
-    ALLOC(child_hash, M);
-    ALLOC(child_key, M);
-    ALLOC(child_slot, M);
-    ALLOC(child_next, M);
-    ALLOC(child_flags, M);
-    ALLOC(child_h, M);
-    ALLOC(nnet_in, M * D + 64);
-    ALLOC(root_nnet, 64);
-    ALLOC(d_moves, kMaxMoves);
-    ALLOC(ctl, 1);
-    if (!rc && onehot_dtype >= 0) {
-        size_t esz = onehot_dtype == DCA_DT_F32 ? 4 : 2;
-        ALLOC(onehot, M * D * E.depth * esz + 64);
-    }
-    if (!rc) rc = dev_alloc(e, &e->d_cost, 1);
+        ALLOC(state, N * D + 64);
+        ALLOC(g, N);
+        ALLOC(parent, N);
+        ALLOC(move, N);
+        ALLOC(solved, N);
+        ALLOC(tab, (size_t)cap);
+        for (int b = 0; b < 4; b++) {  // FRONT ping-pong (0/1) + BACK and its compaction target (2/3)
+            ALLOC(open_key[b], N);
+            ALLOC(open_id[b], N);
+        }
+        ALLOC(hist, NBIN);
+        ALLOC(sub_base, NBIN);
+        ALLOC(part, 4 * 1024);
+        ALLOC(sub_lg, NBIN);
+        ALLOC(cand_key, N);
+        ALLOC(cand_id, N);
+        ALLOC(cand_st, N);
+        ALLOC(tmp_key, Bz);
+        ALLOC(pop_key, Bz);
+        ALLOC(tmp_id, Bz);
+        ALLOC(pop_id, Bz);
+        ALLOC(ord_key, Bz);
+        ALLOC(ord_id, Bz);
+        ALLOC(ord_b, Bz);
+        ALLOC(ord_s, Bz);
+        ALLOC(ord_pb, Bz);
+        ALLOC(spl_key, 2048);
+        ALLOC(spl_id, 2048);
+        ALLOC(bcnt, E.nb2_cap + 8);
+        ALLOC(bpre, E.nb2_cap + 8);
+        ALLOC(child_hash, M);
+        ALLOC(child_key, M);
+        ALLOC(child_slot, M);
+        ALLOC(child_next, M);
+        ALLOC(child_flags, M);
+        ALLOC(root_nnet, 64);
+        ALLOC(d_moves, kMaxMoves);
+        ALLOC(ctl, 1);
 #undef ALLOC
+        if (!rc) {
+            (void)hipMemset(E.hist, 0, NBIN * sizeof(uint32_t));
+            (void)hipMemset(E.bcnt, 0, (E.nb2_cap + 8) * sizeof(uint32_t));
+            (void)hipMemset(E.ctl, 0, sizeof(Ctl));
+        }
+    }
     if (!rc) {
         hipError_t err = hipHostMalloc((void**)&e->h_ctl, sizeof(Ctl) + kMaxMoves * sizeof(int32_t) + 512);
         if (err != hipSuccess) rc = hip_fail(err, "hipHostMalloc");
@@ -1843,53 +1939,75 @@ int dca_engine_create(dca_engine** out, int env, int dim, double weight, int bat
     }
     e->h_moves = reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(e->h_ctl) + ((sizeof(Ctl) + 15) & ~15ul));
     e->h_cost = reinterpret_cast<double*>(e->h_moves + kMaxMoves);
-    (void)hipMemset(E.nnet_in, 0, M * D);
-    (void)hipMemset(E.hist, 0, NBIN * sizeof(uint32_t));
-    (void)hipMemset(E.bcnt, 0, (E.nb2_cap + 8) * sizeof(uint32_t));
-    (void)hipMemset(E.ctl, 0, sizeof(Ctl));
+    e->h_stage = reinterpret_cast<uint8_t*>(e->h_cost + 1);
+    (void)hipMemset(e->nnet_all, 0, K * M * D);
+    if (int urc = upload_engs(e)) {
+        dca_engine_destroy(e);
+        return urc;
+    }
+    // every instance starts "done" until it is reset with a root (so unused instances are inert)
+    for (size_t i = 0; i < K; i++) {
+        int32_t one = 1;
+        (void)hipMemcpy(&e->E[i].ctl->done, &one, sizeof(one), hipMemcpyHostToDevice);
+    }
     *out = e;
     return 0;
 }
 
+int dca_engine_create(dca_engine** out, int env, int dim, double weight, int batch_size, int64_t max_nodes,
+                      int semantics, int onehot_dtype) {
+    return dca_engine_create_multi(out, env, dim, weight, batch_size, max_nodes, semantics, onehot_dtype, 1);
+}
+
+int dca_engine_num_instances(dca_engine* e) { return e ? e->K : 0; }
+
 void dca_engine_destroy(dca_engine* e) {
     if (!e) return;
-    for (int g = 0; g < 2; g++) {
-        if (e->graph_exec[g]) (void)hipGraphExecDestroy(e->graph_exec[g]);
-        if (e->graph[g]) (void)hipGraphDestroy(e->graph[g]);
-    }
+    drop_graphs(e);
     for (int i = 0; i < e->nalloc; i++) (void)hipFree(e->allocs[i]);
     if (e->h_ctl) (void)hipHostFree(e->h_ctl);
     delete e;
 }
 
-int dca_engine_reset(dca_engine* e, const uint8_t* root, void* stream) {
-    DCA_ARG(e != nullptr && root != nullptr);
+int dca_engine_reset_instance(dca_engine* e, int inst, const uint8_t* root, void* stream) {
+    DCA_INST(e, inst);
+    DCA_ARG(root != nullptr);
     hipStream_t s = (hipStream_t)stream;
-    Eng& E = e->E;
+    Eng& E = e->E[inst];
     for (int i = 0; i < E.D; i++) DCA_ARG(root[i] < (E.env == DCA_ENV_CUBE3 ? 54 : E.D));
-    // the root row must outlive this call: stage it in the pinned block
-    uint8_t* stage = reinterpret_cast<uint8_t*>(e->h_cost + 1);
-    memcpy(stage, root, (size_t)E.D);
-    DCA_HIP(hipMemcpyAsync(E.state, stage, (size_t)E.D, hipMemcpyHostToDevice, s));
+    // the staging block is reused: make sure an earlier reset's copy has left it
+    DCA_HIP(hipStreamSynchronize(s));
+    memcpy(e->h_stage, root, (size_t)E.D);
+    DCA_HIP(hipMemcpyAsync(E.state, e->h_stage, (size_t)E.D, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_init_table, dim3(4096), dim3(256), 0, s, E.tab, E.tab_cap);
     hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, s, E);
     e->phase = 0;
-    e->host_iter = 0;
+    if (inst == 0) e->host_iter = 0;
     return launch_check("k_reset");
 }
-
-int dca_engine_root_commit(dca_engine* e, const float* h_root, void* stream) {
-    DCA_ARG(e != nullptr);
-    if (e->E.sem != DCA_SEM_PY) return 0;
-    DCA_ARG(h_root != nullptr);
-    hipLaunchKernelGGL(k_root_commit, dim3(1), dim3(64), 0, (hipStream_t)stream, e->E, h_root);
-    return launch_check("k_root_commit");
+int dca_engine_reset(dca_engine* e, const uint8_t* root, void* stream) {
+    return dca_engine_reset_instance(e, 0, root, stream);
 }
 
-int dca_engine_root_nnet_in(dca_engine* e, const uint8_t** nnet_in) {
-    DCA_ARG(e != nullptr && nnet_in != nullptr);
-    *nnet_in = e->E.root_nnet;
+int dca_engine_root_commit_instance(dca_engine* e, int inst, const float* h_root, void* stream) {
+    DCA_INST(e, inst);
+    if (e->E[inst].sem != DCA_SEM_PY) return 0;
+    DCA_ARG(h_root != nullptr);
+    hipLaunchKernelGGL(k_root_commit, dim3(1), dim3(64), 0, (hipStream_t)stream, e->E[inst], h_root);
+    return launch_check("k_root_commit");
+}
+int dca_engine_root_commit(dca_engine* e, const float* h_root, void* stream) {
+    return dca_engine_root_commit_instance(e, 0, h_root, stream);
+}
+
+int dca_engine_root_nnet_in_instance(dca_engine* e, int inst, const uint8_t** nnet_in) {
+    DCA_INST(e, inst);
+    DCA_ARG(nnet_in != nullptr);
+    *nnet_in = e->E[inst].root_nnet;
     return 0;
+}
+int dca_engine_root_nnet_in(dca_engine* e, const uint8_t** nnet_in) {
+    return dca_engine_root_nnet_in_instance(e, 0, nnet_in);
 }
 
 int dca_engine_pop_expand(dca_engine* e, const uint8_t** nnet_in, const void** onehot, int64_t* m_capacity,
@@ -1900,9 +2018,9 @@ int dca_engine_pop_expand(dca_engine* e, const uint8_t** nnet_in, const void** o
         return DCA_E_STATE;
     }
     if (int rc = enqueue_first_half(e, -1, (e->host_iter++ % kRefillPeriod) == 0, (hipStream_t)stream)) return rc;
-    if (nnet_in) *nnet_in = e->E.nnet_in;
-    if (onehot) *onehot = e->E.onehot;
-    if (m_capacity) *m_capacity = e->E.M;
+    if (nnet_in) *nnet_in = e->nnet_all;
+    if (onehot) *onehot = e->onehot_all;
+    if (m_capacity) *m_capacity = (int64_t)e->E[0].M * e->K;
     e->phase = 1;
     return 0;
 }
@@ -1914,7 +2032,7 @@ int dca_engine_commit(dca_engine* e, const float* h, void* stream) {
         return DCA_E_STATE;
     }
     hipStream_t s = (hipStream_t)stream;
-    DCA_HIP(hipMemcpyAsync(e->E.child_h, h, (size_t)e->E.M * sizeof(float), hipMemcpyDeviceToDevice, s));
+    DCA_HIP(hipMemcpyAsync(e->h_all, h, (size_t)e->E[0].M * e->K * sizeof(float), hipMemcpyDeviceToDevice, s));
     e->phase = 0;
     return enqueue_second_half(e, s);
 }
@@ -1934,11 +2052,8 @@ int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph,
         return 0;
     }
     if (e->graph_exec[0] == nullptr || e->graph_heur != heur_id) {
+        drop_graphs(e);
         for (int g = 0; g < 2; g++) {
-            if (e->graph_exec[g]) (void)hipGraphExecDestroy(e->graph_exec[g]);
-            if (e->graph[g]) (void)hipGraphDestroy(e->graph[g]);
-            e->graph_exec[g] = nullptr;
-            e->graph[g] = nullptr;
             hipStream_t cs;
             DCA_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
             hipError_t err = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
@@ -1961,56 +2076,25 @@ int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph,
 }
 
 int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, float* ms_out, void* stream) {
-    // one hipEvent between every pair of kernels of an iteration (eager launches on `stream`);
+    // one hipEvent between every pair of phases of an iteration (eager launches on `stream`);
     // ms_out[k] = summed milliseconds of phase k over `iters` iterations.  Phases:
-    // 0 refill(3 kernels) 1 sel_hist 2 sel_scan 3 sel_collect 4 sel_cand 5 order(3 kernels) 6 post_pop
-    // 7 expand 8 probe 9 decide 10 commit
+    // 0 refill(3 kernels, every 8th iteration) 1 sel_hist 2 sel_scan 3 sel_collect 4 sel_cand 5 order(4 kernels)
+    // 6 post_pop 7 expand 8 probe 9 decide 10 commit
     DCA_ARG(e != nullptr && ms_out != nullptr && heur_id >= 0 && heur_id <= DCA_HEUR_MANHATTAN && iters >= 0);
     if (e->phase != 0) {
         set_error("dca_engine_profile_builtin between pop_expand and commit");
         return DCA_E_STATE;
     }
     hipStream_t s = (hipStream_t)stream;
-    const Eng& E = e->E;
     constexpr int NP = 11;
-    hipEvent_t ev[NP + 1];
+    hipEvent_t ev[NP + 2];
     for (int k = 0; k <= NP; k++) DCA_HIP(hipEventCreate(&ev[k]));
     for (int k = 0; k < 16; k++) ms_out[k] = 0.f;
-    const unsigned gb = (E.M + 255) / 256;
     int rc = 0;
     for (int it = 0; it < iters && !rc; it++) {
-        int k = 0;
-        (void)hipEventRecord(ev[k++], s);
-        if ((e->host_iter++ % kRefillPeriod) == 0) {
-            hipLaunchKernelGGL(k_refill_hist, dim3(kScanBlocks), dim3(256), 0, s, E);
-            hipLaunchKernelGGL(k_refill_scan, dim3(1), dim3(1024), 0, s, E);
-            hipLaunchKernelGGL(k_refill_move, dim3(kScanBlocks), dim3(256), 0, s, E);
-        }
-        (void)hipEventRecord(ev[k++], s);
-        hipLaunchKernelGGL(k_sel_hist, dim3(kScanBlocks), dim3(256), 0, s, E);
-        (void)hipEventRecord(ev[k++], s);
-        hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(1024), 0, s, E);
-        (void)hipEventRecord(ev[k++], s);
-        hipLaunchKernelGGL(k_sel_collect, dim3(kScanBlocks), dim3(256), 0, s, E);
-        (void)hipEventRecord(ev[k++], s);
-        hipLaunchKernelGGL(k_sel_cand, dim3(1), dim3(1024), 0, s, E);
-        (void)hipEventRecord(ev[k++], s);
-        hipLaunchKernelGGL(k_ord_count, dim3((E.ord_cap + 255) / 256), dim3(256), 0, s, E);
-        hipLaunchKernelGGL(k_ord_scan, dim3(1), dim3(1024), 0, s, E);
-    hipLaunchKernelGGL(k_ord_scatter, dim3((E.ord_cap + 255) / 256), dim3(256), 0, s, E);
-        hipLaunchKernelGGL(k_ord_rank, dim3((E.ord_cap + 255) / 256), dim3(256), 0, s, E);
-        (void)hipEventRecord(ev[k++], s);
-        hipLaunchKernelGGL(k_post_pop, dim3(1), dim3(64), 0, s, E);
-        (void)hipEventRecord(ev[k++], s);
-        rc = launch_expand(E, heur_id, s);
-        (void)hipEventRecord(ev[k++], s);
-        launch_probe(E, s);
-        (void)hipEventRecord(ev[k++], s);
-        hipLaunchKernelGGL(k_decide, dim3(gb), dim3(256), 0, s, E);
-        (void)hipEventRecord(ev[k++], s);
-        hipLaunchKernelGGL(k_commit, dim3((E.M + 1023) / 1024), dim3(1024), 0, s, E);
-        (void)hipEventRecord(ev[k++], s);
-        if (!rc) rc = launch_check("profiled iteration");
+        Marks mk{ev, 0, s};
+        rc = enqueue_first_half(e, heur_id, (e->host_iter++ % kRefillPeriod) == 0, s, &mk);
+        if (!rc) rc = enqueue_second_half(e, s, &mk);
         if (hipStreamSynchronize(s) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipStreamSynchronize");
         for (int p = 0; p < NP && !rc; p++) {
             float ms = 0.f;
@@ -2022,11 +2106,21 @@ int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, float* ms_
     return rc;
 }
 
-int dca_engine_status(dca_engine* e, dca_status* out, void* stream) {
-    DCA_ARG(e != nullptr && out != nullptr);
-    hipStream_t s = (hipStream_t)stream;
-    DCA_HIP(hipMemcpyAsync(e->h_ctl, e->E.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s));
-    DCA_HIP(hipStreamSynchronize(s));
+int dca_engine_set_tiers(dca_engine* e, int64_t front_keep, int64_t front_max) {
+    // test / tuning hook: FRONT hysteresis in entries (defaults 32*B and 96*B).  Search results never depend on it.
+    DCA_ARG(e != nullptr && front_keep >= 1 && front_max >= front_keep && front_max < (1ll << 31));
+    for (int i = 0; i < e->K; i++) {
+        e->E[i].f_keep = (uint32_t)front_keep;
+        e->E[i].f_max = (uint32_t)front_max;
+    }
+    drop_graphs(e);  // (kernel arguments are only the instance-array pointer, but stay on the safe side)
+    return upload_engs(e);
+}
+
+int dca_engine_status_instance(dca_engine* e, int inst, dca_status* out, void* stream) {
+    DCA_INST(e, inst);
+    DCA_ARG(out != nullptr);
+    if (int rc = fetch_ctl(e, inst, (hipStream_t)stream)) return rc;
     const Ctl& c = *e->h_ctl;
     out->done = c.done;
     out->failed = c.failed;
@@ -2039,26 +2133,13 @@ int dca_engine_status(dca_engine* e, dca_status* out, void* stream) {
     out->best_cost = c.has_best ? (double)c.best_cost : __builtin_nan("");
     return 0;
 }
-
-int dca_engine_set_tiers(dca_engine* e, int64_t front_keep, int64_t front_max) {
-    // test / tuning hook: FRONT hysteresis in entries (defaults 32*B and 96*B).  Search results never depend on it.
-    DCA_ARG(e != nullptr && front_keep >= 1 && front_max >= front_keep && front_max < (1ll << 31));
-    e->E.f_keep = (uint32_t)front_keep;
-    e->E.f_max = (uint32_t)front_max;
-    for (int g = 0; g < 2; g++) {  // captured graphs hold the old values
-        if (e->graph_exec[g]) (void)hipGraphExecDestroy(e->graph_exec[g]);
-        if (e->graph[g]) (void)hipGraphDestroy(e->graph[g]);
-        e->graph_exec[g] = nullptr;
-        e->graph[g] = nullptr;
-    }
-    return 0;
+int dca_engine_status(dca_engine* e, dca_status* out, void* stream) {
+    return dca_engine_status_instance(e, 0, out, stream);
 }
 
 int dca_engine_debug(dca_engine* e, double* out, void* stream) {
     DCA_ARG(e != nullptr && out != nullptr);
-    hipStream_t s = (hipStream_t)stream;
-    DCA_HIP(hipMemcpyAsync(e->h_ctl, e->E.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s));
-    DCA_HIP(hipStreamSynchronize(s));
+    if (int rc = fetch_ctl(e, 0, (hipStream_t)stream)) return rc;
     const Ctl& c = *e->h_ctl;
     auto cost = [](uint64_t k) {
         uint64_t b = (k & 0x8000000000000000ull) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
@@ -2087,20 +2168,21 @@ int dca_engine_debug(dca_engine* e, double* out, void* stream) {
 
 int dca_engine_last_children(dca_engine* e, const uint8_t** states, int64_t* m_live, void* stream) {
     DCA_ARG(e != nullptr && states != nullptr && m_live != nullptr);
-    hipStream_t s = (hipStream_t)stream;
-    DCA_HIP(hipMemcpyAsync(e->h_ctl, e->E.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s));
-    DCA_HIP(hipStreamSynchronize(s));
-    *states = e->E.state + (size_t)e->h_ctl->base * e->E.D;
+    if (int rc = fetch_ctl(e, 0, (hipStream_t)stream)) return rc;
+    *states = e->E[0].state + (size_t)e->h_ctl->base * e->E[0].D;
     *m_live = e->h_ctl->m;
     return 0;
 }
 
-int dca_engine_solution(dca_engine* e, int32_t* moves, int cap, int* len, double* path_cost, void* stream) {
-    DCA_ARG(e != nullptr && len != nullptr && cap >= 0 && (cap == 0 || moves != nullptr));
+int dca_engine_solution_instance(dca_engine* e, int inst, int32_t* moves, int cap, int* len, double* path_cost,
+                                 void* stream) {
+    DCA_INST(e, inst);
+    DCA_ARG(len != nullptr && cap >= 0 && (cap == 0 || moves != nullptr));
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_solution, dim3(1), dim3(64), 0, s, e->E, e->E.d_moves, e->d_cost);
+    const Eng& E = e->E[inst];
+    hipLaunchKernelGGL(k_solution, dim3(1), dim3(64), 0, s, E, E.d_moves, e->d_cost);
     if (int rc = launch_check("k_solution")) return rc;
-    DCA_HIP(hipMemcpyAsync(e->h_moves, e->E.d_moves, kMaxMoves * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    DCA_HIP(hipMemcpyAsync(e->h_moves, E.d_moves, kMaxMoves * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     DCA_HIP(hipMemcpyAsync(e->h_cost, e->d_cost, sizeof(double), hipMemcpyDeviceToHost, s));
     DCA_HIP(hipStreamSynchronize(s));
     int n = e->h_moves[0];
@@ -2112,6 +2194,9 @@ int dca_engine_solution(dca_engine* e, int32_t* moves, int cap, int* len, double
     if (path_cost) *path_cost = *e->h_cost;
     for (int i = 0; i < n && i < cap; i++) moves[i] = e->h_moves[1 + i];
     return 0;
+}
+int dca_engine_solution(dca_engine* e, int32_t* moves, int cap, int* len, double* path_cost, void* stream) {
+    return dca_engine_solution_instance(e, 0, moves, cap, len, path_cost, stream);
 }
 
 }  // extern "C"

@@ -61,34 +61,38 @@ def bwas_hip(args, env, states: List) -> Tuple[List[List[int]], List[List], List
     heuristic_fn = _load_heuristic(args, env)
     sem = _lib.SEM_CPP if getattr(args, "semantics", "py") == "cpp" else _lib.SEM_PY
     oh = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[getattr(args, "nnet_dtype", "fp32")]
+    K = max(1, int(getattr(args, "instances_per_gpu", 1)))
     eng = BwasEngine(args.env, args.weight, args.batch_size, max_nodes=int(getattr(args, "max_nodes", 1 << 26)),
-                     semantics=sem, onehot_dtype=oh)
+                     semantics=sem, onehot_dtype=oh, num_instances=K)
     world, rank = sharding.world_info()
     mine = sharding.shard_indices(len(states), world, rank)
     local: Dict[int, Tuple[List[int], List, float, int]] = {}
-    for state_idx in mine:
-        state = states[state_idx]
+    for g0 in range(0, len(mine), K):
+        group = mine[g0:g0 + K]  # K scrambles stepped together by one engine (one network call per iteration)
         start_time = time.time()
-        root = np.ascontiguousarray(env._get_arr(state), dtype=np.uint8)
-        res = eng.solve(root, heuristic_fn)
-        if not res["solved"]:
-            raise _lib.DcaError("state %d: search stopped without a solution (%s) — raise --max_nodes"
-                                % (state_idx, "node pool exhausted" if res["failed"] else "OPEN empty"))
-        soln: List[int] = res["moves"]
-        path_cost: float = res["path_cost"]
-        num_nodes_gen_idx: int = int(res["nodes_generated"])
-        # path of states along the solution (astar.py:213-229 get_path / 534-546 replay)
-        path = [state]
-        cur = state
-        for move in soln:
-            cur = env.next_state([cur], move)[0][0]
-            path.append(cur)
-        solve_time = time.time() - start_time
-        assert search_utils.is_valid_soln(state, soln, env)  # astar.py:443
-        local[state_idx] = (soln, path, solve_time, num_nodes_gen_idx)
-        print("State: %i, SolnCost: %.2f, # Moves: %i, "
-              "# Nodes Gen: %s, Time: %.2f" % (state_idx, path_cost, len(soln), format(num_nodes_gen_idx, ","),
-                                               solve_time))
+        roots = [np.ascontiguousarray(env._get_arr(states[i]), dtype=np.uint8) for i in group]
+        results = eng.solve_many(roots, heuristic_fn) if K > 1 else [eng.solve(roots[0], heuristic_fn)]
+        group_time = time.time() - start_time
+        for state_idx, res in zip(group, results):
+            state = states[state_idx]
+            if not res["solved"]:
+                raise _lib.DcaError("state %d: search stopped without a solution (%s) — raise --max_nodes"
+                                    % (state_idx, "node pool exhausted" if res["failed"] else "OPEN empty"))
+            soln: List[int] = res["moves"]
+            path_cost: float = res["path_cost"]
+            num_nodes_gen_idx: int = int(res["nodes_generated"])
+            # path of states along the solution (astar.py:213-229 get_path / 534-546 replay)
+            path = [state]
+            cur = state
+            for move in soln:
+                cur = env.next_state([cur], move)[0][0]
+                path.append(cur)
+            solve_time = group_time  # with K > 1 the group's wall time is charged to each of its states
+            assert search_utils.is_valid_soln(state, soln, env)  # astar.py:443
+            local[state_idx] = (soln, path, solve_time, num_nodes_gen_idx)
+            print("State: %i, SolnCost: %.2f, # Moves: %i, "
+                  "# Nodes Gen: %s, Time: %.2f" % (state_idx, path_cost, len(soln), format(num_nodes_gen_idx, ","),
+                                                   solve_time))
     eng.close()
     merged = sharding.gather_results(local, len(states), world, rank)
     if merged is None:  # non-zero ranks
@@ -119,6 +123,8 @@ def build_parser() -> ArgumentParser:
     parser.add_argument('--semantics', type=str, default="py", choices=["py", "cpp"],
                         help="which reference search core to reproduce (astar.py vs parallel_weighted_astar.cpp)")
     parser.add_argument('--max_nodes', type=int, default=1 << 26, help="node pool capacity (ids per search)")
+    parser.add_argument('--instances_per_gpu', type=int, default=1,
+                        help="scrambles stepped together by one engine (finer per-instance sharding inside a GPU)")
     parser.add_argument('--nnet_dtype', type=str, default="fp32", choices=["fp32", "bf16", "fp16"],
                         help="fp32 = parity mode (1e-5); bf16/fp16 = faster, NOT parity")
     parser.add_argument('--fold_bn', action='store_true', default=False, help="fold BatchNorm into the Linears")

@@ -25,18 +25,20 @@ class BwasEngine:
     reference's std::priority_queue order is unspecified — SURVEY §3.3)."""
 
     def __init__(self, env_name: str, weight: float, batch_size: int, max_nodes: int = 1 << 24,
-                 semantics: int = _lib.SEM_PY, onehot_dtype: Optional[torch.dtype] = None):
+                 semantics: int = _lib.SEM_PY, onehot_dtype: Optional[torch.dtype] = None, num_instances: int = 1):
         _lib.require_gpu()
         self.env_id, self.dim, self.state_dim, self.num_moves, self.depth = _lib.env_ids(env_name)
         self.batch_size = int(batch_size)
         self.weight = float(weight)
         self.semantics = semantics
         self.onehot_dtype = onehot_dtype
-        self.m_capacity = self.batch_size * self.num_moves
+        self.num_instances = int(num_instances)
+        # K instances share every launch (grid.y = instance); their batch buffers are contiguous, instance-major
+        self.m_capacity = self.batch_size * self.num_moves * self.num_instances
         self._h = C.c_void_p(0)
-        _lib.check(_lib.lib().dca_engine_create(C.byref(self._h), self.env_id, self.dim, C.c_double(self.weight),
-                                                self.batch_size, C.c_int64(int(max_nodes)), semantics,
-                                                _OH[onehot_dtype]), "dca_engine_create")
+        _lib.check(_lib.lib().dca_engine_create_multi(C.byref(self._h), self.env_id, self.dim, C.c_double(self.weight),
+                                                      self.batch_size, C.c_int64(int(max_nodes)), semantics,
+                                                      _OH[onehot_dtype], self.num_instances), "dca_engine_create_multi")
         self._zero_h = torch.zeros(1, dtype=torch.float32, device="cuda")
 
     def close(self):
@@ -51,21 +53,22 @@ class BwasEngine:
             pass
 
     # ---- search control ---------------------------------------------------------------------
-    def reset(self, root: np.ndarray) -> None:
+    def reset(self, root: np.ndarray, instance: int = 0) -> None:
         r = np.ascontiguousarray(root, dtype=np.uint8)
         assert r.shape == (self.state_dim,)
-        _lib.check(_lib.lib().dca_engine_reset(self._h, r.ctypes.data_as(C.c_void_p), _lib.stream_ptr()),
-                   "dca_engine_reset")
+        _lib.check(_lib.lib().dca_engine_reset_instance(self._h, int(instance), r.ctypes.data_as(C.c_void_p),
+                                                        _lib.stream_ptr()), "dca_engine_reset_instance")
 
-    def root_nnet_in(self) -> torch.Tensor:
+    def root_nnet_in(self, instance: int = 0) -> torch.Tensor:
         p = C.c_void_p(0)
-        _lib.check(_lib.lib().dca_engine_root_nnet_in(self._h, C.byref(p)), "dca_engine_root_nnet_in")
+        _lib.check(_lib.lib().dca_engine_root_nnet_in_instance(self._h, int(instance), C.byref(p)),
+                   "dca_engine_root_nnet_in_instance")
         return _wrap_u8(p.value, (1, self.state_dim))
 
-    def root_commit(self, h_root: torch.Tensor) -> None:
+    def root_commit(self, h_root: torch.Tensor, instance: int = 0) -> None:
         h_root = h_root.to(torch.float32).contiguous()
-        _lib.check(_lib.lib().dca_engine_root_commit(self._h, _lib.ptr(h_root), _lib.stream_ptr()),
-                   "dca_engine_root_commit")
+        _lib.check(_lib.lib().dca_engine_root_commit_instance(self._h, int(instance), _lib.ptr(h_root),
+                                                              _lib.stream_ptr()), "dca_engine_root_commit_instance")
 
     def pop_expand(self) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """-> (nnet_in [M,D] uint8 view, onehot [M, D*depth] view or None), M = batch*num_moves fixed."""
@@ -114,9 +117,10 @@ class BwasEngine:
                  "sel_less", "sel_r", "cand_n", "shift", "spill_bin", "npop", "m"]
         return dict(zip(names, list(out)))
 
-    def status(self) -> dict:
+    def status(self, instance: int = 0) -> dict:
         st = _lib.DcaStatus()
-        _lib.check(_lib.lib().dca_engine_status(self._h, C.byref(st), _lib.stream_ptr()), "dca_engine_status")
+        _lib.check(_lib.lib().dca_engine_status_instance(self._h, int(instance), C.byref(st), _lib.stream_ptr()),
+                   "dca_engine_status_instance")
         return {k: getattr(st, k) for k, _ in _lib.DcaStatus._fields_}
 
     def last_children(self) -> torch.Tensor:
@@ -125,11 +129,12 @@ class BwasEngine:
                    "dca_engine_last_children")
         return _wrap_u8(p.value, (m.value, self.state_dim))
 
-    def solution(self) -> Tuple[List[int], float]:
+    def solution(self, instance: int = 0) -> Tuple[List[int], float]:
         moves = np.zeros(4096, np.int32)
         n, pc = C.c_int(0), C.c_double(0)
-        _lib.check(_lib.lib().dca_engine_solution(self._h, moves.ctypes.data_as(C.c_void_p), moves.size, C.byref(n),
-                                                  C.byref(pc), _lib.stream_ptr()), "dca_engine_solution")
+        _lib.check(_lib.lib().dca_engine_solution_instance(self._h, int(instance), moves.ctypes.data_as(C.c_void_p),
+                                                           moves.size, C.byref(n), C.byref(pc), _lib.stream_ptr()),
+                   "dca_engine_solution_instance")
         return moves[:n.value].tolist(), float(pc.value)
 
     # ---- convenience drivers -----------------------------------------------------------------
@@ -162,15 +167,50 @@ class BwasEngine:
                 break
         return self._result()
 
-    def _result(self) -> dict:
-        st = self.status()
+    def _result(self, instance: int = 0) -> dict:
+        st = self.status(instance)
         res = dict(st)
         res["solved"] = bool(st["done"] and not st["failed"])
         if res["solved"]:
-            res["moves"], res["path_cost"] = self.solution()
+            res["moves"], res["path_cost"] = self.solution(instance)
         else:
             res["moves"], res["path_cost"] = None, float("nan")
         return res
+
+    # ---- K instances at once (per-instance sharding inside one GPU) ---------------------------
+    def solve_many_builtin(self, roots, heur_id: int, max_iters: int = 1 << 30, chunk: int = 16,
+                           use_graph: bool = False) -> List[dict]:
+        """len(roots) <= num_instances searches stepped together; returns one result dict per root."""
+        k = len(roots)
+        assert 1 <= k <= self.num_instances
+        for i, root in enumerate(roots):
+            self.reset(root, i)
+            if self.semantics == _lib.SEM_PY:
+                h0 = _lib.heuristic_builtin(heur_id, torch.from_numpy(np.ascontiguousarray(root, np.uint8)[None]).cuda())
+                self.root_commit(h0, i)
+        it = 0
+        while it < max_iters:
+            n = min(chunk, max_iters - it)
+            self.run_builtin(heur_id, n, use_graph)
+            it += n
+            if all(self.status(i)["done"] for i in range(k)):
+                break
+        return [self._result(i) for i in range(k)]
+
+    def solve_many(self, roots, heuristic_fn_dev, max_iters: int = 1 << 30) -> List[dict]:
+        """Same with a device heuristic closure: ONE network call per iteration evaluates the children of all
+        instances (their batch buffers are contiguous)."""
+        k = len(roots)
+        assert 1 <= k <= self.num_instances
+        for i, root in enumerate(roots):
+            self.reset(root, i)
+            if self.semantics == _lib.SEM_PY:
+                self.root_commit(heuristic_fn_dev(self.root_nnet_in(i)).to(torch.float32), i)
+        for _ in range(max_iters):
+            self.step(heuristic_fn_dev)
+            if all(self.status(i)["done"] for i in range(k)):
+                break
+        return [self._result(i) for i in range(k)]
 
 
 def _wrap(ptr: int, shape, dtype: torch.dtype) -> torch.Tensor:

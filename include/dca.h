@@ -163,18 +163,29 @@ typedef struct dca_status {
  * generated child), the CLOSED table (2x, power of two) and OPEN.                                 */
 int dca_engine_create(dca_engine** out, int env, int dim, double weight, int batch_size,
                       int64_t max_nodes, int semantics, int onehot_dtype);
+/* K independent search instances of the same geometry in ONE engine: every kernel is launched once for all of
+ * them (grid.y = instance), the way the reference's AStar steps a list of instances together
+ * (astar.py:232-317).  A batch-20 000 iteration is launch/latency bound, so K scrambles advance in little more
+ * than the time of one.  Instances are inert until reset with a root; each has its own OPEN/CLOSED/pool
+ * (max_nodes each).  The un-suffixed calls below act on instance 0; pop_expand/commit/run_builtin act on all. */
+int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, int batch_size,
+                            int64_t max_nodes, int semantics, int onehot_dtype, int num_instances /*1..64*/);
+int dca_engine_num_instances(dca_engine* e);
 void dca_engine_destroy(dca_engine* e);
 int dca_engine_reset(dca_engine* e, const uint8_t* root /*host [D]*/, void* stream);
+int dca_engine_reset_instance(dca_engine* e, int inst, const uint8_t* root /*host [D]*/, void* stream);
 /* PY semantics: cost(root) = w*0 + max(h,0)*!solved (astar.py:244-249). h_root: device f32[1].
  * CPP semantics never evaluates the root (cpp:160) — the call is then a no-op.                    */
 int dca_engine_root_commit(dca_engine* e, const float* h_root, void* stream);
+int dca_engine_root_commit_instance(dca_engine* e, int inst, const float* h_root, void* stream);
 /* network-input row of the root (device [D]; cube3: colour index), valid after reset            */
 int dca_engine_root_nnet_in(dca_engine* e, const uint8_t** nnet_in);
+int dca_engine_root_nnet_in_instance(dca_engine* e, int inst, const uint8_t** nnet_in);
 /* first half: pop min(B,|OPEN|) by (cost, push order), expand.  *nnet_in = device pointer to the
- * network-input rows [batch*num_moves, D] of the batch's children (cube3: colour index; puzzles:
+ * network-input rows [K*batch*num_moves, D] (instance-major) of the batch's children (cube3: colour index; puzzles:
  * the tiles), child index = pop_rank*num_moves + move; *onehot = their one-hot rows
- * [batch*num_moves, D*depth] (NULL unless enabled at create).  Both buffers have the FIXED row
- * count m_capacity = batch*num_moves so the heuristic can be enqueued without a host sync; rows
+ * [K*batch*num_moves, D*depth] (NULL unless enabled at create).  Both buffers have the FIXED row
+ * count m_capacity = K*batch*num_moves so the heuristic can be enqueued without a host sync; rows
  * past the live child count hold stale but valid rows and their heuristic values are ignored.     */
 int dca_engine_pop_expand(dca_engine* e, const uint8_t** nnet_in, const void** onehot,
                           int64_t* m_capacity, void* stream);
@@ -191,6 +202,7 @@ int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph,
 int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, float* ms_out /*host [16]*/, void* stream);
 /* synchronises the stream */
 int dca_engine_status(dca_engine* e, dca_status* out, void* stream);
+int dca_engine_status_instance(dca_engine* e, int inst, dca_status* out, void* stream);
 /* test / tuning hook: FRONT-tier hysteresis in entries (defaults 32*B / 96*B); results never depend on it */
 int dca_engine_set_tiers(dca_engine* e, int64_t front_keep, int64_t front_max);
 /* internals of the last iteration for diagnostics (host double[16]; layout in dca_engine.hip); synchronises */
@@ -199,6 +211,8 @@ int dca_engine_debug(dca_engine* e, double* out /*host [16]*/, void* stream);
 int dca_engine_last_children(dca_engine* e, const uint8_t** states, int64_t* m_live, void* stream);
 /* root->goal move list (astar.py:213-229 get_path / cpp:336-341).  synchronises.                 */
 int dca_engine_solution(dca_engine* e, int32_t* moves /*host [cap]*/, int cap, int* len, double* path_cost, void* stream);
+int dca_engine_solution_instance(dca_engine* e, int inst, int32_t* moves /*host [cap]*/, int cap, int* len,
+                                 double* path_cost, void* stream);
 
 #ifdef __cplusplus
 }

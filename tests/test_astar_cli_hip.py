@@ -138,3 +138,32 @@ def test_nnet_bf16_mode_still_solves(tmp_path):
         t = co.next_state("cube3", t, a)
     assert co.is_solved("cube3", t)[0]
     eng.close()
+
+
+def test_cli_instances_per_gpu(tmp_path):
+    """--instances_per_gpu K: K scrambles stepped by one engine, one network call per iteration for all of them."""
+    from deepcubea_amd.search_methods import astar
+    from oracle import c_oracle as co
+    scr = [[0, 5, 7], [1, 3, 8, 10], [], [4, 9], [2, 6, 11]]
+    roots = []
+    for mv in scr:
+        s = np.arange(54, dtype=np.uint8)[None]
+        for a in mv:
+            s = co.next_state("cube3", s, a)
+        roots.append(s[0])
+    spath = str(tmp_path / "states.pkl")
+    _ref_pickle(spath, roots)
+    outs = {}
+    for k in (1, 3):
+        rdir = str(tmp_path / ("res%d" % k))
+        astar.main(["--states", spath, "--model", "synthetic:11", "--env", "cube3", "--weight", "0.8", "--batch_size",
+                    "60", "--results_dir", rdir, "--nnet_batch_size", "1000", "--max_nodes", str(1 << 20),
+                    "--instances_per_gpu", str(k), "--debug"])
+        outs[k] = pickle.load(open(os.path.join(rdir, "results.pkl"), "rb"))
+    for i, root in enumerate(roots):
+        for k in (1, 3):
+            s = root[None].copy()
+            for a in outs[k]["solutions"][i]:
+                s = co.next_state("cube3", s, a)
+            assert co.is_solved("cube3", s)[0]
+        assert len(outs[1]["solutions"][i]) == len(outs[3]["solutions"][i]) == len(scr[i])

@@ -248,3 +248,38 @@ def test_tier_thrash_keeps_exactness(L, co, keep, fmax):
         r2 = eng.solve_builtin(root, hid, chunk=5, use_graph=True)
         assert r2["moves"] == ref["moves"] and r2["nodes_generated"] == ref["nodes_generated"]
         eng.close()
+
+
+def test_multi_instance_engine_matches_single_instance_runs(L, co):
+    """K instances stepped by one engine (grid.y = instance) must behave exactly like K separate searches: same
+    per-iteration traces while running, same answers, although they finish at different iterations."""
+    from deepcubea_amd.search_methods.engine import BwasEngine
+    cases = [[3, 8, 1, 10, 6], [0, 5, 7, 2], [], [11, 2, 6, 9, 0], [4, 9, 1]]
+    w, B, hid = 0.8, 64, 1
+    roots = [scramble(co, "cube3", scr) for scr in cases]
+    refs = [co.astar("cube3", r, w, B, co.SEM_PY, heur_builtin_id=hid, trace_cap=100000) for r in roots]
+    eng = BwasEngine("cube3", w, B, max_nodes=1 << 21, num_instances=len(cases) + 1)  # one instance stays unused
+    for i, r in enumerate(roots):
+        eng.reset(r, i)
+        eng.root_commit(L.heuristic_builtin(hid, torch.from_numpy(r[None].copy()).cuda()), i)
+    maxit = max(r["iterations"] for r in refs)
+    for it in range(maxit):
+        eng.run_builtin(hid, 1)
+        for i, ref in enumerate(refs):
+            st = eng.status(i)
+            k = min(it, ref["iterations"] - 1)  # finished instances freeze
+            assert (st["open_size"], st["closed_size"], st["nodes_generated"]) == tuple(ref["trace"][k]), (it, i)
+            assert bool(st["done"]) == (it >= ref["iterations"] - 1)
+    for i, ref in enumerate(refs):
+        res = eng._result(i)
+        assert res["moves"] == ref["moves"] and res["nodes_generated"] == ref["nodes_generated"]
+    assert eng.status(len(cases))["iterations"] == 0  # the unused instance never ran
+    # convenience driver + graph replay, CPP semantics, puzzles
+    eng.close()
+    proots = [scramble(co, "puzzle15", [1, 3, 1, 1, 3, 0, 2, 0, 3, 1]), scramble(co, "puzzle15", [1, 1, 3, 3, 0, 2])]
+    eng = BwasEngine("puzzle15", 0.8, 100, max_nodes=1 << 18, semantics=L.SEM_CPP, num_instances=2)
+    out = eng.solve_many_builtin(proots, 1, chunk=5, use_graph=True)
+    for r, root in zip(out, proots):
+        ref = co.astar("puzzle15", root, 0.8, 100, co.SEM_CPP, heur_builtin_id=1)
+        assert r["moves"] == ref["moves"] and r["nodes_generated"] == ref["nodes_generated"]
+    eng.close()
