@@ -1273,6 +1273,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* lpar = smem;
     uint8_t* ltab = smem + TL::PAR_BYTES;
+    uint8_t* lst = smem + TL::LDS_BYTES;  // child rows of the tile, laid out exactly like their HBM destination
     const uint32_t npop = c->npop, want = c->want, base = c->base;
     const uint32_t r0 = blockIdx.x * kTileParents;
     if (E.sem == DCA_SEM_CPP && r0 + kTileParents > npop) {
@@ -1334,6 +1335,17 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
                 }
             }
             h = hash_word(h, w);
+            // stage the gathered bytes (rows start on even offsets when D is even: 2-byte stores; else bytes)
+            uint8_t* dst = lst + cc * EV::D + k;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                if (k + j + 1 < EV::D && (EV::D % 2) == 0) {
+                    *reinterpret_cast<uint16_t*>(dst + j) = (uint16_t)(w >> (8 * j));
+                } else {
+                    if (k + j < EV::D) dst[j] = (uint8_t)(w >> (8 * j));
+                    if (k + j + 1 < EV::D) dst[j + 1] = (uint8_t)(w >> (8 * j + 8));
+                }
+            }
         }
         h = hash_final(h);
         const uint32_t j = j0 + cc, id = base + j, pid = E.pop_id[r0 + r];
@@ -1345,39 +1357,33 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
         if (heur_id >= 0) E.child_h[j] = heur_from(heur_id, sum, h, manh);
     }
 
-    // child rows -> node pool (final place), network-input rows -> batch buffer; 16 B per lane
+    // child rows -> node pool (final place), network-input rows -> batch buffer: straight 16-byte copies of the
+    // staged tile (the gathers were paid once, in the per-child loop above)
+    __syncthreads();
     {
         const uint32_t tb = nchild * EV::D;
         uint8_t* gpool = E.state + ((size_t)base + j0) * EV::D;
         uint8_t* gnn = E.nnet_in + (size_t)j0 * EV::D;
-        const uint32_t nch = (tb + 15) >> 4;
-        for (uint32_t q = threadIdx.x; q < nch; q += kThreads) {
-            uint32_t b0 = q << 4;
-            uint32_t cch = b0 / EV::D, i = b0 - cch * EV::D;
-            uint32_t r = cch / EV::A, a = cch - r * EV::A;
-            uint32_t w[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                uint32_t b = (b0 + k < tb) ? t.child_byte(r, a, i) : 0u;
-                w[k >> 2] |= b << (8 * (k & 3));
-                if constexpr (ENV == DCA_ENV_CUBE3) v[k >> 2] |= ((b * 57u) >> 9) << (8 * (k & 3));
-                if (++i == EV::D) {
-                    i = 0;
-                    if (++a == EV::A) {
-                        a = 0;
-                        ++r;
-                    }
-                }
-            }
-            if (b0 + 16 <= tb) {
-                store16(gpool + b0, w, true);
-                store16(gnn + b0, ENV == DCA_ENV_CUBE3 ? v : w, true);
+        const uint32_t nfull = tb >> 4;
+        for (uint32_t q = threadIdx.x; q < nfull; q += kThreads) {
+            const uint4 v = reinterpret_cast<const uint4*>(lst)[q];
+            reinterpret_cast<uint4*>(gpool)[q] = v;
+            if constexpr (ENV == DCA_ENV_CUBE3) {
+                // sticker // 9 on 16 bytes at once: (b*57)>>9 per byte, two bytes per 32-bit multiply
+                auto div9 = [](uint32_t x) {
+                    uint32_t lo = (((x & 0x00FF00FFu) * 57u) >> 9) & 0x00FF00FFu;
+                    uint32_t hi = ((((x >> 8) & 0x00FF00FFu) * 57u) >> 9) & 0x00FF00FFu;
+                    return lo | (hi << 8);
+                };
+                reinterpret_cast<uint4*>(gnn)[q] = make_uint4(div9(v.x), div9(v.y), div9(v.z), div9(v.w));
             } else {
-                for (uint32_t k = 0; b0 + k < tb; k++) {
-                    gpool[b0 + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
-                    gnn[b0 + k] = (uint8_t)((ENV == DCA_ENV_CUBE3 ? v : w)[k >> 2] >> (8 * (k & 3)));
-                }
+                reinterpret_cast<uint4*>(gnn)[q] = v;
             }
+        }
+        for (uint32_t bq = (nfull << 4) + threadIdx.x; bq < tb; bq += kThreads) {
+            const uint32_t b = lst[bq];
+            gpool[bq] = (uint8_t)b;
+            gnn[bq] = (uint8_t)(ENV == DCA_ENV_CUBE3 ? (b * 57u) >> 9 : b);
         }
     }
 
@@ -1703,12 +1709,14 @@ int launch_expand_env(const dca_engine* e, int heur_id, hipStream_t s) {
     using TL = Tile<ENV, DIM, kEngTile>;
     const Eng& E = e->E[0];
     dim3 g = gxy((E.B + kEngTile - 1) / kEngTile, e), b(kThreads);
+    // tile + tables, then the staged child rows (16 parents x A children x D bytes)
+    const size_t lds = TL::LDS_BYTES + ((kEngTile * EnvT<ENV, DIM>::A * EnvT<ENV, DIM>::D + 15) / 16) * 16;
     if (E.onehot == nullptr)
-        hipLaunchKernelGGL((k_expand<ENV, DIM, 0>), g, b, TL::LDS_BYTES, s, e->d_engs, heur_id);
+        hipLaunchKernelGGL((k_expand<ENV, DIM, 0>), g, b, lds, s, e->d_engs, heur_id);
     else if (E.oh_dtype == DCA_DT_F32)
-        hipLaunchKernelGGL((k_expand<ENV, DIM, 4>), g, b, TL::LDS_BYTES, s, e->d_engs, heur_id);
+        hipLaunchKernelGGL((k_expand<ENV, DIM, 4>), g, b, lds, s, e->d_engs, heur_id);
     else
-        hipLaunchKernelGGL((k_expand<ENV, DIM, 2>), g, b, TL::LDS_BYTES, s, e->d_engs, heur_id);
+        hipLaunchKernelGGL((k_expand<ENV, DIM, 2>), g, b, lds, s, e->d_engs, heur_id);
     return launch_check("k_expand");
 }
 
