@@ -340,9 +340,11 @@ def run_expand(args, world, rank):
     from deepcubea_amd import _lib
     n = args.n
     S = torch.from_numpy(synth_states(n, 54, rank)).cuda()
+    ohdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[args.onehot]
+    esz = 4 if args.onehot == "f32" else 2
     out = {
         "children": torch.empty((n, 12, 54), dtype=torch.uint8, device="cuda"),
-        "onehot": torch.empty((n * 12, 324), dtype=torch.float32, device="cuda"),
+        "onehot": torch.empty((n * 12, 324), dtype=ohdt, device="cuda"),
         "solved": torch.empty((n * 12,), dtype=torch.uint8, device="cuda"),
         "hash": torch.empty((n * 12,), dtype=torch.int64, device="cuda"),
     }
@@ -365,17 +367,18 @@ def run_expand(args, world, rank):
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     wall = reduce_ranks(wall, world, "max")
     total_exp = reduce_ranks(float(n * args.steps), world, "sum")
-    achieved = CUBE3_EXPAND_BYTES_F32 * n / (kern_ms * 1e-3) / 1e9
+    alg = 54 + 12 * 54 + 12 * 324 * esz  # 16 254 B (f32 one-hot) / 8 478 B (16-bit)
+    achieved = alg * n / (kern_ms * 1e-3) / 1e9
     return {
         "value": total_exp / wall,
         "ms_per_step": wall / args.steps * 1e3,
-        "config": {"workload": "cube3 fused next_state+one-hot(f32)+is_solved+hash kernel, %d synthetic states "
-                               "(BASELINE configs[1])" % n, "states": n, "moves": 12, "onehot": "f32",
-                   "parallelism": "replica-per-gpu x%d" % world},
-        "roofline": {"bound": "hbm", "kernel": "expand_fused_kernel<cube3,f32>", "achieved": achieved,
+        "config": {"workload": "cube3 fused next_state+one-hot(%s)+is_solved+hash kernel, %d synthetic states "
+                               "(BASELINE configs[1])" % (args.onehot, n), "states": n, "moves": 12,
+                   "onehot": args.onehot, "parallelism": "replica-per-gpu x%d" % world},
+        "roofline": {"bound": "hbm", "kernel": "expand_fused_kernel<cube3,%s>" % args.onehot, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic("expand_fused_kernel<cube3,f32>") if n == 1_000_000 else None,
-                     "bytes_per_launch": CUBE3_EXPAND_BYTES_F32 * n, "kernel_ms": kern_ms},
+                     "traffic": pmc_traffic("expand_fused_kernel<cube3,f32>") if (n == 1_000_000 and esz == 4) else None,
+                     "bytes_per_launch": alg * n, "kernel_ms": kern_ms},
     }
 
 
@@ -419,6 +422,7 @@ def main():
     ap.add_argument("--nnet-steps", type=int, default=4, help="astar: timed steps of the ResNet-heuristic leg (0=skip)")
     ap.add_argument("--nnet_batch_size", type=int, default=60000)
     ap.add_argument("--n", type=int, default=1_000_000, help="expand: synthetic states per launch")
+    ap.add_argument("--onehot", default="f32", choices=["f32", "bf16", "f16"], help="expand: one-hot element type")
     ap.add_argument("--concurrent", type=int, default=4, help="astar: also time k concurrent instances per GPU (0/1 = skip)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -13,10 +13,18 @@
 //   CLOSED      open-addressing table of 16-byte slots {tag32|rep32, best g, batch list head},
 //               keyed by the 64-bit state hash, verified against the representative node's state
 //               bytes (exact key equality, like State.__eq__ / NodePointerEq).
-//   OPEN        (cost key u64, node id u32) arrays; pop = exact top-B by (cost, id) via radix select.
+//   OPEN        (cost key u64 = order-preserving bits of the f64 cost, node id u32) arrays in two tiers: FRONT
+//               (entries with key <= T, ping-pong buffers) and BACK (the rest, append-only with tombstones).
+//               pop = exact top-B of FRONT by (cost, id): 2048-bin histogram -> threshold bin -> the batch plus
+//               the rest of the threshold bin are ordered through arithmetic sub-bins and the overshoot goes back;
+//               a threshold bin too large for the ordering buffers (massive cost ties) is refined exactly on the
+//               96-bit (key,id) composite instead.  FRONT is refilled from / spilled to BACK with hysteresis, so an
+//               iteration costs O(|FRONT| + children), independent of |OPEN|.
 //
-// One BWAS iteration = pop -> expand -> heuristic -> dedup -> push, all stream-ordered, no host
-// round trip: counts live in a device control block and every kernel sizes itself from it.
+// One BWAS iteration = pop -> expand -> heuristic -> dedup -> push, all stream-ordered, no host round trip: counts
+// live in a device control block (hot counters on their own cache lines) and every kernel sizes itself from it.
+// One engine steps K independent instances at once: every kernel takes the device array of instance descriptors
+// and picks its instance with blockIdx.y.
 //
 // Sequential-order dedup, done in parallel: children of one batch that hit the same
 // CLOSED slot are chained through the slot's `head`; child j is kept iff g_j < v0 (the slot's value
@@ -1371,8 +1379,9 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
             if constexpr (ENV == DCA_ENV_CUBE3) {
                 // sticker // 9 on 16 bytes at once: (b*57)>>9 per byte, two bytes per 32-bit multiply
                 auto div9 = [](uint32_t x) {
-                    uint32_t lo = (((x & 0x00FF00FFu) * 57u) >> 9) & 0x00FF00FFu;
-                    uint32_t hi = ((((x >> 8) & 0x00FF00FFu) * 57u) >> 9) & 0x00FF00FFu;
+                    // quotients are < 8: keep 3 bits per field (bits above come from the neighbouring 16-bit lane)
+                    uint32_t lo = (((x & 0x00FF00FFu) * 57u) >> 9) & 0x00070007u;
+                    uint32_t hi = ((((x >> 8) & 0x00FF00FFu) * 57u) >> 9) & 0x00070007u;
                     return lo | (hi << 8);
                 };
                 reinterpret_cast<uint4*>(gnn)[q] = make_uint4(div9(v.x), div9(v.y), div9(v.z), div9(v.w));
