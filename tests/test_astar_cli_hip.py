@@ -167,3 +167,37 @@ def test_cli_instances_per_gpu(tmp_path):
                 s = co.next_state("cube3", s, a)
             assert co.is_solved("cube3", s)[0]
         assert len(outs[1]["solutions"][i]) == len(outs[3]["solutions"][i]) == len(scr[i])
+
+
+def test_cli_two_ranks_sharded(tmp_path):
+    """N>1 path end to end on the GPU box: two ranks under torch.distributed.run (sharing the one GPU here; one GPU
+    per rank on a multi-GPU node), scrambles sharded i mod 2, rank 0 writes the merged results.pkl."""
+    import subprocess
+    from oracle import c_oracle as co
+    scr = [[0, 5, 7], [1, 3, 8, 10], [], [4, 9], [2, 6, 11]]
+    roots = []
+    for mv in scr:
+        s = np.arange(54, dtype=np.uint8)[None]
+        for a in mv:
+            s = co.next_state("cube3", s, a)
+        roots.append(s[0])
+    spath = str(tmp_path / "states.pkl")
+    _ref_pickle(spath, roots)
+    rdir = str(tmp_path / "res2")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29541", "-m", "deepcubea_amd.search_methods.astar", "--states", spath,
+           "--model_dir", "synthetic:11", "--env", "cube3", "--weight", "0.8", "--batch_size", "60", "--results_dir", rdir,
+           "--nnet_batch_size", "1000", "--max_nodes", str(1 << 20)]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = pickle.load(open(os.path.join(rdir, "results.pkl"), "rb"))
+    assert len(res["solutions"]) == 5 and len(res["times"]) == 5 and len(res["num_nodes_generated"]) == 5
+    for i, r0 in enumerate(roots):
+        s = r0[None].copy()
+        for a in res["solutions"][i]:
+            s = co.next_state("cube3", s, a)
+        assert co.is_solved("cube3", s)[0] and len(res["solutions"][i]) == len(scr[i])
+    log = open(os.path.join(rdir, "output.txt")).read()
+    assert log.count("State: ") >= 3  # rank 0's own states (0, 2, 4) are logged by rank 0
