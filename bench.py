@@ -220,23 +220,31 @@ def run_astar_concurrent(args, world, rank, sem, hid):
             "how": "one engine, every kernel launched once for all instances (grid.y = instance)"}
 
 
-def run_astar_nnet(args, world, rank, dtype_name: str):
-    """Same loop, heuristic = ResNet(54*6 -> 5000 -> 1000 -> 4 res blocks -> 1) on PyTorch-ROCm, all
-    240 000 children per step, synthetic weights (numpy PCG64 seed 2024)."""
+def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool = False):
+    """Same loop, heuristic = ResNet(54*6 -> 5000 -> 1000 -> 4 res blocks -> 1) on PyTorch-ROCm, synthetic weights
+    (numpy PCG64 seed 2024).  Default = the CLI's default path: dedup-first engine stepping (only the children that
+    survive the CLOSED check are evaluated — same search, astar.py:272-282) + the padded / epilogue-fused network
+    layout (FastResnet).  eval_all_children = the reference's order on the plain BN-folded network."""
     from deepcubea_amd import _lib
     from deepcubea_amd.search_methods.engine import BwasEngine
     from deepcubea_amd.utils import nnet_utils
-    from deepcubea_amd.utils.pytorch_models import ResnetModel, fold_batchnorm
+    from deepcubea_amd.utils.pytorch_models import FastResnet, ResnetModel, fold_batchnorm
     from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
     B, w = args.batch_size, args.weight
     steps, warm = args.nnet_steps, 2
     model = ResnetModel(54, 6, 5000, 1000, 4, 1, True)
     load_synthetic_weights(model, 2024)
-    model = fold_batchnorm(model).cuda().eval()
-    ac = torch.bfloat16 if dtype_name == "bf16" else None
-    hfn = nnet_utils.get_heuristic_fn_dev(model, clip_zero=False, batch_size=args.nnet_batch_size, autocast_dtype=ac)
-    eng = BwasEngine("cube3", w, B, max_nodes=max(1 << 20, (steps + warm + 12) * B * 12),
-                     onehot_dtype=torch.float32 if ac is None else torch.bfloat16)
+    dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[dtype_name]
+    cap = max(1 << 20, (steps + warm + 12) * B * 12)
+    if eval_all_children:
+        model = fold_batchnorm(model).cuda().eval()
+        hfn = nnet_utils.get_heuristic_fn_dev(model, clip_zero=False, batch_size=args.nnet_batch_size,
+                                              autocast_dtype=None if dt == torch.float32 else dt)
+        eng = BwasEngine("cube3", w, B, max_nodes=cap, onehot_dtype=dt)
+    else:
+        fast = FastResnet(model, dt).cuda()
+        hfn = nnet_utils.get_heuristic_fn_dev(fast, clip_zero=False, batch_size=args.nnet_batch_size)
+        eng = BwasEngine("cube3", w, B, max_nodes=cap, onehot_dtype=dt, packed=True, onehot_stride=fast.in_pad)
     root = test_root(rank)
     eng.reset(root)
     eng.root_commit(hfn(eng.root_nnet_in()))
@@ -245,6 +253,7 @@ def run_astar_nnet(args, world, rank, dtype_name: str):
     for _ in range(warm):
         eng.step(hfn)
     st0 = eng.status()
+    rows0 = eng.rows_evaluated
     barrier(world)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -253,12 +262,16 @@ def run_astar_nnet(args, world, rank, dtype_name: str):
     wall = time.perf_counter() - t0
     st1 = eng.status()
     expanded = st1["nodes_expanded"] - st0["nodes_expanded"]
+    rows = (eng.rows_evaluated - rows0) / steps
     wall = reduce_ranks(wall, world, "max")
     total_exp = reduce_ranks(float(expanded), world, "sum")
-    flops = 2.0 * (324 * 5000 + 5000 * 1000 + 8 * 1000 * 1000 + 1000) * (B * 12)
+    flops = 2.0 * (324 * 5000 + 5000 * 1000 + 8 * 1000 * 1000 + 1000) * rows
     eng.close()
+    torch.cuda.empty_cache()
     return {"value": total_exp / wall, "unit": "nodes expanded/s", "ms_per_step": wall / steps * 1e3,
             "steps": steps, "heuristic_dtype": dtype_name, "weights": "synthetic (numpy PCG64 seed 2024, BN folded)",
+            "order": "eval_all_children (reference order)" if eval_all_children else "dedup_first (CLI default)",
+            "network_rows_per_step": rows, "children_per_step": B * 12,
             "heuristic_tflops_per_gpu": flops / (wall / steps) / 1e12,
             "mfma_peak_tflops": 157.3 if dtype_name == "fp32" else 2500.0}
 
@@ -294,16 +307,14 @@ def run_avi(args, world, rank):
     data-generation half of ctg_approx/avi.py:do_update.  value = training states produced per second."""
     from deepcubea_amd.updaters.updater import Updater
     from deepcubea_amd.utils import env_utils, nnet_utils
-    from deepcubea_amd.utils.pytorch_models import fold_batchnorm
+    from deepcubea_amd.utils.pytorch_models import FastResnet
     from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
     env = env_utils.get_environment("cube3")
     model = env.get_nnet_model()
     load_synthetic_weights(model, 2024)
-    model = fold_batchnorm(model).cuda().eval()
-    ac = torch.bfloat16 if args.nnet_dtype == "bf16" else None
-    hfn = nnet_utils.get_heuristic_fn_dev(model, clip_zero=False, batch_size=args.nnet_batch_size, autocast_dtype=ac)
+    oh = torch.bfloat16 if args.nnet_dtype == "bf16" else torch.float32
+    hfn = nnet_utils.get_heuristic_fn_dev(FastResnet(model, oh).cuda(), clip_zero=False, batch_size=args.nnet_batch_size)
     n = args.n if args.n != 1_000_000 else 200_000
-    oh = torch.bfloat16 if ac is not None else torch.float32
 
     def step(i):
         upd = Updater(env, n * world, 30, hfn, 1, update_batch_size=100_000, seed=1000 + i, onehot_dtype=oh)
@@ -456,7 +467,9 @@ def main():
         line["concurrent_instances"] = res["concurrent_instances"]
     if args.workload == "astar" and args.nnet_steps > 0 and args.env == "cube3":
         line["end_to_end_nnet"] = {"fp32": run_astar_nnet(args, world, rank, "fp32"),
-                                   "bf16": run_astar_nnet(args, world, rank, "bf16")}
+                                   "bf16": run_astar_nnet(args, world, rank, "bf16"),
+                                   "fp16": run_astar_nnet(args, world, rank, "fp16"),
+                                   "fp32_eval_all_children": run_astar_nnet(args, world, rank, "fp32", True)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "avi":
         if args.workload == "expand":
             line["cpu_baseline"] = cpu_baseline_expand()

@@ -33,6 +33,7 @@ ABI_SYMBOLS = [
     "dca_engine_reset", "dca_engine_reset_instance", "dca_engine_root_commit", "dca_engine_root_commit_instance",
     "dca_engine_root_nnet_in", "dca_engine_root_nnet_in_instance", "dca_engine_status_instance",
     "dca_engine_solution_instance", "dca_engine_pop_expand", "dca_engine_commit", "dca_engine_run_builtin",
+    "dca_engine_enable_packed", "dca_engine_pop_expand_packed", "dca_engine_commit_packed",
     "dca_engine_profile_builtin", "dca_engine_set_tiers", "dca_engine_debug", "dca_engine_status", "dca_engine_last_children", "dca_engine_solution",
 ]
 

@@ -145,6 +145,15 @@ struct Eng {
     uint8_t* root_nnet;
     int32_t* d_moves;
     Ctl* ctl;
+    // dedup-first ("packed") stepping: only the children that survive the CLOSED check reach the heuristic
+    uint32_t* kept_pos;   // [M] row of child j in the packed batch (NIL = dropped)
+    uint32_t* pk_n;       // rows packed this iteration, shared by every instance of the engine
+    uint32_t* pk_src;     // [K*M] packed row -> instance*M + child index
+    uint8_t* pk_nnet;     // [K*M, D] network-input rows of the kept children
+    uint8_t* pk_onehot;   // [K*M, pk_stride] one-hot rows (pk_dtype), tail of each row zero
+    const float* pk_h;    // [K*M] heuristic of the packed rows (written by the caller between the two halves)
+    uint32_t pk_stride, inst;
+    int pk_dtype;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1517,7 +1526,7 @@ __global__ __launch_bounds__(256) void k_probe(const Eng* __restrict__ engs) {
     E.child_flags[j] = inserted ? F_NEW : 0;  // counted in k_commit (one atomic per block there)
 }
 
-// dedup B: keep decision in sequential order + cost
+// dedup B: keep decision in sequential order
 __global__ __launch_bounds__(256) void k_decide(const Eng* __restrict__ engs) {
     const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
@@ -1548,17 +1557,88 @@ __global__ __launch_bounds__(256) void k_decide(const Eng* __restrict__ engs) {
         uint64_t e = E.tab[slot].entry;
         if ((uint32_t)e >= base && (uint32_t)e != id) E.tab[slot].entry = (e & 0xFFFFFFFF00000000ull) | id;
     }
-    const float hv = fmaxf(E.child_h[j], 0.0f);  // clip_zero (nnet_utils.py:193-194)
-    const bool ns = E.solved[id] == 0;
-    double cost;
-    if (E.sem == DCA_SEM_PY) {
-        // astar.py:196  weights*path_costs + heuristics*logical_not(is_solved), float64, two roundings
-        cost = __dadd_rn(__dmul_rn(E.w, (double)gj), __dmul_rn((double)hv, ns ? 1.0 : 0.0));
-    } else {
-        // cpp:298  values[i]*(!isSolved) + depthPenalty*((float) depth), float32
-        cost = (double)__fadd_rn(__fmul_rn(hv, ns ? 1.0f : 0.0f), __fmul_rn(E.wf, (float)gj));
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// dedup-first stepping: compact the children that survived the CLOSED check into the heuristic batch.
+// The reference evaluates the network on every child and only then drops the duplicates (astar.py:272-282);
+// a dropped child's heuristic is never used, so evaluating only the kept ones (~85 % on cube3, ~60 % on the
+// sliding puzzles) gives the same search.  Row order in the packed batch is arbitrary: kept_pos / pk_src map
+// child -> row and row -> child.  One-hot rows are written with the row stride the GEMM wants (tail zero).
+// ---------------------------------------------------------------------------------------------
+template <int ENV, int DIM, int OH>
+__global__ __launch_bounds__(256) void k_pack(const Eng* __restrict__ engs) {
+    const Eng& E = engs[blockIdx.y];
+    using EV = EnvT<ENV, DIM>;
+    Ctl* c = E.ctl;
+    if (c->done) return;
+    const uint32_t m = c->m, base = c->base;
+    if (blockIdx.x * 256 >= m) return;
+    __shared__ uint32_t sh[6];
+    __shared__ uint32_t lsrc[256];
+    __shared__ __attribute__((aligned(16))) uint8_t lrow[256 * EV::D];
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    const bool keep = j < m && (E.child_flags[j] & F_KEEP);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long mask = __ballot(keep);
+    if (lane == 0) sh[wv] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < 4; w++) {
+            uint32_t t = sh[w];
+            sh[w] = tot;
+            tot += t;
+        }
+        sh[4] = tot;
+        sh[5] = tot ? atomicAdd(E.pk_n, tot) : 0u;  // one atomic per 256 children
     }
-    E.child_key[j] = key_of_cost(cost);
+    __syncthreads();
+    const uint32_t total = sh[4], gbase = sh[5];
+    const uint32_t lr = sh[wv] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (j < m) E.kept_pos[j] = keep ? gbase + lr : NIL;
+    if (keep) lsrc[lr] = j;
+    __syncthreads();
+    if (total == 0) return;
+    if (threadIdx.x < total) E.pk_src[gbase + threadIdx.x] = E.inst * E.M + lsrc[threadIdx.x];
+    // network-input bytes of the kept rows (cube3: sticker // 9, cube3.py:77-85; puzzles: the tiles, n_puzzle.py:84-89)
+    const uint32_t tb = total * EV::D;
+    for (uint32_t q = threadIdx.x; q < tb; q += 256) {
+        const uint32_t r = q / EV::D, b = q - r * EV::D;
+        const uint32_t v = E.state[(size_t)(base + lsrc[r]) * EV::D + b];
+        lrow[q] = (uint8_t)(ENV == DCA_ENV_CUBE3 ? (v * 57u) >> 9 : v);
+    }
+    __syncthreads();
+    uint8_t* gnn = E.pk_nnet + (size_t)gbase * EV::D;
+    for (uint32_t q = threadIdx.x; q < tb; q += 256) gnn[q] = lrow[q];
+    if constexpr (OH != 0) {
+        constexpr uint32_t ROW = EV::D * EV::DEPTH, EPC = 16 / OH;
+        const uint32_t cpr = E.pk_stride / EPC;  // 16-byte chunks per packed row
+        const uint32_t one16 = E.pk_dtype == DCA_DT_F16 ? 0x3C00u : 0x3F80u;
+        uint4* goh = reinterpret_cast<uint4*>(E.pk_onehot + (size_t)gbase * E.pk_stride * OH);
+        const uint32_t nch = total * cpr;
+        for (uint32_t q = threadIdx.x; q < nch; q += 256) {
+            const uint32_t r = q / cpr, e0 = (q - r * cpr) * EPC;
+            uint32_t pos = e0 / EV::DEPTH, col = e0 - pos * EV::DEPTH;
+            uint32_t nb = pos < (uint32_t)EV::D ? lrow[r * EV::D + pos] : 0xFFFFu;
+            uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t k = 0; k < EPC; k++) {
+                const bool hot = (e0 + k < ROW) && nb == col;
+                if constexpr (OH == 4)
+                    w[k] = hot ? 0x3F800000u : 0u;
+                else
+                    w[k >> 1] |= (hot ? one16 : 0u) << (16 * (k & 1));
+                if (++col == EV::DEPTH) {
+                    col = 0;
+                    ++pos;
+                    nb = pos < (uint32_t)EV::D ? lrow[r * EV::D + pos] : 0xFFFFu;
+                }
+            }
+            goh[q] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
 }
 
 // the last workgroup of k_commit to finish closes the iteration (astar.py:317 step_num += 1)
@@ -1575,7 +1655,7 @@ __device__ __forceinline__ void commit_ticket(Ctl* c) {
 }
 
 // dedup C: record the new best g per state, push the kept children (FRONT if key <= T, else BACK)
-__global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs) {
+__global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, int packed) {
     const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
@@ -1606,7 +1686,23 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs) {
             }
         }
     }
-    const uint64_t key = keep ? E.child_key[j] : 0;
+    uint64_t key = 0;
+    if (keep) {
+        // the heuristic is only ever needed for the children that survive the CLOSED check
+        const float hraw = packed ? E.pk_h[E.kept_pos[j]] : E.child_h[j];
+        const float hv = fmaxf(hraw, 0.0f);  // clip_zero (nnet_utils.py:193-194)
+        const bool ns = E.solved[id] == 0;
+        const uint32_t gj = (uint32_t)E.g[id];
+        double cost;
+        if (E.sem == DCA_SEM_PY) {
+            // astar.py:196  weights*path_costs + heuristics*logical_not(is_solved), float64, two roundings
+            cost = __dadd_rn(__dmul_rn(E.w, (double)gj), __dmul_rn((double)hv, ns ? 1.0 : 0.0));
+        } else {
+            // cpp:298  values[i]*(!isSolved) + depthPenalty*((float) depth), float32
+            cost = (double)__fadd_rn(__fmul_rn(hv, ns ? 1.0f : 0.0f), __fmul_rn(E.wf, (float)gj));
+        }
+        key = key_of_cost(cost);
+    }
     const bool tof = keep && key <= T, tob = keep && key > T;
     const uint32_t cnt[3] = {tof ? 1u : 0u, tob ? 1u : 0u, (fl & F_NEW) ? 1u : 0u};
     uint32_t* const ctr[3] = {&c->open_n[fb].v, &c->open_n[bb].v, &c->closed_n.v};
@@ -1685,7 +1781,13 @@ struct dca_engine {
     double* d_cost;
     double* h_cost;
     uint8_t* h_stage;
-    int phase;             // 0 idle, 1 between pop_expand and commit
+    uint32_t* pk_n;        // packed stepping: device row counter, its pinned host mirror, the packed buffers
+    uint32_t* h_pk_n;
+    uint8_t *pk_nnet, *pk_onehot;
+    uint32_t* pk_src;
+    float* pk_h;
+    int64_t pk_rows;       // rows packed by the last dca_engine_pop_expand_packed
+    int phase;             // 0 idle, 1 between pop_expand and commit, 2 between pop_expand_packed and commit_packed
     hipGraph_t graph[2];   // [0] iteration without / [1] with the refill check
     hipGraphExec_t graph_exec[2];
     int graph_heur;
@@ -1714,13 +1816,13 @@ constexpr int kScanGrid = kScanBlocks;
 inline dim3 gxy(unsigned x, const dca_engine* e) { return dim3(x, (unsigned)e->K); }
 
 template <int ENV, int DIM>
-int launch_expand_env(const dca_engine* e, int heur_id, hipStream_t s) {
+int launch_expand_env(const dca_engine* e, int heur_id, bool want_oh, hipStream_t s) {
     using TL = Tile<ENV, DIM, kEngTile>;
     const Eng& E = e->E[0];
     dim3 g = gxy((E.B + kEngTile - 1) / kEngTile, e), b(kThreads);
     // tile + tables, then the staged child rows (16 parents x A children x D bytes)
     const size_t lds = TL::LDS_BYTES + ((kEngTile * EnvT<ENV, DIM>::A * EnvT<ENV, DIM>::D + 15) / 16) * 16;
-    if (E.onehot == nullptr)
+    if (E.onehot == nullptr || !want_oh)
         hipLaunchKernelGGL((k_expand<ENV, DIM, 0>), g, b, lds, s, e->d_engs, heur_id);
     else if (E.oh_dtype == DCA_DT_F32)
         hipLaunchKernelGGL((k_expand<ENV, DIM, 4>), g, b, lds, s, e->d_engs, heur_id);
@@ -1729,14 +1831,39 @@ int launch_expand_env(const dca_engine* e, int heur_id, hipStream_t s) {
     return launch_check("k_expand");
 }
 
-int launch_expand(const dca_engine* e, int heur_id, hipStream_t s) {
+int launch_expand(const dca_engine* e, int heur_id, bool want_oh, hipStream_t s) {
     const Eng& E = e->E[0];
-    if (E.env == DCA_ENV_CUBE3) return launch_expand_env<DCA_ENV_CUBE3, 0>(e, heur_id, s);
+    if (E.env == DCA_ENV_CUBE3) return launch_expand_env<DCA_ENV_CUBE3, 0>(e, heur_id, want_oh, s);
     switch (E.dim) {
-        case 4: return launch_expand_env<DCA_ENV_NPUZZLE, 4>(e, heur_id, s);
-        case 5: return launch_expand_env<DCA_ENV_NPUZZLE, 5>(e, heur_id, s);
-        case 6: return launch_expand_env<DCA_ENV_NPUZZLE, 6>(e, heur_id, s);
-        case 7: return launch_expand_env<DCA_ENV_NPUZZLE, 7>(e, heur_id, s);
+        case 4: return launch_expand_env<DCA_ENV_NPUZZLE, 4>(e, heur_id, want_oh, s);
+        case 5: return launch_expand_env<DCA_ENV_NPUZZLE, 5>(e, heur_id, want_oh, s);
+        case 6: return launch_expand_env<DCA_ENV_NPUZZLE, 6>(e, heur_id, want_oh, s);
+        case 7: return launch_expand_env<DCA_ENV_NPUZZLE, 7>(e, heur_id, want_oh, s);
+    }
+    return DCA_E_BADARG;
+}
+
+template <int ENV, int DIM>
+int launch_pack_env(const dca_engine* e, hipStream_t s) {
+    const Eng& E = e->E[0];
+    const dim3 g = gxy((E.M + 255) / 256, e), b(256);
+    if (E.pk_onehot == nullptr)
+        hipLaunchKernelGGL((k_pack<ENV, DIM, 0>), g, b, 0, s, e->d_engs);
+    else if (E.pk_dtype == DCA_DT_F32)
+        hipLaunchKernelGGL((k_pack<ENV, DIM, 4>), g, b, 0, s, e->d_engs);
+    else
+        hipLaunchKernelGGL((k_pack<ENV, DIM, 2>), g, b, 0, s, e->d_engs);
+    return launch_check("k_pack");
+}
+
+int launch_pack(const dca_engine* e, hipStream_t s) {
+    const Eng& E = e->E[0];
+    if (E.env == DCA_ENV_CUBE3) return launch_pack_env<DCA_ENV_CUBE3, 0>(e, s);
+    switch (E.dim) {
+        case 4: return launch_pack_env<DCA_ENV_NPUZZLE, 4>(e, s);
+        case 5: return launch_pack_env<DCA_ENV_NPUZZLE, 5>(e, s);
+        case 6: return launch_pack_env<DCA_ENV_NPUZZLE, 6>(e, s);
+        case 7: return launch_pack_env<DCA_ENV_NPUZZLE, 7>(e, s);
     }
     return DCA_E_BADARG;
 }
@@ -1763,7 +1890,8 @@ struct Marks {
     }
 };
 
-int enqueue_first_half(dca_engine* e, int heur_id, bool with_refill, hipStream_t s, Marks* mk = nullptr) {
+int enqueue_first_half(dca_engine* e, int heur_id, bool with_refill, hipStream_t s, Marks* mk = nullptr,
+                       bool want_oh = true) {
     const Eng& E = e->E[0];
     const Eng* d = e->d_engs;
     const unsigned ordg = (E.ord_cap + 255) / 256;
@@ -1792,10 +1920,10 @@ int enqueue_first_half(dca_engine* e, int heur_id, bool with_refill, hipStream_t
     hipLaunchKernelGGL(k_post_pop, gxy(1, e), dim3(64), 0, s, d);
     if (int rc = launch_check("select kernels")) return rc;
     m.mark();  // 7 expand
-    return launch_expand(e, heur_id, s);
+    return launch_expand(e, heur_id, want_oh, s);
 }
 
-int enqueue_second_half(dca_engine* e, hipStream_t s, Marks* mk = nullptr) {
+int enqueue_dedup(dca_engine* e, hipStream_t s, Marks* mk = nullptr) {
     const Eng& E = e->E[0];
     Marks none{nullptr, 0, s};
     Marks& m = mk ? *mk : none;
@@ -1803,10 +1931,22 @@ int enqueue_second_half(dca_engine* e, hipStream_t s, Marks* mk = nullptr) {
     launch_probe(e, s);
     m.mark();  // 9 decide
     hipLaunchKernelGGL(k_decide, gxy((E.M + 255) / 256, e), dim3(256), 0, s, e->d_engs);
-    m.mark();  // 10 commit
-    hipLaunchKernelGGL(k_commit, gxy((E.M + 1023) / 1024, e), dim3(1024), 0, s, e->d_engs);
-    m.mark();  // end
     return launch_check("dedup kernels");
+}
+
+int enqueue_commit(dca_engine* e, bool packed, hipStream_t s, Marks* mk = nullptr) {
+    const Eng& E = e->E[0];
+    Marks none{nullptr, 0, s};
+    Marks& m = mk ? *mk : none;
+    m.mark();  // 10 commit
+    hipLaunchKernelGGL(k_commit, gxy((E.M + 1023) / 1024, e), dim3(1024), 0, s, e->d_engs, packed ? 1 : 0);
+    m.mark();  // end
+    return launch_check("k_commit");
+}
+
+int enqueue_second_half(dca_engine* e, hipStream_t s, Marks* mk = nullptr) {
+    if (int rc = enqueue_dedup(e, s, mk)) return rc;
+    return enqueue_commit(e, false, s, mk);
 }
 
 void drop_graphs(dca_engine* e) {
@@ -1983,6 +2123,7 @@ void dca_engine_destroy(dca_engine* e) {
     drop_graphs(e);
     for (int i = 0; i < e->nalloc; i++) (void)hipFree(e->allocs[i]);
     if (e->h_ctl) (void)hipHostFree(e->h_ctl);
+    if (e->h_pk_n) (void)hipHostFree(e->h_pk_n);
     delete e;
 }
 
@@ -2052,6 +2193,84 @@ int dca_engine_commit(dca_engine* e, const float* h, void* stream) {
     DCA_HIP(hipMemcpyAsync(e->h_all, h, (size_t)e->E[0].M * e->K * sizeof(float), hipMemcpyDeviceToDevice, s));
     e->phase = 0;
     return enqueue_second_half(e, s);
+}
+
+
+int dca_engine_enable_packed(dca_engine* e, int onehot_dtype, int64_t onehot_row_stride) {
+    DCA_ARG(e != nullptr && onehot_dtype >= -1 && onehot_dtype <= DCA_DT_BF16);
+    if (e->pk_n != nullptr) {
+        set_error("dca_engine_enable_packed called twice");
+        return DCA_E_STATE;
+    }
+    const Eng& E0 = e->E[0];
+    const int64_t row = (int64_t)E0.D * E0.depth;
+    const int esz = onehot_dtype == DCA_DT_F32 ? 4 : 2;
+    if (onehot_dtype >= 0) DCA_ARG(onehot_row_stride >= row && (onehot_row_stride * esz) % 16 == 0 && onehot_row_stride < (1 << 20));
+    const size_t rows = (((size_t)E0.M * e->K + 1023) / 1024) * 1024;  // callers may round the batch up to 1024 rows
+    if (int rc = dev_alloc(e, &e->pk_n, 64)) return rc;
+    if (int rc = dev_alloc(e, &e->pk_src, rows)) return rc;
+    if (int rc = dev_alloc(e, &e->pk_nnet, rows * E0.D)) return rc;
+    if (int rc = dev_alloc(e, &e->pk_h, rows)) return rc;
+    DCA_HIP(hipMemset(e->pk_nnet, 0, rows * E0.D));
+    if (onehot_dtype >= 0) {
+        if (int rc = dev_alloc(e, &e->pk_onehot, rows * (size_t)onehot_row_stride * esz)) return rc;
+        DCA_HIP(hipMemset(e->pk_onehot, 0, rows * (size_t)onehot_row_stride * esz));
+    }
+    DCA_HIP(hipHostMalloc((void**)&e->h_pk_n, 64, hipHostMallocDefault));
+    for (int i = 0; i < e->K; i++) {
+        Eng& E = e->E[i];
+        if (int rc = dev_alloc(e, &E.kept_pos, (size_t)E.M)) return rc;
+        E.pk_n = e->pk_n;
+        E.pk_src = e->pk_src;
+        E.pk_nnet = e->pk_nnet;
+        E.pk_onehot = e->pk_onehot;
+        E.pk_h = e->pk_h;
+        E.pk_stride = (uint32_t)(onehot_dtype >= 0 ? onehot_row_stride : 0);
+        E.pk_dtype = onehot_dtype;
+        E.inst = (uint32_t)i;
+    }
+    return upload_engs(e);
+}
+
+int dca_engine_pop_expand_packed(dca_engine* e, const uint8_t** nnet_in, const void** onehot, const uint32_t** src,
+                                 int64_t* rows, void* stream) {
+    DCA_ARG(e != nullptr && rows != nullptr);
+    if (e->pk_n == nullptr) {
+        set_error("dca_engine_pop_expand_packed before dca_engine_enable_packed");
+        return DCA_E_STATE;
+    }
+    if (e->phase != 0) {
+        set_error("dca_engine_pop_expand_packed called twice without dca_engine_commit_packed");
+        return DCA_E_STATE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    DCA_HIP(hipMemsetAsync(e->pk_n, 0, sizeof(uint32_t), s));
+    if (int rc = enqueue_first_half(e, -1, (e->host_iter++ % kRefillPeriod) == 0, s, nullptr, false)) return rc;
+    if (int rc = enqueue_dedup(e, s)) return rc;
+    if (int rc = launch_pack(e, s)) return rc;
+    DCA_HIP(hipMemcpyAsync(e->h_pk_n, e->pk_n, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    DCA_HIP(hipStreamSynchronize(s));
+    e->pk_rows = (int64_t)*e->h_pk_n;
+    *rows = e->pk_rows;
+    if (nnet_in) *nnet_in = e->pk_nnet;
+    if (onehot) *onehot = e->pk_onehot;
+    if (src) *src = e->pk_src;
+    e->phase = 2;
+    return 0;
+}
+
+int dca_engine_commit_packed(dca_engine* e, const float* h, void* stream) {
+    DCA_ARG(e != nullptr);
+    if (e->phase != 2) {
+        set_error("dca_engine_commit_packed without a preceding dca_engine_pop_expand_packed");
+        return DCA_E_STATE;
+    }
+    DCA_ARG(h != nullptr || e->pk_rows == 0);
+    hipStream_t s = (hipStream_t)stream;
+    if (e->pk_rows > 0)
+        DCA_HIP(hipMemcpyAsync(e->pk_h, h, (size_t)e->pk_rows * sizeof(float), hipMemcpyDeviceToDevice, s));
+    e->phase = 0;
+    return enqueue_commit(e, true, s);
 }
 
 int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph, void* stream) {

@@ -48,22 +48,29 @@ def _load_heuristic(args, env):
     else:
         nnet = nnet_utils.load_nnet("%s/model_state_dict.pt" % args.model_dir, nnet, device=device)
     nnet.to(device)
+    dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[getattr(args, "nnet_dtype", "fp32")]
+    if not getattr(args, "eval_all_children", False):
+        # default: padded / epilogue-fused inference layout of the same network, fed by the dedup-first engine
+        from ..utils.pytorch_models import FastResnet
+        fast = FastResnet(nnet, dt).to(device)
+        return nnet_utils.get_heuristic_fn_dev(fast, clip_zero=False, batch_size=args.nnet_batch_size), fast.in_pad
     if getattr(args, "fold_bn", False):
         from ..utils.pytorch_models import fold_batchnorm
         nnet = fold_batchnorm(nnet).to(device)
-    ac = {"fp32": None, "bf16": torch.bfloat16, "fp16": torch.float16}[getattr(args, "nnet_dtype", "fp32")]
-    return nnet_utils.get_heuristic_fn_dev(nnet, clip_zero=False, batch_size=args.nnet_batch_size, autocast_dtype=ac)
+    ac = None if dt == torch.float32 else dt
+    return nnet_utils.get_heuristic_fn_dev(nnet, clip_zero=False, batch_size=args.nnet_batch_size, autocast_dtype=ac), None
 
 
 def bwas_hip(args, env, states: List) -> Tuple[List[List[int]], List[List], List[float], List[int]]:
     """astar.py:400-454 (bwas_python) with the engine in place of AStar.  Returns
     (solns, paths, times, num_nodes_gen) for `states`, in order."""
-    heuristic_fn = _load_heuristic(args, env)
+    heuristic_fn, onehot_stride = _load_heuristic(args, env)
     sem = _lib.SEM_CPP if getattr(args, "semantics", "py") == "cpp" else _lib.SEM_PY
     oh = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[getattr(args, "nnet_dtype", "fp32")]
     K = max(1, int(getattr(args, "instances_per_gpu", 1)))
     eng = BwasEngine(args.env, args.weight, args.batch_size, max_nodes=int(getattr(args, "max_nodes", 1 << 26)),
-                     semantics=sem, onehot_dtype=oh, num_instances=K)
+                     semantics=sem, onehot_dtype=oh, num_instances=K, packed=onehot_stride is not None,
+                     onehot_stride=onehot_stride)
     world, rank = sharding.world_info()
     mine = sharding.shard_indices(len(states), world, rank)
     local: Dict[int, Tuple[List[int], List, float, int]] = {}
@@ -127,7 +134,11 @@ def build_parser() -> ArgumentParser:
                         help="scrambles stepped together by one engine (finer per-instance sharding inside a GPU)")
     parser.add_argument('--nnet_dtype', type=str, default="fp32", choices=["fp32", "bf16", "fp16"],
                         help="fp32 = parity mode (1e-5); bf16/fp16 = faster, NOT parity")
-    parser.add_argument('--fold_bn', action='store_true', default=False, help="fold BatchNorm into the Linears")
+    parser.add_argument('--fold_bn', action='store_true', default=False,
+                        help="with --eval_all_children: fold BatchNorm into the Linears (always done otherwise)")
+    parser.add_argument('--eval_all_children', action='store_true', default=False,
+                        help="reference order (astar.py:272-282): run the network on every child, then drop the "
+                             "duplicates.  Default is dedup-first: identical search, fewer network rows")
     return parser
 
 

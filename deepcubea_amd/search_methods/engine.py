@@ -25,7 +25,12 @@ class BwasEngine:
     reference's std::priority_queue order is unspecified — SURVEY §3.3)."""
 
     def __init__(self, env_name: str, weight: float, batch_size: int, max_nodes: int = 1 << 24,
-                 semantics: int = _lib.SEM_PY, onehot_dtype: Optional[torch.dtype] = None, num_instances: int = 1):
+                 semantics: int = _lib.SEM_PY, onehot_dtype: Optional[torch.dtype] = None, num_instances: int = 1,
+                 packed: bool = False, onehot_stride: Optional[int] = None):
+        """packed=True: dedup-first stepping — the CLOSED check runs before the heuristic and only the surviving
+        children are handed out (`pop_expand_packed` / `commit_packed`; `step` picks the mode).  Same search as the
+        reference's order (astar.py:272-282), ~15-40 % fewer network rows.  onehot_stride: elements per packed
+        one-hot row (>= state_dim*depth, tail zero), e.g. FastResnet.in_pad."""
         _lib.require_gpu()
         self.env_id, self.dim, self.state_dim, self.num_moves, self.depth = _lib.env_ids(env_name)
         self.batch_size = int(batch_size)
@@ -36,10 +41,22 @@ class BwasEngine:
         # K instances share every launch (grid.y = instance); their batch buffers are contiguous, instance-major
         self.m_capacity = self.batch_size * self.num_moves * self.num_instances
         self._h = C.c_void_p(0)
+        self.packed = bool(packed)
         _lib.check(_lib.lib().dca_engine_create_multi(C.byref(self._h), self.env_id, self.dim, C.c_double(self.weight),
                                                       self.batch_size, C.c_int64(int(max_nodes)), semantics,
-                                                      _OH[onehot_dtype], self.num_instances), "dca_engine_create_multi")
+                                                      -1 if packed else _OH[onehot_dtype], self.num_instances),
+                   "dca_engine_create_multi")
         self._zero_h = torch.zeros(1, dtype=torch.float32, device="cuda")
+        self.rows_evaluated = 0  # network rows handed to heuristic closures by step()
+        self.onehot_stride = self.state_dim * self.depth
+        if packed:
+            if onehot_stride is not None:
+                self.onehot_stride = int(onehot_stride)
+            elif onehot_dtype is not None:
+                self.onehot_stride = (self.onehot_stride + 7) // 8 * 8
+            _lib.check(_lib.lib().dca_engine_enable_packed(self._h, _OH[onehot_dtype], C.c_int64(self.onehot_stride)),
+                       "dca_engine_enable_packed")
+            self.packed_capacity = (self.m_capacity + 1023) // 1024 * 1024
 
     def close(self):
         if self._h:
@@ -85,8 +102,36 @@ class BwasEngine:
         assert h.is_cuda and h.dtype == torch.float32 and h.numel() == self.m_capacity and h.is_contiguous()
         _lib.check(_lib.lib().dca_engine_commit(self._h, _lib.ptr(h), _lib.stream_ptr()), "dca_engine_commit")
 
+    def pop_expand_packed(self) -> Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor, int]:
+        """-> (nnet_in [cap,D], onehot [cap,stride] or None, src [cap], rows): the first `rows` rows are this
+        iteration's kept children (all instances); cap = K*batch*num_moves rounded up to 1024."""
+        pn, po, ps, m = C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), C.c_int64(0)
+        _lib.check(_lib.lib().dca_engine_pop_expand_packed(self._h, C.byref(pn), C.byref(po), C.byref(ps), C.byref(m),
+                                                           _lib.stream_ptr()), "dca_engine_pop_expand_packed")
+        cap = self.packed_capacity
+        nn = _wrap_u8(pn.value, (cap, self.state_dim))
+        oh = _wrap(po.value, (cap, self.onehot_stride), self.onehot_dtype) if po.value else None
+        src = _wrap(ps.value, (cap,), torch.int32)
+        return nn, oh, src, int(m.value)
+
+    def commit_packed(self, h: torch.Tensor) -> None:
+        assert h.is_cuda and h.dtype == torch.float32 and h.is_contiguous()
+        _lib.check(_lib.lib().dca_engine_commit_packed(self._h, _lib.ptr(h), _lib.stream_ptr()), "dca_engine_commit_packed")
+
     def step(self, heuristic_fn_dev: Callable[[torch.Tensor], torch.Tensor]) -> None:
         """One BWAS iteration (AStar.step, astar.py:256-317) with a device heuristic closure."""
+        if self.packed:
+            nn, oh, _, rows = self.pop_expand_packed()
+            self.rows_evaluated += rows
+            if rows == 0:
+                self.commit_packed(self._zero_h)
+                return
+            n = min((rows + 1023) // 1024 * 1024, self.packed_capacity)  # few distinct GEMM shapes
+            h = heuristic_fn_dev(oh[:n], True) if oh is not None else heuristic_fn_dev(nn[:n])
+            assert h.shape[0] >= rows
+            self.commit_packed(h.to(torch.float32).contiguous())
+            return
+        self.rows_evaluated += self.m_capacity
         nn, oh = self.pop_expand()
         h = heuristic_fn_dev(oh, True) if oh is not None else heuristic_fn_dev(nn)
         self.commit(h.to(torch.float32).contiguous())

@@ -102,3 +102,82 @@ def fold_batchnorm(model: ResnetModel) -> ResnetModel:
         blk[1] = nn.Identity()
         blk[3] = nn.Identity()
     return m
+
+
+def _pad_dim(n: int, spare: int) -> int:
+    """Width a layer is padded to: a multiple of 256 for the wide layers (64 for narrow ones) — the library's MFMA
+    macro-tiles divide these evenly, 1000 -> 1024 nearly doubles the bf16 GEMM rate on gfx950 — with `spare` free units."""
+    q = 256 if n >= 512 else 64
+    return ((n + spare + q - 1) // q) * q
+
+
+class FastResnet(nn.Module):
+    """Inference-only re-layout of a `ResnetModel` (pytorch_models.py:5-86 of the reference), same function:
+
+      * BatchNorm folded into the Linears (eval statistics);
+      * every width padded (`_pad_dim`): padded units have zero weights and zero bias, so they stay 0 through ReLU and
+        contribute nothing — outputs equal the unpadded network's up to fp summation order;
+      * bias + ReLU ride in the GEMM epilogue (`torch._addmm_activation`);
+      * in a residual block the skip connection is the GEMM's C operand, and the second Linear's bias is folded into
+        its weight matrix through a constant-one hidden unit (the first padded unit of the block's hidden layer has
+        zero weights and bias 1), leaving one in-place ReLU pass per block as the only elementwise kernel.
+
+    Input: one-hot rows `[M, in_pad]` in `dtype` (row stride `in_pad` >= state_dim*depth, tail zero) as written by the
+    engine's kept-children pack kernel, or uint8 network inputs through `forward`.  fp32 is the 1e-5 parity mode."""
+
+    def __init__(self, model: ResnetModel, dtype: torch.dtype = torch.float32):
+        super().__init__()
+        m = fold_batchnorm(model)
+        self.state_dim, self.one_hot_depth = m.state_dim, m.one_hot_depth
+        self.dtype = dtype
+        in_dim = m.fc1.in_features
+        self.in_dim = in_dim
+        self.in_pad = ((in_dim + 63) // 64) * 64
+        h1, r = m.fc1.out_features, m.fc2.out_features
+        h1p, rp = _pad_dim(h1, 0), _pad_dim(r, 1)
+        self.res_dim, self.res_pad = r, rp
+
+        def padw(lin: nn.Linear, outp: int, inp: int):
+            w = torch.zeros(outp, inp, dtype=torch.float32)
+            b = torch.zeros(outp, dtype=torch.float32)
+            w[:lin.out_features, :lin.in_features] = lin.weight.detach().float().cpu()
+            b[:lin.out_features] = lin.bias.detach().float().cpu()
+            return w, b
+
+        ws, bs = [], []
+        w, b = padw(m.fc1, h1p, self.in_pad)
+        ws.append(w), bs.append(b)
+        w, b = padw(m.fc2, rp, h1p)
+        ws.append(w), bs.append(b)
+        for blk in m.blocks:
+            wa, ba = padw(blk[0], rp, rp)
+            ba[r] = 1.0  # constant-one unit feeding the next Linear's folded bias
+            wb, bb = padw(blk[2] if len(blk) == 4 else blk[1], rp, rp)
+            wb[:, r] = bb
+            ws += [wa, wb]
+            bs += [ba, torch.zeros(0)]
+        wo, bo = padw(m.fc_out, m.fc_out.out_features, rp)
+        self.weights = nn.ParameterList([nn.Parameter(w.to(dtype), requires_grad=False) for w in ws])
+        self.biases = nn.ParameterList([nn.Parameter(b.to(dtype), requires_grad=False) for b in bs])
+        self.w_out = nn.Parameter(wo.to(dtype), requires_grad=False)
+        self.b_out = nn.Parameter(bo.float(), requires_grad=False)
+
+    @torch.no_grad()
+    def forward_onehot(self, x: torch.Tensor) -> torch.Tensor:
+        """[M, in_pad] one-hot rows (dtype = self.dtype) -> [M, out_dim] float32."""
+        W, B = self.weights, self.biases
+        x = torch._addmm_activation(B[0], x, W[0].t())
+        x = torch._addmm_activation(B[1], x, W[1].t())
+        for k in range(2, len(W), 2):
+            h = torch._addmm_activation(B[k], x, W[k].t())
+            x = torch.addmm(x, h, W[k + 1].t()).relu_()
+        return (x @ self.w_out.t()).float() + self.b_out  # fc_out: [M,rp] x [rp,out_dim], fp32 bias add
+
+    @torch.no_grad()
+    def encode(self, states_nnet: torch.Tensor) -> torch.Tensor:
+        from .. import _lib
+        oh = _lib.onehot(states_nnet, self.one_hot_depth, self.dtype) if self.one_hot_depth > 0 else states_nnet.to(self.dtype)
+        return torch.nn.functional.pad(oh, (0, self.in_pad - oh.shape[1]))
+
+    def forward(self, states_nnet: torch.Tensor) -> torch.Tensor:
+        return self.forward_onehot(self.encode(states_nnet))

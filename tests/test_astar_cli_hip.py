@@ -56,6 +56,13 @@ def test_heuristic_forward_matches_reference_within_1e5(golden, tiny_resnet):
         yf = fold_batchnorm(full)(torch.tensor(golden["cube3_resnet_seed2024_x"]).cuda())[:, 0].cpu().numpy()
     tol = 1e-5 * max(1.0, float(np.abs(ref).max()))
     assert np.max(np.abs(yy - ref)) < tol and np.max(np.abs(yf - ref)) < tol
+    # padded / epilogue-fused inference layout (the CLI default): same function, fp32
+    from deepcubea_amd.utils.pytorch_models import FastResnet
+    fast = FastResnet(full).cuda()
+    ys = fast(torch.tensor(golden["cube3_resnet_seed2024_x"]).cuda())[:, 0].cpu().numpy()
+    assert np.max(np.abs(ys - ref)) < tol
+    yt = FastResnet(m).cuda()(x)[:, 0].cpu().numpy()
+    assert np.max(np.abs(yt - tiny_resnet["y"])) < 1e-5
     # reference-signature closure (lists of State objects -> float64)
     from deepcubea_amd.utils import env_utils
     env = env_utils.get_environment("cube3")
@@ -64,7 +71,8 @@ def test_heuristic_forward_matches_reference_within_1e5(golden, tiny_resnet):
     assert h.dtype == np.float64 and h.shape == (16,) and (h >= 0).all()
 
 
-def test_cli_end_to_end(tmp_path, capsys):
+@pytest.mark.parametrize("mode", ["dedup_first", "eval_all_children"])
+def test_cli_end_to_end(tmp_path, capsys, mode):
     from deepcubea_amd.search_methods import astar
     from deepcubea_amd.utils import env_utils, nnet_utils
     from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
@@ -81,8 +89,8 @@ def test_cli_end_to_end(tmp_path, capsys):
     rdir = str(tmp_path / "res")
     B, w = 60, 0.8
     astar.main(["--states", spath, "--model", "synthetic:11", "--env", "cube3", "--weight", str(w), "--batch_size",
-                str(B), "--results_dir", rdir, "--language", "hip", "--nnet_batch_size", "1000", "--max_nodes",
-                str(1 << 20)])
+                str(B), "--results_dir", rdir, "--language", "hip", "--nnet_batch_size", "1024", "--max_nodes",
+                str(1 << 20)] + (["--eval_all_children"] if mode == "eval_all_children" else []))
     sys.stdout = sys.__stdout__
     res = pickle.load(open(os.path.join(rdir, "results.pkl"), "rb"))
     assert sorted(res.keys()) == ["num_nodes_generated", "paths", "solutions", "states", "times"]  # astar.py:382-397
@@ -94,8 +102,13 @@ def test_cli_end_to_end(tmp_path, capsys):
     nnet = env.get_nnet_model()
     load_synthetic_weights(nnet, 11)
     nnet = nnet.cuda().eval()
-    hfn = nnet_utils.get_heuristic_fn_dev(nnet, batch_size=1000)
-    M = B * 12
+    if mode == "dedup_first":  # the CLI's default network layout; batches are rounded up to 1024 rows
+        from deepcubea_amd.utils.pytorch_models import FastResnet
+        hfn = nnet_utils.get_heuristic_fn_dev(FastResnet(nnet).cuda(), batch_size=1024)
+        M = 1024
+    else:
+        hfn = nnet_utils.get_heuristic_fn_dev(nnet, batch_size=1024)
+        M = B * 12
 
     def heur(states):
         x = torch.zeros((max(M, len(states)), 54), dtype=torch.uint8, device="cuda")

@@ -283,3 +283,92 @@ def test_multi_instance_engine_matches_single_instance_runs(L, co):
         ref = co.astar("puzzle15", root, 0.8, 100, co.SEM_CPP, heur_builtin_id=1)
         assert r["moves"] == ref["moves"] and r["nodes_generated"] == ref["nodes_generated"]
     eng.close()
+
+
+PACKED_CASES = [
+    ("cube3", [3, 8, 1, 10, 6], 0.8, 64, "py", torch.float32, 384),
+    ("cube3", [0, 5, 7, 2, 9, 4], 0.6, 300, "cpp", torch.bfloat16, 328),
+    ("puzzle15", [1, 3, 1, 1, 3, 0, 2, 0, 3, 1], 0.8, 50, "py", torch.float16, 256),
+    ("puzzle24", [1, 1, 3, 3, 0, 2, 0, 3], 0.7, 100, "cpp", torch.float32, 640),
+    ("puzzle48", [1, 3, 1, 3, 0, 2], 1.0, 30, "py", None, None),
+]
+
+
+@pytest.mark.parametrize("env,scr,w,B,sem,dt,stride", PACKED_CASES)
+def test_packed_dedup_first_stepping(L, co, env, scr, w, B, sem, dt, stride):
+    """Dedup-first stepping (CLOSED check before the heuristic, only the kept children handed out) is the same search
+    as the reference's order; the packed rows are exactly the kept children's network inputs / one-hot rows."""
+    from deepcubea_amd.search_methods.engine import BwasEngine
+    from oracle import np_oracle as no
+    semv = L.SEM_PY if sem == "py" else L.SEM_CPP
+    root = scramble(co, env, scr)
+    # reference order (heuristic on every child, then the CLOSED check): the fused built-in stepping of the same engine,
+    # itself pinned to the oracle / the reference traces by the tests above — traces must agree entry for entry
+    eng0 = BwasEngine(env, w, B, max_nodes=1 << 19, semantics=semv)
+    ref = run_traced(L, eng0, root, 1)
+    eng0.close()
+    if sem == "py":
+        orc = co.astar(env, root, w, B, co.SEM_PY, heur_builtin_id=1)
+        assert ref["moves"] == orc["moves"] and ref["nodes_generated"] == orc["nodes_generated"]
+    eng = BwasEngine(env, w, B, max_nodes=1 << 19, semantics=semv, onehot_dtype=dt, packed=True, onehot_stride=stride)
+    D, depth = eng.state_dim, eng.depth
+    eng.reset(root)
+    if semv == L.SEM_PY:
+        eng.root_commit(L.heuristic_builtin(1, torch.from_numpy(root[None].copy()).cuda()))
+    it, total_rows = 0, 0
+    while True:
+        nn, oh, src, rows = eng.pop_expand_packed()
+        ch = eng.last_children()
+        m = ch.shape[0]
+        assert 0 <= rows <= m
+        srcv = src[:rows].long()
+        assert rows == 0 or (int(srcv.max()) < m and len(torch.unique(srcv)) == rows)
+        kept = ch[srcv].contiguous()
+        if it < 4 or it % 7 == 0:
+            kn = kept.cpu().numpy()
+            nin = kn // 9 if env == "cube3" else kn
+            assert np.array_equal(nn[:rows].cpu().numpy(), nin)
+            if dt is not None:
+                got = oh[:rows].float().cpu().numpy()
+                assert np.array_equal(got[:, :D * depth], no.onehot(nin, depth)) and not got[:, D * depth:].any()
+        with pytest.raises(L.DcaError):
+            eng.pop_expand_packed()  # DCA_E_STATE: commit missing
+        h = L.heuristic_builtin(1, kept) if rows else torch.zeros(1, dtype=torch.float32, device="cuda")
+        eng.commit_packed(h)
+        total_rows += rows
+        it += 1
+        st = eng.status()
+        k = min(it, ref["iterations"]) - 1
+        assert (st["open_size"], st["closed_size"], st["nodes_generated"]) == tuple(ref["trace"][k]), it
+        if st["done"]:
+            break
+    res = eng._result()
+    assert res["moves"] == ref["moves"] and res["nodes_generated"] == ref["nodes_generated"]
+    assert res["iterations"] == ref["iterations"]
+    assert total_rows < res["nodes_generated"]  # something was actually skipped
+    with pytest.raises(L.DcaError):
+        eng.commit_packed(torch.zeros(8, dtype=torch.float32, device="cuda"))
+    with pytest.raises(L.DcaError):
+        BwasEngine(env, w, B, max_nodes=1 << 12).pop_expand_packed()  # not enabled
+    eng.close()
+
+
+def test_packed_multi_instance_with_closure(L, co):
+    """K instances share one packed batch (one heuristic call per iteration); `step` picks the packed path."""
+    from deepcubea_amd.search_methods.engine import BwasEngine
+    cases = [[3, 8, 1, 10, 6], [0, 5, 7, 2], [], [4, 9, 1]]
+    w, B = 0.8, 64
+    roots = [scramble(co, "puzzle15", [1, 3, 1, 1, 3, 0, 2, 0, 3, 1][:n]) for n in (10, 6, 0, 8)]
+    eng = BwasEngine("puzzle15", w, B, max_nodes=1 << 19, num_instances=4, packed=True)
+    calls = []
+
+    def hfn(x, is_onehot=False):  # packed network-input rows of a puzzle are the raw tiles
+        calls.append(x.shape[0])
+        return L.heuristic_builtin(1, x.contiguous())
+
+    out = eng.solve_many(roots, hfn)
+    for r, root in zip(out, roots):
+        ref = co.astar("puzzle15", root, w, B, co.SEM_PY, heur_builtin_id=1)
+        assert r["moves"] == ref["moves"] and r["nodes_generated"] == ref["nodes_generated"]
+    assert all(c % 1024 == 0 or c == 1 for c in calls)  # batches are rounded up to 1024 rows (1 = root evaluation)
+    eng.close()

@@ -75,6 +75,15 @@ def test_resnet_matches_reference_outputs(tiny_resnet, golden):
         yy = full(torch.tensor(golden["cube3_resnet_seed2024_x"]))[:, 0].numpy()
     ref = golden["cube3_resnet_seed2024_y"]
     assert np.max(np.abs(yy - ref)) < 1e-5 * max(1.0, float(np.abs(ref).max()))
+    # padded / epilogue-fused inference layout: same function (host arithmetic here; the GPU test repeats it on device)
+    from deepcubea_amd.utils.pytorch_models import FastResnet
+    for model, xin, want in ((m, tiny_resnet["x"], tiny_resnet["y"]), (full, golden["cube3_resnet_seed2024_x"], ref)):
+        fast = FastResnet(model)
+        assert fast.in_pad % 64 == 0 and fast.res_pad > fast.res_dim
+        oh = np.zeros((xin.shape[0], fast.in_pad), np.float32)
+        oh[:, :324] = no.onehot(xin, 6)
+        yfast = fast.forward_onehot(torch.tensor(oh))[:, 0].numpy()
+        assert np.max(np.abs(yfast - want)) < 1e-5 * max(1.0, float(np.abs(want).max()))
 
 
 def test_reference_pickles_load_through_the_mirror(tmp_path):
