@@ -345,6 +345,46 @@ def run_avi(args, world, rank):
 
 
 # --------------------------------------------------------------------------------------------------
+# workload: train (the training step, nnet_utils.train_nnet)
+# --------------------------------------------------------------------------------------------------
+def run_train(args, world, rank):
+    """One step = one Adam iteration of `nnet_utils.train_nnet` on the cube3 network (14.7M parameters, BatchNorm in
+    training mode, fp32) at `--train_batch` examples per GPU, training set resident in HBM.  N > 1: the network is
+    wrapped in DistributedDataParallel (gradient all-reduce over RCCL), weak scaling."""
+    from deepcubea_amd import _lib
+    from deepcubea_amd.utils import env_utils, nnet_utils
+    from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
+    env = env_utils.get_environment("cube3")
+    model = env.get_nnet_model()
+    load_synthetic_weights(model, 2024)
+    model = model.cuda()
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[torch.cuda.current_device()])
+    B = args.train_batch
+    n = B * 8
+    states, nb, _ = _lib.generate_states(env._env_id, env._dim, n, 0, 30, 5, rank * n)
+    x = _lib.nnet_input(env._env_id, env._dim, states)
+    y = nb.float()[:, None].contiguous()  # scramble depth as a stand-in target
+    dev = torch.device("cuda", torch.cuda.current_device())
+    np.random.seed(1 + rank)
+    nnet_utils.train_nnet(net, x, y, dev, B, args.warmup, 0, 1e-3, 0.9999993, display=False)
+    barrier(world)
+    t0 = time.perf_counter()
+    last = nnet_utils.train_nnet(net, x, y, dev, B, args.steps, args.warmup, 1e-3, 0.9999993, display=False)
+    barrier(world)
+    wall = reduce_ranks(time.perf_counter() - t0, world, "max")
+    flops = 3 * 2.0 * 14_621_000 * B  # forward + backward (2x) of the dense layers
+    return {"value": B * world * args.steps / wall, "ms_per_step": wall / args.steps * 1e3,
+            "config": {"workload": "cube3 cost-to-go network training step (nnet_utils.train_nnet: Adam, MSE, lr*lr_d^itr), "
+                                   "batch %d per GPU, fp32, BatchNorm training mode, data resident in HBM" % B,
+                       "batch_per_gpu": B, "last_loss": last, "parallelism": "DDP x%d (RCCL gradient all-reduce)" % world,
+                       "train_tflops_per_gpu": flops / (wall / args.steps) / 1e12, "mfma_peak_tflops": 157.3,
+                       "reference_published": "1.26-1.48e5 samples/s at batch 10000 on 3 GPUs with nn.DataParallel "
+                                              "(saved_models/cube3/output.txt)"}}
+
+
+# --------------------------------------------------------------------------------------------------
 # workload: expand (configs[1])
 # --------------------------------------------------------------------------------------------------
 def run_expand(args, world, rank):
@@ -421,7 +461,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="astar", choices=["astar", "expand", "avi"])
+    ap.add_argument("--workload", default="astar", choices=["astar", "expand", "avi", "train"])
     ap.add_argument("--nnet_dtype", default="fp32", choices=["fp32", "bf16"], help="avi: heuristic precision")
     ap.add_argument("--env", default="cube3", choices=["cube3", "puzzle15", "puzzle24", "puzzle35", "puzzle48"],
                     help="astar: environment of the engine-only leg (nnet / concurrency legs are cube3)")
@@ -432,6 +472,7 @@ def main():
     ap.add_argument("--profile-iters", type=int, default=20, help="astar: extra per-kernel-timed iterations")
     ap.add_argument("--nnet-steps", type=int, default=4, help="astar: timed steps of the ResNet-heuristic leg (0=skip)")
     ap.add_argument("--nnet_batch_size", type=int, default=60000)
+    ap.add_argument("--train_batch", type=int, default=10000, help="train: examples per GPU per step")
     ap.add_argument("--n", type=int, default=1_000_000, help="expand: synthetic states per launch")
     ap.add_argument("--onehot", default="f32", choices=["f32", "bf16", "f16"], help="expand: one-hot element type")
     ap.add_argument("--concurrent", type=int, default=4, help="astar: also time k concurrent instances per GPU (0/1 = skip)")
@@ -440,16 +481,17 @@ def main():
     ap.add_argument("--debug", action="store_true")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = {"astar": 200, "expand": 20, "avi": 3}[args.workload]
+        args.steps = {"astar": 200, "expand": 20, "avi": 3, "train": 30}[args.workload]
     if args.warmup is None:
-        args.warmup = {"astar": 10, "expand": 3, "avi": 1}[args.workload]
+        args.warmup = {"astar": 10, "expand": 3, "avi": 1, "train": 5}[args.workload]
     world, rank, local = dist_setup(args.dist_backend)
-    res = {"astar": run_astar, "expand": run_expand, "avi": run_avi}[args.workload](args, world, rank)
+    res = {"astar": run_astar, "expand": run_expand, "avi": run_avi, "train": run_train}[args.workload](args, world, rank)
     line = {
         "metric": {"astar": "A* nodes expanded/sec on %s, batch 20k" % args.env, "expand": "A* nodes expanded/sec on cube3",
-                   "avi": "AVI update-step training states generated/sec on cube3"}[args.workload],
+                   "avi": "AVI update-step training states generated/sec on cube3",
+                   "train": "cost-to-go network training samples/sec on cube3"}[args.workload],
         "value": res["value"],
-        "unit": "states/s" if args.workload == "avi" else "nodes expanded/s",
+        "unit": {"avi": "states/s", "train": "samples/s"}.get(args.workload, "nodes expanded/s"),
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
@@ -457,7 +499,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u8" if args.workload == "expand" else "u8 states / f64 cost keys / f32 heuristic",
+        "dtype": {"expand": "u8", "train": "f32"}.get(args.workload, "u8 states / f64 cost keys / f32 heuristic"),
         "data": "synthetic",
         "config": res["config"],
     }
@@ -470,7 +512,7 @@ def main():
                                    "bf16": run_astar_nnet(args, world, rank, "bf16"),
                                    "fp16": run_astar_nnet(args, world, rank, "fp16"),
                                    "fp32_eval_all_children": run_astar_nnet(args, world, rank, "fp32", True)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "avi":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("astar", "expand"):
         if args.workload == "expand":
             line["cpu_baseline"] = cpu_baseline_expand()
         elif args.env == "cube3":

@@ -20,8 +20,10 @@ def world_info() -> Tuple[int, int]:
     return 1, 0
 
 
-def init_from_env() -> Tuple[int, int]:
-    """Initialise from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run).  One GPU per rank."""
+def init_from_env(backend: str = "gloo") -> Tuple[int, int]:
+    """Initialise from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run).  One GPU per rank.
+    The search only exchanges CPU objects (gloo); the training step passes backend="nccl" (= RCCL over xGMI) for
+    its gradient all-reduce."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world > 1:
@@ -31,7 +33,7 @@ def init_from_env() -> Tuple[int, int]:
         if torch.cuda.is_available():
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
         if not dist.is_initialized():
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return world, rank
 
 

@@ -8,8 +8,8 @@ one replica per GPU: states are generated, expanded, evaluated and backed up wit
     updater = Updater(env, num_states, back_max, heuristic_fn_dev, num_steps, "GBFS", eps_max=0.0)
     states_nnet, ctg, is_solved = updater.update()      # same triple as updater.py:116-123
 
-Scope note: this is only the update step (targets for the cost-to-go network); the training step itself
-(`nnet_utils.train_nnet`) is out of scope.  ASTAR updates (updater.py:36-54) are not provided.
+The training step that consumes these targets is `utils/nnet_utils.train_nnet`; `ctg_approx/avi.py` ties both into
+the reference's loop.  ASTAR updates (updater.py:36-54) are not provided.
 """
 from __future__ import annotations
 
@@ -35,7 +35,7 @@ def bellman_dev(env, states: torch.Tensor, heuristic_fn_dev: Callable, onehot_dt
 
 def gbfs_update_dev(states: torch.Tensor, env, num_steps: int, heuristic_fn_dev: Callable, eps_max: float = 0.0,
                     generator: Optional[torch.Generator] = None, onehot_dtype=None,
-                    rand_child: Optional[Callable[[int, int], torch.Tensor]] = None):
+                    rand_child: Optional[Callable[[int, int], torch.Tensor]] = None, return_steps: bool = False):
     """updater.py:11-33 gbfs_update with GBFS.step (gbfs.py:43-120) for all instances at once.
     -> (states_update u8 [T,D], cost_to_go f32 [T], is_solved bool [n]) in the reference's instance-major order.
     `rand_child(k, A)` may override the random-child draw (tests stub it, like np.random.choice)."""
@@ -44,6 +44,7 @@ def gbfs_update_dev(states: torch.Tensor, env, num_steps: int, heuristic_fn_dev:
     dev = states.device
     cur = states.clone()
     solved = torch.zeros(n, dtype=torch.bool, device=dev)
+    steps = torch.zeros(n, dtype=torch.int32, device=dev)  # Instance.num_steps (gbfs.py:26-28)
     eps = torch.rand(n, device=dev, generator=generator) * eps_max  # updater.py:12
     traj_states: List[torch.Tensor] = []
     traj_ctg: List[torch.Tensor] = []
@@ -90,6 +91,9 @@ def gbfs_update_dev(states: torch.Tensor, env, num_steps: int, heuristic_fn_dev:
                                                                                    generator=generator)
             nxt[pick_rand] = children[rows[pick_rand], ridx.to(dev).long()]
         cur[uns] = nxt
+        steps[uns] += 1
+    if return_steps:
+        return solved, steps
     if not traj_states:
         return (torch.zeros((0, D), dtype=torch.uint8, device=dev), torch.zeros(0, dtype=torch.float32, device=dev),
                 solved)
@@ -142,3 +146,40 @@ class Updater:
         shard (a trainer on the same rank consumes it; no collective is needed for the update itself)."""
         sn, out, sv = self.update_dev()
         return [sn.cpu().numpy()], out.cpu().numpy(), sv.cpu().numpy()
+
+
+def gbfs_test_dev(num_states: int, back_max: int, env, heuristic_fn_dev: Callable, max_solve_steps: Optional[int] = None,
+                  seed: int = 0) -> List[Tuple[int, float, float, float]]:
+    """search_methods/gbfs.py:126-183 gbfs_test on the device: `num_states` states spread over 30 scramble depths
+    0..back_max, greedy best-first search for `max_solve_steps` steps, one line of statistics per depth in the
+    reference's format.  Returns [(back_step, %solved, avgSolveSteps, ctg mean)] for callers / tests."""
+    back_steps = list(np.linspace(0, back_max, 30, dtype=int))
+    per = [num_states // len(back_steps) + (1 if i < num_states % len(back_steps) else 0) for i in range(len(back_steps))]
+    chunks, depth = [], []
+    index0 = 0
+    for bs, n_i in zip(back_steps, per):
+        if n_i > 0:
+            st, _, _ = _lib.generate_states(env._env_id, env._dim, n_i, int(bs), int(bs), seed, index0)
+            chunks.append(st)
+            depth.append(torch.full((n_i,), int(bs), dtype=torch.int64))
+            index0 += n_i
+    states = torch.cat(chunks)
+    state_back_steps = torch.cat(depth).numpy()
+    if max_solve_steps is None:
+        max_solve_steps = max(int(state_back_steps.max()), 1)
+    print("Solving %i states with GBFS with %i steps" % (states.shape[0], max_solve_steps))
+    solved_d, steps_d = gbfs_update_dev(states, env, max_solve_steps, heuristic_fn_dev, 0.0, return_steps=True)
+    is_solved_all = solved_d.cpu().numpy()
+    num_steps_all = steps_d.cpu().numpy()
+    state_ctg_all = heuristic_fn_dev(_lib.nnet_input(env._env_id, env._dim, states)).float().cpu().numpy()
+    rows = []
+    for back_step_test in np.unique(state_back_steps):
+        idx = np.where(state_back_steps == back_step_test)[0]
+        is_solved, num_steps, ctg = is_solved_all[idx], num_steps_all[idx], state_ctg_all[idx]
+        per_solved = 100 * float(is_solved.sum()) / float(len(is_solved))
+        avg_solve_steps = float(np.mean(num_steps[is_solved])) if per_solved > 0.0 else 0.0
+        print("Back Steps: %i, %%Solved: %.2f, avgSolveSteps: %.2f, CTG Mean(Std/Min/Max): %.2f("
+              "%.2f/%.2f/%.2f)" % (back_step_test, per_solved, avg_solve_steps, float(np.mean(ctg)), float(np.std(ctg)),
+                                   np.min(ctg), np.max(ctg)))
+        rows.append((int(back_step_test), per_solved, avg_solve_steps, float(np.mean(ctg))))
+    return rows

@@ -102,3 +102,73 @@ def load_heuristic_fn(nnet_dir: str, device: torch.device, on_gpu: bool, nnet: n
     nnet.eval()
     nnet.to(device)
     return get_heuristic_fn(nnet, device, env, clip_zero=clip_zero, batch_size=batch_size)
+
+
+# --------------------------------------------------------------------------------------------------
+# training step: mirror of nnet_utils.py:31-118 (make_batches, train_nnet)
+# --------------------------------------------------------------------------------------------------
+def make_batches(num_examples: int, batch_size: int) -> List[np.ndarray]:
+    """Index form of nnet_utils.py:31-50: one `np.random.choice(n, n, replace=False)` permutation cut into FULL
+    batches (the tail is dropped).  Same numpy call as the reference, so a seeded run visits the same examples."""
+    rand_idxs = np.random.choice(num_examples, num_examples, replace=False)
+    return [rand_idxs[s:s + batch_size] for s in range(0, num_examples - batch_size + 1, batch_size)]
+
+
+def train_nnet(nnet: nn.Module, states_nnet, outputs, device: torch.device, batch_size: int, num_itrs: int,
+               train_itr: int, lr: float, lr_d: float, display: bool = True,
+               batches_idx: Optional[List[np.ndarray]] = None) -> float:
+    """nnet_utils.py:53-118, same signature and return value (the last loss): Adam on the MSE between
+    `nnet(x)[:, 0]` and `outputs[:, 0]`, learning rate `lr * lr_d**train_itr` set every iteration, batches from
+    `make_batches`, reshuffled with `random.shuffle` when exhausted, progress line every 100 iterations.
+
+    MI355X differences: the training set (uint8 network inputs + f32 targets) is copied to the device ONCE and
+    batches are gathered there by index — the reference re-uploads every batch; `states_nnet` / `outputs` may
+    already be device tensors (what `Updater.update_dev` returns).  Under `torch.distributed` (world > 1) wrap `nnet`
+    in DistributedDataParallel and give every rank its own shard with `batch_size // world` — the gradient
+    all-reduce over RCCL/xGMI is the only collective of the whole framework and reproduces the reference's
+    `nn.DataParallel` arithmetic (per-replica BatchNorm statistics, loss averaged over the global batch)."""
+    from random import shuffle
+    import time
+
+    display_itrs = 100
+    criterion = nn.MSELoss()
+    optimizer = torch.optim.Adam(nnet.parameters(), lr=lr)
+    start_time = time.time()
+
+    x = states_nnet[0] if isinstance(states_nnet, (list, tuple)) else states_nnet
+    x = (torch.from_numpy(np.ascontiguousarray(x)) if isinstance(x, np.ndarray) else x).to(device)
+    y = torch.from_numpy(np.asarray(outputs, dtype=np.float32)) if isinstance(outputs, np.ndarray) else outputs
+    y = y.to(device=device, dtype=torch.float32)
+    num_examples = int(y.shape[0])
+    batches = batches_idx if batches_idx is not None else make_batches(num_examples, int(batch_size))
+    if len(batches) == 0:
+        raise ValueError("train_nnet: %d examples do not fill one batch of %d" % (num_examples, batch_size))
+    batches = [torch.from_numpy(np.ascontiguousarray(b, dtype=np.int64)).to(device) for b in batches]
+
+    nnet.train()
+    max_itrs = train_itr + num_itrs
+    last_loss = float("inf")
+    batch_idx = 0
+    while train_itr < max_itrs:
+        optimizer.zero_grad()
+        lr_itr = lr * (lr_d ** train_itr)
+        for param_group in optimizer.param_groups:
+            param_group['lr'] = lr_itr
+        idx = batches[batch_idx]
+        nnet_cost_to_go = nnet(x[idx])[:, 0]
+        target_cost_to_go = y[idx][:, 0]
+        loss = criterion(nnet_cost_to_go, target_cost_to_go)
+        loss.backward()
+        optimizer.step()
+        if display and (train_itr % display_itrs == 0):
+            last_loss = loss.item()
+            print("Itr: %i, lr: %.2E, loss: %.2E, targ_ctg: %.2f, nnet_ctg: %.2f, "
+                  "Time: %.2f" % (train_itr, lr_itr, last_loss, target_cost_to_go.mean().item(),
+                                  nnet_cost_to_go.mean().item(), time.time() - start_time))
+            start_time = time.time()
+        train_itr = train_itr + 1
+        batch_idx += 1
+        if batch_idx >= len(batches):
+            shuffle(batches)
+            batch_idx = 0
+    return float(loss.item())  # one host sync per call instead of one per iteration (nnet_utils.py:100)

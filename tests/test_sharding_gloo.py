@@ -80,3 +80,52 @@ def test_cli_rejects_other_languages(tmp_path):
     with pytest.raises(ValueError, match="Unknown language python"):
         astar.main(["--states", str(p), "--model_dir", "x", "--env", "cube3", "--results_dir", str(tmp_path / "r"),
                     "--language", "python", "--debug"])
+
+
+# ---- training step under DistributedDataParallel (the only collective of the framework) --------------------------
+def _train_setup():
+    import torch
+    from deepcubea_amd.utils.pytorch_models import ResnetModel
+    g = np.load(os.path.join(ROOT, "tests", "golden", "train_nnet.npz"))
+    net = ResnetModel(54, 6, 64, 32, 2, 1, False)
+    net.load_state_dict({k.split(":", 2)[2]: torch.tensor(g[k]) for k in g.files if k.startswith("nobn:init:")})
+    perm = np.random.default_rng(3).permutation(40)
+    batches = [perm[s:s + 8] for s in range(0, 40, 8)]  # 5 global batches of 8
+    return net, g["nobn:x"], g["nobn:y"], batches
+
+
+def _train_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import random
+    import torch
+    from deepcubea_amd.search_methods import sharding
+    from deepcubea_amd.utils import nnet_utils
+    torch.set_num_threads(1)
+    w, r = sharding.init_from_env("gloo")
+    net, x, y, batches = _train_setup()
+    ddp = torch.nn.parallel.DistributedDataParallel(net)
+    random.seed(3)
+    half = [b[r * 4:(r + 1) * 4] for b in batches]  # this rank's share of every global batch
+    nnet_utils.train_nnet(ddp, [x], y, torch.device("cpu"), 4, 7, 2, 0.01, 0.95, display=False, batches_idx=half)
+    if r == 0:
+        np.savez(out_path, **{k: v.numpy() for k, v in net.state_dict().items()})
+    sharding.finalize()
+
+
+def test_train_nnet_ddp_two_ranks_equals_full_batch(tmp_path):
+    """2 ranks x half batches under DDP (gradient all-reduce; gloo here, RCCL on the GPUs) == one process on the full
+    batches: the arithmetic of the reference's nn.DataParallel training (nnet_utils.py:53-118, avi.py:207-208)."""
+    import random
+    import torch
+    from deepcubea_amd.utils import nnet_utils
+    torch.set_num_threads(1)
+    out = str(tmp_path / "ddp.npz")
+    mp.spawn(_train_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    net, x, y, batches = _train_setup()
+    random.seed(3)
+    nnet_utils.train_nnet(net, [x], y, torch.device("cpu"), 8, 7, 2, 0.01, 0.95, display=False, batches_idx=batches)
+    for k, v in net.state_dict().items():
+        assert np.allclose(got[k], v.numpy(), rtol=1e-5, atol=1e-6), k
