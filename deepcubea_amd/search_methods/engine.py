@@ -285,3 +285,21 @@ def smoke_check() -> None:
     assert res["solved"] and res["moves"] == ref["moves"], (res, ref)
     assert res["nodes_generated"] == ref["nodes_generated"] and res["iterations"] == ref["iterations"]
     eng.close()
+    # the CLI's default path: dedup-first stepping + the padded network layout, a small seeded network in the loop
+    from ..utils import nnet_utils
+    from ..utils.pytorch_models import FastResnet, ResnetModel
+    torch.manual_seed(0)
+    fast = FastResnet(ResnetModel(54, 6, 64, 32, 1, 1, True).eval()).cuda()
+    hfn = nnet_utils.get_heuristic_fn_dev(fast, batch_size=1024)
+    eng = BwasEngine("cube3", 0.8, 50, max_nodes=1 << 18, onehot_dtype=torch.float32, packed=True, onehot_stride=fast.in_pad)
+    res = eng.solve(root[0], hfn)
+
+    def heur(states):  # the oracle evaluates every child through the same closure (batches padded to 1024 rows)
+        x = torch.zeros((1024, 54), dtype=torch.uint8, device="cuda")
+        x[:len(states)] = torch.from_numpy(np.ascontiguousarray(states // 9)).cuda()
+        return hfn(x)[:len(states)].cpu().numpy()
+
+    ref = co.astar("cube3", root[0], 0.8, 50, co.SEM_PY, heur_fn=heur)
+    assert res["solved"] and res["moves"] == ref["moves"] and res["nodes_generated"] == ref["nodes_generated"], (res, ref)
+    assert eng.rows_evaluated < res["nodes_generated"]
+    eng.close()
