@@ -471,7 +471,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--profile-iters", type=int, default=20, help="astar: extra per-kernel-timed iterations")
     ap.add_argument("--nnet-steps", type=int, default=4, help="astar: timed steps of the ResNet-heuristic leg (0=skip)")
-    ap.add_argument("--nnet_batch_size", type=int, default=60000)
+    ap.add_argument("--nnet_batch_size", type=int, default=245760, help="rows per heuristic call (whole astar batch at once)")
     ap.add_argument("--train_batch", type=int, default=10000, help="train: examples per GPU per step")
     ap.add_argument("--n", type=int, default=1_000_000, help="expand: synthetic states per launch")
     ap.add_argument("--onehot", default="f32", choices=["f32", "bf16", "f16"], help="expand: one-hot element type")

@@ -170,7 +170,7 @@ class FastResnet(nn.Module):
         x = torch._addmm_activation(B[1], x, W[1].t())
         for k in range(2, len(W), 2):
             h = torch._addmm_activation(B[k], x, W[k].t())
-            x = torch.addmm(x, h, W[k + 1].t()).relu_()
+            x = x.addmm_(h, W[k + 1].t()).relu_()  # in place: the skip is the GEMM's C operand, no copy of it
         return (x @ self.w_out.t()).float() + self.b_out  # fc_out: [M,rp] x [rp,out_dim], fp32 bias add
 
     @torch.no_grad()
