@@ -136,7 +136,7 @@ struct Eng {
     uint8_t* cand_st;
     uint64_t *tmp_key, *pop_key, *ord_key, *spl_key;
     uint32_t *tmp_id, *pop_id, *ord_id, *spl_id, *ord_b, *ord_s, *ord_pb, *bcnt, *bpre;
-    uint64_t *child_hash, *child_key;
+    uint64_t* child_hash;
     uint32_t *child_slot, *child_next;
     uint8_t* child_flags;
     float* child_h;
@@ -1800,6 +1800,10 @@ namespace {
 
 template <typename T>
 int dev_alloc(dca_engine* e, T** p, size_t count) {
+    if (e->nalloc >= (int)(sizeof(e->allocs) / sizeof(e->allocs[0]))) {
+        set_error("allocation table full");
+        return DCA_E_NOMEM;
+    }
     void* q = nullptr;
     hipError_t err = hipMalloc(&q, count * sizeof(T) + 256);
     if (err != hipSuccess) {
@@ -2072,7 +2076,6 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
         ALLOC(bcnt, E.nb2_cap + 8);
         ALLOC(bpre, E.nb2_cap + 8);
         ALLOC(child_hash, M);
-        ALLOC(child_key, M);
         ALLOC(child_slot, M);
         ALLOC(child_next, M);
         ALLOC(child_flags, M);
