@@ -35,6 +35,7 @@ ABI_SYMBOLS = [
     "dca_engine_solution_instance", "dca_engine_pop_expand", "dca_engine_commit", "dca_engine_run_builtin",
     "dca_engine_enable_packed", "dca_engine_pop_expand_packed", "dca_engine_commit_packed",
     "dca_engine_profile_builtin", "dca_engine_set_tiers", "dca_engine_debug", "dca_engine_status", "dca_engine_last_children", "dca_engine_solution",
+    "dca_bn_workspace_bytes", "dca_bn_train_forward", "dca_bn_train_backward",
 ]
 
 
@@ -63,8 +64,10 @@ def lib() -> C.CDLL:
         _lib.dca_cube3_perm_table.restype = C.POINTER(C.c_uint8)
         for name in ABI_SYMBOLS:
             fn = getattr(_lib, name)  # AttributeError here = stale build of libdca_hip.so
-            if name not in ("dca_last_error", "dca_cube3_perm_table", "dca_engine_destroy"):
+            if name not in ("dca_last_error", "dca_cube3_perm_table", "dca_engine_destroy", "dca_bn_workspace_bytes"):
                 fn.restype = C.c_int
+        _lib.dca_bn_workspace_bytes.restype = C.c_int64
+        _lib.dca_bn_workspace_bytes.argtypes = [C.c_int64]
         _lib.dca_engine_destroy.restype = None
         if _lib.dca_abi_version() != 1:
             raise DcaError("libdca_hip.so ABI version mismatch")
@@ -240,3 +243,56 @@ def bellman_backup(h_children: torch.Tensor, solved_parent: Optional[torch.Tenso
     check(lib().dca_bellman_backup(ptr(h), ptr(solved_parent), C.c_int64(n), int(num_moves), int(clip_zero), ptr(ctg),
                                    ptr(am), stream_ptr()), "dca_bellman_backup")
     return ctg, am
+
+
+# ------------------------------------------------------------------------------ training step
+class _BnTrainFn(torch.autograd.Function):
+    """BatchNorm1d (training statistics) [+ skip] [+ ReLU] through dca_bn_train_forward / backward."""
+
+    @staticmethod
+    def forward(ctx, x, skip, gamma, beta, eps, relu, stats_out):
+        x = x.contiguous()
+        n, c = x.shape
+        ws = torch.empty(lib().dca_bn_workspace_bytes(c), dtype=torch.uint8, device=x.device)
+        y = torch.empty_like(x)
+        mean = torch.empty(c, dtype=torch.float32, device=x.device)
+        invstd = torch.empty_like(mean)
+        var_u = torch.empty_like(mean)
+        sk = skip.contiguous() if skip is not None else None
+        check(lib().dca_bn_train_forward(ptr(x), ptr(sk), ptr(gamma.contiguous()), ptr(beta.contiguous()), C.c_int64(n),
+                                         C.c_int64(c), C.c_double(eps), int(relu), ptr(y), ptr(mean), ptr(invstd), ptr(var_u),
+                                         ptr(ws), C.c_int64(ws.numel()), stream_ptr()), "dca_bn_train_forward")
+        stats_out.append((mean, var_u))
+        ctx.save_for_backward(x, y, mean, invstd, gamma)
+        ctx.relu, ctx.has_skip = bool(relu), skip is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, invstd, gamma = ctx.saved_tensors
+        n, c = x.shape
+        dy = dy.contiguous()
+        ws = torch.empty(lib().dca_bn_workspace_bytes(c), dtype=torch.uint8, device=x.device)
+        dx = torch.empty_like(x)
+        dskip = torch.empty_like(x) if ctx.has_skip else None
+        dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty_like(dgamma)
+        check(lib().dca_bn_train_backward(ptr(dy), ptr(x), ptr(y), ptr(mean), ptr(invstd), ptr(gamma.contiguous()),
+                                          C.c_int64(n), C.c_int64(c), int(ctx.relu), ptr(dx), ptr(dskip), ptr(dgamma),
+                                          ptr(dbeta), ptr(ws), C.c_int64(ws.numel()), stream_ptr()), "dca_bn_train_backward")
+        return dx, dskip, dgamma, dbeta, None, None, None
+
+
+def bn_train(x: torch.Tensor, bn: "torch.nn.BatchNorm1d", relu: bool, skip: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Training-mode `relu?(bn(x) (+ skip))` on the device, updating bn.running_mean / running_var /
+    num_batches_tracked exactly like nn.BatchNorm1d (momentum average, unbiased variance)."""
+    stats = []
+    y = _BnTrainFn.apply(x, skip, bn.weight, bn.bias, float(bn.eps), bool(relu), stats)
+    if bn.track_running_stats and bn.running_mean is not None:
+        mean, var_u = stats[0]
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            bn.running_mean.mul_(1.0 - mom).add_(mean, alpha=mom)
+            bn.running_var.mul_(1.0 - mom).add_(var_u, alpha=mom)
+    return y

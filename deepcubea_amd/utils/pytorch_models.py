@@ -54,8 +54,22 @@ class ResnetModel(nn.Module):
         x = torch.nn.functional.one_hot(states_nnet.long(), self.one_hot_depth).float()
         return x.view(-1, self.state_dim * self.one_hot_depth)
 
+    def _trunk_train_dev(self, x: torch.Tensor) -> torch.Tensor:
+        """Training mode on the HIP device: the BatchNorms (+ residual add + ReLU) run through the library's column
+        reduction kernels (csrc/dca_train.hip) — same arithmetic as `trunk`, the framework's 2-D BatchNorm kernels
+        were 41 % of the training step."""
+        from .. import _lib
+        x = _lib.bn_train(self.fc1(x), self.bn1, relu=True)
+        x = _lib.bn_train(self.fc2(x), self.bn2, relu=True)
+        for blk in self.blocks:
+            h = _lib.bn_train(blk[0](x), blk[1], relu=True)
+            x = _lib.bn_train(blk[2](h), blk[3], relu=True, skip=x)
+        return self.fc_out(x)
+
     def trunk(self, x: torch.Tensor) -> torch.Tensor:
         bn = self.batch_norm
+        if bn and self.training and x.is_cuda and x.dtype == torch.float32 and isinstance(self.bn1, nn.BatchNorm1d):
+            return self._trunk_train_dev(x)
         x = self.fc1(x)
         x = torch.relu(self.bn1(x) if bn else x)
         x = self.fc2(x)

@@ -230,6 +230,25 @@ int dca_engine_solution(dca_engine* e, int32_t* moves /*host [cap]*/, int cap, i
 int dca_engine_solution_instance(dca_engine* e, int inst, int32_t* moves /*host [cap]*/, int cap, int* len,
                                  double* path_cost, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Training step: BatchNorm1d in training mode over row-major [n, c] float32 activations, as
+ * nn.BatchNorm1d runs inside nnet_utils.train_nnet (utils/nnet_utils.py:53-118, utils/pytorch_models.py:57-86),
+ * optionally fused with the residual add and the ReLU that follow it in the network:
+ *   forward   y = relu?( (x - mean_c) * invstd_c * gamma_c + beta_c (+ skip) ), batch statistics over the n rows
+ *             (biased variance normalises; var_unbiased feeds running_var, momentum is the caller's business)
+ *   backward  g = dy * (y > 0 if relu); dbeta = sum g; dgamma = sum g*xhat;
+ *             dx = gamma*invstd*(g - dbeta/n - xhat*dgamma/n); dskip = g (if dskip != NULL)
+ * Column sums are accumulated in fp64 and folded deterministically.  workspace: dca_bn_workspace_bytes(c) bytes.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int64_t dca_bn_workspace_bytes(int64_t c);
+int dca_bn_train_forward(const float* x, const float* skip /*or NULL*/, const float* gamma, const float* beta, int64_t n,
+                         int64_t c, double eps, int relu, float* y, float* mean /*[c]*/, float* invstd /*[c]*/,
+                         float* var_unbiased /*[c]*/, void* workspace, int64_t workspace_bytes, void* stream);
+int dca_bn_train_backward(const float* dy, const float* x, const float* y /*needed if relu*/, const float* mean,
+                          const float* invstd, const float* gamma, int64_t n, int64_t c, int relu, float* dx,
+                          float* dskip /*or NULL*/, float* dgamma /*[c]*/, float* dbeta /*[c]*/, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

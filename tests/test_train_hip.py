@@ -77,3 +77,45 @@ def test_avi_loop_end_to_end(tmp_path):
     finally:
         sys.stdout = sys.__stdout__
     assert pickle.load(open(os.path.join(cur, "train_itr.pkl"), "rb")) == 9
+
+
+@pytest.mark.parametrize("n,c,relu,use_skip", [(1003, 1000, True, False), (517, 72, True, True), (64, 37, False, False),
+                                               (2, 5000, True, True), (10000, 1024, False, True)])
+def test_bn_train_kernels_match_float64_reference(n, c, relu, use_skip):
+    """csrc/dca_train.hip vs nn.BatchNorm1d(train) [+ skip] [+ ReLU] evaluated in float64: outputs, running statistics,
+    and all gradients (dx, dskip, dgamma, dbeta)."""
+    from deepcubea_amd import _lib
+    torch.manual_seed(n + c)
+    dev = "cuda"
+    x = (torch.randn(n, c, device=dev) * 1.7 + 0.4).requires_grad_(True)
+    skip = torch.randn(n, c, device=dev).requires_grad_(True) if use_skip else None
+    bn = torch.nn.BatchNorm1d(c).to(dev)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.3)
+        bn.running_mean.normal_(0, 0.2)
+        bn.running_var.uniform_(0.5, 2.0)
+    ref = torch.nn.BatchNorm1d(c).to(dev).double()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v.clone() for k, v in bn.state_dict().items()})
+    xd = x.detach().double().requires_grad_(True)
+    sd = skip.detach().double().requires_grad_(True) if use_skip else None
+    yr = ref(xd)
+    if use_skip:
+        yr = yr + sd
+    if relu:
+        yr = torch.relu(yr)
+    w = torch.randn(n, c, device=dev)
+    (yr * w.double()).sum().backward()
+    y = _lib.bn_train(x, bn, relu=relu, skip=skip)
+    (y * w).sum().backward()
+    tol = dict(rtol=2e-4, atol=2e-4)
+    assert torch.allclose(y.double(), yr, **tol)
+    assert torch.allclose(bn.running_mean.double(), ref.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bn.running_var.double(), ref.running_var, rtol=1e-5, atol=1e-6)
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+    scale = max(1.0, float(xd.grad.abs().max()))
+    assert torch.allclose(x.grad.double(), xd.grad, rtol=1e-3, atol=2e-4 * scale)
+    assert torch.allclose(bn.weight.grad.double(), ref.weight.grad, rtol=1e-3, atol=1e-3 * max(1.0, float(ref.weight.grad.abs().max())))
+    assert torch.allclose(bn.bias.grad.double(), ref.bias.grad, rtol=1e-3, atol=1e-3 * max(1.0, float(ref.bias.grad.abs().max())))
+    if use_skip:
+        assert torch.allclose(skip.grad.double(), sd.grad, **tol)
