@@ -133,7 +133,9 @@ __global__ __launch_bounds__(256) void k_bn_grad_final(const double* __restrict_
     dgamma[j] = (float)q;
 }
 
-// elementwise passes, one float4 per lane.  FWD: y = relu?(xhat*gamma + beta (+ skip)).
+// elementwise passes.  Same tiling as the reductions (a workgroup = 256 columns x a slice of rows, one float4 per lane,
+// 4 waves striding the rows): the per-column parameters live in registers and no index arithmetic is left in the loop.
+// FWD: y = relu?(xhat*gamma + beta (+ skip)).
 // BWD: g = dy*(y>0); dx = gamma*invstd*(g - dbeta/n - xhat*dgamma/n); dskip = g.
 template <bool FWD>
 __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, const float* __restrict__ other /*skip | dy*/,
@@ -142,53 +144,73 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, c
                                                   const float* __restrict__ beta, const float* __restrict__ dgamma,
                                                   const float* __restrict__ dbeta, int64_t n, int64_t c, int relu,
                                                   float* __restrict__ out, float* __restrict__ out2 /*dskip or null*/) {
-    const int64_t total = n * c;
-    const bool vec = (c & 3) == 0;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t col = ((int64_t)blockIdx.x * 64 + lane) * 4;
+    if (col >= c) return;
+    const int64_t rows_per = (n + gridDim.y - 1) / gridDim.y;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per, r1 = r0 + rows_per < n ? r0 + rows_per : n;
+    const bool vec = col + 4 <= c && (c & 3) == 0;
     const float inv_n = 1.0f / (float)n;
-    for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; e < total; e += (int64_t)gridDim.x * 1024) {
-        const int64_t col = e % c;
-        float xv[4], ov[4] = {0, 0, 0, 0}, yv[4] = {1, 1, 1, 1}, res[4], res2[4];
-        const int cnt = (int)(total - e < 4 ? total - e : 4);
+    // per column: y = x*sc + sh (fwd);  dx = g*ga - (x*sc2 + sh2) (bwd)
+    float mu[4], is[4], p0[4], p1[4], p2[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int64_t j = col + k < c ? col + k : c - 1;
+        mu[k] = mean[j];
+        is[k] = invstd[j];
+        if (FWD) {
+            p0[k] = gamma[j];
+            p1[k] = beta[j];
+            p2[k] = 0.f;
+        } else {
+            p0[k] = gamma[j] * is[k];                 // gamma*invstd
+            p1[k] = dbeta[j] * inv_n;                 // dbeta/n
+            p2[k] = dgamma[j] * inv_n;                // dgamma/n
+        }
+    }
+    for (int64_t r = r0 + wv; r < r1; r += 4) {
+        const int64_t o = r * c + col;
+        float xv[4] = {0, 0, 0, 0}, ov[4] = {0, 0, 0, 0}, yv[4] = {1, 1, 1, 1}, res[4], res2[4];
         if (vec) {
-            const float4 t = *reinterpret_cast<const float4*>(x + e);
+            const float4 t = *reinterpret_cast<const float4*>(x + o);
             xv[0] = t.x, xv[1] = t.y, xv[2] = t.z, xv[3] = t.w;
             if (other) {
-                const float4 d = *reinterpret_cast<const float4*>(other + e);
+                const float4 d = *reinterpret_cast<const float4*>(other + o);
                 ov[0] = d.x, ov[1] = d.y, ov[2] = d.z, ov[3] = d.w;
             }
             if (!FWD && relu) {
-                const float4 q = *reinterpret_cast<const float4*>(y_in + e);
+                const float4 q = *reinterpret_cast<const float4*>(y_in + o);
                 yv[0] = q.x, yv[1] = q.y, yv[2] = q.z, yv[3] = q.w;
             }
         } else {
-            for (int k = 0; k < cnt; k++) {
-                xv[k] = x[e + k];
-                if (other) ov[k] = other[e + k];
-                if (!FWD && relu) yv[k] = y_in[e + k];
-            }
+            for (int k = 0; k < 4; k++)
+                if (col + k < c) {
+                    xv[k] = x[o + k];
+                    if (other) ov[k] = other[o + k];
+                    if (!FWD && relu) yv[k] = y_in[o + k];
+                }
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            if (k >= cnt) break;
-            const int64_t j = vec ? col + k : (col + k) % c;
-            const float xh = (xv[k] - mean[j]) * invstd[j];
+            const float xh = (xv[k] - mu[k]) * is[k];
             if (FWD) {
-                float v = xh * gamma[j] + beta[j] + ov[k];
+                const float v = xh * p0[k] + p1[k] + ov[k];
                 res[k] = relu ? fmaxf(v, 0.f) : v;
             } else {
                 const float g = yv[k] > 0.f ? ov[k] : 0.f;
-                res[k] = gamma[j] * invstd[j] * (g - dbeta[j] * inv_n - xh * dgamma[j] * inv_n);
+                res[k] = p0[k] * (g - p1[k] - xh * p2[k]);
                 res2[k] = g;
             }
         }
         if (vec) {
-            *reinterpret_cast<float4*>(out + e) = make_float4(res[0], res[1], res[2], res[3]);
-            if (!FWD && out2) *reinterpret_cast<float4*>(out2 + e) = make_float4(res2[0], res2[1], res2[2], res2[3]);
+            *reinterpret_cast<float4*>(out + o) = make_float4(res[0], res[1], res[2], res[3]);
+            if (!FWD && out2) *reinterpret_cast<float4*>(out2 + o) = make_float4(res2[0], res2[1], res2[2], res2[3]);
         } else {
-            for (int k = 0; k < cnt; k++) {
-                out[e + k] = res[k];
-                if (!FWD && out2) out2[e + k] = res2[k];
-            }
+            for (int k = 0; k < 4; k++)
+                if (col + k < c) {
+                    out[o + k] = res[k];
+                    if (!FWD && out2) out2[o + k] = res2[k];
+                }
         }
     }
 }
@@ -196,6 +218,17 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, c
 }  // namespace dca
 
 using namespace dca;
+
+namespace {
+// column tiles x row slices: >= ~2000 workgroups, >= 16 rows per slice
+dim3 apply_grid(int64_t n, int64_t c) {
+    const unsigned gx = (unsigned)((c + 255) / 256);
+    int64_t gy = 4096 / gx;
+    if (gy > (n + 15) / 16) gy = (n + 15) / 16;
+    if (gy < 1) gy = 1;
+    return dim3(gx, (unsigned)gy);
+}
+}  // namespace
 
 extern "C" {
 
@@ -212,9 +245,7 @@ int dca_bn_train_forward(const float* x, const float* skip, const float* gamma, 
     hipLaunchKernelGGL(k_bn_reduce<0>, rg, dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, n, c, 0, part);
     hipLaunchKernelGGL(k_bn_stats_final, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, s, part, n, c, eps, mean, invstd,
                        var_unbiased);
-    const int64_t quads = (n * c + 3) / 4;
-    const unsigned g = (unsigned)(quads / 256 + 1 < 16384 ? quads / 256 + 1 : 16384);
-    hipLaunchKernelGGL(k_bn_apply<true>, dim3(g), dim3(256), 0, s, x, skip, nullptr, mean, invstd, gamma, beta, nullptr, nullptr,
+    hipLaunchKernelGGL(k_bn_apply<true>, apply_grid(n, c), dim3(256), 0, s, x, skip, nullptr, mean, invstd, gamma, beta, nullptr, nullptr,
                        n, c, relu, y, nullptr);
     return launch_check("dca_bn_train_forward");
 }
@@ -229,9 +260,7 @@ int dca_bn_train_backward(const float* dy, const float* x, const float* y, const
     const dim3 rg((unsigned)((c + 255) / 256), kBnSlices);
     hipLaunchKernelGGL(k_bn_reduce<1>, rg, dim3(256), 0, s, x, dy, y, mean, invstd, n, c, relu, part);
     hipLaunchKernelGGL(k_bn_grad_final, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, s, part, c, dgamma, dbeta);
-    const int64_t quads = (n * c + 3) / 4;
-    const unsigned g = (unsigned)(quads / 256 + 1 < 16384 ? quads / 256 + 1 : 16384);
-    hipLaunchKernelGGL(k_bn_apply<false>, dim3(g), dim3(256), 0, s, x, dy, y, mean, invstd, gamma, nullptr, dgamma, dbeta, n, c,
+    hipLaunchKernelGGL(k_bn_apply<false>, apply_grid(n, c), dim3(256), 0, s, x, dy, y, mean, invstd, gamma, nullptr, dgamma, dbeta, n, c,
                        relu, dx, dskip);
     return launch_check("dca_bn_train_backward");
 }
