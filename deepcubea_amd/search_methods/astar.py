@@ -9,8 +9,9 @@ semantics) with the search itself running on the device-resident engine (libdca_
         --results_dir results/cube3/ --language hip --nnet_batch_size 10000
 
 Multi-GPU: launch under `python -m torch.distributed.run --nproc-per-node N ...`; test scrambles are sharded
-per instance (state i -> rank i mod N), every rank holds a replica of the heuristic network and
-its own OPEN/CLOSED/node pool, and rank 0 merges the results in state order.  No collective on the data path.
+per instance (a shared work queue by default — per-state cost varies 40x — or state i -> rank i mod N
+with --static_shards), every rank holds a replica of the heuristic network and its own OPEN/CLOSED/node pool, and
+rank 0 merges the results in state order.  No collective on the data path.
 
 `bwas_hip(args, env, states)` has the signature and return value of the reference's `bwas_python` /
 `bwas_cpp` (astar.py:400-568) so it drops into the `--language` switch at astar.py:385-390.
@@ -72,10 +73,14 @@ def bwas_hip(args, env, states: List) -> Tuple[List[List[int]], List[List], List
                      semantics=sem, onehot_dtype=oh, num_instances=K, packed=onehot_stride is not None,
                      onehot_stride=onehot_stride)
     world, rank = sharding.world_info()
-    mine = sharding.shard_indices(len(states), world, rank)
     local: Dict[int, Tuple[List[int], List, float, int]] = {}
-    for g0 in range(0, len(mine), K):
-        group = mine[g0:g0 + K]  # K scrambles stepped together by one engine (one network call per iteration)
+    if getattr(args, "static_shards", False) or world == 1:
+        mine = sharding.shard_indices(len(states), world, rank)  # state i -> rank i mod world
+        groups = iter([mine[g0:g0 + K] for g0 in range(0, len(mine), K)])
+    else:
+        queue = sharding.WorkQueue(len(states), world, rank)  # ranks draw the next scramble when they are free
+        groups = iter(lambda: queue.next(K), [])
+    for group in groups:  # K scrambles stepped together by one engine (one network call per iteration)
         start_time = time.time()
         roots = [np.ascontiguousarray(env._get_arr(states[i]), dtype=np.uint8) for i in group]
         results = eng.solve_many(roots, heuristic_fn) if K > 1 else [eng.solve(roots[0], heuristic_fn)]
@@ -136,6 +141,8 @@ def build_parser() -> ArgumentParser:
                         help="fp32 = parity mode (1e-5); bf16/fp16 = faster, NOT parity")
     parser.add_argument('--fold_bn', action='store_true', default=False,
                         help="with --eval_all_children: fold BatchNorm into the Linears (always done otherwise)")
+    parser.add_argument('--static_shards', action='store_true', default=False,
+                        help="multi-GPU: state i -> rank i mod N instead of the shared work queue")
     parser.add_argument('--eval_all_children', action='store_true', default=False,
                         help="reference order (astar.py:272-282): run the network on every child, then drop the "
                              "duplicates.  Default is dedup-first: identical search, fewer network rows")

@@ -42,6 +42,29 @@ def shard_indices(n: int, world: int, rank: int) -> List[int]:
     return list(range(rank, n, world))
 
 
+class WorkQueue:
+    """Dynamic per-instance sharding: every rank draws the next unsolved state index from a shared counter kept in the
+    process group's key-value store (`store.add` is atomic) — no collective, and a rank that drew a 40x harder scramble
+    (results/cube3/output.txt spans 1.6e6..6.1e7 nodes) simply draws fewer of them.  world == 1: plain iteration."""
+
+    def __init__(self, n: int, world: int, rank: int, key: str = "dca_next_state"):
+        self.n, self.world, self.rank, self.key = int(n), world, rank, key
+        self._local = 0
+        self._store = None
+        if world > 1:
+            import torch.distributed as dist
+            self._store = dist.distributed_c10d._get_default_store()
+
+    def next(self, k: int = 1) -> List[int]:
+        """Up to k fresh indices (empty list = queue drained)."""
+        if self._store is None:
+            first = self._local
+            self._local += k
+        else:
+            first = int(self._store.add(self.key, k)) - k
+        return list(range(first, min(first + k, self.n)))
+
+
 def gather_results(local: Dict[int, tuple], n: int, world: int, rank: int) -> Optional[Dict[int, tuple]]:
     """Merge per-rank {state index: result} dicts on rank 0 (None elsewhere)."""
     if world == 1:

@@ -35,6 +35,14 @@ def _worker(rank, world, port, out_path):
         roots.append(s[0])
     mine = sharding.shard_indices(len(roots), w, r)
     assert mine == list(range(rank, len(roots), world))
+    # the default of the CLI: a shared work queue (atomic counter in the process group's store)
+    queue = sharding.WorkQueue(len(roots), w, r)
+    mine = []
+    while True:
+        got = queue.next(2)
+        if not got:
+            break
+        mine += got
     local = {}
     for i in mine:
         res = co.astar("cube3", roots[i], 0.8, 50, co.SEM_PY, heur_builtin_id=1)
@@ -65,6 +73,8 @@ def test_two_rank_sharding_and_merge(tmp_path):
     assert sharding.shard_indices(7, 1, 0) == list(range(7))
     assert sharding.gather_results({i: (None,) for i in range(3)}, 3, 1, 0) == {i: (None,) for i in range(3)}
     assert nodes2.shape == (7,) and nodes2[4] == 12  # solved root: one expansion
+    q = sharding.WorkQueue(5, 1, 0)
+    assert [q.next(2), q.next(2), q.next(2), q.next(2)] == [[0, 1], [2, 3], [4], []]
 
 
 def test_cli_rejects_other_languages(tmp_path):
