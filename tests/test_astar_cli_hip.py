@@ -184,7 +184,7 @@ def test_cli_instances_per_gpu(tmp_path):
 
 def test_cli_two_ranks_sharded(tmp_path):
     """N>1 path end to end on the GPU box: two ranks under torch.distributed.run (sharing the one GPU here; one GPU
-    per rank on a multi-GPU node), scrambles sharded i mod 2, rank 0 writes the merged results.pkl."""
+    per rank on a multi-GPU node), scrambles drawn from the shared work queue, rank 0 writes the merged results.pkl."""
     import subprocess
     from oracle import c_oracle as co
     scr = [[0, 5, 7], [1, 3, 8, 10], [], [4, 9], [2, 6, 11]]
@@ -212,5 +212,4 @@ def test_cli_two_ranks_sharded(tmp_path):
         for a in res["solutions"][i]:
             s = co.next_state("cube3", s, a)
         assert co.is_solved("cube3", s)[0] and len(res["solutions"][i]) == len(scr[i])
-    log = open(os.path.join(rdir, "output.txt")).read()
-    assert log.count("State: ") >= 3  # rank 0's own states (0, 2, 4) are logged by rank 0
+    assert os.path.isfile(os.path.join(rdir, "output.txt"))  # rank 0's log (the states it drew from the shared queue)
