@@ -137,7 +137,8 @@ def do_update(back_max: int, update_num: int, env, max_update_steps: int, update
 
 
 def main(argv=None):
-    world, rank = sharding.init_from_env("nccl" if torch.cuda.is_available() else "gloo")
+    # nccl = RCCL over xGMI (one GPU per rank); DCA_DIST_BACKEND=gloo lets several ranks share one GPU (tests)
+    world, rank = sharding.init_from_env(os.environ.get("DCA_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo"))
     args_dict = parse_arguments(build_parser(), argv, rank)
     if not args_dict["debug"] and rank == 0:
         sys.stdout = data_utils.Logger(args_dict["output_save_loc"], "a")

@@ -119,3 +119,25 @@ def test_bn_train_kernels_match_float64_reference(n, c, relu, use_skip):
     assert torch.allclose(bn.bias.grad.double(), ref.bias.grad, rtol=1e-3, atol=1e-3 * max(1.0, float(ref.bias.grad.abs().max())))
     if use_skip:
         assert torch.allclose(skip.grad.double(), sd.grad, **tol)
+
+
+def test_avi_two_ranks_ddp(tmp_path):
+    """N > 1 wiring of the AVI driver on the GPU box: two ranks under torch.distributed.run (sharing the one GPU here, so
+    the process group is gloo; nccl = RCCL on a multi-GPU node), DistributedDataParallel training on per-rank shards,
+    rank 0 writes the checkpoints."""
+    import subprocess
+    save = str(tmp_path / "saved_models")
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), DCA_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29547", "-m", "deepcubea_amd.ctg_approx.avi", "--env", "puzzle15",
+           "--states_per_update", "4000", "--batch_size", "1000", "--nnet_name", "p", "--max_itrs", "4", "--loss_thresh",
+           "1e9", "--back_max", "6", "--num_test", "60", "--save_dir", save, "--update_nnet_batch_size", "2000"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    cur = os.path.join(save, "p", "current")
+    assert pickle.load(open(os.path.join(cur, "train_itr.pkl"), "rb")) == 4  # 2000 states per rank / 500 per rank-batch
+    assert pickle.load(open(os.path.join(cur, "update_num.pkl"), "rb")) == 1
+    sd = torch.load(os.path.join(cur, "model_state_dict.pt"), map_location="cpu")
+    assert all(not k.startswith("module.") for k in sd) and all(torch.isfinite(v.float()).all() for v in sd.values())
+    log = open(os.path.join(save, "p", "output.txt")).read()
+    assert "Training model for update number 0 for 4 iterations" in log and "Updating target network" in log
