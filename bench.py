@@ -302,22 +302,25 @@ def cpu_baseline_astar(args, seconds_budget: float = 20.0):
 # workload: avi (configs[4]'s update step)
 # --------------------------------------------------------------------------------------------------
 def run_avi(args, world, rank):
-    """One step = the AVI update of `--n` cube3 training states on this GPU: random reverse walks from the goal
-    (0..30 moves), expansion, ResNet heuristic on all 12 children, Bellman backup (1 GBFS step, eps 0) — the
-    data-generation half of ctg_approx/avi.py:do_update.  value = training states produced per second."""
+    """One step = the AVI update of `--n` training states of `--env` on this GPU: random reverse walks from the goal,
+    expansion, ResNet heuristic on every child, Bellman backup (1 GBFS step, eps 0) — the data-generation half of
+    ctg_approx/avi.py:do_update.  value = training states produced per second."""
     from deepcubea_amd.updaters.updater import Updater
     from deepcubea_amd.utils import env_utils, nnet_utils
     from deepcubea_amd.utils.pytorch_models import FastResnet
     from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
-    env = env_utils.get_environment("cube3")
+    env = env_utils.get_environment(args.env)
     model = env.get_nnet_model()
     load_synthetic_weights(model, 2024)
+    macs = sum(m.in_features * m.out_features for m in model.modules() if isinstance(m, torch.nn.Linear))
+    A = env.get_num_moves()
+    back_max = {"cube3": 30, "puzzle15": 500, "puzzle24": 500}.get(args.env, 1000)  # the values of the reference's train.sh
     oh = torch.bfloat16 if args.nnet_dtype == "bf16" else torch.float32
     hfn = nnet_utils.get_heuristic_fn_dev(FastResnet(model, oh).cuda(), clip_zero=False, batch_size=args.nnet_batch_size)
     n = args.n if args.n != 1_000_000 else 200_000
 
     def step(i):
-        upd = Updater(env, n * world, 30, hfn, 1, update_batch_size=100_000, seed=1000 + i, onehot_dtype=oh)
+        upd = Updater(env, n * world, back_max, hfn, 1, update_batch_size=100_000, seed=1000 + i, onehot_dtype=oh)
         return upd.update_dev()
 
     for i in range(args.warmup):
@@ -331,16 +334,18 @@ def run_avi(args, world, rank):
     barrier(world)
     wall = reduce_ranks(time.perf_counter() - t0, world, "max")
     total = reduce_ranks(float(tot), world, "sum")
-    flops = 2.0 * 14_621_000 * 12 * (tot / args.steps)
+    flops = 2.0 * macs * A * (tot / args.steps)
+    published = {"cube3": "1.55e5 states/s on 3 GPUs + 30 CPU procs (saved_models/cube3/output.txt)",
+                 "puzzle48": "9.4e4 states/s on 4 GPUs + 30 CPU procs (50M states in 528-530 s, saved_models/puzzle48/output.txt)"}
     return {
         "value": total / wall, "ms_per_step": wall / args.steps * 1e3,
-        "config": {"workload": "cube3 AVI update step (BASELINE configs[4] / avi.py:do_update): generate %d states "
-                               "(back_max 30) -> expand -> ResNet heuristic on 12 children -> Bellman backup; %s "
-                               "heuristic, synthetic weights" % (n, args.nnet_dtype),
-                   "states_per_step_per_gpu": n, "back_max": 30, "gbfs_steps": 1, "nnet_dtype": args.nnet_dtype,
+        "config": {"workload": "%s AVI update step (BASELINE configs[4] / avi.py:do_update): generate %d states "
+                               "(back_max %d) -> expand -> ResNet heuristic on %d children -> Bellman backup; %s "
+                               "heuristic, synthetic weights" % (args.env, n, back_max, A, args.nnet_dtype),
+                   "states_per_step_per_gpu": n, "back_max": back_max, "gbfs_steps": 1, "nnet_dtype": args.nnet_dtype,
                    "parallelism": "state shards per GPU x%d" % world,
                    "heuristic_tflops_per_gpu": flops / (wall / args.steps) / 1e12,
-                   "reference_published": "1.55e5 states/s on 3 GPUs + 30 CPU procs (saved_models/cube3/output.txt)"},
+                   "reference_published": published.get(args.env)},
     }
 
 
@@ -488,7 +493,7 @@ def main():
     res = {"astar": run_astar, "expand": run_expand, "avi": run_avi, "train": run_train}[args.workload](args, world, rank)
     line = {
         "metric": {"astar": "A* nodes expanded/sec on %s, batch 20k" % args.env, "expand": "A* nodes expanded/sec on cube3",
-                   "avi": "AVI update-step training states generated/sec on cube3",
+                   "avi": "AVI update-step training states generated/sec on %s" % args.env,
                    "train": "cost-to-go network training samples/sec on cube3"}[args.workload],
         "value": res["value"],
         "unit": {"avi": "states/s", "train": "samples/s"}.get(args.workload, "nodes expanded/s"),
