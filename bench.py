@@ -230,26 +230,33 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
     from deepcubea_amd.utils import nnet_utils
     from deepcubea_amd.utils.pytorch_models import FastResnet, ResnetModel, fold_batchnorm
     from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
+    from deepcubea_amd.utils import env_utils
     B, w = args.batch_size, args.weight
     steps, warm = args.nnet_steps, 2
-    model = ResnetModel(54, 6, 5000, 1000, 4, 1, True)
+    env = env_utils.get_environment(args.env)
+    A = env.get_num_moves()
+    model = env.get_nnet_model()  # cube3: ResnetModel(54, 6, 5000, 1000, 4, 1, True)
     load_synthetic_weights(model, 2024)
+    macs = sum(m.in_features * m.out_features for m in model.modules() if isinstance(m, torch.nn.Linear))
     dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[dtype_name]
-    cap = max(1 << 20, (steps + warm + 12) * B * 12)
+    cap = max(1 << 20, (steps + warm + 12) * B * A + 64 * B * A // 2)
     if eval_all_children:
         model = fold_batchnorm(model).cuda().eval()
         hfn = nnet_utils.get_heuristic_fn_dev(model, clip_zero=False, batch_size=args.nnet_batch_size,
                                               autocast_dtype=None if dt == torch.float32 else dt)
-        eng = BwasEngine("cube3", w, B, max_nodes=cap, onehot_dtype=dt)
+        eng = BwasEngine(args.env, w, B, max_nodes=cap, onehot_dtype=dt)
     else:
         fast = FastResnet(model, dt).cuda()
         hfn = nnet_utils.get_heuristic_fn_dev(fast, clip_zero=False, batch_size=args.nnet_batch_size)
-        eng = BwasEngine("cube3", w, B, max_nodes=cap, onehot_dtype=dt, packed=True, onehot_stride=fast.in_pad)
-    root = test_root(rank)
+        eng = BwasEngine(args.env, w, B, max_nodes=cap, onehot_dtype=dt, packed=True, onehot_stride=fast.in_pad)
+    root = test_root(rank, args.env)
     eng.reset(root)
     eng.root_commit(hfn(eng.root_nnet_in()))
     # fill OPEN past one batch quickly with the cheap heuristic so every timed step is a full batch
-    eng.run_builtin(_lib.HEUR_HASHU01, 6)
+    for _ in range(64):
+        eng.run_builtin(_lib.HEUR_HASHU01, 1)
+        if eng.status()["open_size"] >= 3 * B:
+            break
     for _ in range(warm):
         eng.step(hfn)
     st0 = eng.status()
@@ -265,13 +272,13 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
     rows = (eng.rows_evaluated - rows0) / steps
     wall = reduce_ranks(wall, world, "max")
     total_exp = reduce_ranks(float(expanded), world, "sum")
-    flops = 2.0 * (324 * 5000 + 5000 * 1000 + 8 * 1000 * 1000 + 1000) * rows
+    flops = 2.0 * macs * rows
     eng.close()
     torch.cuda.empty_cache()
     return {"value": total_exp / wall, "unit": "nodes expanded/s", "ms_per_step": wall / steps * 1e3,
             "steps": steps, "heuristic_dtype": dtype_name, "weights": "synthetic (numpy PCG64 seed 2024, BN folded)",
             "order": "eval_all_children (reference order)" if eval_all_children else "dedup_first (CLI default)",
-            "network_rows_per_step": rows, "children_per_step": B * 12,
+            "network_rows_per_step": rows, "children_per_step": B * A,
             "heuristic_tflops_per_gpu": flops / (wall / steps) / 1e12,
             "mfma_peak_tflops": 157.3 if dtype_name == "fp32" else 2500.0}
 
@@ -512,7 +519,7 @@ def main():
         line["roofline"] = res["roofline"]
     if "concurrent_instances" in res:
         line["concurrent_instances"] = res["concurrent_instances"]
-    if args.workload == "astar" and args.nnet_steps > 0 and args.env == "cube3":
+    if args.workload == "astar" and args.nnet_steps > 0:
         line["end_to_end_nnet"] = {"fp32": run_astar_nnet(args, world, rank, "fp32"),
                                    "bf16": run_astar_nnet(args, world, rank, "bf16"),
                                    "fp16": run_astar_nnet(args, world, rank, "fp16"),
