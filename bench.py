@@ -248,7 +248,10 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
     else:
         fast = FastResnet(model, dt).cuda()
         hfn = nnet_utils.get_heuristic_fn_dev(fast, clip_zero=False, batch_size=args.nnet_batch_size)
-        eng = BwasEngine(args.env, w, B, max_nodes=cap, onehot_dtype=dt, packed=True, onehot_stride=fast.in_pad)
+        if fast.uses_l1_kernel:  # layer 1 = the library's one-hot MFMA kernel on the packed uint8 rows
+            eng = BwasEngine(args.env, w, B, max_nodes=cap, packed=True)
+        else:
+            eng = BwasEngine(args.env, w, B, max_nodes=cap, onehot_dtype=dt, packed=True, onehot_stride=fast.in_pad)
     root = test_root(rank, args.env)
     eng.reset(root)
     eng.root_commit(hfn(eng.root_nnet_in()))
@@ -278,6 +281,8 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
     return {"value": total_exp / wall, "unit": "nodes expanded/s", "ms_per_step": wall / steps * 1e3,
             "steps": steps, "heuristic_dtype": dtype_name, "weights": "synthetic (numpy PCG64 seed 2024, BN folded)",
             "order": "eval_all_children (reference order)" if eval_all_children else "dedup_first (CLI default)",
+            "layer1": "library GEMM on one-hot rows" if eval_all_children or not fast.uses_l1_kernel
+            else "dca_l1_onehot_gemm (hand-written MFMA, %d bf16 plane(s))" % fast.l1_planes,
             "network_rows_per_step": rows, "children_per_step": B * A,
             "heuristic_tflops_per_gpu": flops / (wall / steps) / 1e12,
             "mfma_peak_tflops": 157.3 if dtype_name == "fp32" else 2500.0}

@@ -36,6 +36,7 @@ ABI_SYMBOLS = [
     "dca_engine_enable_packed", "dca_engine_pop_expand_packed", "dca_engine_commit_packed",
     "dca_engine_profile_builtin", "dca_engine_set_tiers", "dca_engine_debug", "dca_engine_status", "dca_engine_last_children", "dca_engine_solution",
     "dca_bn_workspace_bytes", "dca_bn_train_forward", "dca_bn_train_backward",
+    "dca_l1_supported", "dca_l1_kpad", "dca_l1_onehot_gemm",
 ]
 
 
@@ -64,8 +65,10 @@ def lib() -> C.CDLL:
         _lib.dca_cube3_perm_table.restype = C.POINTER(C.c_uint8)
         for name in ABI_SYMBOLS:
             fn = getattr(_lib, name)  # AttributeError here = stale build of libdca_hip.so
-            if name not in ("dca_last_error", "dca_cube3_perm_table", "dca_engine_destroy", "dca_bn_workspace_bytes"):
+            if name not in ("dca_last_error", "dca_cube3_perm_table", "dca_engine_destroy", "dca_bn_workspace_bytes",
+                            "dca_l1_kpad"):
                 fn.restype = C.c_int
+        _lib.dca_l1_kpad.restype = C.c_int64
         _lib.dca_bn_workspace_bytes.restype = C.c_int64
         _lib.dca_bn_workspace_bytes.argtypes = [C.c_int64]
         _lib.dca_engine_destroy.restype = None
@@ -296,3 +299,24 @@ def bn_train(x: torch.Tensor, bn: "torch.nn.BatchNorm1d", relu: bool, skip: Opti
             bn.running_mean.mul_(1.0 - mom).add_(mean, alpha=mom)
             bn.running_var.mul_(1.0 - mom).add_(var_u, alpha=mom)
     return y
+
+
+# ------------------------------------------------------------------------------ heuristic network, layer 1
+def l1_supported(state_dim: int, depth: int) -> bool:
+    return bool(lib().dca_l1_supported(int(state_dim), int(depth)))
+
+
+def l1_kpad(state_dim: int, depth: int) -> int:
+    return int(lib().dca_l1_kpad(int(state_dim), int(depth)))
+
+
+def l1_onehot_gemm(states_nnet: torch.Tensor, depth: int, w_tiles: torch.Tensor, planes: int, bias: torch.Tensor,
+                   relu: bool, out_dtype: torch.dtype) -> torch.Tensor:
+    """relu?(onehot(states_nnet) @ W1^T + b1) from the uint8 rows, [m, n_pad] in out_dtype (dca_l1_onehot_gemm)."""
+    x = _u8(states_nnet)
+    m, d = x.shape
+    n_pad = bias.numel()
+    out = torch.empty((m, n_pad), dtype=out_dtype, device=x.device)
+    check(lib().dca_l1_onehot_gemm(ptr(x), C.c_int64(m), int(d), int(depth), ptr(w_tiles), int(planes), C.c_int64(n_pad),
+                                   ptr(bias), int(relu), ptr(out), _TORCH_DT[out_dtype], stream_ptr()), "dca_l1_onehot_gemm")
+    return out

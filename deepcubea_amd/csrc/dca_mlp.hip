@@ -1,0 +1,201 @@
+// dca_mlp.hip — first layer of the cost-to-go network as a hand-written MFMA kernel for gfx950.
+//
+// Reference arithmetic (utils/pytorch_models.py:49-60): x = one_hot(states_nnet, depth).float().view(-1, D*depth);
+// y = relu(bn1(fc1(x))).  With BatchNorm folded (eval statistics) this is  y = relu(onehot(s) . W1^T + b1),  a GEMM whose
+// A operand has exactly D ones per row.  What the kernel exploits, and a library GEMM cannot:
+//
+//   * the one-hot matrix is never materialised: a lane rebuilds its A fragments from the D colour / tile bytes of its
+//     row (a K-bit mask in registers, 8 bits -> 8 bf16 per MFMA operand);
+//   * A is exactly representable in bf16, so splitting the fp32 weights into P bf16 planes (W = hi + mid + lo, 8+8+8
+//     mantissa bits) makes every MFMA product exact and the fp32-accumulated result an fp32 GEMM — on the bf16 MFMA
+//     pipes, which are 16x faster than the f32-input MFMA the library's fp32 GEMM has to use.  P = 3 is the fp32
+//     parity mode, P = 2 serves fp16 weights, P = 1 bf16;
+//   * bias + ReLU + the output cast ride in the epilogue.
+//
+// Tiling: a workgroup (8 waves) owns 64 output columns.  Their weights — all P planes, all of K — are staged ONCE
+// into LDS (P*KPAD*128 bytes: 129 KB for cube3 with P = 3) in the exact order the B fragments are read
+// ([plane][k/8][column][8] => 512 contiguous bytes per half-wave, conflict-free), then the workgroup walks over row
+// chunks of 512 (64 rows per wave = 2x2 tiles of v_mfma_f32_32x32x16_bf16, 64 accumulator VGPRs).  Per K-step a wave
+// issues 4*P MFMAs for 2 A-fragment rebuilds and 2*P ds_read_b128: the MFMA pipe is the limiter.
+#include "dca_common.h"
+
+namespace dca {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int kL1Threads = 512;  // 8 waves = 2 per SIMD: one wave's mask build / epilogue hides under the other's MFMAs
+constexpr int kL1Rows = kL1Threads;  // rows per chunk (64 per wave)
+
+template <int D, int DEPTH>
+struct L1Geo {
+    static constexpr int K = D * DEPTH;
+    static constexpr int KSTEPS = (K + 15) / 16;  // MFMA K = 16
+    static constexpr int KPAD = KSTEPS * 16;
+    static constexpr int KC = KPAD / 8;           // 16-byte weight chunks along K
+    static constexpr int MW = (KPAD + 31) / 32;   // mask words per row
+};
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <int D, int DEPTH, int P, int OUT /*0 f32, 1 f16, 2 bf16*/>
+__global__ __launch_bounds__(kL1Threads) void k_l1_onehot_gemm(const uint8_t* __restrict__ nn, int64_t m,
+                                                        const uint8_t* __restrict__ wt /*[ntile][P][KC][64][8] bf16*/,
+                                                        const float* __restrict__ bias, int relu, void* __restrict__ out,
+                                                        int64_t ldo) {
+    using G = L1Geo<D, DEPTH>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lw[];
+    constexpr int TILE_BYTES = P * G::KC * 64 * 16;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(wt + (size_t)blockIdx.x * TILE_BYTES);
+        uint4* dst = reinterpret_cast<uint4*>(lw);
+        for (int q = threadIdx.x; q < TILE_BYTES / 16; q += kL1Threads) dst[q] = src[q];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int64_t n0 = (int64_t)blockIdx.x * 64;
+    float bv[2];
+    bv[0] = bias[n0 + l31];
+    bv[1] = bias[n0 + 32 + l31];
+    for (int64_t chunk = blockIdx.y; chunk * kL1Rows < m; chunk += gridDim.y) {
+        const int64_t rw = chunk * kL1Rows + wv * 64;  // first row of this wave
+        if (rw >= m) continue;
+        // K-bit one-hot mask of this lane's two rows
+        uint32_t mk[2][G::MW];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+#pragma unroll
+            for (int w = 0; w < G::MW; w++) mk[i][w] = 0;
+            const int64_t r = rw + 32 * i + l31;
+            if (r < m) {
+                const uint8_t* row = nn + r * D;
+#pragma unroll
+                for (int pos = 0; pos < D; pos++) {
+                    const uint32_t c = row[pos];
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int bit0 = pos * DEPTH, w0 = bit0 >> 5, sh = bit0 & 31;
+                    const uint64_t f = (uint64_t)1 << (c + (uint32_t)sh);
+                    mk[i][w0] |= (uint32_t)f;
+                    if (w0 + 1 < G::MW) mk[i][w0 + 1] |= (uint32_t)(f >> 32);
+                }
+            }
+        }
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int jn = 0; jn < 2; jn++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[i][jn][e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < G::KSTEPS; s++) {
+            bf16x8 a[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const uint32_t byte = (mk[i][s >> 1] >> ((s & 1) * 16 + 8 * h)) & 0xFFu;
+                uint32_t v[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++)  // bits (2j, 2j+1) -> two bf16 ones: spread to bits 0 and 16, scale by 0x3F80
+                    v[j] = ((((byte >> (2 * j)) & 3u) * 0x8001u) & 0x00010001u) * 0x3F80u;
+                __builtin_memcpy(&a[i], v, 16);
+            }
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+#pragma unroll
+                for (int jn = 0; jn < 2; jn++) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(
+                        lw + ((size_t)((p * G::KC + 2 * s + h) * 64 + jn * 32 + l31)) * 16);
+                    acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b, acc[0][jn], 0, 0, 0);
+                    acc[1][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b, acc[1][jn], 0, 0, 0);
+                }
+            }
+        }
+        // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int jn = 0; jn < 2; jn++) {
+                const int64_t col = n0 + jn * 32 + l31;
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++) {
+                    const int64_t r = rw + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    if (r < m) {
+                        float v = acc[i][jn][reg] + bv[jn];
+                        if (relu) v = fmaxf(v, 0.f);
+                        if constexpr (OUT == 0)
+                            reinterpret_cast<float*>(out)[r * ldo + col] = v;
+                        else if constexpr (OUT == 1)
+                            reinterpret_cast<_Float16*>(out)[r * ldo + col] = (_Float16)v;
+                        else
+                            reinterpret_cast<uint16_t*>(out)[r * ldo + col] = f32_to_bf16_rne(v);
+                    }
+                }
+            }
+    }
+}
+
+template <int D, int DEPTH, int P>
+int launch_l1_out(const uint8_t* nn, int64_t m, const uint8_t* wt, const float* bias, int relu, void* out, int out_dtype,
+                  int64_t n_pad, hipStream_t s) {
+    using G = L1Geo<D, DEPTH>;
+    constexpr int LDS = P * G::KC * 64 * 16;
+    static_assert(LDS <= 160 * 1024, "weight tile does not fit LDS");
+    const int64_t chunks = (m + kL1Rows - 1) / kL1Rows;
+    const dim3 grid((unsigned)(n_pad / 64), (unsigned)(chunks < 16 ? (chunks < 1 ? 1 : chunks) : 16)), block(kL1Threads);
+#define DCA_L1_LAUNCH(OUTV)                                                                                          \
+    do {                                                                                                             \
+        auto kern = k_l1_onehot_gemm<D, DEPTH, P, OUTV>;                                                             \
+        DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
+        hipLaunchKernelGGL(kern, grid, block, LDS, s, nn, m, wt, bias, relu, out, n_pad);                            \
+    } while (0)
+    if (out_dtype == DCA_DT_F32)
+        DCA_L1_LAUNCH(0);
+    else if (out_dtype == DCA_DT_F16)
+        DCA_L1_LAUNCH(1);
+    else
+        DCA_L1_LAUNCH(2);
+#undef DCA_L1_LAUNCH
+    return launch_check("k_l1_onehot_gemm");
+}
+
+template <int D, int DEPTH>
+int launch_l1(int planes, const uint8_t* nn, int64_t m, const uint8_t* wt, const float* bias, int relu, void* out,
+              int out_dtype, int64_t n_pad, hipStream_t s) {
+    switch (planes) {
+        case 1: return launch_l1_out<D, DEPTH, 1>(nn, m, wt, bias, relu, out, out_dtype, n_pad, s);
+        case 2: return launch_l1_out<D, DEPTH, 2>(nn, m, wt, bias, relu, out, out_dtype, n_pad, s);
+        default: return launch_l1_out<D, DEPTH, 3>(nn, m, wt, bias, relu, out, out_dtype, n_pad, s);
+    }
+}
+
+}  // namespace dca
+
+using namespace dca;
+
+extern "C" {
+
+int dca_l1_supported(int state_dim, int depth) { return (state_dim == 54 && depth == 6) || (state_dim == 16 && depth == 16); }
+
+int64_t dca_l1_kpad(int state_dim, int depth) { return (((int64_t)state_dim * depth + 15) / 16) * 16; }
+
+int dca_l1_onehot_gemm(const uint8_t* nnet_in, int64_t m, int state_dim, int depth, const void* w_tiles, int planes,
+                       int64_t n_pad, const float* bias, int relu, void* out, int out_dtype, void* stream) {
+    DCA_ARG(nnet_in && w_tiles && bias && out && m >= 0 && planes >= 1 && planes <= 3 && n_pad >= 64 && n_pad % 64 == 0);
+    DCA_ARG(out_dtype >= DCA_DT_F32 && out_dtype <= DCA_DT_BF16);
+    if (!dca_l1_supported(state_dim, depth)) {
+        set_error("dca_l1_onehot_gemm: geometry (%d, %d) not instantiated (weight tile must fit LDS)", state_dim, depth);
+        return DCA_E_BADARG;
+    }
+    if (m == 0) return 0;
+    const uint8_t* wt = reinterpret_cast<const uint8_t*>(w_tiles);
+    hipStream_t s = (hipStream_t)stream;
+    if (state_dim == 54) return launch_l1<54, 6>(planes, nnet_in, m, wt, bias, relu, out, out_dtype, n_pad, s);
+    return launch_l1<16, 16>(planes, nnet_in, m, wt, bias, relu, out, out_dtype, n_pad, s);
+}
+
+}  // extern "C"

@@ -54,7 +54,9 @@ def _load_heuristic(args, env):
         # default: padded / epilogue-fused inference layout of the same network, fed by the dedup-first engine
         from ..utils.pytorch_models import FastResnet
         fast = FastResnet(nnet, dt).to(device)
-        return nnet_utils.get_heuristic_fn_dev(fast, clip_zero=False, batch_size=args.nnet_batch_size), fast.in_pad
+        # layer 1 as the library's one-hot MFMA kernel: the engine then hands out uint8 rows only (stride 0 = no one-hot)
+        stride = 0 if fast.uses_l1_kernel else fast.in_pad
+        return nnet_utils.get_heuristic_fn_dev(fast, clip_zero=False, batch_size=args.nnet_batch_size), stride
     if getattr(args, "fold_bn", False):
         from ..utils.pytorch_models import fold_batchnorm
         nnet = fold_batchnorm(nnet).to(device)
@@ -70,8 +72,8 @@ def bwas_hip(args, env, states: List) -> Tuple[List[List[int]], List[List], List
     oh = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[getattr(args, "nnet_dtype", "fp32")]
     K = max(1, int(getattr(args, "instances_per_gpu", 1)))
     eng = BwasEngine(args.env, args.weight, args.batch_size, max_nodes=int(getattr(args, "max_nodes", 1 << 26)),
-                     semantics=sem, onehot_dtype=oh, num_instances=K, packed=onehot_stride is not None,
-                     onehot_stride=onehot_stride)
+                     semantics=sem, onehot_dtype=None if onehot_stride == 0 else oh, num_instances=K,
+                     packed=onehot_stride is not None, onehot_stride=onehot_stride or None)
     world, rank = sharding.world_info()
     local: Dict[int, Tuple[List[int], List, float, int]] = {}
     if getattr(args, "static_shards", False) or world == 1:

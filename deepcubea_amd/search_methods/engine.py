@@ -291,7 +291,8 @@ def smoke_check() -> None:
     torch.manual_seed(0)
     fast = FastResnet(ResnetModel(54, 6, 64, 32, 1, 1, True).eval()).cuda()
     hfn = nnet_utils.get_heuristic_fn_dev(fast, batch_size=1024)
-    eng = BwasEngine("cube3", 0.8, 50, max_nodes=1 << 18, onehot_dtype=torch.float32, packed=True, onehot_stride=fast.in_pad)
+    assert fast.uses_l1_kernel  # layer 1 = the one-hot MFMA kernel on the packed uint8 rows (no one-hot matrix)
+    eng = BwasEngine("cube3", 0.8, 50, max_nodes=1 << 18, packed=True)
     res = eng.solve(root[0], hfn)
 
     def heur(states):  # the oracle evaluates every child through the same closure (batches padded to 1024 rows)

@@ -125,6 +125,24 @@ def _pad_dim(n: int, spare: int) -> int:
     return ((n + spare + q - 1) // q) * q
 
 
+def l1_weight_tiles(w: torch.Tensor, planes: int, k_pad: int) -> torch.Tensor:
+    """fp32 weight matrix [n_pad, K] (out, in) -> the bf16 plane tiles `dca_l1_onehot_gemm` stages into LDS:
+    W = hi + mid + lo with every plane bf16 (8 + 8 + 8 mantissa bits: the sum is W to fp32 precision), zero padded along K
+    to k_pad, laid out [n_pad/64][planes][k_pad/8][64][8]."""
+    n_pad, k = w.shape
+    assert n_pad % 64 == 0 and k_pad % 8 == 0 and k_pad >= k
+    r = torch.zeros((n_pad, k_pad), dtype=torch.float32)
+    r[:, :k] = w.detach().float().cpu()
+    ps = []
+    for _ in range(planes):
+        p = r.to(torch.bfloat16)
+        ps.append(p)
+        r = r - p.float()
+    t = torch.stack(ps)  # [P, n_pad, k_pad]
+    t = t.view(planes, n_pad // 64, 64, k_pad // 8, 8).permute(1, 0, 3, 2, 4).contiguous()
+    return t
+
+
 class FastResnet(nn.Module):
     """Inference-only re-layout of a `ResnetModel` (pytorch_models.py:5-86 of the reference), same function:
 
@@ -136,8 +154,12 @@ class FastResnet(nn.Module):
         its weight matrix through a constant-one hidden unit (the first padded unit of the block's hidden layer has
         zero weights and bias 1), leaving one in-place ReLU pass per block as the only elementwise kernel.
 
-    Input: one-hot rows `[M, in_pad]` in `dtype` (row stride `in_pad` >= state_dim*depth, tail zero) as written by the
-    engine's kept-children pack kernel, or uint8 network inputs through `forward`.  fp32 is the 1e-5 parity mode."""
+      * layer 1 runs as the library's hand-written one-hot MFMA kernel (`csrc/dca_mlp.hip`, `forward` on uint8 rows) where
+        its geometry is instantiated: no one-hot matrix, fp32-exact through three bf16 weight planes.
+
+    Input: uint8 network inputs `[M, state_dim]` through `forward` (`uses_l1_kernel`: feed the engine's packed
+    network-input rows), or one-hot rows `[M, in_pad]` in `dtype` (row stride `in_pad` >= state_dim*depth, tail zero) as
+    written by the engine's pack kernel through `forward_onehot`.  fp32 is the 1e-5 parity mode."""
 
     def __init__(self, model: ResnetModel, dtype: torch.dtype = torch.float32):
         super().__init__()
@@ -175,12 +197,37 @@ class FastResnet(nn.Module):
         self.biases = nn.ParameterList([nn.Parameter(b.to(dtype), requires_grad=False) for b in bs])
         self.w_out = nn.Parameter(wo.to(dtype), requires_grad=False)
         self.b_out = nn.Parameter(bo.float(), requires_grad=False)
+        # layer 1 straight from the uint8 rows (csrc/dca_mlp.hip) where the geometry is instantiated: fp32 weights as
+        # three bf16 planes (exact), fp16 as two, bf16 as one
+        self.l1_planes = {torch.float32: 3, torch.float16: 2, torch.bfloat16: 1}[dtype]
+        self.l1_tiles = None
+        self.l1_bias = None
+        # measured at 204 800 rows x 5120 units: fp32 2.30 ms vs 5.89 ms for the library's fp32 GEMM; bf16 on par with the
+        # library (and no one-hot rows to write/read); two-plane fp16 is slower than the library's f16 GEMM -> not used
+        if self.one_hot_depth > 0 and dtype != torch.float16:
+            try:
+                from .. import _lib
+                ok = _lib.l1_supported(self.state_dim, self.one_hot_depth)
+                kpad = _lib.l1_kpad(self.state_dim, self.one_hot_depth) if ok else 0
+            except Exception:  # library not built (host-only use of the module)
+                ok = False
+            if ok:
+                w1 = ws[0][:, :in_dim] if dtype == torch.float32 else ws[0][:, :in_dim].to(dtype).float()
+                self.l1_tiles = nn.Parameter(l1_weight_tiles(w1, self.l1_planes, kpad), requires_grad=False)
+                self.l1_bias = nn.Parameter(bs[0].to(dtype).float(), requires_grad=False)
+
+    @property
+    def uses_l1_kernel(self) -> bool:
+        return self.l1_tiles is not None
 
     @torch.no_grad()
     def forward_onehot(self, x: torch.Tensor) -> torch.Tensor:
         """[M, in_pad] one-hot rows (dtype = self.dtype) -> [M, out_dim] float32."""
         W, B = self.weights, self.biases
-        x = torch._addmm_activation(B[0], x, W[0].t())
+        return self._after_l1(torch._addmm_activation(B[0], x, W[0].t()))
+
+    def _after_l1(self, x: torch.Tensor) -> torch.Tensor:
+        W, B = self.weights, self.biases
         x = torch._addmm_activation(B[1], x, W[1].t())
         for k in range(2, len(W), 2):
             h = torch._addmm_activation(B[k], x, W[k].t())
@@ -193,5 +240,12 @@ class FastResnet(nn.Module):
         oh = _lib.onehot(states_nnet, self.one_hot_depth, self.dtype) if self.one_hot_depth > 0 else states_nnet.to(self.dtype)
         return torch.nn.functional.pad(oh, (0, self.in_pad - oh.shape[1]))
 
+    @torch.no_grad()
     def forward(self, states_nnet: torch.Tensor) -> torch.Tensor:
-        return self.forward_onehot(self.encode(states_nnet))
+        """uint8 network inputs [M, state_dim] -> [M, out_dim] float32."""
+        if self.l1_tiles is None or not states_nnet.is_cuda:
+            return self.forward_onehot(self.encode(states_nnet))
+        from .. import _lib
+        x = _lib.l1_onehot_gemm(states_nnet, self.one_hot_depth, self.l1_tiles, self.l1_planes, self.l1_bias, True,
+                                self.dtype)
+        return self._after_l1(x)

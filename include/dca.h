@@ -249,6 +249,21 @@ int dca_bn_train_backward(const float* dy, const float* x, const float* y /*need
                           float* dskip /*or NULL*/, float* dgamma /*[c]*/, float* dbeta /*[c]*/, void* workspace,
                           int64_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Heuristic network, first layer: y = relu?( onehot(states_nnet, depth) . W1^T + b1 ) straight from the
+ * uint8 network-input rows — utils/pytorch_models.py:49-60 with BatchNorm folded — as one MFMA kernel that never
+ * materialises the one-hot matrix.  Weights arrive as `planes` bf16 planes whose sum is the fp32 weight matrix
+ * (planes = 3: exact fp32 products => an fp32 GEMM on the bf16 MFMA pipes; 2 for fp16 weights; 1 for bf16), tiled as
+ * [n_pad/64][planes][k_pad/8][64][8] (k_pad = dca_l1_kpad(state_dim, depth), zero padded; deepcubea_amd/utils/
+ * pytorch_models.py:l1_weight_tiles builds it).  out: [m, n_pad] in out_dtype (DCA_DT_*), row stride n_pad.
+ * Instantiated for the geometries whose weight tile fits LDS: dca_l1_supported(state_dim, depth) != 0.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int dca_l1_supported(int state_dim, int depth);
+int64_t dca_l1_kpad(int state_dim, int depth);
+int dca_l1_onehot_gemm(const uint8_t* nnet_in /*[m, state_dim]*/, int64_t m, int state_dim, int depth, const void* w_tiles,
+                       int planes, int64_t n_pad, const float* bias /*[n_pad]*/, int relu, void* out, int out_dtype,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,3 +38,17 @@ with torch.no_grad():
         ohb = ohp.to(dt)
         ms, yfb = t(lambda: fb.forward_onehot(ohb)[:, 0])
         print("fast   %s      %.3f ms %.1f TF  maxdiff_vs_fp32 %.3g" % (str(dt)[6:], ms, FL / ms / 1e9, (yfb - y32).abs().max().item()))
+
+# layer 1 alone: hand-written one-hot MFMA kernel (csrc/dca_mlp.hip) vs the library GEMM on materialised one-hot rows
+from deepcubea_amd import _lib
+with torch.no_grad():
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        f = FastResnet(model, dt).cuda()
+        ohd = torch.nn.functional.pad(oh, (0, f.in_pad - 324)).to(dt).contiguous()
+        ms_lib, _ = t(lambda: torch._addmm_activation(f.biases[0], ohd, f.weights[0].t()))
+        ms_k, _ = t(lambda: _lib.l1_onehot_gemm(x, 6, f.l1_tiles, f.l1_planes, f.l1_bias, True, dt))
+        ms_all, yk = t(lambda: f(x)[:, 0])
+        fl = 2 * 324 * 5000 * M
+        print("layer1 %s: library %.3f ms (%.0f TF)  kernel(P=%d) %.3f ms (%.0f TF useful, %.0f TF on the MFMA pipe) | whole net via kernel %.3f ms"
+              % (str(dt)[6:], ms_lib, fl / ms_lib / 1e9, f.l1_planes, ms_k, fl / ms_k / 1e9,
+                 2 * 336 * 5120 * M * f.l1_planes / ms_k / 1e9, ms_all))
