@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdca_hip.so")
 
 ENV_CUBE3, ENV_NPUZZLE = 0, 1
-DT_F32, DT_F16, DT_BF16 = 0, 1, 2
+DT_F32, DT_F16, DT_BF16, DT_F16X3 = 0, 1, 2, 3
 SEM_PY, SEM_CPP = 0, 1
 HEUR_MOD97, HEUR_KNUTH3, HEUR_HASHU01, HEUR_ZERO, HEUR_MANHATTAN = 0, 1, 2, 3, 4
 
@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "dca_engine_enable_packed", "dca_engine_pop_expand_packed", "dca_engine_commit_packed",
     "dca_engine_profile_builtin", "dca_engine_set_tiers", "dca_engine_debug", "dca_engine_status", "dca_engine_last_children", "dca_engine_solution",
     "dca_bn_workspace_bytes", "dca_bn_train_forward", "dca_bn_train_backward",
-    "dca_l1_supported", "dca_l1_kpad", "dca_l1_onehot_gemm",
+    "dca_l1_supported", "dca_l1_kpad", "dca_l1_onehot_gemm", "dca_act_split",
 ]
 
 
@@ -311,12 +311,30 @@ def l1_kpad(state_dim: int, depth: int) -> int:
 
 
 def l1_onehot_gemm(states_nnet: torch.Tensor, depth: int, w_tiles: torch.Tensor, planes: int, bias: torch.Tensor,
-                   relu: bool, out_dtype: torch.dtype) -> torch.Tensor:
-    """relu?(onehot(states_nnet) @ W1^T + b1) from the uint8 rows, [m, n_pad] in out_dtype (dca_l1_onehot_gemm)."""
+                   relu: bool, out_dtype, split: bool = False) -> torch.Tensor:
+    """relu?(onehot(states_nnet) @ W1^T + b1) from the uint8 rows, [m, n_pad] in out_dtype (dca_l1_onehot_gemm);
+    split=True: the f16x3 operand [m, 3*n_pad] fp16 of the next layer instead (DCA_DT_F16X3)."""
     x = _u8(states_nnet)
     m, d = x.shape
     n_pad = bias.numel()
-    out = torch.empty((m, n_pad), dtype=out_dtype, device=x.device)
+    if split:
+        out = torch.empty((m, 3 * n_pad), dtype=torch.float16, device=x.device)
+        code = DT_F16X3
+    else:
+        out = torch.empty((m, n_pad), dtype=out_dtype, device=x.device)
+        code = _TORCH_DT[out_dtype]
     check(lib().dca_l1_onehot_gemm(ptr(x), C.c_int64(m), int(d), int(depth), ptr(w_tiles), int(planes), C.c_int64(n_pad),
-                                   ptr(bias), int(relu), ptr(out), _TORCH_DT[out_dtype], stream_ptr()), "dca_l1_onehot_gemm")
+                                   ptr(bias), int(relu), ptr(out), code, stream_ptr()), "dca_l1_onehot_gemm")
     return out
+
+
+def act_split(y: torch.Tensor, bias: Optional[torch.Tensor], skip: Optional[torch.Tensor], alpha: float, relu: bool,
+              want_x: bool, want_a3: bool = True):
+    """v = relu?(y*alpha + bias (+ skip)) -> (a3 [m,3n] fp16, a3[3k..3k+2] = (vh, vl, vh), or None; v fp32 or None)."""
+    assert y.dtype == torch.float32 and y.is_contiguous() and (want_x or want_a3)
+    m, n = y.shape
+    a3 = torch.empty((m, 3 * n), dtype=torch.float16, device=y.device) if want_a3 else None
+    x_out = torch.empty_like(y) if want_x else None
+    check(lib().dca_act_split(ptr(y), ptr(bias), ptr(skip), C.c_double(alpha), int(relu), C.c_int64(m), C.c_int64(n),
+                              ptr(x_out), ptr(a3), stream_ptr()), "dca_act_split")
+    return a3, x_out

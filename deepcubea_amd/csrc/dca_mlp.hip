@@ -41,7 +41,7 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
     return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 
-template <int D, int DEPTH, int P, int OUT /*0 f32, 1 f16, 2 bf16*/>
+template <int D, int DEPTH, int P, int OUT /*0 f32, 1 f16, 2 bf16, 3 f16x3 split (vh, vl, vh) interleaved*/>
 __global__ __launch_bounds__(kL1Threads) void k_l1_onehot_gemm(const uint8_t* __restrict__ nn, int64_t m,
                                                         const uint8_t* __restrict__ wt /*[ntile][P][KC][64][8] bf16*/,
                                                         const float* __restrict__ bias, int relu, void* __restrict__ out,
@@ -131,8 +131,15 @@ __global__ __launch_bounds__(kL1Threads) void k_l1_onehot_gemm(const uint8_t* __
                             reinterpret_cast<float*>(out)[r * ldo + col] = v;
                         else if constexpr (OUT == 1)
                             reinterpret_cast<_Float16*>(out)[r * ldo + col] = (_Float16)v;
-                        else
+                        else if constexpr (OUT == 2)
                             reinterpret_cast<uint16_t*>(out)[r * ldo + col] = f32_to_bf16_rne(v);
+                        else {  // the next layer's f16x3 A operand directly: 192 contiguous bytes per 32 lanes
+                            _Float16* q = reinterpret_cast<_Float16*>(out) + (r * ldo + col) * 3;
+                            const _Float16 hh = (_Float16)v;
+                            q[0] = hh;
+                            q[1] = (_Float16)(v - (float)hh);
+                            q[2] = hh;
+                        }
                     }
                 }
             }
@@ -157,8 +164,10 @@ int launch_l1_out(const uint8_t* nn, int64_t m, const uint8_t* wt, const float* 
         DCA_L1_LAUNCH(0);
     else if (out_dtype == DCA_DT_F16)
         DCA_L1_LAUNCH(1);
-    else
+    else if (out_dtype == DCA_DT_BF16)
         DCA_L1_LAUNCH(2);
+    else
+        DCA_L1_LAUNCH(3);
 #undef DCA_L1_LAUNCH
     return launch_check("k_l1_onehot_gemm");
 }
@@ -170,6 +179,64 @@ int launch_l1(int planes, const uint8_t* nn, int64_t m, const uint8_t* wt, const
         case 1: return launch_l1_out<D, DEPTH, 1>(nn, m, wt, bias, relu, out, out_dtype, n_pad, s);
         case 2: return launch_l1_out<D, DEPTH, 2>(nn, m, wt, bias, relu, out, out_dtype, n_pad, s);
         default: return launch_l1_out<D, DEPTH, 3>(nn, m, wt, bias, relu, out, out_dtype, n_pad, s);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32-accurate dense layers on the f16 MFMA pipes ("f16x3").  An fp32 value splits exactly into two fp16 numbers to
+// 22 bits (x = xh + xl, xh = f16(x), xl = f16(x - xh)); with the weights split the same way (pre-scaled by a power of two
+// so their low parts stay normal)  x.w = xh.wh + xl.wh + xh.wl + O(2^-22 |x.w|).  Laid out along K as A3[3k..3k+2] =
+// (xh, xl, xh) and W3[3k..3k+2] = (wh, wh, wl), ONE library f16 GEMM with fp32 output is an fp32-accurate GEMM at 3x the f16 cost — 2.4-2.9x
+// faster than the library's fp32 GEMM (f32-input MFMA runs at 1/16 of the f16 rate), same error class (measured
+// 1.7e-6 vs 1.2e-6 max-relative at K = 1024).  This kernel is the glue between two such GEMMs: it applies what follows
+// the Linear in the network (scale back, bias, residual add, ReLU — utils/pytorch_models.py:57-86 with BatchNorm folded)
+// and emits the next layer's A3 in one pass (read 4-8 B, write 6-10 B per element).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_act_split(const float* __restrict__ y, const float* __restrict__ bias,
+                                                   const float* __restrict__ skip, float alpha, int relu, int64_t m, int64_t n,
+                                                   float* __restrict__ x_out /*[m,n] or null*/,
+                                                   _Float16* __restrict__ a3 /*[m,3n]*/) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t col = ((int64_t)blockIdx.x * 64 + lane) * 4;
+    if (col >= n) return;
+    const int64_t rows_per = (m + gridDim.y - 1) / gridDim.y;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per, r1 = r0 + rows_per < m ? r0 + rows_per : m;
+    float b[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+        const float4 t = *reinterpret_cast<const float4*>(bias + col);
+        b[0] = t.x, b[1] = t.y, b[2] = t.z, b[3] = t.w;
+    }
+    typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+    for (int64_t r = r0 + wv; r < r1; r += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(y + r * n + col);
+        float v[4] = {t.x, t.y, t.z, t.w};
+        float sk[4] = {0.f, 0.f, 0.f, 0.f};
+        if (skip) {
+            const float4 q = *reinterpret_cast<const float4*>(skip + r * n + col);
+            sk[0] = q.x, sk[1] = q.y, sk[2] = q.z, sk[3] = q.w;
+        }
+        h4 hi, lo;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float u = v[k] * alpha + b[k] + sk[k];
+            if (relu) u = fmaxf(u, 0.f);
+            v[k] = u;
+            const _Float16 hh = (_Float16)u;
+            hi[k] = hh;
+            lo[k] = (_Float16)(u - (float)hh);
+        }
+        if (x_out) *reinterpret_cast<float4*>(x_out + r * n + col) = make_float4(v[0], v[1], v[2], v[3]);
+        if (a3) {  // element k of the row -> halves 3k..3k+2 = (vh, vl, vh): 24 contiguous bytes per lane
+            h4* row = reinterpret_cast<h4*>(a3 + (r * n + col) * 3);
+            h4 q0, q1, q2;
+            q0[0] = hi[0], q0[1] = lo[0], q0[2] = hi[0], q0[3] = hi[1];
+            q1[0] = lo[1], q1[1] = hi[1], q1[2] = hi[2], q1[3] = lo[2];
+            q2[0] = hi[2], q2[1] = hi[3], q2[2] = lo[3], q2[3] = hi[3];
+            row[0] = q0;
+            row[1] = q1;
+            row[2] = q2;
+        }
     }
 }
 
@@ -186,7 +253,7 @@ int64_t dca_l1_kpad(int state_dim, int depth) { return (((int64_t)state_dim * de
 int dca_l1_onehot_gemm(const uint8_t* nnet_in, int64_t m, int state_dim, int depth, const void* w_tiles, int planes,
                        int64_t n_pad, const float* bias, int relu, void* out, int out_dtype, void* stream) {
     DCA_ARG(nnet_in && w_tiles && bias && out && m >= 0 && planes >= 1 && planes <= 3 && n_pad >= 64 && n_pad % 64 == 0);
-    DCA_ARG(out_dtype >= DCA_DT_F32 && out_dtype <= DCA_DT_BF16);
+    DCA_ARG(out_dtype >= DCA_DT_F32 && out_dtype <= DCA_DT_F16X3);
     if (!dca_l1_supported(state_dim, depth)) {
         set_error("dca_l1_onehot_gemm: geometry (%d, %d) not instantiated (weight tile must fit LDS)", state_dim, depth);
         return DCA_E_BADARG;
@@ -196,6 +263,19 @@ int dca_l1_onehot_gemm(const uint8_t* nnet_in, int64_t m, int state_dim, int dep
     hipStream_t s = (hipStream_t)stream;
     if (state_dim == 54) return launch_l1<54, 6>(planes, nnet_in, m, wt, bias, relu, out, out_dtype, n_pad, s);
     return launch_l1<16, 16>(planes, nnet_in, m, wt, bias, relu, out, out_dtype, n_pad, s);
+}
+
+int dca_act_split(const float* y, const float* bias, const float* skip, double alpha, int relu, int64_t m, int64_t n,
+                  float* x_out, void* a3, void* stream) {
+    DCA_ARG(y && (a3 || x_out) && m >= 0 && n >= 4 && n % 4 == 0 && m * n < (1ll << 40));
+    if (m == 0) return 0;
+    const unsigned gx = (unsigned)((n + 255) / 256);
+    int64_t gy = 4096 / gx;
+    if (gy > (m + 15) / 16) gy = (m + 15) / 16;
+    if (gy < 1) gy = 1;
+    hipLaunchKernelGGL(k_act_split, dim3(gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, y, bias, skip, (float)alpha, relu,
+                       m, n, x_out, reinterpret_cast<_Float16*>(a3));
+    return launch_check("k_act_split");
 }
 
 }  // extern "C"

@@ -51,6 +51,7 @@ extern "C" {
 #define DCA_DT_F32 0
 #define DCA_DT_F16 1
 #define DCA_DT_BF16 2
+#define DCA_DT_F16X3 3 /* dca_l1_onehot_gemm only: the f16x3 split operand (vh, vl, vh) per element, [m, 3*n_pad] fp16 */
 
 /* BWAS semantics: which reference implementation is reproduced */
 #define DCA_SEM_PY 0  /* search_methods/astar.py: f64 cost, FIFO ties, CLOSED starts empty */
@@ -255,7 +256,8 @@ int dca_bn_train_backward(const float* dy, const float* x, const float* y /*need
  * materialises the one-hot matrix.  Weights arrive as `planes` bf16 planes whose sum is the fp32 weight matrix
  * (planes = 3: exact fp32 products => an fp32 GEMM on the bf16 MFMA pipes; 2 for fp16 weights; 1 for bf16), tiled as
  * [n_pad/64][planes][k_pad/8][64][8] (k_pad = dca_l1_kpad(state_dim, depth), zero padded; deepcubea_amd/utils/
- * pytorch_models.py:l1_weight_tiles builds it).  out: [m, n_pad] in out_dtype (DCA_DT_*), row stride n_pad.
+ * pytorch_models.py:l1_weight_tiles builds it).  out: [m, n_pad] in out_dtype (DCA_DT_*), row stride n_pad; DCA_DT_F16X3
+ * writes the next f16x3 layer's A operand [m, 3*n_pad] directly (see dca_act_split).
  * Instantiated for the geometries whose weight tile fits LDS: dca_l1_supported(state_dim, depth) != 0.
  * ------------------------------------------------------------------------------------------------------------------ */
 int dca_l1_supported(int state_dim, int depth);
@@ -263,6 +265,14 @@ int64_t dca_l1_kpad(int state_dim, int depth);
 int dca_l1_onehot_gemm(const uint8_t* nnet_in /*[m, state_dim]*/, int64_t m, int state_dim, int depth, const void* w_tiles,
                        int planes, int64_t n_pad, const float* bias /*[n_pad]*/, int relu, void* out, int out_dtype,
                        void* stream);
+
+/* Glue of the fp32-accurate "f16x3" dense layers (csrc/dca_mlp.hip): v = relu?(y*alpha + bias (+ skip)) over the row-major
+ * fp32 GEMM output y [m, n]; writes the next layer's A operand a3 [m, 3n] fp16, a3[3k..3k+2] = (vh, vl, vh) with
+ * vh = f16(v), vl = f16(v - vh), and, if x_out != NULL, v itself (the next residual block's skip).  With the weights as
+ * W3[3k..3k+2] = (wh, wh, wl) (pre-scaled by 1/alpha, a power of two) one f16 GEMM with fp32 output reproduces the fp32 layer
+ * utils/pytorch_models.py:57-86 computes (BatchNorm folded) to fp32 accuracy.  n % 4 == 0.                            */
+int dca_act_split(const float* y, const float* bias /*[n] or NULL*/, const float* skip /*[m,n] or NULL*/, double alpha,
+                  int relu, int64_t m, int64_t n, float* x_out /*[m,n] or NULL*/, void* a3 /*[m,3n] fp16*/, void* stream);
 
 #ifdef __cplusplus
 }

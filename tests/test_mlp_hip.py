@@ -52,3 +52,68 @@ def test_fastresnet_uint8_path_uses_the_kernel_and_matches(golden, tiny_resnet):
     for dt, lim in ((torch.bfloat16, 5e-2), (torch.float16, 1e-2)):
         yl = FastResnet(full, dt).cuda()(x)[:, 0].float().cpu().numpy()
         assert np.max(np.abs(yl - ref)) < lim
+
+
+def test_act_split_kernel_matches_torch():
+    from deepcubea_amd import _lib
+    torch.manual_seed(3)
+    m, n = 777, 1024
+    y = torch.randn(m, n, device="cuda") * 3000.0
+    b = torch.randn(n, device="cuda")
+    sk = torch.randn(m, n, device="cuda")
+    for bias, skip, relu in ((b, sk, True), (None, None, False), (b, None, True)):
+        a3, x = _lib.act_split(y, bias, skip, 2.0 ** -10, relu, True)
+        v = y * 2.0 ** -10 + (bias if bias is not None else 0) + (skip if skip is not None else 0)
+        if relu:
+            v = torch.relu(v)
+        assert torch.equal(x, v)  # same fp32 operations in the same order
+        hi = v.to(torch.float16)
+        lo = (v - hi.float()).to(torch.float16)
+        a3v = a3.view(m, n, 3)  # a3[3k..3k+2] = (vh, vl, vh)
+        assert torch.equal(a3v[:, :, 0], hi) and torch.equal(a3v[:, :, 1], lo) and torch.equal(a3v[:, :, 2], hi)
+        # the split reproduces v to 2^-21
+        assert float((hi.float() + lo.float() - v).abs().max()) <= float(v.abs().max()) * 2.0 ** -21
+    a3, x = _lib.act_split(y, b, None, 1.0, True, True, want_a3=False)
+    assert a3 is None and torch.equal(x, torch.relu(y + b))
+
+
+def test_f16x3_split_network_is_fp32_accurate(golden, tiny_resnet):
+    """fp32 parity mode = every dense layer after the first as one f16 GEMM over split operands (FastResnet.split): must stay
+    within the north star's 1e-5 of the reference's own fp32 forward, like the native fp32 GEMM path."""
+    from deepcubea_amd.utils.pytorch_models import FastResnet, ResnetModel
+    from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
+    full = ResnetModel(54, 6, 5000, 1000, 4, 1, True)
+    load_synthetic_weights(full, 2024)
+    x = torch.tensor(golden["cube3_resnet_seed2024_x"]).cuda()
+    ref = golden["cube3_resnet_seed2024_y"]
+    tol = 1e-5 * max(1.0, float(np.abs(ref).max()))
+    split, native = FastResnet(full).cuda(), FastResnet(full, split=False).cuda()
+    assert split.split and not native.split
+    ys, yn = split(x)[:, 0].cpu().numpy(), native(x)[:, 0].cpu().numpy()
+    assert np.max(np.abs(ys - ref)) < tol and np.max(np.abs(yn - ref)) < tol
+    # a larger batch of random states: split vs native fp32 GEMMs
+    xb = torch.randint(0, 6, (20000, 54), dtype=torch.uint8, device="cuda")
+    d = (split(xb) - native(xb)).abs().max().item()
+    assert d < tol, d
+    # the one-hot input path (geometries without the layer-1 kernel) takes the same split layers
+    oh = split.encode(xb[:512])
+    assert float((split.forward_onehot(oh) - native.forward_onehot(oh)).abs().max()) < tol
+    m = ResnetModel(54, 6, 64, 32, 2, 1, True)
+    m.load_state_dict({k[2:]: torch.tensor(tiny_resnet[k]) for k in tiny_resnet.files if k.startswith("w:")})
+    yt = FastResnet(m).cuda()(torch.tensor(tiny_resnet["x"]).cuda())[:, 0].cpu().numpy()
+    assert np.max(np.abs(yt - tiny_resnet["y"])) < 1e-5
+
+
+def test_l1_kernel_split_epilogue_equals_act_split_of_its_fp32_output():
+    from deepcubea_amd import _lib
+    from deepcubea_amd.utils.pytorch_models import l1_weight_tiles
+    torch.manual_seed(9)
+    m, n_pad = 1111, 128
+    w = torch.randn(n_pad, 324) * 0.3
+    b = torch.randn(n_pad).cuda()
+    x = torch.randint(0, 6, (m, 54), dtype=torch.uint8).cuda()
+    tiles = l1_weight_tiles(w, 3, _lib.l1_kpad(54, 6)).cuda()
+    y = _lib.l1_onehot_gemm(x, 6, tiles, 3, b, True, torch.float32)
+    a3 = _lib.l1_onehot_gemm(x, 6, tiles, 3, b, True, torch.float32, split=True)
+    want, _ = _lib.act_split(y, None, None, 1.0, False, False)
+    assert a3.shape == (m, 3 * n_pad) and torch.equal(a3, want)

@@ -24,10 +24,16 @@ FL = 2 * 14621000 * M
 with torch.no_grad():
     ms, y32 = t(lambda: folded.forward_onehot(oh)[:, 0])
     print("folded fp32        %.3f ms %.1f TF" % (ms, FL / ms / 1e9))
+    f32n = FastResnet(model, torch.float32, split=False).cuda()
+    ohp = torch.nn.functional.pad(oh, (0, f32n.in_pad - 324)).contiguous()
+    ms, yf = t(lambda: f32n.forward_onehot(ohp)[:, 0])
+    print("fast   fp32 native %.3f ms %.1f TF  maxdiff %.3g (|y|max %.3g)" % (ms, FL / ms / 1e9, (yf - y32).abs().max().item(), y32.abs().max().item()))
     f32 = FastResnet(model, torch.float32).cuda()
-    ohp = torch.nn.functional.pad(oh, (0, f32.in_pad - 324)).contiguous()
-    ms, yf = t(lambda: f32.forward_onehot(ohp)[:, 0])
-    print("fast   fp32        %.3f ms %.1f TF  maxdiff %.3g (|y|max %.3g)" % (ms, FL / ms / 1e9, (yf - y32).abs().max().item(), y32.abs().max().item()))
+    ms, yf = t(lambda: f32(x)[:, 0])
+    print("fast   fp32 f16x3 + layer-1 kernel %.3f ms %.1f TF  maxdiff %.3g" % (ms, FL / ms / 1e9, (yf - y32).abs().max().item()))
+    y64 = fold_batchnorm(model).double().cuda().forward_onehot(oh[:4096].double())[:, 0]
+    print("   vs float64: folded fp32 %.3g | native %.3g | f16x3 %.3g" % ((y32[:4096].double() - y64).abs().max().item(),
+          (f32n.forward_onehot(ohp[:4096])[:, 0].double() - y64).abs().max().item(), (f32(x[:4096])[:, 0].double() - y64).abs().max().item()))
     def ac():
         with torch.autocast("cuda", dtype=torch.bfloat16):
             return folded.forward_onehot(oh)[:, 0].float()
