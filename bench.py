@@ -285,7 +285,10 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
             else "dca_l1_onehot_gemm (hand-written MFMA, %d bf16 plane(s))" % fast.l1_planes,
             "network_rows_per_step": rows, "children_per_step": B * A,
             "heuristic_tflops_per_gpu": flops / (wall / steps) / 1e12,
-            "mfma_peak_tflops": 157.3 if dtype_name == "fp32" else 2500.0}
+            # fp32 default path = f16x3 split layers: 3 f16 MFMA flops per useful flop -> ceiling 2500/3 "fp32-equivalent"
+            "mfma_peak_tflops": (157.3 if eval_all_children else 2500.0 / 3) if dtype_name == "fp32" else 2500.0,
+            "mfma_pipe": ("f32-input MFMA" if eval_all_children else "f16/bf16 MFMA, fp32-accurate via operand splitting "
+                          "(useful flops = 1/3 of the issued ones)") if dtype_name == "fp32" else "f16/bf16 MFMA"}
 
 
 def cpu_baseline_astar(args, seconds_budget: float = 20.0):
