@@ -251,7 +251,8 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
         if fast.uses_l1_kernel:  # layer 1 = the library's one-hot MFMA kernel on the packed uint8 rows
             eng = BwasEngine(args.env, w, B, max_nodes=cap, packed=True)
         else:
-            eng = BwasEngine(args.env, w, B, max_nodes=cap, onehot_dtype=dt, packed=True, onehot_stride=fast.in_pad)
+            eng = BwasEngine(args.env, w, B, max_nodes=cap, onehot_dtype=fast.onehot_dtype, packed=True,
+                             onehot_stride=fast.in_pad)
     root = test_root(rank, args.env)
     eng.reset(root)
     eng.root_commit(hfn(eng.root_nnet_in()))
@@ -330,8 +331,9 @@ def run_avi(args, world, rank):
     macs = sum(m.in_features * m.out_features for m in model.modules() if isinstance(m, torch.nn.Linear))
     A = env.get_num_moves()
     back_max = {"cube3": 30, "puzzle15": 500, "puzzle24": 500}.get(args.env, 1000)  # the values of the reference's train.sh
-    oh = torch.bfloat16 if args.nnet_dtype == "bf16" else torch.float32
-    hfn = nnet_utils.get_heuristic_fn_dev(FastResnet(model, oh).cuda(), clip_zero=False, batch_size=args.nnet_batch_size)
+    fast = FastResnet(model, torch.bfloat16 if args.nnet_dtype == "bf16" else torch.float32).cuda()
+    hfn = nnet_utils.get_heuristic_fn_dev(fast, clip_zero=False, batch_size=args.nnet_batch_size)
+    oh = None if fast.uses_l1_kernel else fast.onehot_dtype  # None: the closure gets the uint8 rows (layer-1 MFMA kernel)
     n = args.n if args.n != 1_000_000 else 200_000
 
     def step(i):

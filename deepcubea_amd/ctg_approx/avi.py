@@ -112,7 +112,10 @@ def target_heuristic(targ_dir: str, env, device, batch_size: int):
         return lambda x, is_onehot=False: torch.zeros(x.shape[0], dtype=torch.float32, device=x.device)
     from ..utils.pytorch_models import FastResnet
     targ = nnet_utils.load_nnet(targ_file, env.get_nnet_model(), device=torch.device("cpu"))
-    return nnet_utils.get_heuristic_fn_dev(FastResnet(targ).to(device), clip_zero=True, batch_size=batch_size)
+    fast = FastResnet(targ).to(device)
+    fn = nnet_utils.get_heuristic_fn_dev(fast, clip_zero=True, batch_size=batch_size)
+    fn.onehot_dtype = None if fast.uses_l1_kernel else fast.onehot_dtype  # None: hand the closure the uint8 rows
+    return fn
 
 
 def do_update(back_max: int, update_num: int, env, max_update_steps: int, update_method: str, num_states: int,
@@ -125,7 +128,8 @@ def do_update(back_max: int, update_num: int, env, max_update_steps: int, update
     if max_update_steps > 1:
         print("Using %s with %i step(s) to add extra states to training set" % (update_method.upper(), update_steps))
     updater = Updater(env, num_states, back_max, heuristic_fn_dev, update_steps, update_method,
-                      update_batch_size=update_batch_size, eps_max=eps_max, seed=seed, onehot_dtype=torch.float32)
+                      update_batch_size=update_batch_size, eps_max=eps_max, seed=seed,
+                      onehot_dtype=getattr(heuristic_fn_dev, "onehot_dtype", None))
     states_nnet, outputs, is_solved = updater.update_dev()
     if max_update_steps > 1:
         print("%s produced %s states, %.2f%% solved (%.2f seconds)" % (

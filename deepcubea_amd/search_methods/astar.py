@@ -56,6 +56,7 @@ def _load_heuristic(args, env):
         fast = FastResnet(nnet, dt).to(device)
         # layer 1 as the library's one-hot MFMA kernel: the engine then hands out uint8 rows only (stride 0 = no one-hot)
         stride = 0 if fast.uses_l1_kernel else fast.in_pad
+        args._onehot_dtype = fast.onehot_dtype  # what the engine's pack kernel writes when one-hot rows are needed
         return nnet_utils.get_heuristic_fn_dev(fast, clip_zero=False, batch_size=args.nnet_batch_size), stride
     if getattr(args, "fold_bn", False):
         from ..utils.pytorch_models import fold_batchnorm
@@ -69,7 +70,8 @@ def bwas_hip(args, env, states: List) -> Tuple[List[List[int]], List[List], List
     (solns, paths, times, num_nodes_gen) for `states`, in order."""
     heuristic_fn, onehot_stride = _load_heuristic(args, env)
     sem = _lib.SEM_CPP if getattr(args, "semantics", "py") == "cpp" else _lib.SEM_PY
-    oh = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[getattr(args, "nnet_dtype", "fp32")]
+    oh = getattr(args, "_onehot_dtype", None) or {"fp32": torch.float32, "bf16": torch.bfloat16,
+                                                   "fp16": torch.float16}[getattr(args, "nnet_dtype", "fp32")]
     K = max(1, int(getattr(args, "instances_per_gpu", 1)))
     eng = BwasEngine(args.env, args.weight, args.batch_size, max_nodes=int(getattr(args, "max_nodes", 1 << 26)),
                      semantics=sem, onehot_dtype=None if onehot_stride == 0 else oh, num_instances=K,

@@ -54,8 +54,8 @@ def get_heuristic_fn_dev(nnet: nn.Module, clip_zero: bool = False, batch_size: O
     @torch.no_grad()
     def heuristic_fn_dev(x: torch.Tensor, is_onehot: bool = False) -> torch.Tensor:
         n = x.shape[0]
-        if is_onehot and in_pad is not None and (x.shape[1] != in_pad or x.dtype != nnet.dtype):
-            x = torch.nn.functional.pad(x.to(nnet.dtype), (0, in_pad - x.shape[1]))
+        if is_onehot and in_pad is not None and (x.shape[1] != in_pad or x.dtype != nnet.onehot_dtype):
+            x = torch.nn.functional.pad(x.to(nnet.onehot_dtype), (0, in_pad - x.shape[1]))
         step = n if batch_size is None else batch_size
         outs = []
         for s in range(0, n, max(step, 1)):

@@ -208,7 +208,19 @@ class FastResnet(nn.Module):
         self.split_w = nn.ParameterList()
         self.split_b = nn.ParameterList()
         self.split_alpha: list = []
+        self.l1_split_w = nn.ParameterList()
+        self.l1_split_alpha = 1.0
         if self.split:
+            # layer 1 on materialised one-hot rows (geometries without the MFMA kernel): the rows are exact in fp16, so two
+            # fp16 weight planes (22 bits) and two f16 GEMMs with fp32 output give the fp32 layer
+            w1 = ws[0]
+            amax = float(w1.abs().max())
+            sc = 2.0 ** int(torch.floor(torch.log2(torch.tensor(1024.0 / amax))).item()) if amax > 0 else 1.0
+            w1h = (w1 * sc).to(torch.float16)
+            w1l = (w1 * sc - w1h.float()).to(torch.float16)
+            self.l1_split_w.append(nn.Parameter(w1h, requires_grad=False))
+            self.l1_split_w.append(nn.Parameter(w1l, requires_grad=False))
+            self.l1_split_alpha = 1.0 / sc
             for w, b in raw:
                 amax = float(w.abs().max())
                 sc = 2.0 ** int(torch.floor(torch.log2(torch.tensor(1024.0 / amax))).item()) if amax > 0 else 1.0
@@ -241,10 +253,22 @@ class FastResnet(nn.Module):
     def uses_l1_kernel(self) -> bool:
         return self.l1_tiles is not None
 
+    @property
+    def onehot_dtype(self) -> torch.dtype:
+        """Element type of the one-hot rows `forward_onehot` wants on the device (0/1 are exact in every type)."""
+        return torch.float16 if self.split else self.dtype
+
     @torch.no_grad()
     def forward_onehot(self, x: torch.Tensor) -> torch.Tensor:
-        """[M, in_pad] one-hot rows (dtype = self.dtype) -> [M, out_dim] float32."""
+        """[M, in_pad] one-hot rows (`onehot_dtype` on the device, self.dtype on the host) -> [M, out_dim] float32."""
         W, B = self.weights, self.biases
+        if self.split and x.is_cuda:
+            from .. import _lib
+            x = x if x.dtype == torch.float16 else x.to(torch.float16)
+            y = torch.mm(x, self.l1_split_w[0].t(), out_dtype=torch.float32)
+            y.add_(torch.mm(x, self.l1_split_w[1].t(), out_dtype=torch.float32))
+            a3, _ = _lib.act_split(y, B[0], None, self.l1_split_alpha, True, False)
+            return self._after_l1_split(None, a3)
         return self._after_l1(torch._addmm_activation(B[0], x, W[0].t()))
 
     def _after_l1(self, x: torch.Tensor) -> torch.Tensor:
@@ -260,7 +284,8 @@ class FastResnet(nn.Module):
     @torch.no_grad()
     def encode(self, states_nnet: torch.Tensor) -> torch.Tensor:
         from .. import _lib
-        oh = _lib.onehot(states_nnet, self.one_hot_depth, self.dtype) if self.one_hot_depth > 0 else states_nnet.to(self.dtype)
+        dt = self.onehot_dtype if states_nnet.is_cuda else self.dtype
+        oh = _lib.onehot(states_nnet, self.one_hot_depth, dt) if self.one_hot_depth > 0 else states_nnet.to(dt)
         return torch.nn.functional.pad(oh, (0, self.in_pad - oh.shape[1]))
 
     @torch.no_grad()

@@ -96,8 +96,9 @@ def test_f16x3_split_network_is_fp32_accurate(golden, tiny_resnet):
     d = (split(xb) - native(xb)).abs().max().item()
     assert d < tol, d
     # the one-hot input path (geometries without the layer-1 kernel) takes the same split layers
-    oh = split.encode(xb[:512])
-    assert float((split.forward_onehot(oh) - native.forward_onehot(oh)).abs().max()) < tol
+    assert split.onehot_dtype == torch.float16 and native.onehot_dtype == torch.float32
+    d = (split.forward_onehot(split.encode(xb[:512])) - native.forward_onehot(native.encode(xb[:512]))).abs().max()
+    assert float(d) < tol
     m = ResnetModel(54, 6, 64, 32, 2, 1, True)
     m.load_state_dict({k[2:]: torch.tensor(tiny_resnet[k]) for k in tiny_resnet.files if k.startswith("w:")})
     yt = FastResnet(m).cuda()(torch.tensor(tiny_resnet["x"]).cuda())[:, 0].cpu().numpy()
