@@ -145,6 +145,17 @@ def l1_weight_tiles(w: torch.Tensor, planes: int, k_pad: int) -> torch.Tensor:
     return t
 
 
+def _pow2_scale(w: torch.Tensor) -> float:
+    """Power of two that brings max|w| to ~1024: the fp16 low halves of the scaled weights stay normal numbers."""
+    amax = float(w.abs().max())
+    return 2.0 ** int(torch.floor(torch.log2(torch.tensor(1024.0 / amax))).item()) if amax > 0 else 1.0
+
+
+def _split_f16(w: torch.Tensor, sc: float):
+    wh = (w * sc).to(torch.float16)
+    return wh, (w * sc - wh.float()).to(torch.float16)
+
+
 class FastResnet(nn.Module):
     """Inference-only re-layout of a `ResnetModel` (pytorch_models.py:5-86 of the reference), same function:
 
@@ -154,10 +165,12 @@ class FastResnet(nn.Module):
       * bias + ReLU ride in the GEMM epilogue (`torch._addmm_activation`);
       * in a residual block the skip connection is the GEMM's C operand, and the second Linear's bias is folded into
         its weight matrix through a constant-one hidden unit (the first padded unit of the block's hidden layer has
-        zero weights and bias 1), leaving one in-place ReLU pass per block as the only elementwise kernel.
-
+        zero weights and bias 1), leaving one in-place ReLU pass per block as the only elementwise kernel;
       * layer 1 runs as the library's hand-written one-hot MFMA kernel (`csrc/dca_mlp.hip`, `forward` on uint8 rows) where
-        its geometry is instantiated: no one-hot matrix, fp32-exact through three bf16 weight planes.
+        its geometry is instantiated: no one-hot matrix, fp32-exact through three bf16 weight planes;
+      * dtype float32 on the device (`split=True`, the default): every other dense layer is ONE f16 GEMM with fp32 output
+        over split operands ("f16x3", `dca_act_split`) — fp32 accuracy at 2.4-2.9x the speed of the library's fp32 GEMM.
+        `split=False` keeps the plain fp32 GEMMs (what the host path always uses).
 
     Input: uint8 network inputs `[M, state_dim]` through `forward` (`uses_l1_kernel`: feed the engine's packed
     network-input rows), or one-hot rows `[M, in_pad]` in `dtype` (row stride `in_pad` >= state_dim*depth, tail zero) as
@@ -213,19 +226,14 @@ class FastResnet(nn.Module):
         if self.split:
             # layer 1 on materialised one-hot rows (geometries without the MFMA kernel): the rows are exact in fp16, so two
             # fp16 weight planes (22 bits) and two f16 GEMMs with fp32 output give the fp32 layer
-            w1 = ws[0]
-            amax = float(w1.abs().max())
-            sc = 2.0 ** int(torch.floor(torch.log2(torch.tensor(1024.0 / amax))).item()) if amax > 0 else 1.0
-            w1h = (w1 * sc).to(torch.float16)
-            w1l = (w1 * sc - w1h.float()).to(torch.float16)
+            sc = _pow2_scale(ws[0])
+            w1h, w1l = _split_f16(ws[0], sc)
             self.l1_split_w.append(nn.Parameter(w1h, requires_grad=False))
             self.l1_split_w.append(nn.Parameter(w1l, requires_grad=False))
             self.l1_split_alpha = 1.0 / sc
             for w, b in raw:
-                amax = float(w.abs().max())
-                sc = 2.0 ** int(torch.floor(torch.log2(torch.tensor(1024.0 / amax))).item()) if amax > 0 else 1.0
-                wh = (w * sc).to(torch.float16)
-                wl = (w * sc - wh.float()).to(torch.float16)
+                sc = _pow2_scale(w)
+                wh, wl = _split_f16(w, sc)
                 self.split_w.append(nn.Parameter(torch.stack([wh, wh, wl], dim=2).reshape(w.shape[0], -1).contiguous(),
                                                  requires_grad=False))  # W3[:, 3k..3k+2] = (wh, wh, wl)
                 self.split_b.append(nn.Parameter(b.clone(), requires_grad=False))
