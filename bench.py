@@ -62,10 +62,7 @@ def dist_setup(backend: str = "nccl"):
         os.environ.setdefault("MASTER_PORT", "29511")
         # one rank per GPU (nccl = RCCL); gloo lets several ranks share a device for smoke tests
         torch.cuda.set_device(local if backend == "nccl" else local % torch.cuda.device_count())
-        if backend == "nccl":  # bind the communicator to this rank's GPU up front (no device guessing in barrier())
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     return world, rank, local
