@@ -311,7 +311,7 @@ def l1_kpad(state_dim: int, depth: int) -> int:
 
 
 def l1_onehot_gemm(states_nnet: torch.Tensor, depth: int, w_tiles: torch.Tensor, planes: int, bias: torch.Tensor,
-                   relu: bool, out_dtype, split: bool = False) -> torch.Tensor:
+                   relu: bool, out_dtype, split: bool = False, overflow: Optional[torch.Tensor] = None) -> torch.Tensor:
     """relu?(onehot(states_nnet) @ W1^T + b1) from the uint8 rows, [m, n_pad] in out_dtype (dca_l1_onehot_gemm);
     split=True: the f16x3 operand [m, 3*n_pad] fp16 of the next layer instead (DCA_DT_F16X3)."""
     x = _u8(states_nnet)
@@ -324,17 +324,19 @@ def l1_onehot_gemm(states_nnet: torch.Tensor, depth: int, w_tiles: torch.Tensor,
         out = torch.empty((m, n_pad), dtype=out_dtype, device=x.device)
         code = _TORCH_DT[out_dtype]
     check(lib().dca_l1_onehot_gemm(ptr(x), C.c_int64(m), int(d), int(depth), ptr(w_tiles), int(planes), C.c_int64(n_pad),
-                                   ptr(bias), int(relu), ptr(out), code, stream_ptr()), "dca_l1_onehot_gemm")
+                                   ptr(bias), int(relu), ptr(out), code, ptr(overflow), stream_ptr()), "dca_l1_onehot_gemm")
     return out
 
 
-def act_split(y: torch.Tensor, bias: Optional[torch.Tensor], skip: Optional[torch.Tensor], alpha: float, relu: bool,
-              want_x: bool, want_a3: bool = True):
+def act_split(y: torch.Tensor, bias: Optional[torch.Tensor], skip: Optional[torch.Tensor], alpha, relu: bool,
+              want_x: bool, want_a3: bool = True, overflow: Optional[torch.Tensor] = None):
     """v = relu?(y*alpha + bias (+ skip)) -> (a3 [m,3n] fp16, a3[3k..3k+2] = (vh, vl, vh), or None; v fp32 or None)."""
     assert y.dtype == torch.float32 and y.is_contiguous() and (want_x or want_a3)
     m, n = y.shape
     a3 = torch.empty((m, 3 * n), dtype=torch.float16, device=y.device) if want_a3 else None
     x_out = torch.empty_like(y) if want_x else None
-    check(lib().dca_act_split(ptr(y), ptr(bias), ptr(skip), C.c_double(alpha), int(relu), C.c_int64(m), C.c_int64(n),
-                              ptr(x_out), ptr(a3), stream_ptr()), "dca_act_split")
+    col_scale = alpha if isinstance(alpha, torch.Tensor) else None  # per-output-unit scale vector or one scalar
+    check(lib().dca_act_split(ptr(y), ptr(bias), ptr(skip), ptr(col_scale), C.c_double(1.0 if col_scale is not None else alpha),
+                              int(relu), C.c_int64(m), C.c_int64(n), ptr(x_out), ptr(a3), ptr(overflow), stream_ptr()),
+          "dca_act_split")
     return a3, x_out

@@ -45,7 +45,7 @@ template <int D, int DEPTH, int P, int OUT /*0 f32, 1 f16, 2 bf16, 3 f16x3 split
 __global__ __launch_bounds__(kL1Threads) void k_l1_onehot_gemm(const uint8_t* __restrict__ nn, int64_t m,
                                                         const uint8_t* __restrict__ wt /*[ntile][P][KC][64][8] bf16*/,
                                                         const float* __restrict__ bias, int relu, void* __restrict__ out,
-                                                        int64_t ldo) {
+                                                        int64_t ldo, int* __restrict__ overflow) {
     using G = L1Geo<D, DEPTH>;
     extern __shared__ __attribute__((aligned(16))) uint8_t lw[];
     constexpr int TILE_BYTES = P * G::KC * 64 * 16;
@@ -135,6 +135,7 @@ __global__ __launch_bounds__(kL1Threads) void k_l1_onehot_gemm(const uint8_t* __
                             reinterpret_cast<uint16_t*>(out)[r * ldo + col] = f32_to_bf16_rne(v);
                         else {  // the next layer's f16x3 A operand directly: 192 contiguous bytes per 32 lanes
                             _Float16* q = reinterpret_cast<_Float16*>(out) + (r * ldo + col) * 3;
+                            if (!(fabsf(v) <= 60000.0f) && overflow) *overflow = 1;
                             const _Float16 hh = (_Float16)v;
                             q[0] = hh;
                             q[1] = (_Float16)(v - (float)hh);
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(kL1Threads) void k_l1_onehot_gemm(const uint8_t* __
 
 template <int D, int DEPTH, int P>
 int launch_l1_out(const uint8_t* nn, int64_t m, const uint8_t* wt, const float* bias, int relu, void* out, int out_dtype,
-                  int64_t n_pad, hipStream_t s) {
+                  int64_t n_pad, int* overflow, hipStream_t s) {
     using G = L1Geo<D, DEPTH>;
     constexpr int LDS = P * G::KC * 64 * 16;
     static_assert(LDS <= 160 * 1024, "weight tile does not fit LDS");
@@ -158,7 +159,7 @@ int launch_l1_out(const uint8_t* nn, int64_t m, const uint8_t* wt, const float* 
     do {                                                                                                             \
         auto kern = k_l1_onehot_gemm<D, DEPTH, P, OUTV>;                                                             \
         DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
-        hipLaunchKernelGGL(kern, grid, block, LDS, s, nn, m, wt, bias, relu, out, n_pad);                            \
+        hipLaunchKernelGGL(kern, grid, block, LDS, s, nn, m, wt, bias, relu, out, n_pad, overflow);                            \
     } while (0)
     if (out_dtype == DCA_DT_F32)
         DCA_L1_LAUNCH(0);
@@ -174,11 +175,11 @@ int launch_l1_out(const uint8_t* nn, int64_t m, const uint8_t* wt, const float* 
 
 template <int D, int DEPTH>
 int launch_l1(int planes, const uint8_t* nn, int64_t m, const uint8_t* wt, const float* bias, int relu, void* out,
-              int out_dtype, int64_t n_pad, hipStream_t s) {
+              int out_dtype, int64_t n_pad, int* overflow, hipStream_t s) {
     switch (planes) {
-        case 1: return launch_l1_out<D, DEPTH, 1>(nn, m, wt, bias, relu, out, out_dtype, n_pad, s);
-        case 2: return launch_l1_out<D, DEPTH, 2>(nn, m, wt, bias, relu, out, out_dtype, n_pad, s);
-        default: return launch_l1_out<D, DEPTH, 3>(nn, m, wt, bias, relu, out, out_dtype, n_pad, s);
+        case 1: return launch_l1_out<D, DEPTH, 1>(nn, m, wt, bias, relu, out, out_dtype, n_pad, overflow, s);
+        case 2: return launch_l1_out<D, DEPTH, 2>(nn, m, wt, bias, relu, out, out_dtype, n_pad, overflow, s);
+        default: return launch_l1_out<D, DEPTH, 3>(nn, m, wt, bias, relu, out, out_dtype, n_pad, overflow, s);
     }
 }
 
@@ -190,22 +191,30 @@ int launch_l1(int planes, const uint8_t* nn, int64_t m, const uint8_t* wt, const
 // (xh, xl, xh) and W3[3k..3k+2] = (wh, wh, wl), ONE library f16 GEMM with fp32 output is an fp32-accurate GEMM at 3x the f16 cost — 2.4-2.9x
 // faster than the library's fp32 GEMM (f32-input MFMA runs at 1/16 of the f16 rate), same error class (measured
 // 1.7e-6 vs 1.2e-6 max-relative at K = 1024).  This kernel is the glue between two such GEMMs: it applies what follows
-// the Linear in the network (scale back, bias, residual add, ReLU — utils/pytorch_models.py:57-86 with BatchNorm folded)
+// the Linear in the network (scale back — per output unit, the weight rows carry their own power-of-two scale —, bias,
+// residual add, ReLU — utils/pytorch_models.py:57-86 with BatchNorm folded)
 // and emits the next layer's A3 in one pass (read 4-8 B, write 6-10 B per element).
 // ---------------------------------------------------------------------------------------------------------------------
+constexpr float kF16Safe = 60000.0f;  // |v| above this cannot be split into fp16 halves (fp16 max 65504)
+
 __global__ __launch_bounds__(256) void k_act_split(const float* __restrict__ y, const float* __restrict__ bias,
-                                                   const float* __restrict__ skip, float alpha, int relu, int64_t m, int64_t n,
+                                                   const float* __restrict__ skip, const float* __restrict__ col_scale,
+                                                   float alpha, int relu, int64_t m, int64_t n,
                                                    float* __restrict__ x_out /*[m,n] or null*/,
-                                                   _Float16* __restrict__ a3 /*[m,3n]*/) {
+                                                   _Float16* __restrict__ a3 /*[m,3n]*/, int* __restrict__ overflow) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t col = ((int64_t)blockIdx.x * 64 + lane) * 4;
     if (col >= n) return;
     const int64_t rows_per = (m + gridDim.y - 1) / gridDim.y;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per, r1 = r0 + rows_per < m ? r0 + rows_per : m;
-    float b[4] = {0.f, 0.f, 0.f, 0.f};
+    float b[4] = {0.f, 0.f, 0.f, 0.f}, al[4] = {alpha, alpha, alpha, alpha};
     if (bias) {
         const float4 t = *reinterpret_cast<const float4*>(bias + col);
         b[0] = t.x, b[1] = t.y, b[2] = t.z, b[3] = t.w;
+    }
+    if (col_scale) {  // per-output-unit power-of-two scale of the weight rows (exact)
+        const float4 t = *reinterpret_cast<const float4*>(col_scale + col);
+        al[0] *= t.x, al[1] *= t.y, al[2] *= t.z, al[3] *= t.w;
     }
     typedef __attribute__((ext_vector_type(4))) _Float16 h4;
     for (int64_t r = r0 + wv; r < r1; r += 4) {
@@ -219,9 +228,10 @@ __global__ __launch_bounds__(256) void k_act_split(const float* __restrict__ y, 
         h4 hi, lo;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            float u = v[k] * alpha + b[k] + sk[k];
+            float u = v[k] * al[k] + b[k] + sk[k];
             if (relu) u = fmaxf(u, 0.f);
             v[k] = u;
+            if (!(fabsf(u) <= kF16Safe) && overflow) *overflow = 1;  // beyond fp16 (or NaN): the caller redoes the batch in fp32
             const _Float16 hh = (_Float16)u;
             hi[k] = hh;
             lo[k] = (_Float16)(u - (float)hh);
@@ -251,7 +261,7 @@ int dca_l1_supported(int state_dim, int depth) { return (state_dim == 54 && dept
 int64_t dca_l1_kpad(int state_dim, int depth) { return (((int64_t)state_dim * depth + 15) / 16) * 16; }
 
 int dca_l1_onehot_gemm(const uint8_t* nnet_in, int64_t m, int state_dim, int depth, const void* w_tiles, int planes,
-                       int64_t n_pad, const float* bias, int relu, void* out, int out_dtype, void* stream) {
+                       int64_t n_pad, const float* bias, int relu, void* out, int out_dtype, int* overflow, void* stream) {
     DCA_ARG(nnet_in && w_tiles && bias && out && m >= 0 && planes >= 1 && planes <= 3 && n_pad >= 64 && n_pad % 64 == 0);
     DCA_ARG(out_dtype >= DCA_DT_F32 && out_dtype <= DCA_DT_F16X3);
     if (!dca_l1_supported(state_dim, depth)) {
@@ -261,20 +271,21 @@ int dca_l1_onehot_gemm(const uint8_t* nnet_in, int64_t m, int state_dim, int dep
     if (m == 0) return 0;
     const uint8_t* wt = reinterpret_cast<const uint8_t*>(w_tiles);
     hipStream_t s = (hipStream_t)stream;
-    if (state_dim == 54) return launch_l1<54, 6>(planes, nnet_in, m, wt, bias, relu, out, out_dtype, n_pad, s);
-    return launch_l1<16, 16>(planes, nnet_in, m, wt, bias, relu, out, out_dtype, n_pad, s);
+    if (state_dim == 54) return launch_l1<54, 6>(planes, nnet_in, m, wt, bias, relu, out, out_dtype, n_pad, overflow, s);
+    return launch_l1<16, 16>(planes, nnet_in, m, wt, bias, relu, out, out_dtype, n_pad, overflow, s);
 }
 
-int dca_act_split(const float* y, const float* bias, const float* skip, double alpha, int relu, int64_t m, int64_t n,
-                  float* x_out, void* a3, void* stream) {
+int dca_act_split(const float* y, const float* bias, const float* skip, const float* col_scale, double alpha, int relu,
+                  int64_t m, int64_t n, float* x_out, void* a3, int* overflow, void* stream) {
     DCA_ARG(y && (a3 || x_out) && m >= 0 && n >= 4 && n % 4 == 0 && m * n < (1ll << 40));
     if (m == 0) return 0;
     const unsigned gx = (unsigned)((n + 255) / 256);
     int64_t gy = 4096 / gx;
     if (gy > (m + 15) / 16) gy = (m + 15) / 16;
     if (gy < 1) gy = 1;
-    hipLaunchKernelGGL(k_act_split, dim3(gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, y, bias, skip, (float)alpha, relu,
-                       m, n, x_out, reinterpret_cast<_Float16*>(a3));
+    hipLaunchKernelGGL(k_act_split, dim3(gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, y, bias, skip, col_scale,
+                       (float)alpha, relu,
+                       m, n, x_out, reinterpret_cast<_Float16*>(a3), overflow);
     return launch_check("k_act_split");
 }
 

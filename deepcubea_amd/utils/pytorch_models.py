@@ -145,15 +145,18 @@ def l1_weight_tiles(w: torch.Tensor, planes: int, k_pad: int) -> torch.Tensor:
     return t
 
 
-def _pow2_scale(w: torch.Tensor) -> float:
-    """Power of two that brings max|w| to ~1024: the fp16 low halves of the scaled weights stay normal numbers."""
-    amax = float(w.abs().max())
-    return 2.0 ** int(torch.floor(torch.log2(torch.tensor(1024.0 / amax))).item()) if amax > 0 else 1.0
+def _pow2_scale(w: torch.Tensor) -> torch.Tensor:
+    """Per output unit (row of w) the power of two that brings max|row| to ~1024, so that the fp16 low halves of the
+    scaled weights stay normal numbers whatever the spread of magnitudes ACROSS units (BatchNorm folding can make it large)."""
+    amax = w.abs().amax(dim=1)
+    sc = torch.exp2(torch.floor(torch.log2(1024.0 / amax.clamp_min(1e-30))))
+    return torch.where(amax > 0, sc, torch.ones_like(sc)).clamp(2.0 ** -100, 2.0 ** 100)
 
 
-def _split_f16(w: torch.Tensor, sc: float):
-    wh = (w * sc).to(torch.float16)
-    return wh, (w * sc - wh.float()).to(torch.float16)
+def _split_f16(w: torch.Tensor, sc: torch.Tensor):
+    ws = w * sc[:, None]
+    wh = ws.to(torch.float16)
+    return wh, (ws - wh.float()).to(torch.float16)
 
 
 class FastResnet(nn.Module):
@@ -218,11 +221,14 @@ class FastResnet(nn.Module):
         # operands A3[3k..3k+2] = (xh, xl, xh), W3[3k..3k+2] = (wh, wh, wl) (csrc/dca_mlp.hip k_act_split): fp32-accurate, 2.4-2.9x faster
         # than the library's fp32 GEMM.  Weights are pre-scaled by a power of two so their low halves stay normal numbers.
         self.split = bool(split) and dtype == torch.float32
+        # set by the split kernels when a value does not fit fp16 (|v| > 60000): that batch is redone with fp32 GEMMs
+        self.register_buffer("_overflow", torch.zeros(1, dtype=torch.int32), persistent=False)
+        self.split_fallbacks = 0
         self.split_w = nn.ParameterList()
         self.split_b = nn.ParameterList()
-        self.split_alpha: list = []
+        self.split_alpha = nn.ParameterList()  # per-output-unit 1/scale vectors
         self.l1_split_w = nn.ParameterList()
-        self.l1_split_alpha = 1.0
+        self.l1_split_alpha = None
         if self.split:
             # layer 1 on materialised one-hot rows (geometries without the MFMA kernel): the rows are exact in fp16, so two
             # fp16 weight planes (22 bits) and two f16 GEMMs with fp32 output give the fp32 layer
@@ -230,14 +236,14 @@ class FastResnet(nn.Module):
             w1h, w1l = _split_f16(ws[0], sc)
             self.l1_split_w.append(nn.Parameter(w1h, requires_grad=False))
             self.l1_split_w.append(nn.Parameter(w1l, requires_grad=False))
-            self.l1_split_alpha = 1.0 / sc
+            self.l1_split_alpha = nn.Parameter(1.0 / sc, requires_grad=False)
             for w, b in raw:
                 sc = _pow2_scale(w)
                 wh, wl = _split_f16(w, sc)
                 self.split_w.append(nn.Parameter(torch.stack([wh, wh, wl], dim=2).reshape(w.shape[0], -1).contiguous(),
                                                  requires_grad=False))  # W3[:, 3k..3k+2] = (wh, wh, wl)
                 self.split_b.append(nn.Parameter(b.clone(), requires_grad=False))
-                self.split_alpha.append(1.0 / sc)
+                self.split_alpha.append(nn.Parameter(1.0 / sc, requires_grad=False))
         # layer 1 straight from the uint8 rows (csrc/dca_mlp.hip) where the geometry is instantiated: fp32 weights as
         # three bf16 planes (exact), fp16 as two, bf16 as one
         self.l1_planes = {torch.float32: 3, torch.float16: 2, torch.bfloat16: 1}[dtype]
@@ -273,15 +279,19 @@ class FastResnet(nn.Module):
         if self.split and x.is_cuda:
             from .. import _lib
             x = x if x.dtype == torch.float16 else x.to(torch.float16)
+            self._overflow.zero_()
             y = torch.mm(x, self.l1_split_w[0].t(), out_dtype=torch.float32)
             y.add_(torch.mm(x, self.l1_split_w[1].t(), out_dtype=torch.float32))
-            a3, _ = _lib.act_split(y, B[0], None, self.l1_split_alpha, True, False)
-            return self._after_l1_split(None, a3)
+            a3, _ = _lib.act_split(y, B[0], None, self.l1_split_alpha, True, False, overflow=self._overflow)
+            out = self._after_l1_split(a3)
+            if int(self._overflow.item()) == 0:
+                return out
+            self.split_fallbacks += 1
+            x = x.float()
         return self._after_l1(torch._addmm_activation(B[0], x, W[0].t()))
 
     def _after_l1(self, x: torch.Tensor) -> torch.Tensor:
-        if self.split and x.is_cuda:
-            return self._after_l1_split(x)
+        """fp32 / bf16 / fp16 library GEMMs with fused epilogues."""
         W, B = self.weights, self.biases
         x = torch._addmm_activation(B[1], x, W[1].t())
         for k in range(2, len(W), 2):
@@ -303,27 +313,29 @@ class FastResnet(nn.Module):
             return self.forward_onehot(self.encode(states_nnet))
         from .. import _lib
         if self.split:  # the layer-1 kernel's epilogue writes the next layer's split operand directly
+            self._overflow.zero_()
             a3 = _lib.l1_onehot_gemm(states_nnet, self.one_hot_depth, self.l1_tiles, self.l1_planes, self.l1_bias, True,
-                                     self.dtype, split=True)
-            return self._after_l1_split(None, a3)
+                                     self.dtype, split=True, overflow=self._overflow)
+            out = self._after_l1_split(a3)
+            if int(self._overflow.item()) == 0:
+                return out
+            self.split_fallbacks += 1  # some activation beyond fp16 range: same batch again with fp32 GEMMs
         x = _lib.l1_onehot_gemm(states_nnet, self.one_hot_depth, self.l1_tiles, self.l1_planes, self.l1_bias, True,
                                 self.dtype)
         return self._after_l1(x)
 
-    def _after_l1_split(self, y1: Optional[torch.Tensor], a3: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """y1 = relu(layer 1) fp32 [M, h1_pad] (or its split operand a3) -> [M, out_dim]; the f16x3 path (see __init__)."""
+    def _after_l1_split(self, a3: torch.Tensor) -> torch.Tensor:
+        """split operand of relu(layer 1) [M, 3*h1_pad] fp16 -> [M, out_dim]; the f16x3 path (see __init__)."""
         from .. import _lib
-        W, B, A = self.split_w, self.split_b, self.split_alpha
+        W, B, A, ovf = self.split_w, self.split_b, self.split_alpha, self._overflow
         f32 = torch.float32
-        if a3 is None:
-            a3, _ = _lib.act_split(y1, None, None, 1.0, False, False)
         y = torch.mm(a3, W[0].t(), out_dtype=f32)
         nblk = (len(W) - 1) // 2
-        a3, x = _lib.act_split(y, B[0], None, A[0], True, True, want_a3=nblk > 0)
+        a3, x = _lib.act_split(y, B[0], None, A[0], True, True, want_a3=nblk > 0, overflow=ovf)
         for blk in range(nblk):
             ka, kb = 1 + 2 * blk, 2 + 2 * blk
             y = torch.mm(a3, W[ka].t(), out_dtype=f32)
-            ah, _ = _lib.act_split(y, B[ka], None, A[ka], True, False)
+            ah, _ = _lib.act_split(y, B[ka], None, A[ka], True, False, overflow=ovf)
             y = torch.mm(ah, W[kb].t(), out_dtype=f32)
-            a3, x = _lib.act_split(y, B[kb], x, A[kb], True, True, want_a3=blk + 1 < nblk)
+            a3, x = _lib.act_split(y, B[kb], x, A[kb], True, True, want_a3=blk + 1 < nblk, overflow=ovf)
         return x @ self.w_out.t() + self.b_out

@@ -264,15 +264,18 @@ int dca_l1_supported(int state_dim, int depth);
 int64_t dca_l1_kpad(int state_dim, int depth);
 int dca_l1_onehot_gemm(const uint8_t* nnet_in /*[m, state_dim]*/, int64_t m, int state_dim, int depth, const void* w_tiles,
                        int planes, int64_t n_pad, const float* bias /*[n_pad]*/, int relu, void* out, int out_dtype,
-                       void* stream);
+                       int* overflow /*device flag, set to 1 if a DCA_DT_F16X3 value exceeds fp16; or NULL*/, void* stream);
 
-/* Glue of the fp32-accurate "f16x3" dense layers (csrc/dca_mlp.hip): v = relu?(y*alpha + bias (+ skip)) over the row-major
+/* Glue of the fp32-accurate "f16x3" dense layers (csrc/dca_mlp.hip): v = relu?(y*alpha*col_scale + bias (+ skip)) over the row-major
  * fp32 GEMM output y [m, n]; writes the next layer's A operand a3 [m, 3n] fp16, a3[3k..3k+2] = (vh, vl, vh) with
  * vh = f16(v), vl = f16(v - vh), and, if x_out != NULL, v itself (the next residual block's skip).  With the weights as
- * W3[3k..3k+2] = (wh, wh, wl) (pre-scaled by 1/alpha, a power of two) one f16 GEMM with fp32 output reproduces the fp32 layer
+ * W3[3k..3k+2] = (wh, wh, wl) (row n pre-scaled by the power of two 1/(alpha*col_scale[n])) one f16 GEMM with fp32 output reproduces the fp32 layer
  * utils/pytorch_models.py:57-86 computes (BatchNorm folded) to fp32 accuracy.  n % 4 == 0.                            */
-int dca_act_split(const float* y, const float* bias /*[n] or NULL*/, const float* skip /*[m,n] or NULL*/, double alpha,
-                  int relu, int64_t m, int64_t n, float* x_out /*[m,n] or NULL*/, void* a3 /*[m,3n] fp16*/, void* stream);
+int dca_act_split(const float* y, const float* bias /*[n] or NULL*/, const float* skip /*[m,n] or NULL*/,
+                  const float* col_scale /*[n] or NULL: per-output-unit inverse weight scale*/, double alpha, int relu,
+                  int64_t m, int64_t n, float* x_out /*[m,n] or NULL*/, void* a3 /*[m,3n] fp16*/,
+                  int* overflow /*device flag, set to 1 if some |v| > 60000 (not splittable into fp16); or NULL*/,
+                  void* stream);
 
 #ifdef __cplusplus
 }

@@ -61,9 +61,10 @@ def test_act_split_kernel_matches_torch():
     y = torch.randn(m, n, device="cuda") * 3000.0
     b = torch.randn(n, device="cuda")
     sk = torch.randn(m, n, device="cuda")
-    for bias, skip, relu in ((b, sk, True), (None, None, False), (b, None, True)):
-        a3, x = _lib.act_split(y, bias, skip, 2.0 ** -10, relu, True)
-        v = y * 2.0 ** -10 + (bias if bias is not None else 0) + (skip if skip is not None else 0)
+    cs = torch.exp2(-torch.randint(6, 14, (n,), device="cuda").float())  # per-column powers of two
+    for bias, skip, relu, alpha in ((b, sk, True, 2.0 ** -10), (None, None, False, 2.0 ** -10), (b, None, True, cs)):
+        a3, x = _lib.act_split(y, bias, skip, alpha, relu, True)
+        v = y * alpha + (bias if bias is not None else 0) + (skip if skip is not None else 0)
         if relu:
             v = torch.relu(v)
         assert torch.equal(x, v)  # same fp32 operations in the same order
@@ -118,3 +119,31 @@ def test_l1_kernel_split_epilogue_equals_act_split_of_its_fp32_output():
     a3 = _lib.l1_onehot_gemm(x, 6, tiles, 3, b, True, torch.float32, split=True)
     want, _ = _lib.act_split(y, None, None, 1.0, False, False)
     assert a3.shape == (m, 3 * n_pad) and torch.equal(a3, want)
+
+
+def test_f16x3_survives_a_wide_spread_of_unit_scales():
+    """BatchNorm folding can leave output units with very different weight magnitudes; the per-unit power-of-two scales keep
+    the f16x3 layers as accurate as the fp32 GEMMs (both compared with a float64 evaluation)."""
+    from deepcubea_amd.utils.pytorch_models import FastResnet, ResnetModel, fold_batchnorm
+    from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
+    net = ResnetModel(54, 6, 600, 200, 2, 1, True)
+    load_synthetic_weights(net, 5)
+    with torch.no_grad():
+        for bn in [net.bn1, net.bn2] + [b for blk in net.blocks for b in (blk[1], blk[3])]:
+            c = bn.weight.numel()
+            bn.weight[: c // 4] *= 8.0        # units with large folded weights ...
+            bn.weight[c // 4: c // 2] *= 1.0e-3  # ... next to tiny ones (spread 2e4 across units, activations up to 6e3)
+    x = torch.randint(0, 6, (4096, 54), dtype=torch.uint8, device="cuda")
+    oh = torch.nn.functional.one_hot(x.long(), 6).double().view(-1, 324)
+    y64 = fold_batchnorm(net).double().cuda().forward_onehot(oh)[:, 0]
+    scale = float(y64.abs().max())
+    fs = FastResnet(net).cuda()
+    es = float((fs(x)[:, 0].double() - y64).abs().max()) / scale
+    en = float((FastResnet(net, split=False).cuda()(x)[:, 0].double() - y64).abs().max()) / scale
+    assert fs.split_fallbacks == 0 and es < 1e-5 and en < 1e-5 and es < 4 * en + 1e-6, (es, en)
+    # activations beyond the fp16 range: the kernels raise the overflow flag and the batch is redone with fp32 GEMMs
+    with torch.no_grad():
+        net.bn1.weight *= 1.0e4
+    fo, fnat = FastResnet(net).cuda(), FastResnet(net, split=False).cuda()
+    assert torch.equal(fo(x), fnat(x)) and fo.split_fallbacks == 1
+    assert torch.equal(fo.forward_onehot(fo.encode(x)), fnat.forward_onehot(fnat.encode(x))) and fo.split_fallbacks == 2
