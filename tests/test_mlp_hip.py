@@ -135,7 +135,8 @@ def test_f16x3_survives_a_wide_spread_of_unit_scales():
             bn.weight[c // 4: c // 2] *= 1.0e-3  # ... next to tiny ones (spread 2e4 across units, activations up to 6e3)
     x = torch.randint(0, 6, (4096, 54), dtype=torch.uint8, device="cuda")
     oh = torch.nn.functional.one_hot(x.long(), 6).double().view(-1, 324)
-    y64 = fold_batchnorm(net).double().cuda().forward_onehot(oh)[:, 0]
+    with torch.no_grad():
+        y64 = fold_batchnorm(net).double().cuda().forward_onehot(oh)[:, 0]
     scale = float(y64.abs().max())
     fs = FastResnet(net).cuda()
     es = float((fs(x)[:, 0].double() - y64).abs().max()) / scale
