@@ -47,8 +47,11 @@ class WorkQueue:
     process group's key-value store (`store.add` is atomic) — no collective, and a rank that drew a 40x harder scramble
     (results/cube3/output.txt spans 1.6e6..6.1e7 nodes) simply draws fewer of them.  world == 1: plain iteration."""
 
+    _instances = 0  # queues are created in the same order on every rank: the counter gives each one its own store key
+
     def __init__(self, n: int, world: int, rank: int, key: str = "dca_next_state"):
-        self.n, self.world, self.rank, self.key = int(n), world, rank, key
+        WorkQueue._instances += 1
+        self.n, self.world, self.rank, self.key = int(n), world, rank, "%s/%d" % (key, WorkQueue._instances)
         self._local = 0
         self._store = None
         if world > 1:
