@@ -167,3 +167,46 @@ def test_train_nnet_matches_reference_run():
             assert np.allclose(v.numpy(), want, rtol=1e-5, atol=1e-6), (tag, k)
     with pytest.raises(ValueError):
         nnet_utils.train_nnet(net, [g["nobn:x"][:3]], g["nobn:y"][:3], torch.device("cpu"), 8, 1, 0, 0.1, 1.0, False)
+
+
+def test_network_weight_layouts_for_the_mfma_paths():
+    """Host-side preparation of the heuristic network's device layouts: the bf16 plane tiles of the layer-1 kernel and the
+    per-unit-scaled fp16 split weights of the f16x3 layers reconstruct the fp32 weights."""
+    from deepcubea_amd.utils.pytorch_models import FastResnet, ResnetModel, l1_weight_tiles
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(128, 324, generator=g) * torch.logspace(-3, 2, 128)[:, None]  # rows spanning 5 decades
+    for planes, tol in ((1, 2.0 ** -8), (2, 2.0 ** -16), (3, 2.0 ** -23)):
+        t = l1_weight_tiles(w, planes, 336)
+        assert t.shape == (2, planes, 42, 64, 8) and t.dtype == torch.bfloat16
+        # [ntile][plane][k/8][n][8] -> sum of planes, back to [n_pad, k_pad]
+        rec = t.float().sum(dim=1).permute(0, 2, 1, 3).reshape(128, 336)
+        assert torch.all(rec[:, 324:] == 0)
+        assert float(((rec[:, :324] - w).abs() / w.abs().clamp_min(1e-30)).max()) <= tol
+    m = ResnetModel(54, 6, 64, 32, 2, 1, True).eval()
+    with torch.no_grad():
+        m.bn2.weight[:8] *= 1e3  # spread the folded unit magnitudes
+    f = FastResnet(m)
+    assert f.split and len(f.split_w) == 5 and f.onehot_dtype == torch.float16 and f.in_pad == 384
+    from deepcubea_amd.utils.pytorch_models import fold_batchnorm
+    fm = fold_batchnorm(m)
+    lins = [fm.fc2] + [l for blk in fm.blocks for l in (blk[0], blk[2])]
+    for w3, alpha, bias, lin in zip(f.split_w, f.split_alpha, f.split_b, lins):
+        n, k = lin.weight.shape
+        v = w3.float().view(w3.shape[0], -1, 3)            # W3[:, 3k..3k+2] = (wh, wh, wl)
+        assert torch.equal(v[:, :, 0], v[:, :, 1])
+        rec = (v[:, :, 0] + v[:, :, 2]) * alpha[:, None]  # undo the per-unit power-of-two scale
+        assert torch.all(torch.log2(alpha) == torch.round(torch.log2(alpha)))
+        err = (rec[:n, :k] - lin.weight.detach()).abs().amax(dim=1) / lin.weight.detach().abs().amax(dim=1)
+        assert float(err.max()) <= 2.0 ** -20 and torch.all(rec[n:] == 0) and torch.allclose(bias[:n], lin.bias.detach())
+    oh = torch.zeros(5, f.in_pad)
+    oh[:, ::6] = 1.0
+    with torch.no_grad():  # host path of the same module = plain fp32 GEMMs
+        assert torch.allclose(f.forward_onehot(oh), m.forward_onehot(oh[:, :324]), atol=1e-5)
+
+
+def test_make_batches_drops_the_tail_like_the_reference():
+    from deepcubea_amd.utils import nnet_utils
+    np.random.seed(0)
+    b = nnet_utils.make_batches(10, 4)
+    assert [len(x) for x in b] == [4, 4] and len(set(np.concatenate(b).tolist())) == 8
+    assert nnet_utils.make_batches(3, 4) == []
