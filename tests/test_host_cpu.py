@@ -210,3 +210,23 @@ def test_make_batches_drops_the_tail_like_the_reference():
     b = nnet_utils.make_batches(10, 4)
     assert [len(x) for x in b] == [4, 4] and len(set(np.concatenate(b).tolist())) == 8
     assert nnet_utils.make_batches(3, 4) == []
+
+
+def test_cli_surfaces_match_the_reference_parsers():
+    """Every option of the reference's `search_methods/astar.py` and `ctg_approx/avi.py` parsers (tests/golden/cli_flags.json,
+    recorded by intercepting the reference's own parse_args) exists here with the same flag, type, requiredness and default
+    — except `--language`, whose default is this package's only core (`hip`)."""
+    import json
+    from deepcubea_amd.ctg_approx import avi
+    from deepcubea_amd.search_methods import astar
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "cli_flags.json")))
+    for name, parser in (("astar", astar.build_parser()), ("avi", avi.build_parser())):
+        mine = {a.dest: a for a in parser._actions if a.option_strings and a.dest != "help"}
+        for dest, want in ref[name].items():
+            assert dest in mine, (name, dest)
+            a = mine[dest]
+            assert sorted(a.option_strings) == want["flags"] and bool(a.required) == want["required"], (name, dest)
+            assert getattr(a.type, "__name__", None) == want["type"] and type(a).__name__ == want["action"], (name, dest)
+            if (name, dest) != ("astar", "language"):
+                assert a.default == want["default"], (name, dest, a.default, want["default"])
+    assert astar.build_parser().get_default("language") == "hip" and ref["astar"]["language"]["default"] == "python"
