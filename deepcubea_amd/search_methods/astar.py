@@ -34,6 +34,17 @@ from . import sharding
 from .engine import BwasEngine
 
 
+_MIN_NNET_ROWS = 1 << 17
+
+
+def _nnet_rows(args):
+    """`--nnet_batch_size` only bounds memory in the reference (astar.py:355, results unchanged).  Its train.sh value
+    (10 000 rows) would leave most of an MI355X idle per GEMM and 288 GB of HBM unused, so it is treated as a lower
+    bound here: the network sees at least 131 072 rows per call (a whole batch-10 000 iteration)."""
+    n = getattr(args, "nnet_batch_size", None)
+    return None if n is None else max(int(n), _MIN_NNET_ROWS)
+
+
 def _load_heuristic(args, env):
     """Device heuristic closure.  `--model_dir synthetic:SEED` builds the environment's network with
     deterministic synthetic weights (the reference checkpoints are not redistributable here)."""
@@ -57,12 +68,12 @@ def _load_heuristic(args, env):
         # layer 1 as the library's one-hot MFMA kernel: the engine then hands out uint8 rows only (stride 0 = no one-hot)
         stride = 0 if fast.uses_l1_kernel else fast.in_pad
         args._onehot_dtype = fast.onehot_dtype  # what the engine's pack kernel writes when one-hot rows are needed
-        return nnet_utils.get_heuristic_fn_dev(fast, clip_zero=False, batch_size=args.nnet_batch_size), stride
+        return nnet_utils.get_heuristic_fn_dev(fast, clip_zero=False, batch_size=_nnet_rows(args)), stride
     if getattr(args, "fold_bn", False):
         from ..utils.pytorch_models import fold_batchnorm
         nnet = fold_batchnorm(nnet).to(device)
     ac = None if dt == torch.float32 else dt
-    return nnet_utils.get_heuristic_fn_dev(nnet, clip_zero=False, batch_size=args.nnet_batch_size, autocast_dtype=ac), None
+    return nnet_utils.get_heuristic_fn_dev(nnet, clip_zero=False, batch_size=_nnet_rows(args), autocast_dtype=ac), None
 
 
 def bwas_hip(args, env, states: List) -> Tuple[List[List[int]], List[List], List[float], List[int]]:
@@ -132,7 +143,8 @@ def build_parser() -> ArgumentParser:
     parser.add_argument('--results_dir', type=str, required=True, help="Directory to save results")
     parser.add_argument('--start_idx', type=int, default=0, help="")
     parser.add_argument('--nnet_batch_size', type=int, default=None,
-                        help="How many states the network evaluates at a time (memory only; results unchanged)")
+                        help="How many states the network evaluates at a time (memory only; results unchanged). "
+                             "Treated as a lower bound: at least 131072 rows go to the network per call")
     parser.add_argument('--verbose', action='store_true', default=False, help="Set for verbose")
     parser.add_argument('--debug', action='store_true', default=False, help="Set when debugging")
     # engine options
