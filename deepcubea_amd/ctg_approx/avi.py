@@ -35,62 +35,69 @@ from ..updaters.updater import Updater, gbfs_test_dev
 from ..utils import data_utils, env_utils, nnet_utils
 
 
+# (flag, type | "flag", default | REQUIRED, help) — names, types and defaults are the reference's (avi.py:21-97; pinned by
+# tests/golden/cli_flags.json), `--seed` is the only addition
+REQUIRED = object()
+_OPTIONS = (
+    ("env", str, REQUIRED, "Environment"),
+    ("debug", "flag", False, ""),
+    ("lr", float, 0.001, "Initial learning rate"),
+    ("lr_d", float, 0.9999993, "Learning rate decay: lr * (lr_d ^ itr)"),
+    ("max_itrs", int, 1000000, "Maxmimum number of iterations"),
+    ("batch_size", int, 1000, "Batch size (global: split evenly over the ranks)"),
+    ("single_gpu_training", "flag", False, "accepted for compatibility: one process drives one GPU, more GPUs = more ranks"),
+    ("loss_thresh", float, 0.05, "the target network is replaced by the current one when the last loss is below this"),
+    ("states_per_update", int, 1000, "training states generated per update"),
+    ("epochs_per_update", int, 1, "passes over the generated states per update"),
+    ("num_update_procs", int, 1, "ignored: the update runs on the GPU"),
+    ("update_nnet_batch_size", int, 10000, "states per heuristic call during the update (memory only)"),
+    ("max_update_steps", int, 1, "GBFS steps used to add states to the training set (grows by one per update)"),
+    ("update_method", str, "GBFS", "GBFS (ASTAR updates are not provided)"),
+    ("eps_max", float, 0, "per-instance GBFS eps is uniform in [0, eps_max]"),
+    ("num_test", int, 10000, "Number of test states."),
+    ("back_max", int, REQUIRED, "Maximum number of backwards steps from goal"),
+    ("nnet_name", str, REQUIRED, "Name of neural network"),
+    ("update_num", int, 0, "Update number"),
+    ("save_dir", str, "saved_models", "Director to which to save model"),
+    ("seed", int, 0, "seed of the device state generator (shards are disjoint)"),
+)
+
+
 def build_parser() -> ArgumentParser:
-    p = ArgumentParser()
-    # avi.py:21-97 (same names, defaults and meaning)
-    p.add_argument('--env', type=str, required=True, help="Environment")
-    p.add_argument('--debug', action='store_true', default=False, help="")
-    p.add_argument('--lr', type=float, default=0.001, help="Initial learning rate")
-    p.add_argument('--lr_d', type=float, default=0.9999993, help="Learning rate decay: lr * (lr_d ^ itr)")
-    p.add_argument('--max_itrs', type=int, default=1000000, help="Maxmimum number of iterations")
-    p.add_argument('--batch_size', type=int, default=1000, help="Batch size")
-    p.add_argument('--single_gpu_training', action='store_true', default=False,
-                   help="accepted for compatibility (one process drives one GPU; use torch.distributed.run for more)")
-    p.add_argument('--loss_thresh', type=float, default=0.05,
-                   help="When the loss falls below this value, the target network is updated to the current network.")
-    p.add_argument('--states_per_update', type=int, default=1000,
-                   help="How many states to train on before checking if target network should be updated")
-    p.add_argument('--epochs_per_update', type=int, default=1, help="How many epochs to train for.")
-    p.add_argument('--num_update_procs', type=int, default=1, help="ignored: the update runs on the GPU")
-    p.add_argument('--update_nnet_batch_size', type=int, default=10000,
-                   help="States per heuristic call during the update (memory only).")
-    p.add_argument('--max_update_steps', type=int, default=1, help="GBFS steps when generating training states")
-    p.add_argument('--update_method', type=str, default="GBFS", help="GBFS (ASTAR updates are not provided)")
-    p.add_argument('--eps_max', type=float, default=0, help="per-instance GBFS eps is uniform in [0, eps_max]")
-    p.add_argument('--num_test', type=int, default=10000, help="Number of test states.")
-    p.add_argument('--back_max', type=int, required=True, help="Maximum number of backwards steps from goal")
-    p.add_argument('--nnet_name', type=str, required=True, help="Name of neural network")
-    p.add_argument('--update_num', type=int, default=0, help="Update number")
-    p.add_argument('--save_dir', type=str, default="saved_models", help="Director to which to save model")
-    p.add_argument('--seed', type=int, default=0, help="seed of the device state generator (shards are disjoint)")
-    return p
+    parser = ArgumentParser()
+    for name, kind, default, text in _OPTIONS:
+        if kind == "flag":
+            parser.add_argument("--" + name, action="store_true", default=default, help=text)
+        elif default is REQUIRED:
+            parser.add_argument("--" + name, type=kind, required=True, help=text)
+        else:
+            parser.add_argument("--" + name, type=kind, default=default, help=text)
+    return parser
 
 
 def parse_arguments(parser: ArgumentParser, argv=None, rank: int = 0) -> Dict[str, Any]:
-    """avi.py:99-118: derived directories, args.pkl."""
+    """Derived paths + args.pkl, as avi.py:99-118 leaves them: <save_dir>/<nnet_name>/{target,current}/, output.txt."""
     args = parser.parse_args(argv)
-    args_dict: Dict[str, Any] = vars(args)
-    model_dir = "%s/%s/" % (args_dict['save_dir'], args_dict['nnet_name'])
-    args_dict['targ_dir'] = "%s/%s/" % (model_dir, 'target')
-    args_dict['curr_dir'] = "%s/%s/" % (model_dir, 'current')
-    args_dict["output_save_loc"] = "%s/output.txt" % model_dir
+    cfg: Dict[str, Any] = vars(args)
+    root = "%s/%s/" % (cfg['save_dir'], cfg['nnet_name'])
+    cfg.update(targ_dir="%s/%s/" % (root, 'target'), curr_dir="%s/%s/" % (root, 'current'),
+               output_save_loc="%s/output.txt" % root)
     if rank == 0:
-        os.makedirs(args_dict['targ_dir'], exist_ok=True)
-        os.makedirs(args_dict['curr_dir'], exist_ok=True)
-        args_save_loc = "%s/args.pkl" % model_dir
-        print("Saving arguments to %s" % args_save_loc)
-        with open(args_save_loc, "wb") as f:
+        for d in (cfg['targ_dir'], cfg['curr_dir']):
+            os.makedirs(d, exist_ok=True)
+        where = "%s/args.pkl" % root
+        print("Saving arguments to %s" % where)
+        with open(where, "wb") as f:
             pickle.dump(args, f, protocol=-1)
-        print("Batch size: %i" % args_dict['batch_size'])
-    return args_dict
+        print("Batch size: %i" % cfg['batch_size'])
+    return cfg
 
 
 def copy_files(src_dir: str, dest_dir: str) -> None:
-    """avi.py:121-126."""
-    for file_name in os.listdir(src_dir):
-        full = os.path.join(src_dir, file_name)
-        if os.path.isfile(full):
-            shutil.copy(full, dest_dir)
+    """Plain files of src_dir -> dest_dir (the current -> target hand-over, avi.py:121-126)."""
+    for entry in os.scandir(src_dir):
+        if entry.is_file():
+            shutil.copy(entry.path, dest_dir)
 
 
 def load_nnet(nnet_dir: str, env) -> Tuple[nn.Module, int, int]:
