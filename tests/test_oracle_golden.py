@@ -301,3 +301,31 @@ def test_avi_update_restatement_vs_reference(golden):
     assert np.array_equal(sv, golden["avi_puzzle15_steps2_solved"])
     bk, _, _ = no.bellman("cube3", golden["cube3_synth64_in"], lambda s: no.heur_builtin(0, s))
     assert np.array_equal(bk, golden["avi_cube3_bellman_synth64_mod97"])
+
+
+def test_split_operand_layers_are_fp32_accurate_by_construction():
+    """The arithmetic behind the device's fp32 parity mode, restated on the host (oracle/np_oracle.py): three fp16 products
+    over split operands reproduce an fp32-class GEMM, and three bf16 planes reproduce fp32 weights (one-hot layer 1)."""
+    rng = np.random.default_rng(0)
+    x = np.maximum(rng.standard_normal((64, 1000)), 0).astype(np.float32) * 1.3   # post-ReLU activations
+    w = (rng.standard_normal((96, 1000)) * 0.03).astype(np.float32)
+    w[:8] *= 1.0e3
+    w[8:16] *= 1.0e-3                                                             # unit magnitudes spread over 1e6
+    ref = x.astype(np.float64) @ w.astype(np.float64).T
+    y3 = no.f16x3_linear(x, w)
+    y32 = (x @ w.T).astype(np.float64)                                             # a plain fp32 GEMM for comparison
+    colmax = np.abs(ref).max(axis=0)
+    e3 = (np.abs(y3 - ref) / colmax).max()
+    e32 = (np.abs(y32 - ref) / colmax).max()
+    assert e3 < 2e-6 and e3 < 8 * e32 + 1e-7, (e3, e32)
+    for planes, tol in ((1, 2.0 ** -8), (2, 2.0 ** -16), (3, 2.0 ** -23)):
+        ps = no.bf16_planes(w, planes)
+        assert all(np.all((p.view(np.uint32) & 0xFFFF) == 0) for p in ps)           # every plane is a bf16 number
+        assert (np.abs(sum(ps) - w) / np.abs(w)).max() <= tol
+    # one-hot rows times three planes == the fp32 weights' own row sums, to fp32 accuracy
+    idx = rng.integers(0, 6, size=(32, 54))
+    oh = no.onehot(idx.astype(np.uint8), 6).astype(np.float64)
+    w1 = (rng.standard_normal((40, 324)) * 0.2).astype(np.float32)
+    got = sum(oh @ p.astype(np.float64).T for p in no.bf16_planes(w1, 3))
+    want = oh @ w1.astype(np.float64).T
+    assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max()
