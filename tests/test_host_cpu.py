@@ -230,3 +230,28 @@ def test_cli_surfaces_match_the_reference_parsers():
             if (name, dest) != ("astar", "language"):
                 assert a.default == want["default"], (name, dest, a.default, want["default"])
     assert astar.build_parser().get_default("language") == "hip" and ref["astar"]["language"]["default"] == "python"
+
+
+def test_updater_shards_states_like_split_evenly(monkeypatch):
+    """Updater: rank r owns a contiguous slice of the update's states, sizes as misc_utils.split_evenly (misc_utils.py:29-36),
+    and its counter-RNG stream starts at the slice's first global index (no GPU needed for the bookkeeping)."""
+    from deepcubea_amd.search_methods import sharding
+    from deepcubea_amd.updaters.updater import Updater
+
+    class _Env:
+        pass
+
+    seen = []
+    for world, n in ((1, 10), (3, 10), (8, 50_000_003)):
+        tot, nxt = 0, 0
+        for rank in range(world):
+            monkeypatch.setattr(sharding, "world_info", lambda w=world, r=rank: (w, r))
+            u = Updater(_Env(), n, 30, None, 1)
+            assert u.index0 == nxt and u.local_n in (n // world, n // world + 1)
+            nxt += u.local_n
+            tot += u.local_n
+            seen.append(u.local_n)
+        assert tot == n
+    assert seen[1:4] == [4, 3, 3]
+    with pytest.raises(ValueError):
+        Updater(_Env(), 10, 30, None, 1, update_method="astar")
