@@ -1,23 +1,31 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the MI355X-native BWAS hot path (driver contract in the task statement).
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched under torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-Workloads (DESIGN.md §6):
-  astar   (default)  BASELINE.json configs[2] geometry — the config the metric "A* nodes expanded/sec on
-                     cube3, batch 20k" is quoted on: cube3 weighted A*, w=0.8, batch 20 000, one search
-                     instance per GPU on the device-resident engine.  One step = one full BWAS iteration:
-                     pop 20 000 by (cost, push order) -> expand 240 000 children (+is_solved, hash, node
-                     fields) -> heuristic -> cost -> CLOSED dedup -> push.  `value` is measured with the
-                     built-in hash-derived heuristic 10+5*u01(hash) (SURVEY §8d "engine-only"); the same JSON
-                     line carries `end_to_end_nnet`: the identical loop with the 14.7M-parameter ResNet
-                     heuristic evaluated on PyTorch-ROCm for all 240 000 children per step (synthetic
-                     weights — the reference's checkpoints are not in the mount), fp32 and bf16.
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (the driver) or
+directly — bench.py then re-executes itself under torch.distributed.run, one rank per GPU (rank r pinned to GPU r, the
+process group bound to that device).  `--gpus` must equal the number of ranks.
+
+Workloads (DESIGN.md §5):
+  astar   (default)  BASELINE.json configs[2] geometry — the config the metric "A* nodes expanded/sec on cube3, batch
+                     20k" is quoted on: cube3 weighted A*, w=0.8, batch 20 000, one search instance per GPU on the
+                     device-resident engine.  One step = one full BWAS iteration: pop 20 000 by (cost, push order) ->
+                     expand 240 000 children (+is_solved, hash, node fields) -> heuristic -> cost -> CLOSED dedup ->
+                     push.  `value` is measured with the built-in hash-derived heuristic 10+5*u01(hash) (SURVEY §8d
+                     "engine-only") over episodes of W untimed + K timed iterations on fresh test-set scrambles, repeated
+                     until >= 0.25 s were timed.  The same JSON line carries: `roofline` (dominant launch, timed by
+                     device-side stamps inside the replayed hipGraph), `roofline_iteration` (SURVEY §8(d) bytes x batch /
+                     ms_per_step), `engine_onehot_f32` (the same iteration with the fp32 one-hot rows fused into the
+                     expansion launch), `end_to_end_nnet` (the 14.7M-parameter ResNet heuristic in the loop; synthetic
+                     weights — the reference's checkpoints are not in the mount), `concurrent_instances`, `sharded_queue`
+                     (configs[3] in miniature: scrambles drawn from the shared work queue) and `cpu_baseline`.
   expand             BASELINE.json configs[1]: fused next_state + one-hot(f32) + is_solved + hash kernel on
                      1M synthetic cube3 states (one step = one launch over the 1M parents).
+  avi / train        SURVEY §8(f) rows: AVI update step (configs[4]) and the training step.
 
 Multi-GPU: the path shards per search instance — every rank runs its own replica on its own
-scramble, no collective on the data path; only the timing barrier uses RCCL.  scaling = weak.
+scrambles, no collective on the data path; only the timing barrier / reductions use RCCL.  scaling = weak.
 """
 from __future__ import annotations
 
@@ -34,12 +42,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (≈6.3 TB/s achievable)
-# SURVEY §8d algorithmic bytes per cube3 expansion with the fp32 fused one-hot:
-#   54 (parent read) + 12*54 (children u8) + 12*324*4 (one-hot f32) = 16 254 B
-CUBE3_EXPAND_BYTES_F32 = 54 + 12 * 54 + 12 * 324 * 4
-# engine expansion launch (no one-hot), per parent:
-#   54 parent row + 4 id + 12*(54 child row + 54 network-input row + 8 hash + 4 h + 4 g + 4 parent + 1 move + 1 solved)
-CUBE3_ENGINE_EXPAND_BYTES = 54 + 4 + 12 * (54 + 54 + 8 + 4 + 4 + 4 + 1 + 1)
+MIN_TIMED_S = 0.25     # the astar legs repeat their K-step region on fresh scrambles until this much time was timed
+STATE_DIM = {"cube3": 54, "puzzle15": 16, "puzzle24": 25, "puzzle35": 36, "puzzle48": 49}
 
 
 def synth_states(n: int, d: int, seed: int = 0) -> np.ndarray:
@@ -50,30 +54,60 @@ def synth_states(n: int, d: int, seed: int = 0) -> np.ndarray:
 _BACKEND = "nccl"
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` outside a launcher: re-exec under torch.distributed.run, one rank per GPU
+    (the reference pins a worker to its GPU the same way, one process each: nnet_utils.py:292-301)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def dist_setup(backend: str = "nccl"):
+    """One rank per GPU: rank r is pinned to device LOCAL_RANK before anything touches HIP, and the process group is
+    bound to that device (RCCL never has to guess it).  gloo lets several ranks share a device (CPU-side smoke tests)."""
     global _BACKEND
     _BACKEND = backend
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        # one rank per GPU (nccl = RCCL); gloo lets several ranks share a device for smoke tests
-        torch.cuda.set_device(local if backend == "nccl" else local % torch.cuda.device_count())
-        dist.init_process_group(backend, rank=rank, world_size=world)
-    else:
+        if backend == "nccl":
+            if local >= ndev:
+                raise SystemExit("bench.py: rank %d wants GPU %d but only %d are visible (one rank per GPU)" % (rank, local, ndev))
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            if ndev:
+                torch.cuda.set_device(local % ndev)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif ndev:
         torch.cuda.set_device(0)
     return world, rank, local
 
 
 def barrier(world: int):
-    torch.cuda.synchronize()
+    gpu = torch.cuda.is_available()
+    if gpu:
+        torch.cuda.synchronize()
     if world > 1:
         import torch.distributed as dist
-        dist.barrier()
-    torch.cuda.synchronize()
+        if _BACKEND == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
+    if gpu:
+        torch.cuda.synchronize()
 
 
 def reduce_ranks(x: float, world: int, op: str) -> float:
@@ -85,106 +119,238 @@ def reduce_ranks(x: float, world: int, op: str) -> float:
     return float(t.item())
 
 
-def pmc_traffic(kernel: str):
-    """HBM bytes per launch measured separately with rocprofv3 PMC passes (profiles/pmc_traffic.json), or None."""
+def gather_ranks(x: float, world: int):
+    if world == 1:
+        return [x]
+    import torch.distributed as dist
+    t = torch.tensor([x], dtype=torch.float64, device="cuda" if _BACKEND == "nccl" else "cpu")
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
+def pmc_traffic(kernel: str, env: str, B: int):
+    """HBM bytes per launch from the rocprofv3 PMC passes of THIS command (`tools/pmc_summary.py` writes
+    profiles/r02_pmc_traffic.json from `rocprofv3 --pmc ... -- python bench.py`): counters cannot be read from inside
+    the process, so the entry is matched on kernel, environment and batch size and otherwise left null."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        return d.get(kernel)
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
     except (OSError, ValueError):
         return None
+    if d.get("env") != env or d.get("batch_size") != B:
+        return None
+    return d.get("kernels", {}).get(kernel)
 
 
-def test_root(rank: int, env: str = "cube3") -> np.ndarray:
-    """Rank r searches scramble r of the shipped test set of `env` (data/<env>/test, kept as a fixture)."""
+def test_root(idx: int, env: str = "cube3") -> np.ndarray:
+    """Scramble `idx` of the shipped test set of `env` (data/<env>/test, kept as a fixture)."""
     g = np.load(os.path.join(ROOT, "tests", "golden", "golden.npz"))
     st = g[env + "_test_states"]
-    return np.ascontiguousarray(st[rank % st.shape[0]])
+    return np.ascontiguousarray(st[idx % st.shape[0]])
+
+
+def run_selftest(args, world, rank):
+    """No GPU work: exercises the launcher / rendezvous / timing-barrier / reduction plumbing and the JSON contract
+    (tests/test_bench_cpu.py runs it with 2 gloo ranks on the CPU box)."""
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    barrier(world)
+    wall = reduce_ranks(time.perf_counter() - t0, world, "max")
+    units = reduce_ranks(float(args.steps * (rank + 1)), world, "sum")
+    return {"value": units / wall, "ms_per_step": wall / args.steps * 1e3,
+            "config": {"workload": "selftest (no GPU work)", "parallelism": "x%d" % world},
+            "per_rank_value": gather_ranks(float(rank), world)}
 
 
 # --------------------------------------------------------------------------------------------------
 # workload: astar (configs[2] geometry, engine + heuristic)
 # --------------------------------------------------------------------------------------------------
-def run_astar(args, world, rank):
+def engine_bytes(env: str, B: int, onehot_bytes: int):
+    """Algorithmic bytes per launch of the iteration's kernels and SURVEY §8(d)'s per-expansion
+    figure for the whole iteration: n^2-free, each array the kernel must touch counted once."""
+    D = STATE_DIM[env]
+    A = 12 if env == "cube3" else 4
+    depth = 6 if env == "cube3" else D
+    M = B * A
+    per_child_expand = 2 * D + 8 + 4 + 4 + 4 + 1 + 1 + 1 + D * depth * onehot_bytes
+    return {
+        "expand": B * (D + 4 + 4) + M * per_child_expand,
+        # hash 8, own row D, slot compare-and-swap 16 + 8, chain hook 8, next/slot/v0/flags 13, representative's row
+        # for the ~15 % duplicates
+        "probe": M * (8 + D + 24 + 8 + 13 + 0.15 * D),
+        "commit": M * (1 + 4 + 4 + 1 + 4 + 1 + 0.85 * 16),
+        "per_expansion_8d": (D + A * D + A * D * depth * onehot_bytes) + A * 64,
+    }
+
+
+def run_astar_leg(args, world, rank, onehot_dtype, min_timed_s, profile_iters):
+    """Episodes of [reset on a fresh scramble, W untimed iterations, K timed iterations], repeated until min_timed_s of
+    timed region accumulated (a batch-20 000 iteration is ~0.1 ms: K alone would be a few milliseconds).  A real cube3
+    search lasts a few hundred iterations (results/cube3: <= 6.1e7 nodes), so episodes — not one endless search — are
+    the workload.  Every timed region is bracketed by barrier + synchronize on all ranks."""
     from deepcubea_amd import _lib
     from deepcubea_amd.search_methods.engine import BwasEngine
     B, w = args.batch_size, args.weight
     sem = _lib.SEM_CPP if args.semantics == "cpp" else _lib.SEM_PY
     hid = _lib.HEUR_HASHU01
-    total_iters = args.warmup + args.steps + args.profile_iters + 16
-    max_nodes = max(1 << 20, total_iters * B * 12 + (1 << 16))
     A = 12 if args.env == "cube3" else 4
-    max_nodes = max(1 << 20, total_iters * B * A + (1 << 16))
-    eng = BwasEngine(args.env, w, B, max_nodes=max_nodes, semantics=sem)
-    root = test_root(rank, args.env)
-    eng.reset(root)
-    if sem == _lib.SEM_PY:
-        eng.root_commit(_lib.heuristic_builtin(hid, torch.from_numpy(root[None].copy()).cuda()))
-    eng.run_builtin(hid, args.warmup, use_graph=not args.no_graph)
-    st0 = eng.status()
-    barrier(world)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    eng.run_builtin(hid, args.steps, use_graph=not args.no_graph)
-    e1.record()
-    barrier(world)
-    wall = time.perf_counter() - t0
-    st1 = eng.status()
-    assert not st1["failed"] and not st1["done"], "benchmark search ended early: %r" % (st1,)
-    expanded = st1["nodes_expanded"] - st0["nodes_expanded"]
-    assert st1["iterations"] - st0["iterations"] == args.steps
-    dev_ms = e0.elapsed_time(e1)
-    wall = reduce_ranks(wall, world, "max")
-    total_exp = reduce_ranks(float(expanded), world, "sum")
-    # per-kernel HIP-event timings of further iterations (same stream, eager, events between kernels)
-    prof = eng.profile_builtin(hid, args.profile_iters) if args.profile_iters > 0 else {}
-    st2 = eng.status()
-    dbg = eng.debug()
-    if args.debug:
-        for _ in range(12):
-            eng.run_builtin(hid, 1)
-            print("DEBUG", json.dumps(eng.debug()), file=sys.stderr)
-    res = {
-        "value": total_exp / wall,
-        "ms_per_step": wall / args.steps * 1e3,
-        "config": {"workload": "%s BWAS iteration on the device-resident engine, batch %d, weight %.2f, "
-                               "%s semantics, heuristic = built-in 10+5*u01(hash) (engine-only, SURVEY §8d); "
-                               "BASELINE configs[2] geometry" % (args.env, B, w, args.semantics),
-                   "env": args.env, "batch_size": B, "weight": w, "children_per_step": B * A, "semantics": args.semantics,
-                   "hipgraph": not args.no_graph, "parallelism": "one search instance per GPU x%d" % world,
-                   "open_size_end": st1["open_size"], "closed_size_end": st1["closed_size"],
-                   "nodes_generated_timed": st1["nodes_generated"] - st0["nodes_generated"],
-                   "device_ms_per_step": dev_ms / args.steps},
-    }
-    if prof:
-        # "refill" and "order" are groups of 3-4 kernels timed together; the dominant KERNEL is picked among the
-        # single-kernel phases (rocprofv3 per-kernel averages in profiles/ agree: k_probe)
-        single = {k: v for k, v in prof.items() if k not in ("refill", "order")}
-        dom = max(single, key=single.get)
-        # algorithmic bytes of the dominant kernel per launch (DESIGN.md §4)
-        n_front = dbg["front_n"] + B  # FRONT tier at the last profiled iteration (pops only scan FRONT)
-        Dn = 54 if args.env == "cube3" else {"puzzle15": 16, "puzzle24": 25, "puzzle35": 36, "puzzle48": 49}[args.env]
-        alg = {
-            "expand": (Dn + 4 + A * (2 * Dn + 22)) * B,
-            "sel_hist": 8.0 * n_front,
-            "sel_collect": 24.0 * n_front,
-            "probe": B * A * (8 + 16 + 2 * Dn + 8 + 8),
-            "decide": B * A * (16 + 4 + 4 + 4 + 1 + 4 + 8),
-            "commit": B * A * (1 + 8 + 12),
-        }
-        ach = alg.get(dom, 0.0) / (prof[dom] * 1e-3) / 1e9 if prof[dom] > 0 else 0.0
-        res["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "achieved": ach, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": pmc_traffic("k_" + dom) if args.env == "cube3" and B == 20000 else None,
-                           "bytes_per_launch": alg.get(dom, 0.0), "kernel_ms": prof[dom],
-                           "phase_ms": {k: round(v, 5) for k, v in prof.items()},
-                           "sum_phase_ms": sum(prof.values())}
+    fill = 8  # iterations a fresh search needs before every pop is a full batch (12^5 > 20 000)
+    warm = max(args.warmup, fill)
+    iters_cap = warm + args.steps + profile_iters + 24
+    max_nodes = max(1 << 20, iters_cap * B * A + (1 << 16))
+    eng = BwasEngine(args.env, w, B, max_nodes=max_nodes, semantics=sem, onehot_dtype=onehot_dtype)
+    graph = not args.no_graph
+    total_t, total_exp, total_gen, local_exp, episodes, dev_ms = 0.0, 0.0, 0.0, 0.0, 0, 0.0
+    st1 = None
+    while True:
+        root = test_root(rank + world * episodes, args.env)
+        eng.reset(root)
+        if sem == _lib.SEM_PY:
+            eng.root_commit(_lib.heuristic_builtin(hid, torch.from_numpy(root[None].copy()).cuda()))
+        eng.run_builtin(hid, warm, use_graph=graph)
+        st0 = eng.status()
+        barrier(world)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        eng.run_builtin(hid, args.steps, use_graph=graph)
+        e1.record()
+        barrier(world)
+        wall = time.perf_counter() - t0
+        st1 = eng.status()
+        assert not st1["failed"] and not st1["done"], "benchmark search ended early: %r" % (st1,)
+        assert st1["iterations"] - st0["iterations"] == args.steps
+        total_t += reduce_ranks(wall, world, "max")
+        total_exp += reduce_ranks(float(st1["nodes_expanded"] - st0["nodes_expanded"]), world, "sum")
+        total_gen += float(st1["nodes_generated"] - st0["nodes_generated"])
+        local_exp += float(st1["nodes_expanded"] - st0["nodes_expanded"])
+        dev_ms += e0.elapsed_time(e1)
+        episodes += 1
+        # every rank takes the same decision (total_t is already the max over ranks)
+        if total_t >= min_timed_s or episodes >= 400:
+            break
+    res = {"value": total_exp / total_t, "ms_per_step": total_t / (episodes * args.steps) * 1e3, "episodes": episodes,
+           "timed_s": total_t, "device_ms_per_step": dev_ms / (episodes * args.steps), "local_value": local_exp / total_t,
+           "open_size_end": st1["open_size"], "closed_size_end": st1["closed_size"],
+           "nodes_generated_timed_rank0": total_gen}
+    if profile_iters > 0:
+        # the same graph replays, one at a time, with the device-side stamps switched on (dca.h: profile_builtin)
+        prof = eng.profile_builtin(hid, profile_iters, use_graph=graph)
+        res["profile"] = prof
+        res["front_n"] = eng.debug()["front_n"]
     eng.close()
     del eng
     torch.cuda.empty_cache()
-    if args.concurrent > 1 and args.env == "cube3":
-        res["concurrent_instances"] = run_astar_concurrent(args, world, rank, sem, hid)
     return res
+
+
+def run_astar(args, world, rank):
+    B, w = args.batch_size, args.weight
+    A = 12 if args.env == "cube3" else 4
+    leg = run_astar_leg(args, world, rank, None, MIN_TIMED_S, args.profile_iters)
+    per_rank = gather_ranks(leg["local_value"], world)
+    res = {
+        "value": leg["value"],
+        "ms_per_step": leg["ms_per_step"],
+        "config": {"workload": "%s BWAS iteration on the device-resident engine, batch %d, weight %.2f, "
+                               "%s semantics, heuristic = built-in 10+5*u01(hash) (engine-only, SURVEY §8d), no one-hot "
+                               "rows (see engine_onehot_f32 for the north star's fused one-hot); BASELINE configs[2] "
+                               "geometry; %d episode(s) of %d timed steps on fresh test-set scrambles"
+                               % (args.env, B, w, args.semantics, leg["episodes"], args.steps),
+                   "env": args.env, "batch_size": B, "weight": w, "children_per_step": B * A, "semantics": args.semantics,
+                   "hipgraph": not args.no_graph, "parallelism": "one search instance per GPU x%d" % world,
+                   "episodes": leg["episodes"], "timed_s": leg["timed_s"],
+                   "open_size_end": leg["open_size_end"], "closed_size_end": leg["closed_size_end"],
+                   "device_ms_per_step": leg["device_ms_per_step"]},
+    }
+    alg = engine_bytes(args.env, B, 0)
+    if "profile" in leg:
+        span, gap = leg["profile"]["span_ms"], leg["profile"]["gap_ms"]
+        n_front = leg["front_n"] + B
+        alg_k = dict(alg, sel_hist=8.0 * n_front, sel_collect=24.0 * n_front)
+        cand = {k: v for k, v in span.items() if k in alg_k and not k.startswith("per_")}
+        dom = max(cand, key=cand.get)
+        ach = alg_k[dom] / (span[dom] * 1e-3) / 1e9
+        res["roofline"] = {
+            "bound": "hbm", "kernel": "k_" + dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("k_" + dom, args.env, B),
+            "bytes_per_launch": alg_k[dom], "kernel_ms": span[dom],
+            "timing": "device wall-clock stamps written by every workgroup of the launch INSIDE the replayed hipGraph "
+                      "(dca_engine_profile_builtin; max end - min start over %d replays); HIP events bracket the "
+                      "K-step regions (device_ms_per_step)" % args.profile_iters,
+            "launch_span_ms": {k: round(v, 5) for k, v in span.items()},
+            "launch_gap_ms": {k: round(v, 5) for k, v in gap.items()},
+            "sum_span_ms": sum(span.values()), "sum_gap_ms": sum(gap.values()),
+            "launches_per_iteration": len([k for k in span if not k.startswith("refill")]),
+        }
+    it_bytes = alg["per_expansion_8d"] * B
+    res["roofline_iteration"] = {"bound": "hbm", "what": "whole BWAS iteration: SURVEY §8(d) bytes per expansion "
+                                 "(%d B, no one-hot) x batch / ms_per_step" % alg["per_expansion_8d"],
+                                 "achieved": it_bytes / (leg["ms_per_step"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": it_bytes / (leg["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    res["per_rank_value"] = per_rank
+    if args.onehot_leg:
+        oh = run_astar_leg(args, world, rank, torch.float32, 0.1, min(args.profile_iters, 8))
+        algo = engine_bytes(args.env, B, 4)
+        ob = algo["per_expansion_8d"] * B
+        leg_o = {"value": oh["value"], "unit": "nodes expanded/s", "ms_per_step": oh["ms_per_step"], "episodes": oh["episodes"],
+                 "what": "same iteration with the fp32 one-hot rows of all %d children written by the expansion launch "
+                         "(north star: one-hot fused into the same launch)" % (B * A),
+                 "roofline_iteration": {"bytes_per_expansion_8d": algo["per_expansion_8d"],
+                                        "achieved": ob / (oh["ms_per_step"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": ob / (oh["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        if "profile" in oh and "expand" in oh["profile"]["span_ms"]:
+            sp = oh["profile"]["span_ms"]["expand"]
+            leg_o["roofline_expand"] = {"kernel": "k_expand<cube3,onehot f32>", "bytes_per_launch": algo["expand"],
+                                        "kernel_ms": sp, "achieved": algo["expand"] / (sp * 1e-3) / 1e9,
+                                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": algo["expand"] / (sp * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        res["engine_onehot_f32"] = leg_o
+    if args.concurrent > 1 and args.env == "cube3":
+        from deepcubea_amd import _lib
+        sem = _lib.SEM_CPP if args.semantics == "cpp" else _lib.SEM_PY
+        res["concurrent_instances"] = run_astar_concurrent(args, world, rank, sem, _lib.HEUR_HASHU01)
+    if args.queue_states > 0:
+        res["sharded_queue"] = run_sharded_queue(args, world, rank)
+    return res
+
+
+def run_sharded_queue(args, world, rank):
+    """BASELINE configs[3] in miniature: `--queue-states` x world test-set scrambles drawn from the shared work queue
+    (search_methods/sharding.WorkQueue: an atomic counter in the process group's store, no collective), each searched
+    for a fixed budget of iterations with the built-in heuristic.  Measures the sharding path the CLI uses at N > 1."""
+    from deepcubea_amd import _lib
+    from deepcubea_amd.search_methods import sharding
+    from deepcubea_amd.search_methods.engine import BwasEngine
+    B, w = args.batch_size, args.weight
+    n_states = args.queue_states * world
+    iters = args.queue_iters
+    eng = BwasEngine("cube3", w, B, max_nodes=max(1 << 20, (iters + 8) * B * 12 + (1 << 16)))
+    queue = sharding.WorkQueue(n_states, world, rank, key="dca_bench_queue")
+    barrier(world)
+    t0 = time.perf_counter()
+    mine, expanded = 0, 0
+    while True:
+        nxt = queue.next(1)
+        if not nxt:
+            break
+        root = test_root(nxt[0])
+        eng.reset(root)
+        eng.root_commit(_lib.heuristic_builtin(_lib.HEUR_HASHU01, torch.from_numpy(root[None].copy()).cuda()))
+        eng.run_builtin(_lib.HEUR_HASHU01, iters, use_graph=not args.no_graph)
+        expanded += eng.status()["nodes_expanded"]
+        mine += 1
+    barrier(world)
+    wall = reduce_ranks(time.perf_counter() - t0, world, "max")
+    total = reduce_ranks(float(expanded), world, "sum")
+    counts = gather_ranks(float(mine), world)
+    eng.close()
+    torch.cuda.empty_cache()
+    return {"value": total / wall, "unit": "nodes expanded/s", "states": n_states, "iterations_per_state": iters,
+            "states_per_rank": counts, "seconds": wall,
+            "how": "per-instance sharding through the shared work queue, resets and ramp-up included"}
 
 
 def run_astar_concurrent(args, world, rank, sem, hid):
@@ -194,7 +360,7 @@ def run_astar_concurrent(args, world, rank, sem, hid):
     from deepcubea_amd import _lib
     from deepcubea_amd.search_methods.engine import BwasEngine
     k, B, w = args.concurrent, args.batch_size, args.weight
-    steps, warm = args.steps, args.warmup
+    steps, warm = args.steps, max(args.warmup, 8)
     eng = BwasEngine("cube3", w, B, max_nodes=max(1 << 20, (steps + warm + 8) * B * 12 + (1 << 16)), semantics=sem,
                      num_instances=k)
     for i in range(k):
@@ -450,7 +616,7 @@ def run_expand(args, world, rank):
                    "onehot": args.onehot, "parallelism": "replica-per-gpu x%d" % world},
         "roofline": {"bound": "hbm", "kernel": "expand_fused_kernel<cube3,%s>" % args.onehot, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic("expand_fused_kernel<cube3,f32>") if (n == 1_000_000 and esz == 4) else None,
+                     "traffic": pmc_traffic("expand_fused_kernel<cube3,f32>", "cube3", n) if esz == 4 else None,
                      "bytes_per_launch": alg * n, "kernel_ms": kern_ms},
     }
 
@@ -483,7 +649,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="astar", choices=["astar", "expand", "avi", "train"])
+    ap.add_argument("--workload", default="astar", choices=["astar", "expand", "avi", "train", "selftest"])
     ap.add_argument("--nnet_dtype", default="fp32", choices=["fp32", "bf16"], help="avi: heuristic precision")
     ap.add_argument("--env", default="cube3", choices=["cube3", "puzzle15", "puzzle24", "puzzle35", "puzzle48"],
                     help="astar: environment of the engine-only leg (nnet / concurrency legs are cube3)")
@@ -491,27 +657,36 @@ def main():
     ap.add_argument("--weight", type=float, default=0.8)
     ap.add_argument("--semantics", default="py", choices=["py", "cpp"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--profile-iters", type=int, default=20, help="astar: extra per-kernel-timed iterations")
+    ap.add_argument("--profile-iters", type=int, default=20, help="astar: extra iterations replayed with the device-side profile on")
     ap.add_argument("--nnet-steps", type=int, default=4, help="astar: timed steps of the ResNet-heuristic leg (0=skip)")
     ap.add_argument("--nnet_batch_size", type=int, default=245760, help="rows per heuristic call (whole astar batch at once)")
     ap.add_argument("--train_batch", type=int, default=10000, help="train: examples per GPU per step")
     ap.add_argument("--n", type=int, default=1_000_000, help="expand: synthetic states per launch")
     ap.add_argument("--onehot", default="f32", choices=["f32", "bf16", "f16"], help="expand: one-hot element type")
+    ap.add_argument("--no-onehot-leg", dest="onehot_leg", action="store_false",
+                    help="astar: skip the engine leg with the fused fp32 one-hot rows")
     ap.add_argument("--concurrent", type=int, default=4, help="astar: also time k concurrent instances per GPU (0/1 = skip)")
+    ap.add_argument("--queue-states", type=int, default=4,
+                    help="astar: scrambles per rank drawn from the shared work queue in the sharded leg (0 = skip)")
+    ap.add_argument("--queue-iters", type=int, default=64, help="astar: iteration budget per scramble of the sharded leg")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--debug", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))  # one rank per GPU under torch.distributed.run
     if args.steps is None:
-        args.steps = {"astar": 200, "expand": 20, "avi": 3, "train": 30}[args.workload]
+        args.steps = {"astar": 200, "expand": 20, "avi": 3, "train": 30, "selftest": 3}[args.workload]
     if args.warmup is None:
-        args.warmup = {"astar": 10, "expand": 3, "avi": 1, "train": 5}[args.workload]
+        args.warmup = {"astar": 10, "expand": 3, "avi": 1, "train": 5, "selftest": 0}[args.workload]
     world, rank, local = dist_setup(args.dist_backend)
-    res = {"astar": run_astar, "expand": run_expand, "avi": run_avi, "train": run_train}[args.workload](args, world, rank)
+    if world != max(args.gpus, 1):
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    res = {"astar": run_astar, "expand": run_expand, "avi": run_avi, "train": run_train,
+           "selftest": run_selftest}[args.workload](args, world, rank)
     line = {
         "metric": {"astar": "A* nodes expanded/sec on %s, batch 20k" % args.env, "expand": "A* nodes expanded/sec on cube3",
                    "avi": "AVI update-step training states generated/sec on %s" % args.env,
-                   "train": "cost-to-go network training samples/sec on cube3"}[args.workload],
+                   "train": "cost-to-go network training samples/sec on cube3", "selftest": "selftest units/sec"}[args.workload],
         "value": res["value"],
         "unit": {"avi": "states/s", "train": "samples/s"}.get(args.workload, "nodes expanded/s"),
         "n_gpus": world,
@@ -525,14 +700,12 @@ def main():
         "data": "synthetic",
         "config": res["config"],
     }
-    if "roofline" in res:
-        line["roofline"] = res["roofline"]
-    if "concurrent_instances" in res:
-        line["concurrent_instances"] = res["concurrent_instances"]
+    for k in ("roofline", "roofline_iteration", "per_rank_value", "engine_onehot_f32", "concurrent_instances", "sharded_queue"):
+        if k in res:
+            line[k] = res[k]
     if args.workload == "astar" and args.nnet_steps > 0:
         line["end_to_end_nnet"] = {"fp32": run_astar_nnet(args, world, rank, "fp32"),
                                    "bf16": run_astar_nnet(args, world, rank, "bf16"),
-                                   "fp16": run_astar_nnet(args, world, rank, "fp16"),
                                    "fp32_eval_all_children": run_astar_nnet(args, world, rank, "fp32", True)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("astar", "expand"):
         if args.workload == "expand":

@@ -15,20 +15,26 @@
 //               bytes (exact key equality, like State.__eq__ / NodePointerEq).
 //   OPEN        (cost key u64 = order-preserving bits of the f64 cost, node id u32) arrays in two tiers: FRONT
 //               (entries with key <= T, ping-pong buffers) and BACK (the rest, append-only with tombstones).
-//               pop = exact top-B of FRONT by (cost, id): 2048-bin histogram -> threshold bin -> the batch plus
-//               the rest of the threshold bin are ordered through arithmetic sub-bins and the overshoot goes back;
-//               a threshold bin too large for the ordering buffers (massive cost ties) is refined exactly on the
-//               96-bit (key,id) composite instead.  FRONT is refilled from / spilled to BACK with hysteresis, so an
-//               iteration costs O(|FRONT| + children), independent of |OPEN|.
+//               pop = exact top-B of FRONT by (cost, id): 2048-bin histogram -> threshold bin -> every entry at or
+//               below the threshold bin is moved, grouped by bin, into a scratch array; one workgroup per bin then
+//               orders its bin exactly on the 96-bit (key,id) composite (bitonic network in LDS; a bin too large for
+//               LDS — massive cost ties — is first cut down by radix refinement on the composite and ordered through
+//               arithmetic sub-bins of its own exact range) and hands the overshoot of the threshold bin back.
+//               FRONT is refilled from / spilled to BACK with hysteresis, so an iteration costs
+//               O(|FRONT| + children), independent of |OPEN|.
 //
-// One BWAS iteration = pop -> expand -> heuristic -> dedup -> push, all stream-ordered, no host round trip: counts
-// live in a device control block (hot counters on their own cache lines) and every kernel sizes itself from it.
-// One engine steps K independent instances at once: every kernel takes the device array of instance descriptors
-// and picks its instance with blockIdx.y.
+// One BWAS iteration = pop -> expand -> heuristic -> dedup -> push in SEVEN launches (hist, scan, collect, rank,
+// expand, probe, commit), all stream-ordered, no host round trip: counts live in a device control block (hot counters
+// on their own cache lines) and every kernel sizes itself from it.  The per-iteration batch geometry is double
+// buffered by iteration parity (IterState), so the expansion launch itself closes the pop (no single-thread kernel
+// in between).  One engine steps K independent instances at once: every kernel takes the device array of instance
+// descriptors and picks its instance with blockIdx.y.
 //
 // Sequential-order dedup, done in parallel: children of one batch that hit the same
 // CLOSED slot are chained through the slot's `head`; child j is kept iff g_j < v0 (the slot's value
-// before the batch) and no earlier chain member has g <= g_j — exactly astar.py:78-90 / cpp:244-265.
+// before the batch, recorded by the probe) and no earlier chain member has g <= g_j — exactly astar.py:78-90 /
+// cpp:244-265.  A child whose chain has a single member (the common case, flagged by the probe) decides from its
+// own registers inside the push kernel.
 #include <string.h>
 
 #include <new>
@@ -40,6 +46,9 @@ namespace dca {
 
 constexpr int NBIN = 2048;            // radix-select fan-out per level
 constexpr int kScanBlocks = 256;      // grid of the OPEN scans: few fat blocks (cheap when they early-exit)
+constexpr int kRankBlocks = 256;      // k_rank: one 1024-thread workgroup per CU, the bins to order strided over them
+constexpr int kSortCap = 8192;        // entries one workgroup orders inside LDS (96 KB of (key,id) pairs)
+constexpr int kStash = 3072;          // per-workgroup LDS stash of k_sel_collect (entries at or below the threshold bin)
 constexpr uint32_t NIL = 0xFFFFFFFFu;
 constexpr uint64_t EMPTY = ~0ull;
 constexpr uint32_t GINF = 0xFFFFFFFFu;
@@ -63,34 +72,39 @@ struct alignas(128) Rng {
     uint64_t kmin, kmax;
     uint64_t pad[14];
 };
+// What one iteration hands to the next, double buffered by iteration parity: kernels up to and including the
+// expansion read S[iters & 1]; workgroup 0 of the expansion writes S[(iters + 1) & 1] (nobody reads that copy during
+// the launch), the dedup / push kernels of the same iteration read it, and the push kernel's last workgroup makes it
+// current by incrementing `iters`.
+struct IterState {
+    uint32_t pool_n;        // node ids handed out
+    uint32_t cur_f;         // live FRONT buffer (0/1)
+    uint32_t npop, m, base; // batch of the iteration that produced this state
+    uint32_t best_id;       // cpp: cheapest solved node popped so far
+    int32_t has_best;
+    float best_cost;
+};
 struct Ctl {
-    // ---- read-mostly parameters, written by single-thread / single-workgroup kernels ----------
-    int32_t done, failed, stop_after, skip;
+    // ---- read-mostly parameters, written by single-thread / single-workgroup code ----------------
+    int32_t done, failed, stop_after, pad0;
     int64_t iters, gen, expanded;
-    uint32_t pool_n;
+    IterState S[2];
     // OPEN is two tiers of (key,id) arrays.  FRONT (buffers 0/1, ping-pong) holds every entry with
-    // key <= T, BACK (buffer 2) the rest; pops only ever look at FRONT, so an iteration costs
+    // key <= T, BACK (buffer 2/3) the rest; pops only ever look at FRONT, so an iteration costs
     // O(|FRONT| + children), independent of |OPEN|.
-    uint32_t cur_f, cur_b;  // live FRONT buffer (0/1) and the BACK buffer (2)
+    uint32_t cur_b;         // the BACK buffer (2/3)
     uint64_t T;             // tier threshold key (inclusive upper bound of FRONT)
     uint32_t refill, compact, r_bstar, spill_bin;
     uint64_t r_kmin;
     uint32_t r_shift;
     // selection
-    uint32_t want, bstar, sel_less, sel_r, shift;
-    uint32_t superset, n_ord;  // superset: the whole threshold bin is ordered too and the overshoot goes back to FRONT
-    uint32_t nb2;              // number of ordering buckets this iteration
+    uint32_t want, bstar, shift;
     uint64_t sel_kmin;
-    // batch
-    uint32_t npop, m, base;
     // goals
     uint32_t goal_id;
-    int32_t has_best;
-    float best_cost;
-    uint32_t best_id;
     // ---- hot words -----------------------------------------------------------------------------
     Cnt open_n[4];   // physical entries per OPEN buffer (0/1 FRONT ping-pong, 2/3 BACK + its compaction target)
-    Cnt cand_n, sel_fill, closed_n, back_dead, ticket_a, ticket_b;
+    Cnt closed_n, back_dead, ticket_a;
     Rng rng[4];      // running key range per OPEN buffer
     alignas(128) unsigned long long goal_best;  // PY: min over solved popped of (g << 32 | pop rank)
     alignas(128) uint32_t first_solved;         // CPP: smallest pop rank holding a solved node
@@ -113,6 +127,13 @@ __device__ __forceinline__ bool pair_less(uint64_t ka, uint32_t ia, uint64_t kb,
     return ka < kb || (ka == kb && ia < ib);
 }
 
+// launch slots of the device-side profile (dca_engine_profile_builtin)
+enum {
+    P_REFILL_HIST = 0, P_REFILL_SCAN, P_REFILL_MOVE, P_SEL_HIST, P_SEL_SCAN, P_SEL_COLLECT, P_RANK, P_EXPAND, P_PROBE,
+    P_DECIDE, P_PACK, P_COMMIT, P_COUNT
+};
+constexpr int kProfSlots = 1024;
+
 struct Eng {
     int env, dim, D, A, B, sem, oh_dtype, depth;
     double w;
@@ -126,25 +147,28 @@ struct Eng {
     Slot* tab;
     uint64_t* open_key[4];
     uint32_t* open_id[4];
-    uint32_t f_keep, f_max, ord_cap;  // FRONT hysteresis: refill/spill down to ~f_keep, spill when above f_max
-    uint32_t *hist, *sub_base;
+    uint32_t f_keep, f_max;  // FRONT hysteresis: refill/spill down to ~f_keep, spill when above f_max
+    uint32_t *hist, *pre, *fill;  // selection histogram, its exclusive prefix [NBIN+1], per-bin fill of the scratch array
     uint64_t* part;  // [4][kScanBlocks] per-block key ranges of k_sel_collect (survivor min/max, spill min/max)
-    uint8_t* sub_lg;
-    uint32_t nb2_cap;
-    uint64_t* cand_key;
-    uint32_t* cand_id;
-    uint8_t* cand_st;
-    uint64_t *tmp_key, *pop_key, *ord_key, *spl_key;
-    uint32_t *tmp_id, *pop_id, *ord_id, *spl_id, *ord_b, *ord_s, *ord_pb, *bcnt, *bpre;
+    // scratch of the pop: every FRONT entry at or below the threshold bin, grouped by bin (bin f occupies
+    // [pre[f], pre[f+1])), and — only for bins too large for LDS — the single-workgroup sub-bin ordering
+    uint64_t* tmp_key;
+    uint32_t* tmp_id;
+    uint8_t* tmp_st;
+    uint64_t* ord_key;
+    uint32_t *ord_id, *ord_b, *ord_s, *ord_pb, *bcnt, *bpre;
+    uint64_t* pop_key;   // the batch in pop order
+    uint32_t *pop_id, *pop_g;
     uint64_t* child_hash;
-    uint32_t *child_slot, *child_next;
-    uint8_t* child_flags;
+    uint32_t *child_slot, *child_next, *child_v0;
+    uint8_t *child_flags, *child_multi;
     float* child_h;
     uint8_t* nnet_in;
     uint8_t* onehot;
     uint8_t* root_nnet;
     int32_t* d_moves;
     Ctl* ctl;
+    unsigned long long* prof;  // [P_COUNT][kProfSlots][2] device wall-clock stamps (min start, max end) or null
     // dedup-first ("packed") stepping: only the children that survive the CLOSED check reach the heuristic
     uint32_t* kept_pos;   // [M] row of child j in the packed batch (NIL = dropped)
     uint32_t* pk_n;       // rows packed this iteration, shared by every instance of the engine
@@ -154,6 +178,29 @@ struct Eng {
     const float* pk_h;    // [K*M] heuristic of the packed rows (written by the caller between the two halves)
     uint32_t pk_stride, inst;
     int pk_dtype;
+};
+
+__device__ __forceinline__ const IterState& st_cur(const Ctl* c) { return c->S[c->iters & 1]; }
+__device__ __forceinline__ const IterState& st_next(const Ctl* c) { return c->S[(c->iters + 1) & 1]; }
+
+// Device-side profile: thread 0 of every workgroup (instance 0 only) folds its wall-clock start / end into the
+// launch's slot, so the host can read each launch's busy span and the gap to the next one INSIDE a replayed hipGraph.
+// Off (prof == nullptr) it costs one scalar compare.
+struct Stamp {
+    unsigned long long* p;
+    unsigned long long t0;
+    __device__ __forceinline__ Stamp(const Eng& E, int kid) : p(nullptr), t0(0) {
+        if (E.prof != nullptr && threadIdx.x == 0 && blockIdx.y == 0) {
+            p = E.prof + ((size_t)kid * kProfSlots + (blockIdx.x & (kProfSlots - 1))) * 2;
+            t0 = wall_clock64();
+        }
+    }
+    __device__ __forceinline__ ~Stamp() {
+        if (p) {
+            atomicMin(p, t0);
+            atomicMax(p + 1, (unsigned long long)wall_clock64());
+        }
+    }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -363,14 +410,16 @@ __global__ void k_reset(Eng E) {
     E.parent[0] = NIL;
     E.move[0] = 0xFF;
     E.solved[0] = ok ? 1 : 0;
-    c->pool_n = 1;
+    for (int p = 0; p < 2; p++) {
+        c->S[p].pool_n = 1;
+        c->S[p].cur_f = 0;
+    }
     c->goal_best = ~0ull;
     c->first_solved = NIL;
     for (int b = 0; b < 4; b++) {
         c->rng[b].kmin = ~0ull;
         c->rng[b].kmax = 0;
     }
-    c->cur_f = 0;
     c->cur_b = 2;
     c->T = ~0ull;  // everything is FRONT until the first spill
     if (E.sem == DCA_SEM_CPP) {
@@ -391,12 +440,12 @@ __global__ void k_reset(Eng E) {
 __global__ void k_root_commit(Eng E, const float* h_root) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Ctl* c = E.ctl;
-    if (E.sem != DCA_SEM_PY || c->open_n[c->cur_f].v != 0) return;
+    if (E.sem != DCA_SEM_PY || c->open_n[st_cur(c).cur_f].v != 0) return;
     // astar.py:246-249,196: cost = w*0.0 + max(h,0)*!solved   (float64)
     double hv = fmax((double)h_root[0], 0.0);
     double cost = __dadd_rn(__dmul_rn(E.w, 0.0), __dmul_rn(hv, E.solved[0] ? 0.0 : 1.0));
     uint64_t key = key_of_cost(cost);
-    uint32_t b = c->cur_f;
+    uint32_t b = st_cur(c).cur_f;
     E.open_key[b][0] = key;
     E.open_id[b][0] = 0;
     c->open_n[b].v = 1;
@@ -418,7 +467,7 @@ __device__ __forceinline__ uint32_t front_keep(const Eng& E) {
 }
 __device__ __forceinline__ bool need_refill(const Eng& E, const Ctl* c) {
     return c->open_n[c->cur_b].v != c->back_dead.v &&
-           c->open_n[c->cur_f].v < (uint32_t)(kRefillPeriod + 1) * (uint32_t)E.B;
+           c->open_n[st_cur(c).cur_f].v < (uint32_t)(kRefillPeriod + 1) * (uint32_t)E.B;
 }
 constexpr uint64_t DEAD = ~0ull;  // tombstone key of a BACK entry that moved to FRONT
 
@@ -426,6 +475,7 @@ __global__ __launch_bounds__(256) void k_refill_hist(const Eng* __restrict__ eng
     const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done || !need_refill(E, c)) return;
+    Stamp stamp(E, P_REFILL_HIST);
     __shared__ uint32_t lh[NBIN];
     for (int i = threadIdx.x; i < NBIN; i += 256) lh[i] = 0;
     __syncthreads();
@@ -477,6 +527,7 @@ __global__ __launch_bounds__(1024) void k_refill_scan(const Eng* __restrict__ en
     const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
+    Stamp stamp(E, P_REFILL_SCAN);
     if (!need_refill(E, c)) {
         if (threadIdx.x == 0) c->refill = 0;
         return;
@@ -521,8 +572,9 @@ __global__ __launch_bounds__(256) void k_refill_move(const Eng* __restrict__ eng
     const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done || !c->refill) return;
+    Stamp stamp(E, P_REFILL_MOVE);
     __shared__ uint32_t sh[2 * 4 + 2];
-    const uint32_t sb = c->cur_b, fb = c->cur_f, db = sb ^ 1;  // BACK buffers are 2 and 3
+    const uint32_t sb = c->cur_b, fb = st_cur(c).cur_f, db = sb ^ 1;  // BACK buffers are 2 and 3
     const bool compact = c->compact != 0;  // also squeeze the tombstones out into the other BACK buffer
     const uint32_t n = c->open_n[sb].v;
     const uint64_t kmin = c->r_kmin;
@@ -585,10 +637,11 @@ __global__ __launch_bounds__(256) void k_sel_hist(const Eng* __restrict__ engs) 
     const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
+    Stamp stamp(E, P_SEL_HIST);
     __shared__ uint32_t lh[NBIN];
     for (int i = threadIdx.x; i < NBIN; i += 256) lh[i] = 0;
     __syncthreads();
-    const uint32_t b = c->cur_f, n = c->open_n[b].v;
+    const uint32_t b = st_cur(c).cur_f, n = c->open_n[b].v;
     const uint64_t kmin = c->rng[b].kmin;
     const uint32_t shift = select_shift(kmin, c->rng[b].kmax);
     const uint64_t* __restrict__ keys = E.open_key[b];
@@ -618,9 +671,10 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs)
     const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
+    Stamp stamp(E, P_SEL_SCAN);
     __shared__ uint32_t pre[NBIN + 1];
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t s_spill;
+    __shared__ uint32_t s_spill, s_bstar;
     const int t = threadIdx.x;
     if (t == 0) {
         if (c->refill && c->compact) {  // the compacted copy becomes BACK
@@ -630,86 +684,32 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs)
         }
         c->refill = 0;
         s_spill = NBIN;  // no spill
+        s_bstar = 0;
     }
     scan_bins(E, pre, wsum);
-    const uint32_t cb = c->cur_f, n = c->open_n[cb].v;
+    const uint32_t cb = st_cur(c).cur_f, n = c->open_n[cb].v;
     const uint32_t want = n < (uint32_t)E.B ? n : (uint32_t)E.B;
-    // threshold bin: first bin with pre[b] < want <= pre[b+1]
     for (int k = 0; k < 2; k++) {
         int bin = 2 * t + k;
-        if (pre[bin] < want && want <= pre[bin + 1]) {
-            c->bstar = (uint32_t)bin;
-            c->sel_less = pre[bin];
-            c->sel_r = want - pre[bin];
-            // normal case: order the whole threshold bin with the batch and hand the overshoot back to
-            // FRONT (k_ord_rank); only a bin too big for the ordering buffers takes the exact
-            // candidate-refinement path (k_sel_cand)
-            const bool sup = pre[bin + 1] <= E.ord_cap;
-            c->superset = sup ? 1u : 0u;
-            c->n_ord = sup ? pre[bin + 1] : want;
-        }
+        // threshold bin: first bin with pre[b] < want <= pre[b+1].  Everything at or below it is handed to k_rank
+        // grouped by bin (E.pre gives every bin its slice of the scratch array); the overshoot of the threshold
+        // bin comes back to FRONT from there.
+        if (pre[bin] < want && want <= pre[bin + 1]) s_bstar = (uint32_t)bin;
         // spill: FRONT grew past f_max -> keep the bins that hold the batch plus ~f_keep more
         if (n > E.f_max) {
             const uint32_t keepn = want + front_keep(E);
             if (pre[bin] < keepn && keepn <= pre[bin + 1]) s_spill = (uint32_t)bin;
         }
+        E.pre[bin] = pre[bin];
+        E.fill[bin] = 0;
     }
-    __syncthreads();
-    {
-        // ordering layout: coarse bin f <= bstar is cut into 2^lg uniform sub-bins (~8 entries each; inside
-        // one coarse bin the keys are close to uniform, whatever the global distribution looks like), so
-        // bucket(key) is pure arithmetic and k_ord_rank only ever ranks inside a handful of entries
-        const uint32_t bstar = c->bstar;
-        const uint32_t shiftv = select_shift(c->rng[cb].kmin, c->rng[cb].kmax);
-        __shared__ uint32_t nsub[NBIN];
-        __shared__ uint32_t wsum2[16];
-        uint32_t lgv[2], ns[2];
-        for (int k = 0; k < 2; k++) {
-            const uint32_t bin = 2 * t + k;
-            const uint32_t cnt = pre[bin + 1] - pre[bin];
-            uint32_t lg = 0;
-            while ((8u << lg) < cnt && lg < 20) lg++;
-            if (lg > shiftv) lg = shiftv;  // cannot cut finer than one key unit
-            lgv[k] = lg;
-            ns[k] = bin <= bstar ? (1u << lg) : 0u;
-        }
-        // exclusive scan of ns over the bins
-        const int lane = t & 63, wv = t >> 6;
-        uint32_t ssum = ns[0] + ns[1], incl = ssum;
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
-        }
-        if (lane == 63) wsum2[wv] = incl;
-        __syncthreads();
-        if (t < 16) {
-            uint32_t v = wsum2[t], acc = v;
-            for (int o = 1; o < 16; o <<= 1) {
-                uint32_t u = __shfl_up(acc, o, 16);
-                if (t >= o) acc += u;
-            }
-            wsum2[t] = acc - v;
-        }
-        __syncthreads();
-        const uint32_t excl = incl - ssum + wsum2[wv];
-        E.sub_base[2 * t] = excl;
-        E.sub_base[2 * t + 1] = excl + ns[0];
-        E.sub_lg[2 * t] = (uint8_t)lgv[0];
-        E.sub_lg[2 * t + 1] = (uint8_t)lgv[1];
-        if (t == 1023) c->nb2 = excl + ssum;
-        (void)nsub;
-    }
+    if (t == 1023) E.pre[NBIN] = pre[NBIN];
     __syncthreads();
     if (t == 0) {
-        if (c->superset && c->nb2 > E.nb2_cap) {  // cannot happen with ~8 entries per sub-bin; stay exact anyway
-            c->superset = 0;
-            c->n_ord = want;
-        }
         const uint64_t kmin = c->rng[cb].kmin;
         const uint32_t shift = select_shift(kmin, c->rng[cb].kmax);
         c->want = want;
-        c->cand_n.v = 0;
-        c->sel_fill.v = 0;
+        c->bstar = s_bstar;
         c->sel_kmin = kmin;
         c->shift = shift;
         uint32_t sp = s_spill;
@@ -725,7 +725,6 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs)
         c->rng[cb ^ 1].kmax = 0;
         c->goal_best = ~0ull;
         c->first_solved = NIL;
-        c->skip = 0;
         if (want == 0) {  // OPEN ran empty: no solution reachable
             c->failed = 1;
             c->done = 1;
@@ -733,29 +732,38 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs)
     }
 }
 
-// S3: scatter FRONT — below the threshold bin: popped (unordered); in it: candidates; above:
-// survivors -> the other FRONT buffer, or BACK when a spill lowered T.  One atomic per array per tile.
+// S3: scatter FRONT — at or below the threshold bin: into the scratch array, grouped by bin (k_rank orders each
+// bin); above: survivors -> the other FRONT buffer, or BACK when a spill lowered T.  One atomic per array per tile
+// for the survivors; the few entries bound for the scratch array are stashed in LDS and placed with one global
+// atomic per (workgroup, bin).
 __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ engs) {
     const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
-    __shared__ uint32_t sh[4 * 4 + 4];
-    const uint32_t b = c->cur_f, nf = b ^ 1, bb = c->cur_b;
+    Stamp stamp(E, P_SEL_COLLECT);
+    __shared__ uint32_t sh[2 * 4 + 2];
+    __shared__ uint64_t st_key[kStash];
+    __shared__ uint32_t st_id[kStash];
+    __shared__ uint16_t st_f[kStash];
+    __shared__ uint32_t lcnt[NBIN];
+    __shared__ uint32_t st_n;
+    const uint32_t b = st_cur(c).cur_f, nf = b ^ 1, bb = c->cur_b;
     const uint32_t n = c->open_n[b].v;
     const uint64_t kmin = c->sel_kmin;
     const uint32_t shift = c->shift, bstar = c->bstar, spill = c->spill_bin;
-    const uint32_t candd = c->superset ? 1u : 4u;  // where the threshold bin goes
     const uint64_t* __restrict__ keys = E.open_key[b];
     const uint32_t* __restrict__ ids = E.open_id[b];
     constexpr uint32_t ITEMS = 8, TILE = 256 * ITEMS;
     uint64_t fmn = ~0ull, fmx = 0, bmn = ~0ull, bmx = 0;
     const uint32_t ntiles = (n + TILE - 1) / TILE;
-    uint32_t* const ctr[4] = {&c->sel_fill.v, &c->open_n[nf].v, &c->open_n[bb].v, &c->cand_n.v};
+    for (int i = threadIdx.x; i < NBIN; i += 256) lcnt[i] = 0;
+    if (threadIdx.x == 0) st_n = 0;
+    __syncthreads();
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint64_t k[ITEMS];
         uint32_t id[ITEMS];
-        uint32_t dest = 0;  // 3 bits per item: 0 dead, 1 popped, 2 FRONT', 3 BACK, 4 candidate
-        uint32_t cnt[4] = {0, 0, 0, 0};
+        uint32_t dest = 0;  // 2 bits per item: 0 dead, 1 scratch (ordered by k_rank), 2 FRONT', 3 BACK
+        uint32_t cf = 0, cb = 0;
 #pragma unroll
         for (uint32_t i = 0; i < ITEMS; i++) {
             uint32_t idx = tile * TILE + i * 256 + threadIdx.x;
@@ -764,42 +772,65 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
             id[i] = live ? ids[idx] : 0;
             uint64_t f64 = (k[i] - kmin) >> shift;
             uint32_t f = f64 < NBIN ? (uint32_t)f64 : NBIN - 1;
-            uint32_t d = !live ? 0u : (f < bstar ? 1u : (f == bstar ? candd : (f > spill ? 3u : 2u)));
-            dest |= d << (3 * i);
-            if (d) cnt[d - 1]++;
+            uint32_t d = !live ? 0u : (f <= bstar ? 1u : (f > spill ? 3u : 2u));
+            dest |= d << (2 * i);
+            cf += d == 2u ? 1u : 0u;
+            cb += d == 3u ? 1u : 0u;
+            if (d == 1u) {
+                const uint32_t p = atomicAdd(&st_n, 1u);
+                if (p < kStash) {
+                    st_key[p] = k[i];
+                    st_id[p] = id[i];
+                    st_f[p] = (uint16_t)f;
+                    atomicAdd(&lcnt[f], 1u);
+                } else {  // stash full (a workgroup rarely sees this many): place directly
+                    const uint32_t pos = E.pre[f] + atomicAdd(&E.fill[f], 1u);
+                    E.tmp_key[pos] = k[i];
+                    E.tmp_id[pos] = id[i];
+                    E.tmp_st[pos] = 0;
+                }
+            }
         }
-        uint32_t pos[4];
-        block_reserveK<256, 4>(cnt, ctr, pos, sh);
+        Pos2 p = block_reserve2<256>(cf, cb, &c->open_n[nf].v, &c->open_n[bb].v, sh);
 #pragma unroll
         for (uint32_t i = 0; i < ITEMS; i++) {
-            uint32_t d = (dest >> (3 * i)) & 7u;
-            if (d == 1u) {
-                E.tmp_key[pos[0]] = k[i];
-                E.tmp_id[pos[0]] = id[i];
-                pos[0]++;
-            } else if (d == 2u) {
-                E.open_key[nf][pos[1]] = k[i];
-                E.open_id[nf][pos[1]] = id[i];
-                pos[1]++;
+            uint32_t d = (dest >> (2 * i)) & 3u;
+            if (d == 2u) {
+                E.open_key[nf][p.a] = k[i];
+                E.open_id[nf][p.a] = id[i];
+                p.a++;
                 fmn = k[i] < fmn ? k[i] : fmn;
                 fmx = k[i] > fmx ? k[i] : fmx;
             } else if (d == 3u) {
-                if (pos[2] < E.max_nodes) {
-                    E.open_key[bb][pos[2]] = k[i];
-                    E.open_id[bb][pos[2]] = id[i];
+                if (p.b < E.max_nodes) {
+                    E.open_key[bb][p.b] = k[i];
+                    E.open_id[bb][p.b] = id[i];
                 }
-                pos[2]++;
+                p.b++;
                 bmn = k[i] < bmn ? k[i] : bmn;
                 bmx = k[i] > bmx ? k[i] : bmx;
-            } else if (d == 4u) {
-                E.cand_key[pos[3]] = k[i];
-                E.cand_id[pos[3]] = id[i];
-                E.cand_st[pos[3]] = 0;
-                pos[3]++;
             }
         }
     }
-    // key ranges: reduced per block into E.part and folded into the control block by k_ord_scan (one thread) —
+    __syncthreads();
+    {
+        // the stash: one global atomic per bin this workgroup touched reserves its slice of the bin, then every
+        // stashed entry takes its slot inside the slice (LDS atomic)
+        const uint32_t ns = st_n < (uint32_t)kStash ? st_n : (uint32_t)kStash;
+        for (uint32_t f = threadIdx.x; f <= bstar; f += 256) {
+            const uint32_t cn = lcnt[f];
+            if (cn) lcnt[f] = atomicAdd(&E.fill[f], cn);
+        }
+        __syncthreads();
+        for (uint32_t p = threadIdx.x; p < ns; p += 256) {
+            const uint32_t f = st_f[p];
+            const uint32_t pos = E.pre[f] + atomicAdd(&lcnt[f], 1u);
+            E.tmp_key[pos] = st_key[p];
+            E.tmp_id[pos] = st_id[p];
+            E.tmp_st[pos] = 0;
+        }
+    }
+    // key ranges: reduced per block into E.part and folded into the control block by k_rank (four atomics) —
     // a thousand waves doing atomicMin/Max on two words cost as much as the whole scatter
     {
         __shared__ uint64_t red[4][4];
@@ -824,10 +855,15 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
     }
 }
 
-// S4: one workgroup — exact choice of the sel_r smallest (key,id) among the candidates of the
-// threshold bin by adaptive radix refinement on the 96-bit composite; the rest survive.  The chosen
-// ones are written to the tail of the popped list grouped into 2048 sub-bins of their own range, so
-// that S5 only has to rank inside small groups.
+// ---------------------------------------------------------------------------------------------
+// k_rank: exact order of the batch.  One 1024-thread workgroup per bin at or below the threshold bin (bins strided
+// over the grid).  A bin of up to kSortCap entries is sorted on the 96-bit (key,id) composite by a bitonic network
+// in LDS; rank = entries in lower bins + position.  Ranks below `want` are the batch in pop order (which fixes the
+// children's node ids and therefore every later tie-break), the overshoot of the threshold bin returns to FRONT'.
+// A larger bin (massive cost ties: integer-valued heuristics, uniform-cost search) is first cut down to the entries
+// that belong to the batch by adaptive radix refinement on the composite, then ordered in LDS if they fit, else
+// through arithmetic sub-bins of their own exact composite range — all by the bin's one workgroup, in global memory.
+// ---------------------------------------------------------------------------------------------
 typedef unsigned __int128 u128;
 __device__ __forceinline__ u128 comp_of(uint64_t key, uint32_t id) { return ((u128)key << 32) | (u128)id; }
 __device__ __forceinline__ int clz128(u128 v) {
@@ -841,20 +877,100 @@ struct CandShared {
     uint32_t wsum[16];
     uint64_t red_lo[32], red_hi[32];
     uint64_t vmin_hi, vmin_lo;
-    uint32_t active, rr, shift, bsel, cnt;
+    uint32_t active, rr, shift, bits, bsel, cnt, carry;
     uint64_t fk[1024];
     uint32_t fi[1024], fidx[1024];
-    uint64_t fk2[2048];
-    uint32_t fi2[2048];
+};
+struct SortLds {
+    uint64_t sk[kSortCap];
+    uint32_t si[kSortCap];
+};
+union RankLds {
+    SortLds s;
+    CandShared c;
 };
 
-// min / max composite over the candidates whose status equals `want_st`; result -> S.vmin_*, S.shift
-__device__ __forceinline__ void cand_range(const Eng& E, CandShared& S, uint32_t n, uint8_t want_st) {
+// one ranked entry: into the batch (pop order) or back to FRONT'.  Wave-collective (open_append).
+__device__ __forceinline__ void emit_ranked(const Eng& E, Ctl* c, uint32_t nf, bool live, uint32_t rank, uint32_t want,
+                                            uint64_t key, uint32_t id) {
+    if (live && rank < want) {
+        E.pop_key[rank] = key;
+        E.pop_id[rank] = id;
+        E.pop_g[rank] = (uint32_t)E.g[id];
+        if (E.solved[id]) {
+            if (E.sem == DCA_SEM_PY)
+                atomicMin(&c->goal_best, ((unsigned long long)(uint32_t)E.g[id] << 32) | rank);
+            else
+                atomicMin(&c->first_solved, rank);
+        }
+    }
+    open_append(E, c, nf, live && rank >= want, key, id);
+}
+
+// order m entries in LDS and emit them with ranks base_rank + position.  ST == nullptr: the first m entries of K/I;
+// else the m entries of K/I[0..n_src) whose status is 1.
+__device__ __forceinline__ void lds_sort_emit(const Eng& E, Ctl* c, SortLds& S, const uint64_t* __restrict__ K,
+                                              const uint32_t* __restrict__ I, const uint8_t* __restrict__ ST,
+                                              uint32_t n_src, uint32_t m, uint32_t base_rank, uint32_t want,
+                                              uint32_t nf, uint32_t* s_cnt) {
+    const uint32_t t = threadIdx.x;
+    uint32_t P = 2;
+    while (P < m) P <<= 1;
+    if (ST == nullptr) {
+        for (uint32_t i = t; i < P; i += 1024) {
+            S.sk[i] = i < m ? K[i] : ~0ull;
+            S.si[i] = i < m ? I[i] : 0xFFFFFFFFu;
+        }
+    } else {
+        if (t == 0) *s_cnt = 0;
+        __syncthreads();
+        for (uint32_t i = t; i < n_src; i += 1024)
+            if (ST[i] == 1) {
+                const uint32_t p = atomicAdd(s_cnt, 1u);
+                if (p < (uint32_t)kSortCap) {
+                    S.sk[p] = K[i];
+                    S.si[p] = I[i];
+                }
+            }
+        for (uint32_t i = m + t; i < P; i += 1024) {
+            S.sk[i] = ~0ull;
+            S.si[i] = 0xFFFFFFFFu;
+        }
+    }
+    __syncthreads();
+    const uint32_t half = P >> 1;
+    for (uint32_t k2 = 2; k2 <= P; k2 <<= 1)
+        for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            for (uint32_t x = t; x < half; x += 1024) {
+                const uint32_t i = ((x & ~(j2 - 1u)) << 1) | (x & (j2 - 1u)), l = i + j2;
+                const bool up = (i & k2) == 0;
+                const uint64_t ka = S.sk[i], kb = S.sk[l];
+                const uint32_t ia = S.si[i], ib = S.si[l];
+                if (pair_less(kb, ib, ka, ia) == up) {
+                    S.sk[i] = kb;
+                    S.si[i] = ib;
+                    S.sk[l] = ka;
+                    S.si[l] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i0 = 0; i0 < P; i0 += 1024) {
+        const uint32_t i = i0 + t;
+        const bool live = i < m;
+        emit_ranked(E, c, nf, live, base_rank + i, want, live ? S.sk[i] : 0, live ? S.si[i] : 0);
+    }
+    __syncthreads();
+}
+
+// min / max composite over the entries whose status equals `want_st`; result -> S.vmin_*, S.bits, S.shift (= bits - 11)
+__device__ __forceinline__ void cand_range(CandShared& S, const uint64_t* __restrict__ K, const uint32_t* __restrict__ I,
+                                           const uint8_t* __restrict__ ST, uint32_t n, uint8_t want_st) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     u128 vmin = ~(u128)0, vmax = 0;
     for (uint32_t i = t; i < n; i += 1024)
-        if (E.cand_st[i] == want_st) {
-            u128 v = comp_of(E.cand_key[i], E.cand_id[i]);
+        if (ST[i] == want_st) {
+            u128 v = comp_of(K[i], I[i]);
             vmin = v < vmin ? v : vmin;
             vmax = v > vmax ? v : vmax;
         }
@@ -883,6 +999,7 @@ __device__ __forceinline__ void cand_range(const Eng& E, CandShared& S, uint32_t
         }
         u128 range = mx >= mn ? mx - mn : 0;
         int bits = range ? 128 - clz128(range) : 0;
+        S.bits = (uint32_t)bits;
         S.shift = bits > 11 ? (uint32_t)(bits - 11) : 0u;
         S.vmin_hi = (uint64_t)(mn >> 64);
         S.vmin_lo = (uint64_t)mn;
@@ -916,54 +1033,52 @@ __device__ __forceinline__ void cand_scan(CandShared& S) {
     __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void k_sel_cand(const Eng* __restrict__ engs) {
-    const Eng& E = engs[blockIdx.y];
-    Ctl* c = E.ctl;
-    if (c->done) return;
-    if (c->superset) return;  // normal case: nothing to refine, ordering buckets are arithmetic
-    __shared__ CandShared S;
+// mark exactly `need` of the n entries (all status 0 on entry) with the smallest (key,id) as 1, the others as 2:
+// adaptive radix refinement on the 96-bit composite, 2048 bins per level, all-pairs once <= 1024 are undecided
+__device__ __noinline__ void select_smallest(CandShared& S, const uint64_t* __restrict__ K, const uint32_t* __restrict__ I,
+                                                uint8_t* __restrict__ ST, uint32_t n, uint32_t need) {
     const int t = threadIdx.x;
-    const uint32_t n = c->cand_n.v;
+    __syncthreads();
     if (t == 0) {
         S.active = n;
-        S.rr = n ? c->sel_r : 0u;
+        S.rr = need;
     }
     __syncthreads();
-    while (n != 0) {
-        uint32_t active = S.active, rr = S.rr;
+    for (;;) {
+        const uint32_t active = S.active, rr = S.rr;
         if (rr == 0 || rr == active) {  // take none / take all of what is still undecided
             for (uint32_t i = t; i < n; i += 1024)
-                if (E.cand_st[i] == 0) E.cand_st[i] = rr ? 1 : 2;
+                if (ST[i] == 0) ST[i] = rr ? 1 : 2;
             break;
         }
         if (active <= 1024) {  // final: all-pairs rank in LDS
             if (t == 0) S.cnt = 0;
             __syncthreads();
             for (uint32_t i = t; i < n; i += 1024)
-                if (E.cand_st[i] == 0) {
+                if (ST[i] == 0) {
                     uint32_t p = atomicAdd(&S.cnt, 1u);
-                    S.fk[p] = E.cand_key[i];
-                    S.fi[p] = E.cand_id[i];
+                    S.fk[p] = K[i];
+                    S.fi[p] = I[i];
                     S.fidx[p] = i;
                 }
             __syncthreads();
             if ((uint32_t)t < active) {
                 uint32_t rank = 0;
-                uint64_t k0 = S.fk[t];
-                uint32_t i0 = S.fi[t];
+                const uint64_t k0 = S.fk[t];
+                const uint32_t i0 = S.fi[t];
                 for (uint32_t j = 0; j < active; j++) rank += pair_less(S.fk[j], S.fi[j], k0, i0) ? 1u : 0u;
-                E.cand_st[S.fidx[t]] = rank < rr ? 1 : 2;
+                ST[S.fidx[t]] = rank < rr ? 1 : 2;
             }
             break;
         }
         // ---- one refinement level on the undecided set
-        cand_range(E, S, n, 0);
+        cand_range(S, K, I, ST, n, 0);
         const u128 base = ((u128)S.vmin_hi << 64) | S.vmin_lo;
         const uint32_t sh = S.shift;
         for (uint32_t i = t; i < n; i += 1024)
-            if (E.cand_st[i] == 0) {
-                uint32_t f = (uint32_t)((comp_of(E.cand_key[i], E.cand_id[i]) - base) >> sh);
-                atomicAdd(&S.lh[f], 1u);
+            if (ST[i] == 0) {
+                uint32_t f = (uint32_t)((comp_of(K[i], I[i]) - base) >> sh);
+                atomicAdd(&S.lh[f < NBIN ? f : NBIN - 1], 1u);
             }
         __syncthreads();
         cand_scan(S);
@@ -974,12 +1089,13 @@ __global__ __launch_bounds__(1024) void k_sel_cand(const Eng* __restrict__ engs)
         __syncthreads();
         const uint32_t bsel = S.bsel;
         for (uint32_t i = t; i < n; i += 1024)
-            if (E.cand_st[i] == 0) {
-                uint32_t f = (uint32_t)((comp_of(E.cand_key[i], E.cand_id[i]) - base) >> sh);
+            if (ST[i] == 0) {
+                uint32_t f = (uint32_t)((comp_of(K[i], I[i]) - base) >> sh);
+                f = f < NBIN ? f : NBIN - 1;
                 if (f < bsel)
-                    E.cand_st[i] = 1;
+                    ST[i] = 1;
                 else if (f > bsel)
-                    E.cand_st[i] = 2;
+                    ST[i] = 2;
             }
         __syncthreads();
         if (t == 0) {
@@ -989,168 +1105,109 @@ __global__ __launch_bounds__(1024) void k_sel_cand(const Eng* __restrict__ engs)
         __syncthreads();
     }
     __syncthreads();
-    // ---- emit: chosen -> tail of the (still unordered) popped list, the rest -> FRONT'
-    const uint32_t out0 = c->sel_less;
-    const uint32_t nb = c->cur_f ^ 1;
-    if (t == 0) S.cnt = 0;
-    __syncthreads();
-    {
-        const uint32_t total = ((n + 1023) / 1024) * 1024;
-        for (uint32_t i = t; i < total; i += 1024) {
-            bool live = i < n;
-            uint8_t st = live ? E.cand_st[i] : 0;
-            uint64_t key = live ? E.cand_key[i] : 0;
-            uint32_t id = live ? E.cand_id[i] : 0;
-            if (live && st == 1) {
-                uint32_t p = out0 + atomicAdd(&S.cnt, 1u);
-                E.tmp_key[p] = key;
-                E.tmp_id[p] = id;
-            }
-            open_append(E, c, nb, live && st == 2, key, id);
-        }
-    }
-    __syncthreads();
-
-    // ---- order the popped list by (key, id), step 1: 2048 sampled entries are bitonic-sorted here and
-    // become the splitters of a sample sort whose bucket/scatter/rank passes run chip-wide (k_ord_*).
-    // Works for any key distribution (ids make the composite unique), unlike fixed-width bins.
-    const uint32_t want = c->n_ord;  // entries to order (batch, or batch + rest of the threshold bin)
-    uint64_t* sk = S.fk2;
-    uint32_t* si = S.fi2;
-    const bool small = want <= 2048;
-    for (uint32_t j = t; j < 2048; j += 1024) {
-        uint32_t idx = small ? j : (uint32_t)(((uint64_t)j * want) >> 11);
-        bool ok = idx < want;
-        sk[j] = ok ? E.tmp_key[idx] : ~0ull;
-        si[j] = ok ? E.tmp_id[idx] : 0xFFFFFFFFu;
-    }
-    __syncthreads();
-    for (uint32_t k2 = 2; k2 <= 2048; k2 <<= 1)
-        for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-            uint32_t i = ((t / j2) * 2 * j2) + (t % j2), l = i + j2;
-            bool up = (i & k2) == 0;
-            uint64_t ka = sk[i], kb = sk[l];
-            uint32_t ia = si[i], ib = si[l];
-            bool gt = pair_less(kb, ib, ka, ia);
-            if (gt == up) {
-                sk[i] = kb;
-                si[i] = ib;
-                sk[l] = ka;
-                si[l] = ia;
-            }
-            __syncthreads();
-        }
-    for (uint32_t j = t; j < 2048; j += 1024) {
-        E.spl_key[j] = sk[j];
-        E.spl_id[j] = si[j];
-    }
-    if (t == 0) c->nb2 = 2049;
 }
 
-// ---------------------------------------------------------------------------------------------
-// sample sort of the popped list (2049 buckets delimited by the sorted sample)
-// ---------------------------------------------------------------------------------------------
-struct OrdShared {
-    uint64_t sk[2048];
-    uint32_t si[2048];
-};
-__device__ __forceinline__ void ord_load_splitters(const Eng& E, OrdShared& S) {
-    for (uint32_t j = threadIdx.x; j < 2048; j += blockDim.x) {
-        S.sk[j] = E.spl_key[j];
-        S.si[j] = E.spl_id[j];
-    }
-    __syncthreads();
-}
-// bucket = number of splitters < (k,id)  (0..2048)
-__device__ __forceinline__ uint32_t ord_bucket(const OrdShared& S, uint64_t k, uint32_t id) {
-    uint32_t lo = 0, hi = 2048;
-    while (lo < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (pair_less(S.sk[mid], S.si[mid], k, id))
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    return lo;
-}
-
-// O1: bucket of every popped entry + its arrival slot inside the bucket
-__global__ __launch_bounds__(256) void k_ord_count(const Eng* __restrict__ engs) {
-    const Eng& E = engs[blockIdx.y];
-    Ctl* c = E.ctl;
-    if (c->done) return;
-    const uint32_t want = c->n_ord;
-    if (blockIdx.x * 256 >= want) return;
-    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
-    uint32_t b;
-    if (c->superset) {
-        if (e >= want) return;
-        const uint64_t key = E.tmp_key[e];
-        const uint32_t shift = c->shift;
-        const uint64_t off = key - c->sel_kmin;
-        uint64_t f64 = off >> shift;
-        const uint32_t f = f64 < NBIN ? (uint32_t)f64 : NBIN - 1;
-        const uint32_t lg = E.sub_lg[f];
-        uint64_t sub = (off - ((uint64_t)f << shift)) >> (shift - lg);
-        const uint32_t smax = (1u << lg) - 1u;
-        b = E.sub_base[f] + (sub < smax ? (uint32_t)sub : smax);
-    } else {
-        __shared__ OrdShared S;
-        ord_load_splitters(E, S);
-        if (e >= want) return;
-        b = ord_bucket(S, E.tmp_key[e], E.tmp_id[e]);
-    }
-    E.ord_b[e] = b;
-    E.ord_s[e] = atomicAdd(&E.bcnt[b], 1u);
-}
-
-// O2: one workgroup — exclusive prefix of the bucket counts (and reset them for the next iteration)
-__global__ __launch_bounds__(1024) void k_ord_scan(const Eng* __restrict__ engs) {
-    const Eng& E = engs[blockIdx.y];
-    Ctl* c = E.ctl;
-    if (c->done) return;
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t s_carry;
+// order the m (> kSortCap) status-1 entries of K/I[0..n) in global memory: 2^lg arithmetic sub-bins over their own
+// exact composite range (a tie group is cut on its ids), count -> prefix -> scatter -> rank inside the sub-bin.
+// Scratch: E.ord_* at entry offset o, E.bcnt / E.bpre at sub-bin offset sb (both regions private to this bin).
+__device__ __noinline__ void giant_order(const Eng& E, Ctl* c, CandShared& S, const uint64_t* __restrict__ K,
+                                            const uint32_t* __restrict__ I, const uint8_t* __restrict__ ST, uint32_t n,
+                                            uint32_t m, uint32_t o, uint32_t sb, uint32_t want, uint32_t nf) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const uint32_t nb = c->nb2;
-    if (t == 0) s_carry = 0;
+    cand_range(S, K, I, ST, n, 1);
+    const u128 vmin = ((u128)S.vmin_hi << 64) | S.vmin_lo;
+    uint32_t lg = 0;
+    while ((16u << lg) <= m && lg < 26) lg++;  // 2^lg <= m / 8: ~8-16 entries per sub-bin when the composites spread evenly
+    const uint32_t nsub = 1u << lg;
+    const uint32_t shc = S.bits > lg ? S.bits - lg : 0u;
+    uint32_t* bcnt = E.bcnt + sb;
+    uint32_t* bpre = E.bpre + sb;
+    for (uint32_t i = t; i < n; i += 1024)
+        if (ST[i] == 1) {
+            const u128 q = (comp_of(K[i], I[i]) - vmin) >> shc;
+            const uint32_t sub = q < (u128)nsub ? (uint32_t)q : nsub - 1u;
+            E.ord_b[o + i] = sub;
+            E.ord_s[o + i] = atomicAdd(&bcnt[sub], 1u);
+        }
     __syncthreads();
-    for (uint32_t base = 0; base < nb; base += 4096) {
+    // exclusive prefix of the sub-bin counts (and reset them for the next user of the region)
+    if (t == 0) S.carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < nsub; b0 += 4096) {
         uint32_t v[4], s4 = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            uint32_t i = base + 4 * t + k;
-            v[k] = i < nb ? E.bcnt[i] : 0u;
-            if (i < nb) E.bcnt[i] = 0;
+            const uint32_t i = b0 + 4 * t + k;
+            v[k] = i < nsub ? bcnt[i] : 0u;
+            if (i < nsub) bcnt[i] = 0;
             s4 += v[k];
         }
         uint32_t incl = s4;
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t u = __shfl_up(incl, o);
-            if (lane >= o) incl += u;
+        for (int q = 1; q < 64; q <<= 1) {
+            uint32_t u = __shfl_up(incl, q);
+            if (lane >= q) incl += u;
         }
-        if (lane == 63) wsum[wv] = incl;
+        if (lane == 63) S.wsum[wv] = incl;
         __syncthreads();
-        uint32_t woff = s_carry;
-        for (int w = 0; w < wv; w++) woff += wsum[w];
+        uint32_t woff = S.carry;
+        for (int w = 0; w < wv; w++) woff += S.wsum[w];
         uint32_t run = incl - s4 + woff;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            uint32_t i = base + 4 * t + k;
-            if (i < nb) E.bpre[i] = run;
+            const uint32_t i = b0 + 4 * t + k;
+            if (i < nsub) bpre[i] = run;
             run += v[k];
         }
         __syncthreads();
-        if (t == 1023) s_carry = run;
+        if (t == 1023) S.carry = run;
         __syncthreads();
     }
-    if (t == 0) E.bpre[nb] = s_carry;
-    // fold k_sel_collect's per-block key ranges (survivors -> the new FRONT buffer, spills -> BACK)
-    {
+    if (t == 0) bpre[nsub] = S.carry;
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += 1024)
+        if (ST[i] == 1) {
+            const uint32_t sub = E.ord_b[o + i];
+            const uint32_t p = bpre[sub] + E.ord_s[o + i];
+            E.ord_key[o + p] = K[i];
+            E.ord_id[o + p] = I[i];
+            E.ord_pb[o + p] = sub;
+        }
+    __syncthreads();
+    for (uint32_t p0 = 0; p0 < m; p0 += 1024) {
+        const uint32_t p = p0 + t;
+        const bool live = p < m;
+        uint64_t k = 0;
+        uint32_t id = 0, rank = 0;
+        if (live) {
+            k = E.ord_key[o + p];
+            id = E.ord_id[o + p];
+            const uint32_t sub = E.ord_pb[o + p];
+            const uint32_t s0 = bpre[sub], e0 = bpre[sub + 1];
+            rank = s0;
+            for (uint32_t j = s0; j < e0; j++) rank += pair_less(E.ord_key[o + j], E.ord_id[o + j], k, id) ? 1u : 0u;
+        }
+        emit_ranked(E, c, nf, live, o + rank, want, k, id);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void k_rank(const Eng* __restrict__ engs) {
+    const Eng& E = engs[blockIdx.y];
+    Ctl* c = E.ctl;
+    if (c->done) return;
+    Stamp stamp(E, P_RANK);
+    extern __shared__ __attribute__((aligned(16))) uint8_t rank_lds[];
+    RankLds& L = *reinterpret_cast<RankLds*>(rank_lds);
+    __shared__ uint32_t s_cnt;
+    const uint32_t t = threadIdx.x;
+    const uint32_t nf = st_cur(c).cur_f ^ 1, bb = c->cur_b;
+    if (blockIdx.x == 0) {
+        // fold k_sel_collect's per-block key ranges (survivors -> the new FRONT buffer, spills -> BACK)
         __shared__ uint64_t red[4][16];
+        const int lane = t & 63, wv = t >> 6;
         uint64_t v[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) v[q] = t < kScanBlocks ? E.part[q * kScanBlocks + t] : ((q & 1) ? 0ull : ~0ull);
+        for (int q = 0; q < 4; q++) v[q] = t < (uint32_t)kScanBlocks ? E.part[q * kScanBlocks + t] : ((q & 1) ? 0ull : ~0ull);
         for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -1161,123 +1218,102 @@ __global__ __launch_bounds__(1024) void k_ord_scan(const Eng* __restrict__ engs)
         if (lane == 0)
             for (int q = 0; q < 4; q++) red[q][wv] = v[q];
         __syncthreads();
-        if (t == 0) {
-            uint64_t r[4];
-            for (int q = 0; q < 4; q++) {
-                r[q] = red[q][0];
-                for (int w = 1; w < 16; w++)
-                    r[q] = (q & 1) ? (red[q][w] > r[q] ? red[q][w] : r[q]) : (red[q][w] < r[q] ? red[q][w] : r[q]);
-            }
-            const uint32_t rb = c->cur_f ^ 1, bb = c->cur_b;
-            if (r[0] < c->rng[rb].kmin) c->rng[rb].kmin = r[0];
-            if (r[1] > c->rng[rb].kmax) c->rng[rb].kmax = r[1];
-            if (r[2] < c->rng[bb].kmin) c->rng[bb].kmin = r[2];
-            if (r[3] > c->rng[bb].kmax) c->rng[bb].kmax = r[3];
-        }
-    }
-}
-
-// O3: scatter bucket-contiguously
-__global__ __launch_bounds__(256) void k_ord_scatter(const Eng* __restrict__ engs) {
-    const Eng& E = engs[blockIdx.y];
-    Ctl* c = E.ctl;
-    if (c->done) return;
-    const uint32_t want = c->n_ord;
-    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= want) return;
-    const uint32_t b = E.ord_b[e];
-    const uint32_t p = E.bpre[b] + E.ord_s[e];
-    E.ord_key[p] = E.tmp_key[e];
-    E.ord_id[p] = E.tmp_id[e];
-    E.ord_pb[p] = b;
-}
-
-// O4: rank inside the bucket -> final pop order; entries ranked past the batch return to FRONT'
-__global__ __launch_bounds__(256) void k_ord_rank(const Eng* __restrict__ engs) {
-    const Eng& E = engs[blockIdx.y];
-    Ctl* c = E.ctl;
-    if (c->done) return;
-    const uint32_t n_ord = c->n_ord, want = c->want;
-    if (blockIdx.x * 256 >= n_ord) return;
-    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
-    const bool live = e < n_ord;
-    uint64_t k = 0;
-    uint32_t id = 0, rank = 0;
-    if (live) {
-        k = E.ord_key[e];
-        id = E.ord_id[e];
-        const uint32_t b = E.ord_pb[e];
-        const uint32_t s0 = E.bpre[b], e0 = E.bpre[b + 1];
-        rank = s0;
-        for (uint32_t j = s0; j < e0; j++) rank += pair_less(E.ord_key[j], E.ord_id[j], k, id) ? 1u : 0u;
-        if (rank < want) {
-            E.pop_key[rank] = k;
-            E.pop_id[rank] = id;
-            if (E.solved[id]) {
-                if (E.sem == DCA_SEM_PY)
-                    atomicMin(&c->goal_best, ((unsigned long long)(uint32_t)E.g[id] << 32) | rank);
-                else
-                    atomicMin(&c->first_solved, rank);
+        if (t < 4) {
+            const int q = (int)t;
+            uint64_t r = red[q][0];
+            for (int w = 1; w < 16; w++) r = (q & 1) ? (red[q][w] > r ? red[q][w] : r) : (red[q][w] < r ? red[q][w] : r);
+            const uint32_t buf = q < 2 ? nf : bb;
+            // other workgroups append to FRONT' meanwhile (open_append): atomics, not plain stores
+            if (q & 1) {
+                if (r != 0ull) atomicMax((unsigned long long*)&c->rng[buf].kmax, (unsigned long long)r);
+            } else {
+                if (r != ~0ull) atomicMin((unsigned long long*)&c->rng[buf].kmin, (unsigned long long)r);
             }
         }
     }
-    open_append(E, c, c->cur_f ^ 1, live && rank >= want, k, id);
-}
-
-// S6: single thread — fix the batch geometry, goal bookkeeping, swap OPEN buffers
-__global__ void k_post_pop(const Eng* __restrict__ engs) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const Eng& E = engs[blockIdx.y];
-    Ctl* c = E.ctl;
-    if (c->done) return;
-    const uint32_t want = c->want;
-    uint32_t npop = want;
-    if (E.sem == DCA_SEM_PY) {
-        // astar.py:73,421: any solved node among the popped ends the search after this iteration;
-        // answer = solved popped node of smallest path cost, first in pop order on ties (327-333)
-        if (c->goal_best != ~0ull) {
-            c->stop_after = 1;
-            c->goal_id = E.pop_id[(uint32_t)(c->goal_best & 0xFFFFFFFFull)];
+    const uint32_t bstar = c->bstar, want = c->want;
+    for (uint32_t f = blockIdx.x; f <= bstar; f += gridDim.x) {
+        const uint32_t o = E.pre[f], n = E.pre[f + 1] - o;
+        if (n == 0) continue;
+        // entries of this bin that belong to the batch: all of it below the threshold bin
+        const uint32_t need = (f == bstar) ? want - o : n;
+        if (n <= (uint32_t)kSortCap) {
+            lds_sort_emit(E, c, L.s, E.tmp_key + o, E.tmp_id + o, nullptr, n, n, o, want, nf, &s_cnt);
+            continue;
         }
-    } else {
-        // cpp:185-208
-        const uint32_t fs = c->first_solved;
-        const int prev = c->has_best;
-        if (fs != NIL) {
-            npop = fs + 1;  // break at the first solved node popped
-            float cst = (float)cost_of_key(E.pop_key[fs]);
-            if (E.B == 1) {
-                c->best_id = E.pop_id[fs];
-                c->best_cost = cst;
-                c->has_best = 1;
-                c->stop_after = 1;
-            } else if (!c->has_best || c->best_cost > cst) {
-                c->best_id = E.pop_id[fs];
-                c->best_cost = cst;
-                c->has_best = 1;
+        const uint64_t* K = E.tmp_key + o;
+        const uint32_t* I = E.tmp_id + o;
+        uint8_t* ST = E.tmp_st + o;
+        if (need < n) {
+            select_smallest(L.c, K, I, ST, n, need);
+            // the rest of the threshold bin stays in OPEN
+            for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
+                const uint32_t i = i0 + t;
+                const bool rest = i < n && ST[i] == 2;
+                open_append(E, c, nf, rest, rest ? K[i] : 0, rest ? I[i] : 0);
             }
+        } else {
+            for (uint32_t i = t; i < n; i += 1024) ST[i] = 1;
         }
-        if (prev && (float)cost_of_key(E.pop_key[0]) >= c->best_cost) c->stop_after = 1;
+        __syncthreads();
+        if (need <= (uint32_t)kSortCap)
+            lds_sort_emit(E, c, L.s, K, I, ST, n, need, o, want, nf, &s_cnt);
+        else
+            giant_order(E, c, L.c, K, I, ST, n, need, o, o / 4 + f, want, nf);
     }
-    const uint32_t base = (c->pool_n + 15u) & ~15u;  // 16-aligned ids => 16-byte aligned child rows for every D
-    const uint64_t m = (uint64_t)npop * (uint64_t)E.A;
-    if ((uint64_t)base + m > (uint64_t)E.max_nodes) {
-        c->failed = 1;
-        c->done = 1;
-        return;
-    }
-    c->npop = npop;
-    c->m = (uint32_t)m;
-    c->base = base;
-    c->pool_n = base + (uint32_t)m;
-    c->gen += (int64_t)m;
-    c->expanded += npop;
-    c->cur_f ^= 1;  // the survivors' buffer becomes FRONT; un-popped entries and cheap children are appended to it
 }
 
 // ---------------------------------------------------------------------------------------------
 // expand: gather the popped parents by id, write children rows + node fields + hash/solved/heuristic
 // ---------------------------------------------------------------------------------------------
+// The pop's single-thread epilogue (thread 0 of the expansion's workgroup 0): goal bookkeeping and the state the rest
+// of the iteration — and the next one — starts from.
+__device__ __forceinline__ void close_pop(const Eng& E, Ctl* c, const IterState& S0, uint32_t it, uint32_t want,
+                                          uint32_t npop, uint32_t base, bool fail, uint32_t cur_new) {
+    IterState N = S0;
+    if (E.sem == DCA_SEM_PY) {
+        // astar.py:73,421: any solved node among the popped ends the search after this iteration;
+        // answer = solved popped node of smallest path cost, first in pop order on ties (327-333)
+        const unsigned long long gb = c->goal_best;
+        if (gb != ~0ull) {
+            c->stop_after = 1;
+            c->goal_id = E.pop_id[(uint32_t)(gb & 0xFFFFFFFFull)];
+        }
+    } else {
+        // cpp:185-208
+        const uint32_t fs = c->first_solved;
+        if (fs != NIL) {
+            const float cst = (float)cost_of_key(E.pop_key[fs]);
+            if (E.B == 1) {
+                N.best_id = E.pop_id[fs];
+                N.best_cost = cst;
+                N.has_best = 1;
+                c->stop_after = 1;
+            } else if (!S0.has_best || S0.best_cost > cst) {
+                N.best_id = E.pop_id[fs];
+                N.best_cost = cst;
+                N.has_best = 1;
+            }
+        }
+        if (S0.has_best && (float)cost_of_key(E.pop_key[0]) >= N.best_cost) c->stop_after = 1;
+    }
+    if (fail) {  // node pool exhausted
+        c->failed = 1;
+        c->done = 1;
+        return;
+    }
+    const uint32_t m = npop * (uint32_t)E.A;
+    N.npop = npop;
+    N.m = m;
+    N.base = base;
+    N.pool_n = base + m;
+    N.cur_f = cur_new;
+    c->S[(it + 1) & 1] = N;
+    c->gen += (int64_t)m;
+    c->expanded += npop;
+    (void)want;
+}
+
 constexpr int kEngTile = 16;  // parents per workgroup: a 20 000-parent batch then fills the chip (1250 workgroups)
 template <int ENV, int DIM, int OH>
 __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ engs, int heur_id) {
@@ -1287,17 +1323,32 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
     constexpr int kTileParents = kEngTile;  // shadows the stand-alone kernels' 64
     Ctl* c = E.ctl;
     if (c->done) return;
+    Stamp stamp(E, P_EXPAND);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* lpar = smem;
     uint8_t* ltab = smem + TL::PAR_BYTES;
     uint8_t* lst = smem + TL::LDS_BYTES;  // child rows of the tile, laid out exactly like their HBM destination
-    const uint32_t npop = c->npop, want = c->want, base = c->base;
+    // batch geometry: every workgroup derives it from the state the previous iteration left (S[iters & 1]) and the
+    // pop that k_rank just finished; workgroup 0 also records it for the rest of the iteration (close_pop)
+    const uint32_t it = (uint32_t)c->iters;
+    const IterState S0 = c->S[it & 1];
+    const uint32_t want = c->want;
+    uint32_t npop = want;
+    if (E.sem == DCA_SEM_CPP) {
+        const uint32_t fs = c->first_solved;
+        if (fs != NIL) npop = fs + 1;  // cpp:203 break at the first solved node popped
+    }
+    const uint32_t base = (S0.pool_n + 15u) & ~15u;  // 16-aligned ids => 16-byte aligned child rows for every D
+    const bool fail = (uint64_t)base + (uint64_t)npop * (uint64_t)EV::A > (uint64_t)E.max_nodes;
+    const uint32_t cur_new = S0.cur_f ^ 1;  // the survivors' buffer becomes FRONT; children are appended to it
+    if (blockIdx.x == 0 && threadIdx.x == 0) close_pop(E, c, S0, it, want, npop, base, fail, cur_new);
+    if (fail) return;
     const uint32_t r0 = blockIdx.x * kTileParents;
     if (E.sem == DCA_SEM_CPP && r0 + kTileParents > npop) {
         // cpp:203 `break`: entries selected after the first solved node were never popped — put them back
         uint32_t r = r0 + threadIdx.x;
         bool back = threadIdx.x < kTileParents && r >= npop && r < want;
-        open_append(E, c, c->cur_f, back, back ? E.pop_key[r] : 0, back ? E.pop_id[r] : 0);
+        open_append(E, c, cur_new, back, back ? E.pop_key[r] : 0, back ? E.pop_id[r] : 0);
     }
     if (r0 >= npop) return;
     const uint32_t np = min((uint32_t)kTileParents, npop - r0);
@@ -1367,7 +1418,8 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
         h = hash_final(h);
         const uint32_t j = j0 + cc, id = base + j, pid = E.pop_id[r0 + r];
         E.child_hash[j] = h;
-        E.g[id] = E.g[pid] + 1;  // path cost + unit transition cost (astar.py:125-126 / cpp:219)
+        E.g[id] = (int32_t)(E.pop_g[r0 + r] + 1u);  // path cost + unit transition cost (astar.py:125-126 / cpp:219)
+        E.child_multi[j] = 0;
         E.parent[id] = pid;
         E.move[id] = (uint8_t)a;
         E.solved[id] = ok ? 1 : 0;
@@ -1463,8 +1515,10 @@ __global__ __launch_bounds__(256) void k_probe(const Eng* __restrict__ engs) {
     const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
+    Stamp stamp(E, P_PROBE);
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t m = c->m, base = c->base;
+    const IterState& S1 = st_next(c);
+    const uint32_t m = S1.m, base = S1.base;
     if (j >= m) return;
     constexpr int NW = (D + 3) / 4;
     const uint32_t id = base + j;
@@ -1487,15 +1541,13 @@ __global__ __launch_bounds__(256) void k_probe(const Eng* __restrict__ engs) {
     bool inserted = false;
     uint32_t slot = (uint32_t)h & E.tab_mask;
     for (uint32_t probes = 0;; probes++) {
-        uint64_t e = __hip_atomic_load(&E.tab[slot].entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (e == EMPTY) {
-            uint64_t old = atomicCAS((unsigned long long*)&E.tab[slot].entry, (unsigned long long)EMPTY,
+        // claim first, look second: most children are new states, and for them the compare-and-swap IS the lookup
+        // (one memory round trip instead of a load followed by the swap)
+        const uint64_t e = atomicCAS((unsigned long long*)&E.tab[slot].entry, (unsigned long long)EMPTY,
                                      (unsigned long long)((tag << 32) | id));
-            if (old == EMPTY) {
-                inserted = true;
-                break;
-            }
-            e = old;
+        if (e == EMPTY) {
+            inserted = true;
+            break;
         }
         if ((e >> 32) == tag) {
             // exact key equality against the representative's state bytes (State.__eq__, cube3.py:23-24)
@@ -1520,28 +1572,38 @@ __global__ __launch_bounds__(256) void k_probe(const Eng* __restrict__ engs) {
             break;
         }
     }
-    uint32_t old_head = atomicExch(&E.tab[slot].head, id);
-    E.child_next[j] = old_head >= base ? old_head - base : NIL;
+    // the slot's value before this batch (only k_commit writes it) and the chain hook, issued together
+    const uint32_t v0 = E.tab[slot].g;
+    const uint32_t old_head = atomicExch(&E.tab[slot].head, id);
+    const bool chained = old_head >= base;  // another child of this batch already sits on the slot
+    E.child_next[j] = chained ? old_head - base : NIL;
     E.child_slot[j] = slot;
+    E.child_v0[j] = v0;
     E.child_flags[j] = inserted ? F_NEW : 0;  // counted in k_commit (one atomic per block there)
+    if (chained) {  // both ends of the link learn that their chain has company (k_expand cleared the marks)
+        E.child_multi[j] = 1;
+        E.child_multi[old_head - base] = 1;
+    }
 }
 
-// dedup B: keep decision in sequential order
-__global__ __launch_bounds__(256) void k_decide(const Eng* __restrict__ engs) {
-    const Eng& E = engs[blockIdx.y];
-    Ctl* c = E.ctl;
-    if (c->done) return;
-    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t m = c->m, base = c->base;
-    if (j >= m) return;
-    const uint32_t id = base + j;
-    const uint32_t slot = E.child_slot[j];
-    const uint32_t v0 = E.tab[slot].g;
-    const uint32_t gj = (uint32_t)E.g[id];
+// dedup B: keep decision in sequential order for child j of the batch (astar.py:81-88 / cpp:247-265): kept iff its
+// path cost beats the slot's value before the batch and no earlier child of the batch on the same state has g <= g_j.
+// is_min: j is the first occurrence of the batch minimum on its slot (it records the slot's new value);
+// first: the sequentially first child on the slot.  A child alone on its slot needs no memory access at all.
+struct Dec {
+    bool keep, is_min;
+    uint32_t first;
+};
+__device__ __forceinline__ Dec decide_child(const Eng& E, uint32_t base, uint32_t m, uint32_t j, uint32_t slot,
+                                            uint32_t v0, uint32_t gj, bool multi) {
+    if (!multi) return Dec{gj < v0, true, j};
     bool dominated = false;
     uint32_t gmin = GINF, pmin = NIL, first = j;
-    for (uint32_t k = E.tab[slot].head - base; k != NIL; k = E.child_next[k]) {
-        uint32_t gk = (uint32_t)E.g[base + k];
+    const uint32_t A = (uint32_t)E.A;
+    // chain members are children of this batch: indices below m (NIL ends the chain; the step bound is a safety net)
+    uint32_t steps = 0;
+    for (uint32_t k = E.tab[slot].head - base; k < m && steps <= m; k = E.child_next[k], steps++) {
+        const uint32_t gk = E.pop_g[k / A] + 1u;
         dominated |= (k < j && gk <= gj);
         if (gk < gmin || (gk == gmin && k < pmin)) {
             gmin = gk;
@@ -1549,16 +1611,34 @@ __global__ __launch_bounds__(256) void k_decide(const Eng* __restrict__ engs) {
         }
         first = k < first ? k : first;
     }
-    const bool keep = (gj < v0) && !dominated;  // astar.py:81-88 / cpp:247-265 in sequential order
-    E.child_flags[j] = (E.child_flags[j] & F_NEW) | (keep ? F_KEEP : 0) | (j == pmin ? F_MIN : 0);
-    if (j == first) {
-        // a state first seen in this batch is represented by its sequentially-first child (the node
-        // the reference inserts, cpp:250) whichever lane won the CAS
-        uint64_t e = E.tab[slot].entry;
-        if ((uint32_t)e >= base && (uint32_t)e != id) E.tab[slot].entry = (e & 0xFFFFFFFF00000000ull) | id;
-    }
+    return Dec{(gj < v0) && !dominated, j == pmin, first};
 }
 
+// a state first seen in this batch is represented by its sequentially-first child (the node the reference
+// inserts, cpp:250) whichever lane won the CAS
+__device__ __forceinline__ void fix_representative(const Eng& E, uint32_t base, uint32_t slot, uint32_t id) {
+    const uint64_t e = E.tab[slot].entry;
+    if ((uint32_t)e >= base && (uint32_t)e != id) E.tab[slot].entry = (e & 0xFFFFFFFF00000000ull) | id;
+}
+
+// stand-alone decision launch of the dedup-first ("packed") stepping, where the keep flags are needed before the
+// heuristic runs; the fused stepping decides inside k_commit
+__global__ __launch_bounds__(256) void k_decide(const Eng* __restrict__ engs) {
+    const Eng& E = engs[blockIdx.y];
+    Ctl* c = E.ctl;
+    if (c->done) return;
+    Stamp stamp(E, P_DECIDE);
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    const IterState& S1 = st_next(c);
+    const uint32_t m = S1.m, base = S1.base;
+    if (j >= m) return;
+    const uint32_t slot = E.child_slot[j];
+    const bool multi = E.child_multi[j] != 0;
+    const uint32_t gj = E.pop_g[j / (uint32_t)E.A] + 1u;
+    const Dec d = decide_child(E, base, m, j, slot, E.child_v0[j], gj, multi);
+    E.child_flags[j] = (E.child_flags[j] & F_NEW) | (d.keep ? F_KEEP : 0) | (d.is_min ? F_MIN : 0);
+    if (multi && j == d.first) fix_representative(E, base, slot, base + j);
+}
 
 // ---------------------------------------------------------------------------------------------
 // dedup-first stepping: compact the children that survived the CLOSED check into the heuristic batch.
@@ -1573,7 +1653,8 @@ __global__ __launch_bounds__(256) void k_pack(const Eng* __restrict__ engs) {
     using EV = EnvT<ENV, DIM>;
     Ctl* c = E.ctl;
     if (c->done) return;
-    const uint32_t m = c->m, base = c->base;
+    Stamp stamp(E, P_PACK);
+    const uint32_t m = st_next(c).m, base = st_next(c).base;
     if (blockIdx.x * 256 >= m) return;
     __shared__ uint32_t sh[6];
     __shared__ uint32_t lsrc[256];
@@ -1641,7 +1722,8 @@ __global__ __launch_bounds__(256) void k_pack(const Eng* __restrict__ engs) {
     }
 }
 
-// the last workgroup of k_commit to finish closes the iteration (astar.py:317 step_num += 1)
+// the last workgroup of k_commit to finish closes the iteration (astar.py:317 step_num += 1) and thereby makes the
+// state the expansion recorded (S[(iters + 1) & 1]) the current one
 __device__ __forceinline__ void commit_ticket(Ctl* c) {
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1654,14 +1736,17 @@ __device__ __forceinline__ void commit_ticket(Ctl* c) {
     }
 }
 
-// dedup C: record the new best g per state, push the kept children (FRONT if key <= T, else BACK)
+// dedup C: (FUSED: the keep decision,) the new best g per state, push of the kept children (FRONT if key <= T, else BACK)
+template <bool FUSED>
 __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, int packed) {
     const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
+    Stamp stamp(E, P_COMMIT);
     __shared__ uint32_t sh[3 * 16 + 3];
-    const uint32_t m = c->m, base = c->base;
-    const uint32_t fb = c->cur_f, bb = c->cur_b;
+    const IterState& S1 = st_next(c);
+    const uint32_t m = S1.m, base = S1.base;
+    const uint32_t fb = S1.cur_f, bb = c->cur_b;
     const uint64_t T = c->T;
     const uint32_t j = blockIdx.x * 1024 + threadIdx.x;
     if (blockIdx.x * 1024 >= m) {
@@ -1669,22 +1754,43 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
         return;
     }
     const bool live = j < m;
-    const uint8_t fl = live ? E.child_flags[j] : 0;
-    const bool keep = (fl & F_KEEP) != 0;
     const uint32_t id = base + j;
-    if (keep && (fl & F_MIN)) {
+    bool keep = false, is_new = false;
+    uint32_t gj = 0;
+    if (live) {
+        const uint8_t fl = E.child_flags[j];
+        is_new = (fl & F_NEW) != 0;
+        gj = E.pop_g[j / (uint32_t)E.A] + 1u;
         const uint32_t slot = E.child_slot[j];
-        const uint32_t gj = (uint32_t)E.g[id];
-        E.tab[slot].g = gj;  // one writer per slot: the first occurrence of the batch minimum
-        if (E.sem == DCA_SEM_CPP) {
-            // cpp:254-257: a shallower duplicate rewrites the CLOSED node's depth/parent/move in place
-            uint32_t rep = (uint32_t)E.tab[slot].entry;
-            if (rep != id) {
-                E.g[rep] = (int32_t)gj;
-                E.parent[rep] = E.parent[id];
-                E.move[rep] = E.move[id];
+        bool is_min;
+        uint32_t first = j;
+        bool multi = false;
+        if constexpr (FUSED) {
+            multi = E.child_multi[j] != 0;
+            const Dec d = decide_child(E, base, m, j, slot, E.child_v0[j], gj, multi);
+            keep = d.keep;
+            is_min = d.is_min;
+            first = d.first;
+        } else {
+            keep = (fl & F_KEEP) != 0;
+            is_min = (fl & F_MIN) != 0;
+        }
+        if (keep && is_min) {
+            E.tab[slot].g = gj;  // one writer per slot: the first occurrence of the batch minimum
+            if (E.sem == DCA_SEM_CPP) {
+                // cpp:254-257: a shallower duplicate rewrites the CLOSED node's depth/parent/move in place.  A state
+                // first seen in this batch is represented by its sequentially-first child (fix_representative may
+                // be rewriting the entry right now: both its old and its new id are >= base).
+                uint32_t rep = (uint32_t)E.tab[slot].entry;
+                if (FUSED && rep >= base) rep = base + first;
+                if (rep != id) {
+                    E.g[rep] = (int32_t)gj;
+                    E.parent[rep] = E.parent[id];
+                    E.move[rep] = E.move[id];
+                }
             }
         }
+        if (FUSED && multi && j == first) fix_representative(E, base, slot, id);
     }
     uint64_t key = 0;
     if (keep) {
@@ -1692,7 +1798,6 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
         const float hraw = packed ? E.pk_h[E.kept_pos[j]] : E.child_h[j];
         const float hv = fmaxf(hraw, 0.0f);  // clip_zero (nnet_utils.py:193-194)
         const bool ns = E.solved[id] == 0;
-        const uint32_t gj = (uint32_t)E.g[id];
         double cost;
         if (E.sem == DCA_SEM_PY) {
             // astar.py:196  weights*path_costs + heuristics*logical_not(is_solved), float64, two roundings
@@ -1704,7 +1809,7 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
         key = key_of_cost(cost);
     }
     const bool tof = keep && key <= T, tob = keep && key > T;
-    const uint32_t cnt[3] = {tof ? 1u : 0u, tob ? 1u : 0u, (fl & F_NEW) ? 1u : 0u};
+    const uint32_t cnt[3] = {tof ? 1u : 0u, tob ? 1u : 0u, is_new ? 1u : 0u};
     uint32_t* const ctr[3] = {&c->open_n[fb].v, &c->open_n[bb].v, &c->closed_n.v};
     uint32_t pos[3];
     block_reserveK<1024, 3>(cnt, ctr, pos, sh);
@@ -1739,8 +1844,8 @@ __global__ void k_solution(Eng E, int32_t* out /*[0]=len, [1..]=moves root->goal
         n = c->goal_id;
         *path_cost = (double)E.g[n];  // astar.py:229 node.path_cost
     } else {
-        if (!c->has_best) return;
-        n = c->best_id;
+        if (!st_cur(c).has_best) return;
+        n = st_cur(c).best_id;
     }
     int len = 0;
     // astar.py:218-223 walks parents to the root; cpp:337-341 walks while depth > 0
@@ -1759,6 +1864,7 @@ __global__ void k_solution(Eng E, int32_t* out /*[0]=len, [1..]=moves root->goal
 
 
 }  // namespace dca
+
 
 using namespace dca;
 
@@ -1792,6 +1898,8 @@ struct dca_engine {
     hipGraphExec_t graph_exec[2];
     int graph_heur;
     long host_iter;        // iterations enqueued since the last reset of instance 0 (drives the refill cadence)
+    unsigned long long* d_prof;  // [P_COUNT][kProfSlots][2] device wall-clock stamps of the profiled launches
+    unsigned long long* h_prof;  // pinned mirror
     void* allocs[kMaxInstances * 48 + 16];
     int nalloc;
 };
@@ -1884,73 +1992,45 @@ void launch_probe(const dca_engine* e, hipStream_t s) {
     }
 }
 
-// phase boundaries for the per-kernel profile: an event is recorded before phase p when ev != nullptr
-struct Marks {
-    hipEvent_t* ev;
-    int k;
-    hipStream_t s;
-    void mark() {
-        if (ev) (void)hipEventRecord(ev[k++], s);
-    }
-};
+constexpr size_t kRankLdsBytes = sizeof(RankLds);
 
-int enqueue_first_half(dca_engine* e, int heur_id, bool with_refill, hipStream_t s, Marks* mk = nullptr,
-                       bool want_oh = true) {
-    const Eng& E = e->E[0];
+int enqueue_first_half(dca_engine* e, int heur_id, bool with_refill, hipStream_t s, bool want_oh = true) {
     const Eng* d = e->d_engs;
-    const unsigned ordg = (E.ord_cap + 255) / 256;
-    Marks none{nullptr, 0, s};
-    Marks& m = mk ? *mk : none;
-    m.mark();  // 0 refill
     if (with_refill) {
         hipLaunchKernelGGL(k_refill_hist, gxy(kScanGrid, e), dim3(256), 0, s, d);
         hipLaunchKernelGGL(k_refill_scan, gxy(1, e), dim3(1024), 0, s, d);
         hipLaunchKernelGGL(k_refill_move, gxy(kScanGrid, e), dim3(256), 0, s, d);
     }
-    m.mark();  // 1 sel_hist
     hipLaunchKernelGGL(k_sel_hist, gxy(kScanGrid, e), dim3(256), 0, s, d);
-    m.mark();  // 2 sel_scan
     hipLaunchKernelGGL(k_sel_scan, gxy(1, e), dim3(1024), 0, s, d);
-    m.mark();  // 3 sel_collect
     hipLaunchKernelGGL(k_sel_collect, gxy(kScanGrid, e), dim3(256), 0, s, d);
-    m.mark();  // 4 sel_cand
-    hipLaunchKernelGGL(k_sel_cand, gxy(1, e), dim3(1024), 0, s, d);
-    m.mark();  // 5 order
-    hipLaunchKernelGGL(k_ord_count, gxy(ordg, e), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(k_ord_scan, gxy(1, e), dim3(1024), 0, s, d);
-    hipLaunchKernelGGL(k_ord_scatter, gxy(ordg, e), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(k_ord_rank, gxy(ordg, e), dim3(256), 0, s, d);
-    m.mark();  // 6 post_pop
-    hipLaunchKernelGGL(k_post_pop, gxy(1, e), dim3(64), 0, s, d);
+    hipLaunchKernelGGL(k_rank, gxy(kRankBlocks, e), dim3(1024), kRankLdsBytes, s, d);
     if (int rc = launch_check("select kernels")) return rc;
-    m.mark();  // 7 expand
     return launch_expand(e, heur_id, want_oh, s);
 }
 
-int enqueue_dedup(dca_engine* e, hipStream_t s, Marks* mk = nullptr) {
+// CLOSED check of the batch's children.  with_decide: the stand-alone keep decision of the dedup-first stepping
+// (k_pack needs the flags before the heuristic runs); otherwise k_commit<true> decides while it pushes.
+int enqueue_dedup(dca_engine* e, bool with_decide, hipStream_t s) {
     const Eng& E = e->E[0];
-    Marks none{nullptr, 0, s};
-    Marks& m = mk ? *mk : none;
-    m.mark();  // 8 probe
     launch_probe(e, s);
-    m.mark();  // 9 decide
-    hipLaunchKernelGGL(k_decide, gxy((E.M + 255) / 256, e), dim3(256), 0, s, e->d_engs);
+    if (with_decide) hipLaunchKernelGGL(k_decide, gxy((E.M + 255) / 256, e), dim3(256), 0, s, e->d_engs);
     return launch_check("dedup kernels");
 }
 
-int enqueue_commit(dca_engine* e, bool packed, hipStream_t s, Marks* mk = nullptr) {
+int enqueue_commit(dca_engine* e, bool packed, hipStream_t s) {
     const Eng& E = e->E[0];
-    Marks none{nullptr, 0, s};
-    Marks& m = mk ? *mk : none;
-    m.mark();  // 10 commit
-    hipLaunchKernelGGL(k_commit, gxy((E.M + 1023) / 1024, e), dim3(1024), 0, s, e->d_engs, packed ? 1 : 0);
-    m.mark();  // end
+    const dim3 g = gxy((E.M + 1023) / 1024, e);
+    if (packed)
+        hipLaunchKernelGGL(k_commit<false>, g, dim3(1024), 0, s, e->d_engs, 1);
+    else
+        hipLaunchKernelGGL(k_commit<true>, g, dim3(1024), 0, s, e->d_engs, 0);
     return launch_check("k_commit");
 }
 
-int enqueue_second_half(dca_engine* e, hipStream_t s, Marks* mk = nullptr) {
-    if (int rc = enqueue_dedup(e, s, mk)) return rc;
-    return enqueue_commit(e, false, s, mk);
+int enqueue_second_half(dca_engine* e, hipStream_t s) {
+    if (int rc = enqueue_dedup(e, false, s)) return rc;
+    return enqueue_commit(e, false, s);
 }
 
 void drop_graphs(dca_engine* e) {
@@ -2012,7 +2092,7 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
     memset(e, 0, sizeof(*e));
     e->K = num_instances;
     const size_t K = (size_t)num_instances;
-    const size_t N = (size_t)max_nodes, M = (size_t)Mll, Bz = (size_t)(2 * batch_size + 131072);
+    const size_t N = (size_t)max_nodes, M = (size_t)Mll, Bz = (size_t)batch_size + 64;
     int rc = 0;
     // batch buffers shared by all instances (contiguous, so one heuristic call serves every instance)
     rc = dev_alloc(e, &e->nnet_all, K * M * D + 64);
@@ -2034,12 +2114,10 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
         E.wf = (float)weight;  // cpp:353 (float) atof(argv[2])
         E.max_nodes = (uint32_t)max_nodes;
         E.M = (uint32_t)Mll;
-        E.ord_cap = (uint32_t)Bz;
         E.f_keep = (uint32_t)(32 * batch_size > 65536 ? 32 * batch_size : 65536);
         E.f_max = 3 * E.f_keep;
         E.tab_cap = (uint32_t)cap;
         E.tab_mask = (uint32_t)(cap - 1);
-        E.nb2_cap = (uint32_t)(Bz / 2 + 4096);
         E.nnet_in = e->nnet_all + i * M * D;
         E.child_h = e->h_all + i * M;
         E.onehot = e->onehot_all ? e->onehot_all + i * M * D * depth * (onehot_dtype == DCA_DT_F32 ? 4 : 2) : nullptr;
@@ -2056,42 +2134,49 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
             ALLOC(open_id[b], N);
         }
         ALLOC(hist, NBIN);
-        ALLOC(sub_base, NBIN);
+        ALLOC(pre, NBIN + 8);
+        ALLOC(fill, NBIN);
         ALLOC(part, 4 * 1024);
-        ALLOC(sub_lg, NBIN);
-        ALLOC(cand_key, N);
-        ALLOC(cand_id, N);
-        ALLOC(cand_st, N);
-        ALLOC(tmp_key, Bz);
+        ALLOC(tmp_key, N);
+        ALLOC(tmp_id, N);
+        ALLOC(tmp_st, N);
+        ALLOC(ord_key, N);
+        ALLOC(ord_id, N);
+        ALLOC(ord_b, N);
+        ALLOC(ord_s, N);
+        ALLOC(ord_pb, N);
+        ALLOC(bcnt, N / 4 + NBIN + 16);
+        ALLOC(bpre, N / 4 + NBIN + 16);
         ALLOC(pop_key, Bz);
-        ALLOC(tmp_id, Bz);
         ALLOC(pop_id, Bz);
-        ALLOC(ord_key, Bz);
-        ALLOC(ord_id, Bz);
-        ALLOC(ord_b, Bz);
-        ALLOC(ord_s, Bz);
-        ALLOC(ord_pb, Bz);
-        ALLOC(spl_key, 2048);
-        ALLOC(spl_id, 2048);
-        ALLOC(bcnt, E.nb2_cap + 8);
-        ALLOC(bpre, E.nb2_cap + 8);
+        ALLOC(pop_g, Bz);
         ALLOC(child_hash, M);
         ALLOC(child_slot, M);
         ALLOC(child_next, M);
         ALLOC(child_flags, M);
+        ALLOC(child_v0, M);
+        ALLOC(child_multi, M);
         ALLOC(root_nnet, 64);
         ALLOC(d_moves, kMaxMoves);
         ALLOC(ctl, 1);
 #undef ALLOC
         if (!rc) {
             (void)hipMemset(E.hist, 0, NBIN * sizeof(uint32_t));
-            (void)hipMemset(E.bcnt, 0, (E.nb2_cap + 8) * sizeof(uint32_t));
+            (void)hipMemset(E.fill, 0, NBIN * sizeof(uint32_t));
+            (void)hipMemset(E.bcnt, 0, (N / 4 + NBIN + 16) * sizeof(uint32_t));
+            (void)hipMemset(E.child_multi, 0, M);
             (void)hipMemset(E.ctl, 0, sizeof(Ctl));
         }
     }
     if (!rc) {
         hipError_t err = hipHostMalloc((void**)&e->h_ctl, sizeof(Ctl) + kMaxMoves * sizeof(int32_t) + 512);
         if (err != hipSuccess) rc = hip_fail(err, "hipHostMalloc");
+    }
+    if (!rc) {
+        // k_rank orders a bin inside 96 KB of LDS: beyond the default dynamic limit
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRankLdsBytes);
+        if (err != hipSuccess) rc = hip_fail(err, "hipFuncSetAttribute(k_rank)");
     }
     if (rc) {
         dca_engine_destroy(e);
@@ -2127,6 +2212,7 @@ void dca_engine_destroy(dca_engine* e) {
     for (int i = 0; i < e->nalloc; i++) (void)hipFree(e->allocs[i]);
     if (e->h_ctl) (void)hipHostFree(e->h_ctl);
     if (e->h_pk_n) (void)hipHostFree(e->h_pk_n);
+    if (e->h_prof) (void)hipHostFree(e->h_prof);
     delete e;
 }
 
@@ -2248,8 +2334,8 @@ int dca_engine_pop_expand_packed(dca_engine* e, const uint8_t** nnet_in, const v
     }
     hipStream_t s = (hipStream_t)stream;
     DCA_HIP(hipMemsetAsync(e->pk_n, 0, sizeof(uint32_t), s));
-    if (int rc = enqueue_first_half(e, -1, (e->host_iter++ % kRefillPeriod) == 0, s, nullptr, false)) return rc;
-    if (int rc = enqueue_dedup(e, s)) return rc;
+    if (int rc = enqueue_first_half(e, -1, (e->host_iter++ % kRefillPeriod) == 0, s, false)) return rc;
+    if (int rc = enqueue_dedup(e, true, s)) return rc;
     if (int rc = launch_pack(e, s)) return rc;
     DCA_HIP(hipMemcpyAsync(e->h_pk_n, e->pk_n, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     DCA_HIP(hipStreamSynchronize(s));
@@ -2314,34 +2400,63 @@ int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph,
     return 0;
 }
 
-int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, float* ms_out, void* stream) {
-    // one hipEvent between every pair of phases of an iteration (eager launches on `stream`);
-    // ms_out[k] = summed milliseconds of phase k over `iters` iterations.  Phases:
-    // 0 refill(3 kernels, every 8th iteration) 1 sel_hist 2 sel_scan 3 sel_collect 4 sel_cand 5 order(4 kernels)
-    // 6 post_pop 7 expand 8 probe 9 decide 10 commit
-    DCA_ARG(e != nullptr && ms_out != nullptr && heur_id >= 0 && heur_id <= DCA_HEUR_MANHATTAN && iters >= 0);
+int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, int use_graph, float* span_ms, float* gap_ms,
+                               void* stream) {
+    // Device-side profile of `iters` iterations of run_builtin, eager or as hipGraph replays: every workgroup stamps
+    // the device wall clock at entry and exit (Stamp), per launch the host takes max(end) - min(start) as the launch's
+    // busy span and min(start of the next launch) - max(end) as the gap in front of it.  Slots (span_ms / gap_ms
+    // [DCA_PROF_SLOTS], summed over the iterations): 0-2 refill hist/scan/move (every 8th iteration), 3 sel_hist,
+    // 4 sel_scan, 5 sel_collect, 6 rank, 7 expand, 8 probe, 9 decide, 10 pack (dedup-first stepping only), 11 commit.
+    // gap_ms[k] = idle time in front of launch k inside an iteration (the first launch of an iteration has none).
+    DCA_ARG(e != nullptr && span_ms != nullptr && heur_id >= 0 && heur_id <= DCA_HEUR_MANHATTAN && iters >= 0);
     if (e->phase != 0) {
         set_error("dca_engine_profile_builtin between pop_expand and commit");
         return DCA_E_STATE;
     }
     hipStream_t s = (hipStream_t)stream;
-    constexpr int NP = 11;
-    hipEvent_t ev[NP + 2];
-    for (int k = 0; k <= NP; k++) DCA_HIP(hipEventCreate(&ev[k]));
-    for (int k = 0; k < 16; k++) ms_out[k] = 0.f;
+    constexpr size_t kWords = (size_t)P_COUNT * kProfSlots * 2;
+    if (e->d_prof == nullptr) {
+        if (int rc = dev_alloc(e, &e->d_prof, kWords)) return rc;
+        DCA_HIP(hipHostMalloc((void**)&e->h_prof, kWords * sizeof(unsigned long long), hipHostMallocDefault));
+    }
+    int rate_khz = 100000;  // s_memrealtime: 100 MHz on gfx950
+    (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, 0);
+    if (rate_khz <= 0) rate_khz = 100000;
+    for (int k = 0; k < DCA_PROF_SLOTS; k++) {
+        span_ms[k] = 0.f;
+        if (gap_ms) gap_ms[k] = 0.f;
+    }
+    DCA_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < e->K; i++) e->E[i].prof = e->d_prof;
+    if (int rc = upload_engs(e)) return rc;
     int rc = 0;
     for (int it = 0; it < iters && !rc; it++) {
-        Marks mk{ev, 0, s};
-        rc = enqueue_first_half(e, heur_id, (e->host_iter++ % kRefillPeriod) == 0, s, &mk);
-        if (!rc) rc = enqueue_second_half(e, s, &mk);
-        if (hipStreamSynchronize(s) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipStreamSynchronize");
-        for (int p = 0; p < NP && !rc; p++) {
-            float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, ev[p], ev[p + 1]);
-            ms_out[p] += ms;
+        for (size_t w = 0; w < kWords; w += 2) {
+            e->h_prof[w] = ~0ull;
+            e->h_prof[w + 1] = 0ull;
+        }
+        if (hipMemcpyAsync(e->d_prof, e->h_prof, kWords * sizeof(unsigned long long), hipMemcpyHostToDevice, s) != hipSuccess)
+            rc = hip_fail(hipGetLastError(), "hipMemcpyAsync(prof)");
+        if (!rc) rc = dca_engine_run_builtin(e, heur_id, 1, use_graph, stream);
+        if (!rc && hipMemcpyAsync(e->h_prof, e->d_prof, kWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, s) != hipSuccess)
+            rc = hip_fail(hipGetLastError(), "hipMemcpyAsync(prof)");
+        if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipStreamSynchronize");
+        unsigned long long prev_end = 0;
+        for (int k = 0; k < P_COUNT && !rc; k++) {
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int b = 0; b < kProfSlots; b++) {
+                const unsigned long long a = e->h_prof[((size_t)k * kProfSlots + b) * 2], z = e->h_prof[((size_t)k * kProfSlots + b) * 2 + 1];
+                if (a != ~0ull && a < t0) t0 = a;
+                if (z > t1) t1 = z;
+            }
+            if (t0 == ~0ull || t1 < t0) continue;  // launch not part of this iteration (or it exited before stamping)
+            span_ms[k] += (float)((double)(t1 - t0) / (double)rate_khz);
+            if (gap_ms && prev_end != 0 && t0 > prev_end) gap_ms[k] += (float)((double)(t0 - prev_end) / (double)rate_khz);
+            prev_end = t1;
         }
     }
-    for (int k = 0; k <= NP; k++) (void)hipEventDestroy(ev[k]);
+    for (int i = 0; i < e->K; i++) e->E[i].prof = nullptr;
+    if (int urc = upload_engs(e)) return urc;
     return rc;
 }
 
@@ -2361,15 +2476,17 @@ int dca_engine_status_instance(dca_engine* e, int inst, dca_status* out, void* s
     DCA_ARG(out != nullptr);
     if (int rc = fetch_ctl(e, inst, (hipStream_t)stream)) return rc;
     const Ctl& c = *e->h_ctl;
+    // between the two halves of an iteration the expansion's record (S[(iters + 1) & 1]) is not current yet
+    const IterState& S = c.S[(c.iters + (e->phase != 0 ? 1 : 0)) & 1];
     out->done = c.done;
     out->failed = c.failed;
     out->iterations = c.iters;
     out->nodes_generated = c.gen;
     out->nodes_expanded = c.expanded;
-    out->open_size = (int64_t)c.open_n[c.cur_f].v + (int64_t)c.open_n[c.cur_b].v - (int64_t)c.back_dead.v;
+    out->open_size = (int64_t)c.open_n[S.cur_f].v + (int64_t)c.open_n[c.cur_b].v - (int64_t)c.back_dead.v;
     out->closed_size = c.closed_n.v;
-    out->pool_size = c.pool_n;
-    out->best_cost = c.has_best ? (double)c.best_cost : __builtin_nan("");
+    out->pool_size = S.pool_n;
+    out->best_cost = S.has_best ? (double)S.best_cost : __builtin_nan("");
     return 0;
 }
 int dca_engine_status(dca_engine* e, dca_status* out, void* stream) {
@@ -2386,30 +2503,32 @@ int dca_engine_debug(dca_engine* e, double* out, void* stream) {
         memcpy(&d, &b, 8);
         return d;
     };
-    out[0] = c.open_n[c.cur_f].v;
+    const IterState& S = c.S[(c.iters + (e->phase != 0 ? 1 : 0)) & 1];
+    out[0] = c.open_n[S.cur_f].v;
     out[1] = (double)c.open_n[c.cur_b].v - (double)c.back_dead.v;
-    out[2] = cost(c.rng[c.cur_f].kmin);
-    out[3] = cost(c.rng[c.cur_f].kmax);
+    out[2] = cost(c.rng[S.cur_f].kmin);
+    out[3] = cost(c.rng[S.cur_f].kmax);
     out[4] = cost(c.rng[c.cur_b].kmin);
     out[5] = cost(c.rng[c.cur_b].kmax);
     out[6] = cost(c.T);
     out[7] = c.want;
     out[8] = c.bstar;
-    out[9] = c.sel_less;
-    out[10] = c.sel_r;
-    out[11] = c.cand_n.v;
+    out[9] = 0;
+    out[10] = 0;
+    out[11] = 0;
     out[12] = c.shift;
     out[13] = c.spill_bin;
-    out[14] = c.npop;
-    out[15] = c.m;
+    out[14] = S.npop;
+    out[15] = S.m;
     return 0;
 }
 
 int dca_engine_last_children(dca_engine* e, const uint8_t** states, int64_t* m_live, void* stream) {
     DCA_ARG(e != nullptr && states != nullptr && m_live != nullptr);
     if (int rc = fetch_ctl(e, 0, (hipStream_t)stream)) return rc;
-    *states = e->E[0].state + (size_t)e->h_ctl->base * e->E[0].D;
-    *m_live = e->h_ctl->m;
+    const IterState& S = e->h_ctl->S[(e->h_ctl->iters + (e->phase != 0 ? 1 : 0)) & 1];
+    *states = e->E[0].state + (size_t)S.base * e->E[0].D;
+    *m_live = S.m;
     return 0;
 }
 

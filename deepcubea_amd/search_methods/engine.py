@@ -140,15 +140,20 @@ class BwasEngine:
         _lib.check(_lib.lib().dca_engine_run_builtin(self._h, heur_id, int(iters), int(use_graph),
                                                      _lib.stream_ptr()), "dca_engine_run_builtin")
 
-    PHASES = ["refill", "sel_hist", "sel_scan", "sel_collect", "sel_cand", "order", "post_pop", "expand", "probe",
-              "decide", "commit"]
+    PROF_SLOTS = ["refill_hist", "refill_scan", "refill_move", "sel_hist", "sel_scan", "sel_collect", "rank", "expand",
+                  "probe", "decide", "pack", "commit"]
 
-    def profile_builtin(self, heur_id: int, iters: int) -> dict:
-        """Per-kernel HIP-event timings (ms per iteration) of `iters` eager iterations."""
-        ms = (C.c_float * 16)()
-        _lib.check(_lib.lib().dca_engine_profile_builtin(self._h, heur_id, int(iters), ms, _lib.stream_ptr()),
-                   "dca_engine_profile_builtin")
-        return {name: ms[k] / max(iters, 1) for k, name in enumerate(self.PHASES)}
+    def profile_builtin(self, heur_id: int, iters: int, use_graph: bool = True) -> dict:
+        """Device-side profile of `iters` built-in iterations (graph replays by default): per launch the busy span
+        (max workgroup end - min workgroup start on the device wall clock) and the idle gap in front of it, in ms per
+        iteration -> {"span_ms": {launch: ms}, "gap_ms": {launch: ms}}.  Launches that did not run are omitted."""
+        n = len(self.PROF_SLOTS)
+        span, gap = (C.c_float * n)(), (C.c_float * n)()
+        _lib.check(_lib.lib().dca_engine_profile_builtin(self._h, heur_id, int(iters), int(use_graph), span, gap,
+                                                         _lib.stream_ptr()), "dca_engine_profile_builtin")
+        it = max(iters, 1)
+        return {"span_ms": {nm: span[k] / it for k, nm in enumerate(self.PROF_SLOTS) if span[k] > 0},
+                "gap_ms": {nm: gap[k] / it for k, nm in enumerate(self.PROF_SLOTS) if span[k] > 0}}
 
     def set_tiers(self, front_keep: int, front_max: int) -> None:
         """Override the FRONT-tier hysteresis (tests use tiny values to force constant refills / spills)."""
@@ -271,36 +276,3 @@ def _wrap(ptr: int, shape, dtype: torch.dtype) -> torch.Tensor:
 
 def _wrap_u8(ptr: int, shape) -> torch.Tensor:
     return _wrap(ptr, shape, torch.uint8)
-
-
-def smoke_check() -> None:
-    """Used by __graft_entry__.smoke(): a short device-resident solve checked against the oracle."""
-    from oracle import c_oracle as co
-    root = np.arange(54, dtype=np.uint8)[None]
-    for a in (0, 5, 7, 2):
-        root = co.next_state("cube3", root, a)
-    eng = BwasEngine("cube3", 0.8, 50, max_nodes=1 << 16)
-    res = eng.solve_builtin(root[0], _lib.HEUR_MOD97)
-    ref = co.astar("cube3", root[0], 0.8, 50, co.SEM_PY, heur_builtin_id=0)
-    assert res["solved"] and res["moves"] == ref["moves"], (res, ref)
-    assert res["nodes_generated"] == ref["nodes_generated"] and res["iterations"] == ref["iterations"]
-    eng.close()
-    # the CLI's default path: dedup-first stepping + the padded network layout, a small seeded network in the loop
-    from ..utils import nnet_utils
-    from ..utils.pytorch_models import FastResnet, ResnetModel
-    torch.manual_seed(0)
-    fast = FastResnet(ResnetModel(54, 6, 64, 32, 1, 1, True).eval()).cuda()
-    hfn = nnet_utils.get_heuristic_fn_dev(fast, batch_size=1024)
-    assert fast.uses_l1_kernel  # layer 1 = the one-hot MFMA kernel on the packed uint8 rows (no one-hot matrix)
-    eng = BwasEngine("cube3", 0.8, 50, max_nodes=1 << 18, packed=True)
-    res = eng.solve(root[0], hfn)
-
-    def heur(states):  # the oracle evaluates every child through the same closure (batches padded to 1024 rows)
-        x = torch.zeros((1024, 54), dtype=torch.uint8, device="cuda")
-        x[:len(states)] = torch.from_numpy(np.ascontiguousarray(states // 9)).cuda()
-        return hfn(x)[:len(states)].cpu().numpy()
-
-    ref = co.astar("cube3", root[0], 0.8, 50, co.SEM_PY, heur_fn=heur)
-    assert res["solved"] and res["moves"] == ref["moves"] and res["nodes_generated"] == ref["nodes_generated"], (res, ref)
-    assert eng.rows_evaluated < res["nodes_generated"]
-    eng.close()

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DCA_ABI_VERSION 1
+#define DCA_ABI_VERSION 2
 
 /* library error codes (negative; positive values are hipError_t) */
 #define DCA_E_BADARG (-1)
@@ -213,10 +213,16 @@ int dca_engine_commit_packed(dca_engine* e, const float* h, void* stream);
  * iterations enqueued without any host sync (kernels no-op once the search is done).
  * use_graph != 0 replays one captured hipGraph per iteration instead of eager launches.           */
 int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph, void* stream);
-/* like run_builtin (eager) but with a hipEvent between every pair of kernels; ms_out (host float[16])
- * receives the summed milliseconds per phase: 0 refill 1 sel_hist 2 sel_scan 3 sel_collect 4 sel_cand
- * 5 order 6 post_pop 7 expand 8 probe 9 decide 10 commit.  Synchronises every iteration.              */
-int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, float* ms_out /*host [16]*/, void* stream);
+/* Device-side profile of `iters` iterations of run_builtin (use_graph as there): every workgroup stamps the device wall
+ * clock at entry and exit, per launch the host takes max(end) - min(start) as the launch's busy span and the distance to
+ * the previous launch's end as the gap in front of it — measured INSIDE the replayed hipGraph, which HIP events between
+ * eager launches cannot do.  span_ms / gap_ms: host float[DCA_PROF_SLOTS], summed milliseconds over the iterations
+ * (gap_ms may be NULL).  Slots: 0 refill_hist 1 refill_scan 2 refill_move (every 8th iteration) 3 sel_hist 4 sel_scan
+ * 5 sel_collect 6 rank 7 expand 8 probe 9 decide 10 pack (dedup-first stepping only) 11 commit.  Synchronises every
+ * iteration.                                                                                                          */
+#define DCA_PROF_SLOTS 12
+int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, int use_graph, float* span_ms /*host [12]*/,
+                               float* gap_ms /*host [12] or NULL*/, void* stream);
 /* synchronises the stream */
 int dca_engine_status(dca_engine* e, dca_status* out, void* stream);
 int dca_engine_status_instance(dca_engine* e, int inst, dca_status* out, void* stream);
