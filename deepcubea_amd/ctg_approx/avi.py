@@ -175,7 +175,15 @@ def main(argv=None):
                                          args_dict['update_method'], args_dict['states_per_update'], args_dict['eps_max'],
                                          hfn, args_dict['seed'] + 7919 * (itr + 1), max(args_dict['update_nnet_batch_size'], 1) * 10)
         del hfn
-        # train
+        # train.  Under DDP every rank must run the SAME number of steps (each one is a gradient all-reduce), but the
+        # shards differ in size: GBFS trajectories end early where an instance solves (--max_update_steps > 1) and
+        # states_per_update need not divide evenly.  Agree on the smallest shard and train on that many examples.
+        if world > 1:
+            cnt = torch.tensor([outputs.shape[0]], dtype=torch.int64, device=device)
+            torch.distributed.all_reduce(cnt, op=torch.distributed.ReduceOp.MIN)
+            n_common = int(cnt.item())
+            if n_common < outputs.shape[0]:
+                states_nnet, outputs = states_nnet[:n_common], outputs[:n_common]
         num_train_itrs = int(args_dict['epochs_per_update'] * np.ceil(outputs.shape[0] / local_batch))
         print("Training model for update number %i for %i iterations" % (update_num, num_train_itrs))
         last_loss = nnet_utils.train_nnet(model, states_nnet, outputs, device, local_batch, num_train_itrs, itr,

@@ -98,9 +98,13 @@ def bwas_hip(args, env, states: List) -> Tuple[List[List[int]], List[List], List
     for group in groups:  # K scrambles stepped together by one engine (one network call per iteration)
         start_time = time.time()
         roots = [np.ascontiguousarray(env._get_arr(states[i]), dtype=np.uint8) for i in group]
-        results = eng.solve_many(roots, heuristic_fn) if K > 1 else [eng.solve(roots[0], heuristic_fn)]
+        if K > 1:
+            done_at: Dict[int, float] = {}
+            results = eng.solve_many(roots, heuristic_fn, on_done=lambda i: done_at.setdefault(i, time.time() - start_time))
+        else:
+            results = [eng.solve(roots[0], heuristic_fn)]
         group_time = time.time() - start_time
-        for state_idx, res in zip(group, results):
+        for slot, (state_idx, res) in enumerate(zip(group, results)):
             state = states[state_idx]
             if not res["solved"]:
                 raise _lib.DcaError("state %d: search stopped without a solution (%s) — raise --max_nodes"
@@ -114,7 +118,9 @@ def bwas_hip(args, env, states: List) -> Tuple[List[List[int]], List[List], List
             for move in soln:
                 cur = env.next_state([cur], move)[0][0]
                 path.append(cur)
-            solve_time = group_time  # with K > 1 the group's wall time is charged to each of its states
+            # per-state time like astar.py:417,434: with K > 1 the moment THIS instance finished (its search shares
+            # every launch with the group's other instances, but it stops generating nodes when it is done)
+            solve_time = done_at.get(slot, group_time) if K > 1 else group_time
             assert search_utils.is_valid_soln(state, soln, env)  # astar.py:443
             local[state_idx] = (soln, path, solve_time, num_nodes_gen_idx)
             print("State: %i, SolnCost: %.2f, # Moves: %i, "
@@ -191,7 +197,7 @@ def main(argv=None):
         results["paths"] = paths
         results["times"] = times
         results["num_nodes_generated"] = num_nodes_gen
-        pickle.dump(results, open(results_file, "wb"), protocol=-1)
+        data_utils.dump_pickle(results, results_file)  # reference class paths: loads in the reference tree too
     sharding.finalize()
 
 

@@ -247,18 +247,24 @@ class BwasEngine:
                 break
         return [self._result(i) for i in range(k)]
 
-    def solve_many(self, roots, heuristic_fn_dev, max_iters: int = 1 << 30) -> List[dict]:
+    def solve_many(self, roots, heuristic_fn_dev, max_iters: int = 1 << 30, on_done=None) -> List[dict]:
         """Same with a device heuristic closure: ONE network call per iteration evaluates the children of all
-        instances (their batch buffers are contiguous)."""
+        instances (their batch buffers are contiguous).  on_done(i) is called once when instance i finishes."""
         k = len(roots)
         assert 1 <= k <= self.num_instances
         for i, root in enumerate(roots):
             self.reset(root, i)
             if self.semantics == _lib.SEM_PY:
                 self.root_commit(heuristic_fn_dev(self.root_nnet_in(i)).to(torch.float32), i)
+        finished = [False] * k
         for _ in range(max_iters):
             self.step(heuristic_fn_dev)
-            if all(self.status(i)["done"] for i in range(k)):
+            for i in range(k):
+                if not finished[i] and self.status(i)["done"]:
+                    finished[i] = True
+                    if on_done is not None:
+                        on_done(i)
+            if all(finished):
                 break
         return [self._result(i) for i in range(k)]
 

@@ -22,20 +22,23 @@ from .. import _lib
 from ..search_methods import sharding
 
 
-def bellman_dev(env, states: torch.Tensor, heuristic_fn_dev: Callable, onehot_dtype=None):
+def bellman_dev(env, states: torch.Tensor, heuristic_fn_dev: Callable, onehot_dtype=None, clip_zero: bool = True):
     """search_utils.bellman (search_utils.py:16-32) on device.
-    -> (ctg_backup f32 [n], argmin i32 [n], children u8 [n,A,D])."""
+    -> (ctg_backup f32 [n], argmin i32 [n], children u8 [n,A,D]).
+    clip_zero: max(h, 0) before the backup — what the update's heuristic servers do (avi.py:213 clip_zero=True);
+    gbfs_test runs on the unclipped current network (avi.py:251 / nnet_utils.get_heuristic_fn default)."""
     A = env.get_num_moves()
     out = env.expand_dev(states, children=True, nnet_in=(onehot_dtype is None), onehot_dtype=onehot_dtype, solved=False,
                          hashes=False)
     h = heuristic_fn_dev(out["onehot"], True) if onehot_dtype is not None else heuristic_fn_dev(out["nnet_in"])
-    ctg, am = _lib.bellman_backup(h, env.is_solved_dev(states), A, clip_zero=True)  # avi.py:213 clip_zero=True
+    ctg, am = _lib.bellman_backup(h, env.is_solved_dev(states), A, clip_zero=clip_zero)
     return ctg, am, out["children"]
 
 
 def gbfs_update_dev(states: torch.Tensor, env, num_steps: int, heuristic_fn_dev: Callable, eps_max: float = 0.0,
                     generator: Optional[torch.Generator] = None, onehot_dtype=None,
-                    rand_child: Optional[Callable[[int, int], torch.Tensor]] = None, return_steps: bool = False):
+                    rand_child: Optional[Callable[[int, int], torch.Tensor]] = None, return_steps: bool = False,
+                    clip_zero: bool = True):
     """updater.py:11-33 gbfs_update with GBFS.step (gbfs.py:43-120) for all instances at once.
     -> (states_update u8 [T,D], cost_to_go f32 [T], is_solved bool [n]) in the reference's instance-major order.
     `rand_child(k, A)` may override the random-child draw (tests stub it, like np.random.choice)."""
@@ -65,7 +68,7 @@ def gbfs_update_dev(states: torch.Tensor, env, num_steps: int, heuristic_fn_dev:
         if uns.numel() == 0:
             continue
         st = cur[uns].contiguous()  # _move (gbfs.py:86-120)
-        ctg, am, children = bellman_dev(env, st, heuristic_fn_dev, onehot_dtype)
+        ctg, am, children = bellman_dev(env, st, heuristic_fn_dev, onehot_dtype, clip_zero)
         traj_states.append(st)
         traj_ctg.append(ctg)
         traj_inst.append(uns)
@@ -168,7 +171,9 @@ def gbfs_test_dev(num_states: int, back_max: int, env, heuristic_fn_dev: Callabl
     if max_solve_steps is None:
         max_solve_steps = max(int(state_back_steps.max()), 1)
     print("Solving %i states with GBFS with %i steps" % (states.shape[0], max_solve_steps))
-    solved_d, steps_d = gbfs_update_dev(states, env, max_solve_steps, heuristic_fn_dev, 0.0, return_steps=True)
+    # the reference's gbfs_test greedy-walks on the UNCLIPPED current network (gbfs.py:126-183, avi.py:251)
+    solved_d, steps_d = gbfs_update_dev(states, env, max_solve_steps, heuristic_fn_dev, 0.0, return_steps=True,
+                                        clip_zero=False)
     is_solved_all = solved_d.cpu().numpy()
     num_steps_all = steps_d.cpu().numpy()
     state_ctg_all = heuristic_fn_dev(_lib.nnet_input(env._env_id, env._dim, states)).float().cpu().numpy()

@@ -52,7 +52,17 @@ def summarize(res: Dict[str, np.ndarray]) -> Dict[str, Dict[str, float]]:
             "Nodes Generated": stats(res["num_nodes_generated"]), "Nodes/Sec": stats(nps[np.isfinite(nps)])}
 
 
-def compare(res1, res2) -> Dict[str, object]:
+def compare(res1, res2, offset: int = 0) -> Dict[str, object]:
+    """offset: state index of soln1 that soln2's first entry corresponds to (a `--start_idx` run).  Result sets of
+    different length without an explicit offset are refused — the reference script fails on the shape mismatch too,
+    and silently comparing misaligned states would be worse."""
+    n1, n2 = len(res1["lens"]), len(res2["lens"])
+    if offset == 0 and n1 != n2:
+        raise ValueError("result sets differ in length (%d vs %d states): pass --offset for a --start_idx run" % (n1, n2))
+    if offset:
+        if offset < 0 or offset + n2 > n1:
+            raise ValueError("offset %d + %d states does not fit the %d states of soln1" % (offset, n2, n1))
+        res1 = {k: v[offset:offset + n2] for k, v in res1.items()}
     n = min(len(res1["lens"]), len(res2["lens"]))
     diff = res2["lens"][:n] - res1["lens"][:n]
     return {"num_states": n, "soln1": summarize(res1), "soln2": summarize(res2), "length_diff": stats(diff),
@@ -80,8 +90,9 @@ def main(argv=None):
     parser = ArgumentParser()
     parser.add_argument('--soln1', type=str, required=True, help="results.pkl / data_0.pkl / output.txt")
     parser.add_argument('--soln2', type=str, required=True, help="results.pkl / output.txt")
+    parser.add_argument('--offset', type=int, default=0, help="soln2's first state is soln1's state number OFFSET")
     args = parser.parse_args(argv)
-    print(format_report(compare(load_results(args.soln1), load_results(args.soln2))))
+    print(format_report(compare(load_results(args.soln1), load_results(args.soln2), args.offset)))
 
 
 if __name__ == "__main__":

@@ -34,3 +34,23 @@ def load_pickle(path: str):
     """pickle.load that maps the reference's State class paths onto this package's classes."""
     with open(path, "rb") as f:
         return _RefUnpickler(io.BufferedReader(f)).load()
+
+
+class _RefPickler(pickle._Pickler):
+    """Writes this package's State classes under the REFERENCE's class paths (`environments.cube3.Cube3State`, ...), so
+    a results.pkl produced here unpickles in the reference tree (scripts/compare_solutions.py and friends) without this
+    package installed.  Same __slots__ (`colors` / `tiles`, `hash`) on both sides, so the object state is compatible."""
+    _MAP = {v: k for k, v in _RefUnpickler._MAP.items()}
+
+    def save_global(self, obj, name=None):
+        path = self._MAP.get((getattr(obj, "__module__", None), getattr(obj, "__qualname__", None)))
+        if path is None:
+            return super().save_global(obj, name)
+        self.write(pickle.GLOBAL + path[0].encode("ascii") + b"\n" + path[1].encode("ascii") + b"\n")
+        self.memoize(obj)
+
+
+def dump_pickle(obj, path: str) -> None:
+    """pickle.dump with the reference's State class paths (inverse of load_pickle)."""
+    with open(path, "wb") as f:
+        _RefPickler(f, protocol=2).dump(obj)

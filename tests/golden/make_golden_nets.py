@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Network-forward fixtures recorded from the REFERENCE's own `ResnetModel` (utils/pytorch_models.py:5-86), imported from
+/root/reference in the build container (the reference never travels):
+
+    python tests/golden/make_golden_nets.py        ->  tests/golden/nets.npz
+
+  puzzle48_resnet_seed2026_{x,y}     reference NPuzzle(7).get_nnet_model() (n_puzzle.py:94-98: 49x49 = 2401-wide one-hot),
+                                     deterministic weights (same recipe as make_golden.py:det_weights /
+                                     deepcubea_amd.utils.synthetic_weights), 64 random tile permutations -> fp32 outputs
+  puzzle24_resnet_seed2027_{x,y}     same for NPuzzle(5)
+  cube3_big_seed2028_{x,y32,y64,out_scale,out_shift}
+                                     cube3 architecture whose fc_out is rescaled so that the outputs sit at trained-network
+                                     magnitudes (|h| ~ 20-30, where fp32 has the least headroom for the 1e-5 tolerance):
+                                     y32 = the reference's fp32 forward, y64 = the same module evaluated in float64
+                                     (SURVEY §7.3's protocol: both implementations are judged against the fp64 evaluation).
+Only data is written (inputs + the reference's outputs); the weights are regenerated from the seed on both sides.
+"""
+import os
+import sys
+
+import numpy as np
+
+np.float = float  # noqa: the reference targets numpy 1.22
+np.int = int  # noqa
+
+REF = "/root/reference"
+sys.path.insert(0, REF)
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+import torch  # noqa: E402
+from environments.cube3 import Cube3  # noqa: E402
+from environments.n_puzzle import NPuzzle  # noqa: E402
+
+
+def synth_states(n, d, seed):
+    rng = np.random.default_rng(seed)
+    return rng.permuted(np.tile(np.arange(d, dtype=np.uint8), (n, 1)), axis=1)
+
+
+def det_weights(model, seed):
+    rng = np.random.default_rng(seed)
+    new = {}
+    for k, v in model.state_dict().items():
+        shp = tuple(v.shape)
+        if k.endswith("num_batches_tracked"):
+            new[k] = torch.tensor(7, dtype=torch.long)
+        elif k.endswith("running_var"):
+            new[k] = torch.tensor(rng.uniform(0.5, 1.5, shp).astype(np.float32))
+        elif k.endswith("running_mean"):
+            new[k] = torch.tensor(rng.normal(0, 0.1, shp).astype(np.float32))
+        elif k.endswith("weight") and len(shp) == 2:
+            new[k] = torch.tensor((rng.normal(0, 1.0, shp) / np.sqrt(shp[1])).astype(np.float32))
+        elif k.endswith("weight"):
+            new[k] = torch.tensor(rng.uniform(0.8, 1.2, shp).astype(np.float32))
+        else:
+            new[k] = torch.tensor(rng.normal(0, 0.1, shp).astype(np.float32))
+    model.load_state_dict(new)
+
+
+def forward_fp64(sd, x, depth, eps=1e-5):
+    """float64 evaluation of the reference module's arithmetic (pytorch_models.py:45-86, BatchNorm in eval mode) from
+    its state dict — the module itself casts to float32 inside forward, so the fp64 yardstick is computed here."""
+    f = lambda k: sd[k].astype(np.float64)  # noqa: E731
+    n, d = x.shape
+    h = np.zeros((n, d * depth))
+    h[np.arange(n)[:, None], np.arange(d)[None] * depth + x] = 1.0
+
+    def lin(h, name):
+        return h @ f(name + ".weight").T + f(name + ".bias")
+
+    def bn(h, name):
+        return (h - f(name + ".running_mean")) / np.sqrt(f(name + ".running_var") + eps) * f(name + ".weight") + f(name + ".bias")
+
+    h = np.maximum(bn(lin(h, "fc1"), "bn1"), 0)
+    h = np.maximum(bn(lin(h, "fc2"), "bn2"), 0)
+    b = 0
+    while "blocks.%d.0.weight" % b in sd:
+        r = h
+        h = np.maximum(bn(lin(h, "blocks.%d.0" % b), "blocks.%d.1" % b), 0)
+        h = bn(lin(h, "blocks.%d.2" % b), "blocks.%d.3" % b)
+        h = np.maximum(h + r, 0)
+        b += 1
+    return lin(h, "fc_out")[:, 0]
+
+
+def main():
+    torch.set_num_threads(1)
+    out = {}
+    for name, dim, seed, xs in (("puzzle48", 7, 2026, 11), ("puzzle24", 5, 2027, 12)):
+        net = NPuzzle(dim).get_nnet_model()
+        det_weights(net, seed)
+        net.eval()
+        x = synth_states(64, dim * dim, xs)
+        with torch.no_grad():
+            y = net(torch.tensor(x)).numpy()[:, 0]
+        out["%s_resnet_seed%d_x" % (name, seed)] = x
+        out["%s_resnet_seed%d_y" % (name, seed)] = y.astype(np.float32)
+        print(name, "outputs", y[:4], "max|y|", np.abs(y).max())
+    # trained-network magnitudes: rescale fc_out (weights * s, bias + t) so the outputs land in ~[20, 30]
+    net = Cube3().get_nnet_model()
+    det_weights(net, 2028)
+    net.eval()
+    x = (synth_states(512, 54, 13) // 9).astype(np.uint8)
+    with torch.no_grad():
+        y0 = net(torch.tensor(x)).numpy()[:, 0]
+    s = np.float32(4.0 / max(float(np.abs(y0 - y0.mean()).max()), 1e-6))  # spread +-4 around ...
+    t = np.float32(25.0)                                                   # ... 25
+    with torch.no_grad():
+        net.fc_out.weight.mul_(float(s))
+        net.fc_out.bias.mul_(float(s)).add_(float(t) - float(s) * float(y0.mean()))
+        y32 = net(torch.tensor(x)).numpy()[:, 0]
+    y64 = forward_fp64({k: v.numpy() for k, v in net.state_dict().items()}, x, 6)
+    print("cube3_big: y32 range", y32.min(), y32.max(), " reference fp32 vs its own fp64 evaluation: max abs",
+          np.abs(y32.astype(np.float64) - y64).max())
+    out["cube3_big_seed2028_x"] = x
+    out["cube3_big_seed2028_y32"] = y32.astype(np.float32)
+    out["cube3_big_seed2028_y64"] = y64.astype(np.float64)
+    out["cube3_big_seed2028_out_scale"] = np.array(s, np.float32)
+    out["cube3_big_seed2028_out_shift"] = np.array(np.float32(float(t) - float(s) * float(y0.mean())), np.float32)
+    np.savez_compressed(os.path.join(OUT, "nets.npz"), **out)
+    print("wrote", os.path.join(OUT, "nets.npz"))
+
+
+if __name__ == "__main__":
+    main()

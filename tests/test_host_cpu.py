@@ -255,3 +255,56 @@ def test_updater_shards_states_like_split_evenly(monkeypatch):
     assert seen[1:4] == [4, 3, 3]
     with pytest.raises(ValueError):
         Updater(_Env(), 10, 30, None, 1, update_method="astar")
+
+
+def test_results_pickle_names_the_reference_classes(tmp_path):
+    """results.pkl must load in the reference tree — `dump_pickle` writes this package's State classes
+    under `environments.cube3.Cube3State` / `environments.n_puzzle.NPuzzleState` (same __slots__ on both sides)."""
+    import pickletools
+    from deepcubea_amd.environments.cube3 import Cube3State
+    from deepcubea_amd.environments.n_puzzle import NPuzzleState
+    from deepcubea_amd.utils import data_utils
+    res = {"states": [Cube3State(np.arange(54, dtype=np.uint8))], "paths": [[NPuzzleState(np.arange(16, dtype=np.uint8))]],
+           "solutions": [[1, 2]], "times": [0.5], "num_nodes_generated": [12]}
+    p = tmp_path / "results.pkl"
+    data_utils.dump_pickle(res, str(p))
+    names = [arg for op, arg, _ in pickletools.genops(p.read_bytes()) if op.name == "GLOBAL"]
+    assert "environments.cube3 Cube3State" in names and "environments.n_puzzle NPuzzleState" in names
+    assert not any(n.startswith("deepcubea_amd") for n in names)
+    # a reader that only knows the reference's module layout (stand-in classes with the reference's __slots__)
+    import sys
+    import types
+    mods = {}
+    for mname, cname, slot in (("environments.cube3", "Cube3State", "colors"), ("environments.n_puzzle", "NPuzzleState", "tiles")):
+        cls = type(cname, (), {"__slots__": [slot, "hash"], "__module__": mname})
+        mod = types.ModuleType(mname)
+        setattr(mod, cname, cls)
+        mods[mname] = mod
+    mods["environments"] = types.ModuleType("environments")
+    saved = {k: sys.modules.get(k) for k in mods}
+    sys.modules.update(mods)
+    try:
+        back = pickle.load(open(p, "rb"))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                del sys.modules[k]
+            else:
+                sys.modules[k] = v
+    assert type(back["states"][0]).__module__ == "environments.cube3" and back["states"][0].colors.tolist() == list(range(54))
+    assert back["paths"][0][0].tiles.tolist() == list(range(16)) and back["solutions"] == [[1, 2]]
+    # and back through this package's loader
+    mine = data_utils.load_pickle(str(p))
+    assert isinstance(mine["states"][0], Cube3State) and mine["states"][0] == res["states"][0]
+
+
+def test_compare_solutions_refuses_misaligned_sets():
+    from deepcubea_amd.utils import compare_solutions as cs
+    a = {"lens": np.array([5, 6, 7, 8]), "times": np.ones(4), "num_nodes_generated": np.ones(4) * 10}
+    b = {"lens": np.array([7, 8]), "times": np.ones(2), "num_nodes_generated": np.ones(2) * 10}
+    with pytest.raises(ValueError):
+        cs.compare(a, b)
+    c = cs.compare(a, b, offset=2)  # a --start_idx 2 run
+    assert c["num_states"] == 2 and c["pct_equal"] == 100.0
+    with pytest.raises(ValueError):
+        cs.compare(a, b, offset=3)

@@ -5,6 +5,7 @@ the cpp-semantics known answers are the rows of SURVEY.md Appendix A (outputs of
 reference binary recorded during the survey).  CPU only.
 """
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -329,3 +330,24 @@ def test_split_operand_layers_are_fp32_accurate_by_construction():
     got = sum(oh @ p.astype(np.float64).T for p in no.bf16_planes(w1, 3))
     want = oh @ w1.astype(np.float64).T
     assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max()
+
+
+def test_resnet_restatement_puzzle_nets_and_trained_magnitudes():
+    """tests/golden/nets.npz (recorded from the reference's ResnetModel): the puzzle architectures (one-hot depth n*n,
+    n_puzzle.py:94-98) and a cube3 network rescaled to trained-network output magnitudes (|h| 21-29)."""
+    nets = np.load(os.path.join(os.path.dirname(__file__), "golden", "nets.npz"))
+    for name, dim, seed in (("puzzle48", 7, 2026), ("puzzle24", 5, 2027)):
+        D = dim * dim
+        w = no.resnet_det_weights(no.resnet_shapes(D, D, 5000, 1000, 4), seed)
+        y = no.resnet_forward(w, nets["%s_resnet_seed%d_x" % (name, seed)], D, 4, np.float64)
+        assert np.max(np.abs(y - nets["%s_resnet_seed%d_y" % (name, seed)])) < 1e-5
+    w = no.resnet_det_weights(no.resnet_shapes(54, 6, 5000, 1000, 4), 2028)
+    s, t = np.float64(nets["cube3_big_seed2028_out_scale"]), np.float64(nets["cube3_big_seed2028_out_shift"])
+    w["fc_out.weight"] = (w["fc_out.weight"] * np.float32(s)).astype(np.float32)
+    w["fc_out.bias"] = (w["fc_out.bias"] * np.float32(s) + np.float32(t)).astype(np.float32)
+    y64 = no.resnet_forward(w, nets["cube3_big_seed2028_x"], 6, 4, np.float64)
+    assert 20.0 < y64.min() and y64.max() < 30.0
+    # the oracle's fp64 evaluation IS the fixture's fp64 yardstick (same weights, same arithmetic) ...
+    assert np.max(np.abs(y64 - nets["cube3_big_seed2028_y64"])) < 1e-9
+    # ... and the reference's own fp32 forward sits within the north star's 1e-5 of it even at this magnitude
+    assert np.max(np.abs(nets["cube3_big_seed2028_y32"] - y64)) < 1e-5

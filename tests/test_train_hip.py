@@ -141,3 +141,24 @@ def test_avi_two_ranks_ddp(tmp_path):
     assert all(not k.startswith("module.") for k in sd) and all(torch.isfinite(v.float()).all() for v in sd.values())
     log = open(os.path.join(save, "p", "output.txt")).read()
     assert "Training model for update number 0 for 4 iterations" in log and "Updating target network" in log
+
+
+def test_avi_two_ranks_ddp_uneven_shards(tmp_path):
+    """with --max_update_steps 3 the ranks' GBFS shards differ in size (trajectories end where an instance
+    solves; puzzle15 at back_max 6 solves many) and 4001 states do not split evenly — the ranks must still agree on the
+    number of DDP steps (all_reduce MIN of the shard sizes) instead of hanging in the gradient all-reduce."""
+    import subprocess
+    save = str(tmp_path / "saved_models")
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), DCA_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29548", "-m", "deepcubea_amd.ctg_approx.avi", "--env", "puzzle15",
+           "--states_per_update", "4001", "--batch_size", "1000", "--nnet_name", "q", "--max_itrs", "6", "--loss_thresh",
+           "1e9", "--back_max", "6", "--num_test", "60", "--save_dir", save, "--update_nnet_batch_size", "2000",
+           "--max_update_steps", "3", "--update_num", "2"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    cur = os.path.join(save, "q", "current")
+    itr = pickle.load(open(os.path.join(cur, "train_itr.pkl"), "rb"))
+    assert itr >= 6
+    log = open(os.path.join(save, "q", "output.txt")).read()
+    assert "Using GBFS with 3 step(s)" in log and "Done" in log

@@ -29,7 +29,7 @@ def _upd(L, env_name, roots, steps, hid, onehot_dtype=None):
     A = env.get_num_moves()
     orig = up.bellman_dev
 
-    def bellman_builtin(env_, states, hfn, oh=None):
+    def bellman_builtin(env_, states, hfn, oh=None, clip_zero=True):
         out = env_.expand_dev(states, children=True, solved=False, hashes=False)
         h = L.heuristic_builtin(hid, out["children"].view(-1, states.shape[1]))
         ctg, am = L.bellman_backup(h, env_.is_solved_dev(states), A, clip_zero=True)
