@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdca_hip.so")
 
 ENV_CUBE3, ENV_NPUZZLE = 0, 1
-DT_F32, DT_F16, DT_BF16, DT_F16X3 = 0, 1, 2, 3
+DT_F32, DT_F16, DT_BF16, DT_F16X3, DT_F16_PLANES = 0, 1, 2, 3, 4
 SEM_PY, SEM_CPP = 0, 1
 HEUR_MOD97, HEUR_KNUTH3, HEUR_HASHU01, HEUR_ZERO, HEUR_MANHATTAN = 0, 1, 2, 3, 4
 
@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "dca_engine_enable_packed", "dca_engine_pop_expand_packed", "dca_engine_commit_packed",
     "dca_engine_profile_builtin", "dca_engine_set_tiers", "dca_engine_debug", "dca_engine_status", "dca_engine_last_children", "dca_engine_solution",
     "dca_bn_workspace_bytes", "dca_bn_train_forward", "dca_bn_train_backward",
-    "dca_l1_supported", "dca_l1_kpad", "dca_l1_onehot_gemm", "dca_act_split",
+    "dca_l1_supported", "dca_l1_kpad", "dca_l1_onehot_gemm", "dca_act_split", "dca_f16x3_gemm", "dca_split_planes",
 ]
 
 
@@ -311,13 +311,17 @@ def l1_kpad(state_dim: int, depth: int) -> int:
 
 
 def l1_onehot_gemm(states_nnet: torch.Tensor, depth: int, w_tiles: torch.Tensor, planes: int, bias: torch.Tensor,
-                   relu: bool, out_dtype, split: bool = False, overflow: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   relu: bool, out_dtype, split=False, overflow: Optional[torch.Tensor] = None) -> torch.Tensor:
     """relu?(onehot(states_nnet) @ W1^T + b1) from the uint8 rows, [m, n_pad] in out_dtype (dca_l1_onehot_gemm);
-    split=True: the f16x3 operand [m, 3*n_pad] fp16 of the next layer instead (DCA_DT_F16X3)."""
+    split=True: the library-GEMM f16x3 operand [m, 3*n_pad] fp16 of the next layer instead (DCA_DT_F16X3);
+    split="planes": dca_f16x3_gemm's operand [2, m, n_pad] fp16 (high halves, low halves; DCA_DT_F16_PLANES)."""
     x = _u8(states_nnet)
     m, d = x.shape
     n_pad = bias.numel()
-    if split:
+    if split == "planes":
+        out = torch.empty((2, m, n_pad), dtype=torch.float16, device=x.device)
+        code = DT_F16_PLANES
+    elif split:
         out = torch.empty((m, 3 * n_pad), dtype=torch.float16, device=x.device)
         code = DT_F16X3
     else:
@@ -329,14 +333,50 @@ def l1_onehot_gemm(states_nnet: torch.Tensor, depth: int, w_tiles: torch.Tensor,
 
 
 def act_split(y: torch.Tensor, bias: Optional[torch.Tensor], skip: Optional[torch.Tensor], alpha, relu: bool,
-              want_x: bool, want_a3: bool = True, overflow: Optional[torch.Tensor] = None):
-    """v = relu?(y*alpha + bias (+ skip)) -> (a3 [m,3n] fp16, a3[3k..3k+2] = (vh, vl, vh), or None; v fp32 or None)."""
+              want_x: bool, want_a3=True, overflow: Optional[torch.Tensor] = None):
+    """v = relu?(y*alpha + bias (+ skip)) -> (a3, v fp32 or None).  want_a3=True: the library-GEMM operand [m,3n] fp16,
+    a3[3k..3k+2] = (vh, vl, vh); want_a3="planes": dca_f16x3_gemm's operand [2,m,n] fp16; False: None."""
     assert y.dtype == torch.float32 and y.is_contiguous() and (want_x or want_a3)
     m, n = y.shape
-    a3 = torch.empty((m, 3 * n), dtype=torch.float16, device=y.device) if want_a3 else None
+    planes = want_a3 == "planes"
+    a3 = None
+    if planes:
+        a3 = torch.empty((2, m, n), dtype=torch.float16, device=y.device)
+    elif want_a3:
+        a3 = torch.empty((m, 3 * n), dtype=torch.float16, device=y.device)
     x_out = torch.empty_like(y) if want_x else None
     col_scale = alpha if isinstance(alpha, torch.Tensor) else None  # per-output-unit scale vector or one scalar
     check(lib().dca_act_split(ptr(y), ptr(bias), ptr(skip), ptr(col_scale), C.c_double(1.0 if col_scale is not None else alpha),
-                              int(relu), C.c_int64(m), C.c_int64(n), ptr(x_out), ptr(a3), ptr(overflow), stream_ptr()),
-          "dca_act_split")
+                              int(relu), C.c_int64(m), C.c_int64(n), ptr(x_out), ptr(a3), int(planes), ptr(overflow),
+                              stream_ptr()), "dca_act_split")
     return a3, x_out
+
+
+def split_planes(x: torch.Tensor, overflow: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 [m, n] -> its fp16 planes [2, m, n] (x = planes[0] + planes[1] to 22 bits): the operand of f16x3_gemm."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] % 4 == 0
+    m, n = x.shape
+    out = torch.empty((2, m, n), dtype=torch.float16, device=x.device)
+    check(lib().dca_split_planes(ptr(x), C.c_int64(m), C.c_int64(n), C.c_int64(n), ptr(out[0]), ptr(out[1]), C.c_int64(n),
+                                 ptr(overflow), stream_ptr()), "dca_split_planes")
+    return out
+
+
+def f16x3_gemm(a_planes: torch.Tensor, w_h: torch.Tensor, w_l: torch.Tensor, col_scale: Optional[torch.Tensor], alpha: float,
+               bias: Optional[torch.Tensor], skip: Optional[torch.Tensor], relu: bool, want_planes: bool, want_x: bool,
+               overflow: Optional[torch.Tensor] = None):
+    """One dense layer of the cost-to-go network as the hand-written fp32-accurate MFMA kernel (dca_f16x3_gemm):
+    v = relu?((a . w^T) * alpha * col_scale + bias (+ skip)).  a_planes [2, m, k] fp16, w_h / w_l [n, k] fp16.
+    -> (planes of v [2, m, n] fp16 or None, v fp32 [m, n] or None)."""
+    assert a_planes.dtype == torch.float16 and a_planes.dim() == 3 and a_planes.is_contiguous()
+    assert w_h.dtype == torch.float16 and w_h.is_contiguous() and w_l.is_contiguous() and w_h.shape == w_l.shape
+    _, m, k = a_planes.shape
+    n = w_h.shape[0]
+    assert w_h.shape[1] == k and (want_planes or want_x)
+    planes = torch.empty((2, m, n), dtype=torch.float16, device=a_planes.device) if want_planes else None
+    x_out = torch.empty((m, n), dtype=torch.float32, device=a_planes.device) if want_x else None
+    check(lib().dca_f16x3_gemm(ptr(a_planes[0]), ptr(a_planes[1]), C.c_int64(m), int(k), C.c_int64(k), ptr(w_h), ptr(w_l),
+                               int(n), C.c_int64(k), ptr(col_scale), C.c_double(alpha), ptr(bias), ptr(skip), int(relu),
+                               ptr(planes[0]) if want_planes else C.c_void_p(0), ptr(planes[1]) if want_planes else C.c_void_p(0),
+                               ptr(x_out), C.c_int64(n), ptr(overflow), stream_ptr()), "dca_f16x3_gemm")
+    return planes, x_out

@@ -46,8 +46,10 @@ namespace dca {
 
 constexpr int NBIN = 2048;            // radix-select fan-out per level
 constexpr int kScanBlocks = 256;      // grid of the OPEN scans: few fat blocks (cheap when they early-exit)
+constexpr int kCollectBlocks = 512;   // k_sel_collect: two workgroups per CU keep twice the loads in flight
 constexpr int kRankBlocks = 256;      // k_rank: one 1024-thread workgroup per CU, the bins to order strided over them
-constexpr int kSortCap = 8192;        // entries one workgroup orders inside LDS (96 KB of (key,id) pairs)
+constexpr int kTinyBin = 64;          // bins up to this size are ranked by one wave
+constexpr int kSortCap = 8192;        // diagnostics only: bins beyond this many entries are counted as "giant"
 constexpr int kStash = 3072;          // per-workgroup LDS stash of k_sel_collect (entries at or below the threshold bin)
 constexpr uint32_t NIL = 0xFFFFFFFFu;
 constexpr uint64_t EMPTY = ~0ull;
@@ -98,10 +100,13 @@ struct Ctl {
     uint64_t r_kmin;
     uint32_t r_shift;
     // selection
-    uint32_t want, bstar, shift;
+    uint32_t want, bstar, shift, n_big, n_tiny;
     uint64_t sel_kmin;
     // goals
     uint32_t goal_id;
+    // diagnostics of the last pop (dca_engine_debug): entries handed to k_rank, largest bin among them, bins beyond
+    // the LDS sort capacity (those take the refinement path)
+    uint32_t dbg_nord, dbg_maxbin, dbg_giant, dbg_giant_seen;
     // ---- hot words -----------------------------------------------------------------------------
     Cnt open_n[4];   // physical entries per OPEN buffer (0/1 FRONT ping-pong, 2/3 BACK + its compaction target)
     Cnt closed_n, back_dead, ticket_a;
@@ -149,14 +154,14 @@ struct Eng {
     uint32_t* open_id[4];
     uint32_t f_keep, f_max;  // FRONT hysteresis: refill/spill down to ~f_keep, spill when above f_max
     uint32_t *hist, *pre, *fill;  // selection histogram, its exclusive prefix [NBIN+1], per-bin fill of the scratch array
-    uint64_t* part;  // [4][kScanBlocks] per-block key ranges of k_sel_collect (survivor min/max, spill min/max)
+    uint64_t* part;  // [4][kCollectBlocks] per-block key ranges of k_sel_collect (survivor min/max, spill min/max)
     // scratch of the pop: every FRONT entry at or below the threshold bin, grouped by bin (bin f occupies
     // [pre[f], pre[f+1])), and — only for bins too large for LDS — the single-workgroup sub-bin ordering
     uint64_t* tmp_key;
     uint32_t* tmp_id;
-    uint8_t* tmp_st;
     uint64_t* ord_key;
-    uint32_t *ord_id, *ord_b, *ord_s, *ord_pb, *bcnt, *bpre;
+    uint32_t* ord_id;
+    uint32_t *big_list, *tiny_list;  // bins at or below the threshold bin with more than / at most kTinyBin entries
     uint64_t* pop_key;   // the batch in pop order
     uint32_t *pop_id, *pop_g;
     uint64_t* child_hash;
@@ -674,9 +679,13 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs)
     Stamp stamp(E, P_SEL_SCAN);
     __shared__ uint32_t pre[NBIN + 1];
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t s_spill, s_bstar;
+    __shared__ uint32_t s_spill, s_bstar, s_maxbin, s_giant, s_nbig, s_ntiny;
     const int t = threadIdx.x;
     if (t == 0) {
+        s_maxbin = 0;
+        s_giant = 0;
+        s_nbig = 0;
+        s_ntiny = 0;
         if (c->refill && c->compact) {  // the compacted copy becomes BACK
             c->cur_b ^= 1;
             c->back_dead.v = 0;
@@ -705,7 +714,27 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs)
     }
     if (t == 1023) E.pre[NBIN] = pre[NBIN];
     __syncthreads();
+    for (int k = 0; k < 2; k++) {
+        const uint32_t bin = 2 * t + k;
+        if (bin <= s_bstar && want != 0) {
+            const uint32_t cn = pre[bin + 1] - pre[bin];
+            if (cn > 256) atomicMax(&s_maxbin, cn);
+            if (cn > (uint32_t)kSortCap) atomicAdd(&s_giant, 1u);
+            // work lists of k_rank: one workgroup per bin of more than kTinyBin entries, one wave per smaller bin
+            if (cn > (uint32_t)kTinyBin)
+                E.big_list[atomicAdd(&s_nbig, 1u)] = bin;
+            else if (cn != 0)
+                E.tiny_list[atomicAdd(&s_ntiny, 1u)] = bin;
+        }
+    }
+    __syncthreads();
     if (t == 0) {
+        c->n_big = s_nbig;
+        c->n_tiny = s_ntiny;
+        c->dbg_nord = want ? pre[s_bstar + 1] : 0;
+        c->dbg_maxbin = s_maxbin;
+        c->dbg_giant = s_giant;
+        c->dbg_giant_seen += s_giant;
         const uint64_t kmin = c->rng[cb].kmin;
         const uint32_t shift = select_shift(kmin, c->rng[cb].kmax);
         c->want = want;
@@ -764,19 +793,32 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
         uint32_t id[ITEMS];
         uint32_t dest = 0;  // 2 bits per item: 0 dead, 1 scratch (ordered by k_rank), 2 FRONT', 3 BACK
         uint32_t cf = 0, cb = 0;
+        // all 16 loads of the tile first (nothing with a side effect in this loop: they stay in flight together) ...
 #pragma unroll
         for (uint32_t i = 0; i < ITEMS; i++) {
-            uint32_t idx = tile * TILE + i * 256 + threadIdx.x;
-            bool live = idx < n;
+            const uint32_t idx = tile * TILE + i * 256 + threadIdx.x;
+            const bool live = idx < n;
             k[i] = live ? keys[idx] : 0;
             id[i] = live ? ids[idx] : 0;
-            uint64_t f64 = (k[i] - kmin) >> shift;
-            uint32_t f = f64 < NBIN ? (uint32_t)f64 : NBIN - 1;
-            uint32_t d = !live ? 0u : (f <= bstar ? 1u : (f > spill ? 3u : 2u));
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < ITEMS; i++) {
+            const uint32_t idx = tile * TILE + i * 256 + threadIdx.x;
+            const bool live = idx < n;
+            const uint64_t f64 = (k[i] - kmin) >> shift;
+            const uint32_t f = f64 < NBIN ? (uint32_t)f64 : NBIN - 1;
+            const uint32_t d = !live ? 0u : (f <= bstar ? 1u : (f > spill ? 3u : 2u));
             dest |= d << (2 * i);
             cf += d == 2u ? 1u : 0u;
             cb += d == 3u ? 1u : 0u;
-            if (d == 1u) {
+        }
+        // ... then the few entries bound for the scratch array (about one in seventy)
+        if (dest & 0x5555u & ~(dest >> 1)) {
+#pragma unroll
+            for (uint32_t i = 0; i < ITEMS; i++) {
+                if (((dest >> (2 * i)) & 3u) != 1u) continue;
+                const uint64_t f64 = (k[i] - kmin) >> shift;
+                const uint32_t f = f64 < NBIN ? (uint32_t)f64 : NBIN - 1;
                 const uint32_t p = atomicAdd(&st_n, 1u);
                 if (p < kStash) {
                     st_key[p] = k[i];
@@ -787,7 +829,6 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
                     const uint32_t pos = E.pre[f] + atomicAdd(&E.fill[f], 1u);
                     E.tmp_key[pos] = k[i];
                     E.tmp_id[pos] = id[i];
-                    E.tmp_st[pos] = 0;
                 }
             }
         }
@@ -827,7 +868,6 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
             const uint32_t pos = E.pre[f] + atomicAdd(&lcnt[f], 1u);
             E.tmp_key[pos] = st_key[p];
             E.tmp_id[pos] = st_id[p];
-            E.tmp_st[pos] = 0;
         }
     }
     // key ranges: reduced per block into E.part and folded into the control block by k_rank (four atomics) —
@@ -850,19 +890,26 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
             const int q = threadIdx.x;
             uint64_t r = red[q][0];
             for (int w = 1; w < 4; w++) r = (q & 1) ? (red[q][w] > r ? red[q][w] : r) : (red[q][w] < r ? red[q][w] : r);
-            E.part[q * kScanBlocks + blockIdx.x] = r;
+            E.part[q * kCollectBlocks + blockIdx.x] = r;
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_rank: exact order of the batch.  One 1024-thread workgroup per bin at or below the threshold bin (bins strided
-// over the grid).  A bin of up to kSortCap entries is sorted on the 96-bit (key,id) composite by a bitonic network
-// in LDS; rank = entries in lower bins + position.  Ranks below `want` are the batch in pop order (which fixes the
-// children's node ids and therefore every later tie-break), the overshoot of the threshold bin returns to FRONT'.
-// A larger bin (massive cost ties: integer-valued heuristics, uniform-cost search) is first cut down to the entries
-// that belong to the batch by adaptive radix refinement on the composite, then ordered in LDS if they fit, else
-// through arithmetic sub-bins of their own exact composite range — all by the bin's one workgroup, in global memory.
+// k_rank: exact order of the batch.  k_sel_scan listed the non-empty bins at or below the threshold bin: "tiny" ones
+// (<= 64 entries — most of them) are ranked by ONE WAVE each (all-pairs through lane shuffles, no LDS, no barrier),
+// the others by one 1024-thread workgroup each with a streamed bucket sort on the 96-bit (key,id) composite:
+//   pass 0  exact min / max of the bin's composites
+//   pass 1  counts of up to 2048 arithmetic sub-bins of that exact range (LDS atomics); prefix; the sub-bin that holds
+//           the last entry the batch still needs
+//   pass 2  entries in lower-or-equal sub-bins are scattered, grouped by sub-bin, into the bin's slice of the second
+//           scratch array; the rest of a threshold bin goes straight back to FRONT'
+//   pass 3  rank inside the (few-entry) sub-bin = final pop rank; a sub-bin that is still large (ids of a tie group
+//           clustered, a few distinct keys with huge multiplicities) becomes a work item of its own, with its own exact
+//           range, reading the slice the scatter just wrote and scattering back into the first array (ping-pong).
+// Only counters live in LDS, so a bin of any size — a whole OPEN tied on one cost — takes the same path; ranks below
+// `want` are the batch in pop order (which fixes the children's node ids and therefore every later tie-break), the
+// overshoot of the threshold bin returns to FRONT'.
 // ---------------------------------------------------------------------------------------------
 typedef unsigned __int128 u128;
 __device__ __forceinline__ u128 comp_of(uint64_t key, uint32_t id) { return ((u128)key << 32) | (u128)id; }
@@ -871,23 +918,21 @@ __device__ __forceinline__ int clz128(u128 v) {
     return hi ? __clzll((long long)hi) : 64 + (lo ? __clzll((long long)lo) : 64);
 }
 
-struct CandShared {
-    uint32_t lh[NBIN];
-    uint32_t pre[NBIN + 1];
+constexpr int kRankStack = 512;    // pending oversized sub-bins of one bin
+constexpr uint32_t kDirectMax = 512;  // items up to this size are ranked all-pairs out of LDS
+constexpr uint32_t kSubMax = 512;     // sub-bins up to this size are ranked in place, larger ones are refined again
+
+struct RankItem {
+    uint32_t off, n, need, src;  // slice [off, off+n) of scratch array `src` (0 tmp, 1 ord); pop rank of its first entry = off
+};
+struct RankShared {
+    uint32_t cnt[NBIN];      // sub-bin counts, then running scatter slots   (direct path: 1024 keys)
+    uint32_t off[NBIN + 1];  // exclusive prefix                              (direct path: ids)
     uint32_t wsum[16];
     uint64_t red_lo[32], red_hi[32];
     uint64_t vmin_hi, vmin_lo;
-    uint32_t active, rr, shift, bits, bsel, cnt, carry;
-    uint64_t fk[1024];
-    uint32_t fi[1024], fidx[1024];
-};
-struct SortLds {
-    uint64_t sk[kSortCap];
-    uint32_t si[kSortCap];
-};
-union RankLds {
-    SortLds s;
-    CandShared c;
+    uint32_t bits, tsub, sp, fail;
+    RankItem stack[kRankStack];
 };
 
 // one ranked entry: into the batch (pop order) or back to FRONT'.  Wave-collective (open_append).
@@ -907,286 +952,186 @@ __device__ __forceinline__ void emit_ranked(const Eng& E, Ctl* c, uint32_t nf, b
     open_append(E, c, nf, live && rank >= want, key, id);
 }
 
-// order m entries in LDS and emit them with ranks base_rank + position.  ST == nullptr: the first m entries of K/I;
-// else the m entries of K/I[0..n_src) whose status is 1.
-__device__ __forceinline__ void lds_sort_emit(const Eng& E, Ctl* c, SortLds& S, const uint64_t* __restrict__ K,
-                                              const uint32_t* __restrict__ I, const uint8_t* __restrict__ ST,
-                                              uint32_t n_src, uint32_t m, uint32_t base_rank, uint32_t want,
-                                              uint32_t nf, uint32_t* s_cnt) {
-    const uint32_t t = threadIdx.x;
-    uint32_t P = 2;
-    while (P < m) P <<= 1;
-    if (ST == nullptr) {
-        for (uint32_t i = t; i < P; i += 1024) {
-            S.sk[i] = i < m ? K[i] : ~0ull;
-            S.si[i] = i < m ? I[i] : 0xFFFFFFFFu;
-        }
-    } else {
-        if (t == 0) *s_cnt = 0;
-        __syncthreads();
-        for (uint32_t i = t; i < n_src; i += 1024)
-            if (ST[i] == 1) {
-                const uint32_t p = atomicAdd(s_cnt, 1u);
-                if (p < (uint32_t)kSortCap) {
-                    S.sk[p] = K[i];
-                    S.si[p] = I[i];
-                }
-            }
-        for (uint32_t i = m + t; i < P; i += 1024) {
-            S.sk[i] = ~0ull;
-            S.si[i] = 0xFFFFFFFFu;
-        }
+// a bin of at most 64 entries, by one wave: rank = number of smaller composites, counted through lane shuffles
+__device__ __forceinline__ void rank_tiny_bin(const Eng& E, Ctl* c, uint32_t nf, uint32_t o, uint32_t n, uint32_t want) {
+    const uint32_t lane = threadIdx.x & 63;
+    const bool live = lane < n;
+    const uint64_t k = live ? E.tmp_key[o + lane] : ~0ull;
+    const uint32_t id = live ? E.tmp_id[o + lane] : 0xFFFFFFFFu;
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < n; j++) {
+        const uint64_t kj = __shfl(k, (int)j);
+        const uint32_t ij = __shfl(id, (int)j);
+        rank += pair_less(kj, ij, k, id) ? 1u : 0u;
     }
-    __syncthreads();
-    const uint32_t half = P >> 1;
-    for (uint32_t k2 = 2; k2 <= P; k2 <<= 1)
-        for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-            for (uint32_t x = t; x < half; x += 1024) {
-                const uint32_t i = ((x & ~(j2 - 1u)) << 1) | (x & (j2 - 1u)), l = i + j2;
-                const bool up = (i & k2) == 0;
-                const uint64_t ka = S.sk[i], kb = S.sk[l];
-                const uint32_t ia = S.si[i], ib = S.si[l];
-                if (pair_less(kb, ib, ka, ia) == up) {
-                    S.sk[i] = kb;
-                    S.si[i] = ib;
-                    S.sk[l] = ka;
-                    S.si[l] = ia;
-                }
-            }
-            __syncthreads();
-        }
-    for (uint32_t i0 = 0; i0 < P; i0 += 1024) {
-        const uint32_t i = i0 + t;
-        const bool live = i < m;
-        emit_ranked(E, c, nf, live, base_rank + i, want, live ? S.sk[i] : 0, live ? S.si[i] : 0);
-    }
-    __syncthreads();
+    emit_ranked(E, c, nf, live, o + rank, want, k, id);
 }
 
-// min / max composite over the entries whose status equals `want_st`; result -> S.vmin_*, S.bits, S.shift (= bits - 11)
-__device__ __forceinline__ void cand_range(CandShared& S, const uint64_t* __restrict__ K, const uint32_t* __restrict__ I,
-                                           const uint8_t* __restrict__ ST, uint32_t n, uint8_t want_st) {
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    u128 vmin = ~(u128)0, vmax = 0;
-    for (uint32_t i = t; i < n; i += 1024)
-        if (ST[i] == want_st) {
-            u128 v = comp_of(K[i], I[i]);
-            vmin = v < vmin ? v : vmin;
-            vmax = v > vmax ? v : vmax;
-        }
-    for (int o = 32; o > 0; o >>= 1) {
-        uint64_t ahi = __shfl_xor((uint64_t)(vmin >> 64), o), alo = __shfl_xor((uint64_t)vmin, o);
-        uint64_t bhi = __shfl_xor((uint64_t)(vmax >> 64), o), blo = __shfl_xor((uint64_t)vmax, o);
-        u128 a = ((u128)ahi << 64) | alo, b = ((u128)bhi << 64) | blo;
-        vmin = a < vmin ? a : vmin;
-        vmax = b > vmax ? b : vmax;
-    }
-    __syncthreads();  // earlier readers of the shared words are done
-    if (lane == 0) {
-        S.red_hi[wv] = (uint64_t)(vmin >> 64);
-        S.red_lo[wv] = (uint64_t)vmin;
-        S.red_hi[16 + wv] = (uint64_t)(vmax >> 64);
-        S.red_lo[16 + wv] = (uint64_t)vmax;
-    }
-    for (int i = t; i < NBIN; i += 1024) S.lh[i] = 0;
-    __syncthreads();
-    if (t == 0) {
-        u128 mn = ~(u128)0, mx = 0;
-        for (int k = 0; k < 16; k++) {
-            u128 a = ((u128)S.red_hi[k] << 64) | S.red_lo[k], b = ((u128)S.red_hi[16 + k] << 64) | S.red_lo[16 + k];
-            mn = a < mn ? a : mn;
-            mx = b > mx ? b : mx;
-        }
-        u128 range = mx >= mn ? mx - mn : 0;
-        int bits = range ? 128 - clz128(range) : 0;
-        S.bits = (uint32_t)bits;
-        S.shift = bits > 11 ? (uint32_t)(bits - 11) : 0u;
-        S.vmin_hi = (uint64_t)(mn >> 64);
-        S.vmin_lo = (uint64_t)mn;
-    }
-    __syncthreads();
+__device__ __forceinline__ uint32_t sub_of(uint64_t k, uint32_t id, u128 vmin, uint32_t shc, uint32_t nsub) {
+    const u128 q = (comp_of(k, id) - vmin) >> shc;
+    return q < (u128)nsub ? (uint32_t)q : nsub - 1u;
 }
 
-// exclusive scan of S.lh into S.pre (1024 threads, 2 bins each)
-__device__ __forceinline__ void cand_scan(CandShared& S) {
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    uint32_t a = S.lh[2 * t], b2 = S.lh[2 * t + 1], s = a + b2, incl = s;
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
-    }
-    if (lane == 63) S.wsum[wv] = incl;
-    __syncthreads();
-    if (t < 16) {
-        uint32_t v = S.wsum[t], acc = v;
-        for (int o = 1; o < 16; o <<= 1) {
-            uint32_t u = __shfl_up(acc, o, 16);
-            if (t >= o) acc += u;
-        }
-        S.wsum[t] = acc - v;
-    }
-    __syncthreads();
-    uint32_t excl = incl - s + S.wsum[wv];
-    S.pre[2 * t] = excl;
-    S.pre[2 * t + 1] = excl + a;
-    if (t == 1023) S.pre[NBIN] = excl + s;
-    __syncthreads();
-}
-
-// mark exactly `need` of the n entries (all status 0 on entry) with the smallest (key,id) as 1, the others as 2:
-// adaptive radix refinement on the 96-bit composite, 2048 bins per level, all-pairs once <= 1024 are undecided
-__device__ __noinline__ void select_smallest(CandShared& S, const uint64_t* __restrict__ K, const uint32_t* __restrict__ I,
-                                                uint8_t* __restrict__ ST, uint32_t n, uint32_t need) {
-    const int t = threadIdx.x;
-    __syncthreads();
-    if (t == 0) {
-        S.active = n;
-        S.rr = need;
-    }
-    __syncthreads();
-    for (;;) {
-        const uint32_t active = S.active, rr = S.rr;
-        if (rr == 0 || rr == active) {  // take none / take all of what is still undecided
-            for (uint32_t i = t; i < n; i += 1024)
-                if (ST[i] == 0) ST[i] = rr ? 1 : 2;
-            break;
-        }
-        if (active <= 1024) {  // final: all-pairs rank in LDS
-            if (t == 0) S.cnt = 0;
-            __syncthreads();
-            for (uint32_t i = t; i < n; i += 1024)
-                if (ST[i] == 0) {
-                    uint32_t p = atomicAdd(&S.cnt, 1u);
-                    S.fk[p] = K[i];
-                    S.fi[p] = I[i];
-                    S.fidx[p] = i;
-                }
-            __syncthreads();
-            if ((uint32_t)t < active) {
-                uint32_t rank = 0;
-                const uint64_t k0 = S.fk[t];
-                const uint32_t i0 = S.fi[t];
-                for (uint32_t j = 0; j < active; j++) rank += pair_less(S.fk[j], S.fi[j], k0, i0) ? 1u : 0u;
-                ST[S.fidx[t]] = rank < rr ? 1 : 2;
-            }
-            break;
-        }
-        // ---- one refinement level on the undecided set
-        cand_range(S, K, I, ST, n, 0);
-        const u128 base = ((u128)S.vmin_hi << 64) | S.vmin_lo;
-        const uint32_t sh = S.shift;
-        for (uint32_t i = t; i < n; i += 1024)
-            if (ST[i] == 0) {
-                uint32_t f = (uint32_t)((comp_of(K[i], I[i]) - base) >> sh);
-                atomicAdd(&S.lh[f < NBIN ? f : NBIN - 1], 1u);
-            }
-        __syncthreads();
-        cand_scan(S);
-        for (int k = 0; k < 2; k++) {
-            int bin = 2 * t + k;
-            if (S.pre[bin] < rr && rr <= S.pre[bin + 1]) S.bsel = (uint32_t)bin;
+// one work item of a bin's workgroup (see the banner above).  All 1024 threads.
+__device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint32_t nf, uint32_t want, RankItem it) {
+    const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint64_t* __restrict__ K = (it.src ? E.ord_key : E.tmp_key) + it.off;
+    const uint32_t* __restrict__ I = (it.src ? E.ord_id : E.tmp_id) + it.off;
+    uint64_t* __restrict__ K2 = (it.src ? E.tmp_key : E.ord_key) + it.off;
+    uint32_t* __restrict__ I2 = (it.src ? E.tmp_id : E.ord_id) + it.off;
+    const uint32_t n = it.n, need = it.need;
+    if (n <= kDirectMax) {
+        // small item: all-pairs out of LDS (keys in S.cnt viewed as u64, ids in S.off)
+        uint64_t* sk = reinterpret_cast<uint64_t*>(S.cnt);
+        uint32_t* si = S.off;
+        if (t < n) {
+            sk[t] = K[t];
+            si[t] = I[t];
         }
         __syncthreads();
-        const uint32_t bsel = S.bsel;
-        for (uint32_t i = t; i < n; i += 1024)
-            if (ST[i] == 0) {
-                uint32_t f = (uint32_t)((comp_of(K[i], I[i]) - base) >> sh);
-                f = f < NBIN ? f : NBIN - 1;
-                if (f < bsel)
-                    ST[i] = 1;
-                else if (f > bsel)
-                    ST[i] = 2;
-            }
-        __syncthreads();
-        if (t == 0) {
-            S.rr = rr - S.pre[bsel];
-            S.active = S.pre[bsel + 1] - S.pre[bsel];
-        }
-        __syncthreads();
-    }
-    __syncthreads();
-}
-
-// order the m (> kSortCap) status-1 entries of K/I[0..n) in global memory: 2^lg arithmetic sub-bins over their own
-// exact composite range (a tie group is cut on its ids), count -> prefix -> scatter -> rank inside the sub-bin.
-// Scratch: E.ord_* at entry offset o, E.bcnt / E.bpre at sub-bin offset sb (both regions private to this bin).
-__device__ __noinline__ void giant_order(const Eng& E, Ctl* c, CandShared& S, const uint64_t* __restrict__ K,
-                                            const uint32_t* __restrict__ I, const uint8_t* __restrict__ ST, uint32_t n,
-                                            uint32_t m, uint32_t o, uint32_t sb, uint32_t want, uint32_t nf) {
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    cand_range(S, K, I, ST, n, 1);
-    const u128 vmin = ((u128)S.vmin_hi << 64) | S.vmin_lo;
-    uint32_t lg = 0;
-    while ((16u << lg) <= m && lg < 26) lg++;  // 2^lg <= m / 8: ~8-16 entries per sub-bin when the composites spread evenly
-    const uint32_t nsub = 1u << lg;
-    const uint32_t shc = S.bits > lg ? S.bits - lg : 0u;
-    uint32_t* bcnt = E.bcnt + sb;
-    uint32_t* bpre = E.bpre + sb;
-    for (uint32_t i = t; i < n; i += 1024)
-        if (ST[i] == 1) {
-            const u128 q = (comp_of(K[i], I[i]) - vmin) >> shc;
-            const uint32_t sub = q < (u128)nsub ? (uint32_t)q : nsub - 1u;
-            E.ord_b[o + i] = sub;
-            E.ord_s[o + i] = atomicAdd(&bcnt[sub], 1u);
-        }
-    __syncthreads();
-    // exclusive prefix of the sub-bin counts (and reset them for the next user of the region)
-    if (t == 0) S.carry = 0;
-    __syncthreads();
-    for (uint32_t b0 = 0; b0 < nsub; b0 += 4096) {
-        uint32_t v[4], s4 = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t i = b0 + 4 * t + k;
-            v[k] = i < nsub ? bcnt[i] : 0u;
-            if (i < nsub) bcnt[i] = 0;
-            s4 += v[k];
-        }
-        uint32_t incl = s4;
-        for (int q = 1; q < 64; q <<= 1) {
-            uint32_t u = __shfl_up(incl, q);
-            if (lane >= q) incl += u;
-        }
-        if (lane == 63) S.wsum[wv] = incl;
-        __syncthreads();
-        uint32_t woff = S.carry;
-        for (int w = 0; w < wv; w++) woff += S.wsum[w];
-        uint32_t run = incl - s4 + woff;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t i = b0 + 4 * t + k;
-            if (i < nsub) bpre[i] = run;
-            run += v[k];
-        }
-        __syncthreads();
-        if (t == 1023) S.carry = run;
-        __syncthreads();
-    }
-    if (t == 0) bpre[nsub] = S.carry;
-    __syncthreads();
-    for (uint32_t i = t; i < n; i += 1024)
-        if (ST[i] == 1) {
-            const uint32_t sub = E.ord_b[o + i];
-            const uint32_t p = bpre[sub] + E.ord_s[o + i];
-            E.ord_key[o + p] = K[i];
-            E.ord_id[o + p] = I[i];
-            E.ord_pb[o + p] = sub;
-        }
-    __syncthreads();
-    for (uint32_t p0 = 0; p0 < m; p0 += 1024) {
-        const uint32_t p = p0 + t;
-        const bool live = p < m;
+        const bool live = t < n;
         uint64_t k = 0;
         uint32_t id = 0, rank = 0;
         if (live) {
-            k = E.ord_key[o + p];
-            id = E.ord_id[o + p];
-            const uint32_t sub = E.ord_pb[o + p];
-            const uint32_t s0 = bpre[sub], e0 = bpre[sub + 1];
-            rank = s0;
-            for (uint32_t j = s0; j < e0; j++) rank += pair_less(E.ord_key[o + j], E.ord_id[o + j], k, id) ? 1u : 0u;
+            k = sk[t];
+            id = si[t];
+            for (uint32_t j = 0; j < n; j++) rank += pair_less(sk[j], si[j], k, id) ? 1u : 0u;
         }
-        emit_ranked(E, c, nf, live, o + rank, want, k, id);
+        emit_ranked(E, c, nf, live, it.off + rank, want, k, id);
+        __syncthreads();
+        return;
+    }
+    // ---- pass 0: exact composite range
+    {
+        u128 vmin = ~(u128)0, vmax = 0;
+        for (uint32_t i = t; i < n; i += 1024) {
+            const u128 v = comp_of(K[i], I[i]);
+            vmin = v < vmin ? v : vmin;
+            vmax = v > vmax ? v : vmax;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            uint64_t ahi = __shfl_xor((uint64_t)(vmin >> 64), o), alo = __shfl_xor((uint64_t)vmin, o);
+            uint64_t bhi = __shfl_xor((uint64_t)(vmax >> 64), o), blo = __shfl_xor((uint64_t)vmax, o);
+            u128 a = ((u128)ahi << 64) | alo, b = ((u128)bhi << 64) | blo;
+            vmin = a < vmin ? a : vmin;
+            vmax = b > vmax ? b : vmax;
+        }
+        if (lane == 0) {
+            S.red_hi[wv] = (uint64_t)(vmin >> 64);
+            S.red_lo[wv] = (uint64_t)vmin;
+            S.red_hi[16 + wv] = (uint64_t)(vmax >> 64);
+            S.red_lo[16 + wv] = (uint64_t)vmax;
+        }
+        for (uint32_t i = t; i < NBIN; i += 1024) S.cnt[i] = 0;
+        __syncthreads();
+        if (t == 0) {
+            u128 mn = ~(u128)0, mx = 0;
+            for (int k = 0; k < 16; k++) {
+                u128 a = ((u128)S.red_hi[k] << 64) | S.red_lo[k], b = ((u128)S.red_hi[16 + k] << 64) | S.red_lo[16 + k];
+                mn = a < mn ? a : mn;
+                mx = b > mx ? b : mx;
+            }
+            const u128 range = mx - mn;
+            S.bits = range ? (uint32_t)(128 - clz128(range)) : 0u;
+            S.vmin_hi = (uint64_t)(mn >> 64);
+            S.vmin_lo = (uint64_t)mn;
+        }
+        __syncthreads();
+    }
+    const u128 vmin = ((u128)S.vmin_hi << 64) | S.vmin_lo;
+    uint32_t lg = 0;
+    while ((8u << lg) <= n && lg < 11) lg++;  // 2^lg <= n / 4, at most NBIN sub-bins
+    const uint32_t bits = S.bits;
+    if (lg > bits) lg = bits;                 // cannot cut finer than one composite value
+    const uint32_t nsub = 1u << lg, shc = bits - lg;
+    // ---- pass 1: sub-bin counts
+    for (uint32_t i = t; i < n; i += 1024) atomicAdd(&S.cnt[sub_of(K[i], I[i], vmin, shc, nsub)], 1u);
+    __syncthreads();
+    {   // exclusive prefix of cnt[0..nsub) into off[0..nsub] (2 per thread), threshold sub-bin, counters back to zero
+        const uint32_t a = 2 * t < nsub ? S.cnt[2 * t] : 0u, b2 = 2 * t + 1 < nsub ? S.cnt[2 * t + 1] : 0u;
+        const uint32_t s2 = a + b2;
+        uint32_t incl = s2;
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t v = __shfl_up(incl, o);
+            if (lane >= (uint32_t)o) incl += v;
+        }
+        if (lane == 63) S.wsum[wv] = incl;
+        __syncthreads();
+        if (t < 16) {
+            uint32_t v = S.wsum[t], acc = v;
+            for (int o = 1; o < 16; o <<= 1) {
+                uint32_t u = __shfl_up(acc, o, 16);
+                if (t >= (uint32_t)o) acc += u;
+            }
+            S.wsum[t] = acc - v;
+        }
+        __syncthreads();
+        const uint32_t excl = incl - s2 + S.wsum[wv];
+        if (2 * t < nsub) {
+            S.off[2 * t] = excl;
+            S.cnt[2 * t] = 0;
+            if (excl < need && need <= excl + a) S.tsub = 2 * t;
+        }
+        if (2 * t + 1 < nsub) {
+            S.off[2 * t + 1] = excl + a;
+            S.cnt[2 * t + 1] = 0;
+            if (excl + a < need && need <= excl + s2) S.tsub = 2 * t + 1;
+        }
+        if (2 * t + 2 == nsub || (nsub == 1 && t == 0)) S.off[nsub] = excl + s2;
+        __syncthreads();
+    }
+    const uint32_t tsub = S.tsub;
+    // ---- pass 2: scatter the sub-bins that reach into the batch, hand the rest of a threshold bin back
+    for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
+        const uint32_t i = i0 + t;
+        const bool live = i < n;
+        uint64_t k = 0;
+        uint32_t id = 0, sub = 0;
+        if (live) {
+            k = K[i];
+            id = I[i];
+            sub = sub_of(k, id, vmin, shc, nsub);
+            if (sub <= tsub) {
+                const uint32_t p = S.off[sub] + atomicAdd(&S.cnt[sub], 1u);
+                K2[p] = k;
+                I2[p] = id;
+            }
+        }
+        open_append(E, c, nf, live && sub > tsub, k, id);
+    }
+    __syncthreads();
+    // ---- pass 3: rank inside the sub-bin; oversized sub-bins become work items
+    const uint32_t m = S.off[tsub + 1];
+    for (uint32_t p0 = 0; p0 < m; p0 += 1024) {
+        const uint32_t p = p0 + t;
+        bool live = p < m;
+        uint64_t k = 0;
+        uint32_t id = 0, rank = 0;
+        if (live) {
+            k = K2[p];
+            id = I2[p];
+            const uint32_t sub = sub_of(k, id, vmin, shc, nsub);
+            const uint32_t s0 = S.off[sub], e0 = S.off[sub + 1];
+            if (e0 - s0 > kSubMax && shc > 0) {
+                live = false;  // ranked by the sub-bin's own work item
+            } else {
+                rank = s0;
+                for (uint32_t j = s0; j < e0; j++) rank += pair_less(K2[j], I2[j], k, id) ? 1u : 0u;
+            }
+        }
+        emit_ranked(E, c, nf, live, it.off + rank, want, k, id);
+    }
+    for (uint32_t sb = t; sb <= tsub; sb += 1024) {
+        const uint32_t s0 = S.off[sb], e0 = S.off[sb + 1];
+        if (e0 - s0 > kSubMax && shc > 0) {
+            const uint32_t slot = atomicAdd(&S.sp, 1u);
+            if (slot < (uint32_t)kRankStack) {
+                const uint32_t nd = sb == tsub ? need - s0 : e0 - s0;
+                S.stack[slot] = RankItem{it.off + s0, e0 - s0, nd, it.src ^ 1u};
+            } else {
+                S.fail = 1;
+            }
+        }
     }
     __syncthreads();
 }
@@ -1196,9 +1141,7 @@ __global__ __launch_bounds__(1024) void k_rank(const Eng* __restrict__ engs) {
     Ctl* c = E.ctl;
     if (c->done) return;
     Stamp stamp(E, P_RANK);
-    extern __shared__ __attribute__((aligned(16))) uint8_t rank_lds[];
-    RankLds& L = *reinterpret_cast<RankLds*>(rank_lds);
-    __shared__ uint32_t s_cnt;
+    __shared__ RankShared S;
     const uint32_t t = threadIdx.x;
     const uint32_t nf = st_cur(c).cur_f ^ 1, bb = c->cur_b;
     if (blockIdx.x == 0) {
@@ -1207,7 +1150,7 @@ __global__ __launch_bounds__(1024) void k_rank(const Eng* __restrict__ engs) {
         const int lane = t & 63, wv = t >> 6;
         uint64_t v[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) v[q] = t < (uint32_t)kScanBlocks ? E.part[q * kScanBlocks + t] : ((q & 1) ? 0ull : ~0ull);
+        for (int q = 0; q < 4; q++) v[q] = t < (uint32_t)kCollectBlocks ? E.part[q * kCollectBlocks + t] : ((q & 1) ? 0ull : ~0ull);
         for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -1232,34 +1175,36 @@ __global__ __launch_bounds__(1024) void k_rank(const Eng* __restrict__ engs) {
         }
     }
     const uint32_t bstar = c->bstar, want = c->want;
-    for (uint32_t f = blockIdx.x; f <= bstar; f += gridDim.x) {
+    const uint32_t n_big = c->n_big, n_tiny = c->n_tiny;
+    // ---- bins of more than 64 entries: one workgroup each
+    for (uint32_t bi = blockIdx.x; bi < n_big; bi += gridDim.x) {
+        const uint32_t f = E.big_list[bi];
         const uint32_t o = E.pre[f], n = E.pre[f + 1] - o;
-        if (n == 0) continue;
-        // entries of this bin that belong to the batch: all of it below the threshold bin
-        const uint32_t need = (f == bstar) ? want - o : n;
-        if (n <= (uint32_t)kSortCap) {
-            lds_sort_emit(E, c, L.s, E.tmp_key + o, E.tmp_id + o, nullptr, n, n, o, want, nf, &s_cnt);
-            continue;
-        }
-        const uint64_t* K = E.tmp_key + o;
-        const uint32_t* I = E.tmp_id + o;
-        uint8_t* ST = E.tmp_st + o;
-        if (need < n) {
-            select_smallest(L.c, K, I, ST, n, need);
-            // the rest of the threshold bin stays in OPEN
-            for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
-                const uint32_t i = i0 + t;
-                const bool rest = i < n && ST[i] == 2;
-                open_append(E, c, nf, rest, rest ? K[i] : 0, rest ? I[i] : 0);
-            }
-        } else {
-            for (uint32_t i = t; i < n; i += 1024) ST[i] = 1;
-        }
         __syncthreads();
-        if (need <= (uint32_t)kSortCap)
-            lds_sort_emit(E, c, L.s, K, I, ST, n, need, o, want, nf, &s_cnt);
-        else
-            giant_order(E, c, L.c, K, I, ST, n, need, o, o / 4 + f, want, nf);
+        if (t == 0) {
+            // entries of this bin that belong to the batch: all of it below the threshold bin
+            S.stack[0] = RankItem{o, n, (f == bstar) ? want - o : n, 0u};
+            S.sp = 1;
+            S.fail = 0;
+        }
+        for (;;) {
+            __syncthreads();
+            const uint32_t sp = S.sp;
+            if (sp == 0 || sp > (uint32_t)kRankStack) break;
+            const RankItem it = S.stack[sp - 1];
+            __syncthreads();
+            if (t == 0) S.sp = sp - 1;
+            __syncthreads();
+            rank_item(E, c, S, nf, want, it);
+        }
+        if (t == 0 && (S.fail || S.sp != 0)) c->failed = 1;  // (cannot happen: every refinement level narrows the range)
+    }
+    // ---- bins of at most 64 entries: one wave each
+    const uint32_t gw = blockIdx.x * 16 + (t >> 6);
+    for (uint32_t ti = gw; ti < n_tiny; ti += gridDim.x * 16) {
+        const uint32_t f = E.tiny_list[ti];
+        const uint32_t o = E.pre[f];
+        rank_tiny_bin(E, c, nf, o, E.pre[f + 1] - o, want);
     }
 }
 
@@ -1540,14 +1485,24 @@ __global__ __launch_bounds__(256) void k_probe(const Eng* __restrict__ engs) {
     }
     bool inserted = false;
     uint32_t slot = (uint32_t)h & E.tab_mask;
+    uint32_t v0 = GINF;
     for (uint32_t probes = 0;; probes++) {
-        // claim first, look second: most children are new states, and for them the compare-and-swap IS the lookup
-        // (one memory round trip instead of a load followed by the swap)
-        const uint64_t e = atomicCAS((unsigned long long*)&E.tab[slot].entry, (unsigned long long)EMPTY,
-                                     (unsigned long long)((tag << 32) | id));
+        // look first, claim second (a compare-and-swap on every probed slot — one round trip instead of two for a new
+        // state — was measured and lost badly: 61 us vs 26 us per launch; returning atomics are that much dearer here).
+        // ONE 16-byte load fetches the slot's entry together with its value: entries never change once written and
+        // values only change in k_commit, so a line cached by an earlier reader on this CU is either current or shows an
+        // EMPTY entry that the compare-and-swap then corrects.
+        const uint4 sl = *reinterpret_cast<const uint4*>(&E.tab[slot]);
+        uint64_t e = ((uint64_t)sl.y << 32) | sl.x;
+        v0 = sl.z;  // the slot's value before this batch (GINF while nothing was recorded)
         if (e == EMPTY) {
-            inserted = true;
-            break;
+            const uint64_t old = atomicCAS((unsigned long long*)&E.tab[slot].entry, (unsigned long long)EMPTY,
+                                           (unsigned long long)((tag << 32) | id));
+            if (old == EMPTY) {
+                inserted = true;
+                break;
+            }
+            e = old;  // claimed meanwhile by another child of this batch: its value is still GINF, as loaded
         }
         if ((e >> 32) == tag) {
             // exact key equality against the representative's state bytes (State.__eq__, cube3.py:23-24)
@@ -1572,8 +1527,6 @@ __global__ __launch_bounds__(256) void k_probe(const Eng* __restrict__ engs) {
             break;
         }
     }
-    // the slot's value before this batch (only k_commit writes it) and the chain hook, issued together
-    const uint32_t v0 = E.tab[slot].g;
     const uint32_t old_head = atomicExch(&E.tab[slot].head, id);
     const bool chained = old_head >= base;  // another child of this batch already sits on the slot
     E.child_next[j] = chained ? old_head - base : NIL;
@@ -1992,8 +1945,6 @@ void launch_probe(const dca_engine* e, hipStream_t s) {
     }
 }
 
-constexpr size_t kRankLdsBytes = sizeof(RankLds);
-
 int enqueue_first_half(dca_engine* e, int heur_id, bool with_refill, hipStream_t s, bool want_oh = true) {
     const Eng* d = e->d_engs;
     if (with_refill) {
@@ -2003,8 +1954,8 @@ int enqueue_first_half(dca_engine* e, int heur_id, bool with_refill, hipStream_t
     }
     hipLaunchKernelGGL(k_sel_hist, gxy(kScanGrid, e), dim3(256), 0, s, d);
     hipLaunchKernelGGL(k_sel_scan, gxy(1, e), dim3(1024), 0, s, d);
-    hipLaunchKernelGGL(k_sel_collect, gxy(kScanGrid, e), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(k_rank, gxy(kRankBlocks, e), dim3(1024), kRankLdsBytes, s, d);
+    hipLaunchKernelGGL(k_sel_collect, gxy(kCollectBlocks, e), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(k_rank, gxy(kRankBlocks, e), dim3(1024), 0, s, d);
     if (int rc = launch_check("select kernels")) return rc;
     return launch_expand(e, heur_id, want_oh, s);
 }
@@ -2139,14 +2090,10 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
         ALLOC(part, 4 * 1024);
         ALLOC(tmp_key, N);
         ALLOC(tmp_id, N);
-        ALLOC(tmp_st, N);
         ALLOC(ord_key, N);
         ALLOC(ord_id, N);
-        ALLOC(ord_b, N);
-        ALLOC(ord_s, N);
-        ALLOC(ord_pb, N);
-        ALLOC(bcnt, N / 4 + NBIN + 16);
-        ALLOC(bpre, N / 4 + NBIN + 16);
+        ALLOC(big_list, NBIN);
+        ALLOC(tiny_list, NBIN);
         ALLOC(pop_key, Bz);
         ALLOC(pop_id, Bz);
         ALLOC(pop_g, Bz);
@@ -2163,7 +2110,6 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
         if (!rc) {
             (void)hipMemset(E.hist, 0, NBIN * sizeof(uint32_t));
             (void)hipMemset(E.fill, 0, NBIN * sizeof(uint32_t));
-            (void)hipMemset(E.bcnt, 0, (N / 4 + NBIN + 16) * sizeof(uint32_t));
             (void)hipMemset(E.child_multi, 0, M);
             (void)hipMemset(E.ctl, 0, sizeof(Ctl));
         }
@@ -2171,12 +2117,6 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
     if (!rc) {
         hipError_t err = hipHostMalloc((void**)&e->h_ctl, sizeof(Ctl) + kMaxMoves * sizeof(int32_t) + 512);
         if (err != hipSuccess) rc = hip_fail(err, "hipHostMalloc");
-    }
-    if (!rc) {
-        // k_rank orders a bin inside 96 KB of LDS: beyond the default dynamic limit
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRankLdsBytes);
-        if (err != hipSuccess) rc = hip_fail(err, "hipFuncSetAttribute(k_rank)");
     }
     if (rc) {
         dca_engine_destroy(e);
@@ -2513,9 +2453,9 @@ int dca_engine_debug(dca_engine* e, double* out, void* stream) {
     out[6] = cost(c.T);
     out[7] = c.want;
     out[8] = c.bstar;
-    out[9] = 0;
-    out[10] = 0;
-    out[11] = 0;
+    out[9] = c.dbg_nord;
+    out[10] = c.dbg_maxbin;
+    out[11] = c.dbg_giant_seen;
     out[12] = c.shift;
     out[13] = c.spill_bin;
     out[14] = S.npop;

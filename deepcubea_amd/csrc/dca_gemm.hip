@@ -1,0 +1,263 @@
+// dca_gemm.hip — the dense layers of the cost-to-go network as ONE hand-written MFMA kernel per layer:
+// an fp32-accurate GEMM on the f16 matrix pipes of gfx950 ("f16x3") with the whole layer tail in its epilogue.
+//
+// Reference arithmetic (utils/pytorch_models.py:57-86, BatchNorm folded): v = relu?(x . W^T + b (+ skip)), fp32.
+// gfx950 has no TF32-like mode and its f32-input MFMA runs at 1/16 of the f16 rate, so the fp32 parity mode runs here
+// on the f16 pipes instead: an fp32 value splits exactly into two fp16 numbers to 22 bits (x = xh + xl, xh = f16(x),
+// xl = f16(x - xh)); with the weights split the same way (rows pre-scaled by a power of two so the low halves stay
+// normal)          x.w = xh.wh + xl.wh + xh.wl + O(2^-22 |x.w|)          accumulated in the MFMA's fp32 accumulator.
+//
+// Round 1 expressed this as one LIBRARY f16 GEMM over a materialised 3x-wide operand plus a glue kernel per layer.
+// This kernel keeps the operands as two fp16 PLANES (high / low halves; 4 bytes per activation, exactly what an fp32
+// tensor costs — the 3x operand never exists), issues the three products per K-step from the same LDS fragments, and
+// applies scale, bias, residual add, ReLU and the split of the RESULT into the next layer's planes in the epilogue: one
+// launch per dense layer, activations cross HBM once in each direction.
+//
+// Tiling: workgroup = 128 x 128 outputs, 4 waves as 2 (M) x 2 (N), each wave 2 x 2 tiles of v_mfma_f32_32x32x16_f16
+// (64 accumulator VGPRs).  K-step 64: the four operand images (A high/low, W high/low; 128 rows x 128 bytes each = 64 KB)
+// are staged through registers — 16-byte coalesced global loads issued a whole K-step ahead of their LDS write, so they
+// fly under the 48 MFMAs per wave of the current step — into row-major LDS rows whose 16-byte chunks are XOR-swizzled
+// with (row >> 1) & 7: every ds_read_b128 lane group then touches each LDS bank exactly once.  Two workgroups per CU
+// (2 x 64 KB LDS, <= 256 VGPRs) overlap one group's staging with the other's MFMAs.  Workgroup ids are remapped so that
+// the N tiles sharing an A tile run on ONE XCD (its L2 then reads the A tile from HBM once).
+#include "dca_common.h"
+
+namespace dca {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GBM = 128, GBN = 128, GBK = 64, GTHREADS = 256;
+constexpr int GIMG = GBM * GBK * 2;     // bytes of one operand image (16 KB)
+constexpr int GLDS = 4 * GIMG;          // A high, A low, W high, W low
+
+struct GemmArgs {
+    const _Float16 *ah, *al;  // activation planes [m, lda]
+    const _Float16 *wh, *wl;  // weight planes [n, ldw] (row = output unit, pre-scaled by 1 / col_scale)
+    const float* col_scale;   // [n] or null
+    const float* bias;        // [n] or null
+    const float* skip;        // [m, ldo] fp32 or null
+    float alpha;
+    int relu;
+    int64_t m;
+    int n, k;
+    int64_t lda, ldw, ldo;
+    _Float16 *oh, *ol;        // result planes [m, ldo] or null
+    float* x_out;             // result fp32 [m, ldo] or null
+    int* overflow;
+};
+
+__device__ __forceinline__ uint32_t swz(uint32_t row, uint32_t chunk) { return row * 128u + ((chunk ^ ((row >> 1) & 7u)) << 4); }
+
+__global__ __launch_bounds__(GTHREADS, 2) void k_f16x3_gemm(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, h = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    // workgroup -> output tile: the N tiles of one M tile sit on one XCD (workgroup b runs on XCD b % 8)
+    const int nNt = (p.n + GBN - 1) / GBN;
+    const int64_t nMt = (p.m + GBM - 1) / GBM;
+    const int64_t bid = blockIdx.x;
+    const int64_t slot = bid >> 3;
+    const int64_t mt = (slot / nNt) * 8 + (bid & 7);
+    const int nt = (int)(slot % nNt);
+    if (mt >= nMt) return;
+    const int64_t m0 = mt * GBM;
+    const int n0 = nt * GBN;
+
+    // staging map: an image is 128 rows x 8 chunks of 16 B; thread t moves chunks q*256 + t (row = slot / 8: eight
+    // neighbouring lanes read one row's 128 contiguous bytes)
+    uint4 pre[4][4];
+    const uint32_t srow = (uint32_t)t >> 3, schunk = (uint32_t)t & 7u;
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t r = srow + 32u * q;
+            const int64_t gr = m0 + r;
+            const int gn = n0 + (int)r;
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            if (gr < p.m) {
+                const int64_t o = gr * p.lda + k0 + schunk * 8;
+                pre[0][q] = *reinterpret_cast<const uint4*>(p.ah + o);
+                pre[1][q] = *reinterpret_cast<const uint4*>(p.al + o);
+            } else {
+                pre[0][q] = z;
+                pre[1][q] = z;
+            }
+            if (gn < p.n) {
+                const int64_t o = (int64_t)gn * p.ldw + k0 + schunk * 8;
+                pre[2][q] = *reinterpret_cast<const uint4*>(p.wh + o);
+                pre[3][q] = *reinterpret_cast<const uint4*>(p.wl + o);
+            } else {
+                pre[2][q] = z;
+                pre[3][q] = z;
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t off = swz(srow + 32u * q, schunk);
+#pragma unroll
+            for (int img = 0; img < 4; img++) *reinterpret_cast<uint4*>(lds + img * GIMG + off) = pre[img][q];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int jn = 0; jn < 2; jn++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][jn][e] = 0.f;
+
+    const int nk = p.k / GBK;
+    load_tile(0);
+    for (int kt = 0; kt < nk; kt++) {
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < nk) load_tile((kt + 1) * GBK);  // in flight under this step's MFMAs
+#pragma unroll
+        for (int s = 0; s < GBK / 16; s++) {
+            const uint32_t c = 2u * s + (uint32_t)h;
+            f16x8 ah[2], al[2], wh[2], wl[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const uint32_t off = swz((uint32_t)(wm * 64 + i * 32 + l31), c);
+                ah[i] = *reinterpret_cast<const f16x8*>(lds + off);
+                al[i] = *reinterpret_cast<const f16x8*>(lds + GIMG + off);
+            }
+#pragma unroll
+            for (int jn = 0; jn < 2; jn++) {
+                const uint32_t off = swz((uint32_t)(wn * 64 + jn * 32 + l31), c);
+                wh[jn] = *reinterpret_cast<const f16x8*>(lds + 2 * GIMG + off);
+                wl[jn] = *reinterpret_cast<const f16x8*>(lds + 3 * GIMG + off);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int jn = 0; jn < 2; jn++) {
+                    // small terms first, then the leading product: x.w = xl.wh + xh.wl + xh.wh
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[jn], acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[jn], acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[jn], acc[i][jn], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    bool ovf = false;
+#pragma unroll
+    for (int jn = 0; jn < 2; jn++) {
+        const int col = n0 + wn * 64 + jn * 32 + l31;
+        if (col >= p.n) continue;
+        const float cs = p.col_scale ? p.alpha * p.col_scale[col] : p.alpha;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const int64_t r = m0 + wm * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (r >= p.m) continue;
+                const int64_t o = r * p.ldo + col;
+                float u = acc[i][jn][reg] * cs + bv;
+                if (p.skip) u += p.skip[o];
+                if (p.relu) u = fmaxf(u, 0.f);
+                if (p.x_out) p.x_out[o] = u;
+                if (p.oh) {
+                    ovf |= !(fabsf(u) <= 60000.0f);  // beyond fp16 (or NaN): the caller redoes the batch in fp32
+                    const _Float16 hh = (_Float16)u;
+                    p.oh[o] = hh;
+                    p.ol[o] = (_Float16)(u - (float)hh);
+                }
+            }
+    }
+    if (ovf && p.overflow) *p.overflow = 1;
+}
+
+// fp32 [m, n] (row stride ld) -> its two fp16 planes (and the overflow flag): the entry into an f16x3 layer for
+// activations that did not come out of an f16x3 epilogue
+__global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ x, int64_t m, int64_t n, int64_t ld,
+                                                      _Float16* __restrict__ oh, _Float16* __restrict__ ol,
+                                                      int64_t ldo, int* __restrict__ overflow) {
+    const int64_t n4 = n / 4;
+    const int64_t total = m * n4;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / n4, c = (i - r * n4) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
+        const float u[4] = {v.x, v.y, v.z, v.w};
+        h4 hi, lo;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (!(fabsf(u[k]) <= 60000.0f) && overflow) *overflow = 1;
+            hi[k] = (_Float16)u[k];
+            lo[k] = (_Float16)(u[k] - (float)hi[k]);
+        }
+        *reinterpret_cast<h4*>(oh + r * ldo + c) = hi;
+        *reinterpret_cast<h4*>(ol + r * ldo + c) = lo;
+    }
+}
+
+}  // namespace dca
+
+using namespace dca;
+
+extern "C" {
+
+int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t lda, const void* w_h, const void* w_l, int n,
+                   int64_t ldw, const float* col_scale, double alpha, const float* bias, const float* skip, int relu,
+                   void* out_h, void* out_l, float* x_out, int64_t ldo, int* overflow, void* stream) {
+    DCA_ARG(a_h && a_l && w_h && w_l && m >= 0 && n >= 1 && k >= GBK && k % GBK == 0);
+    DCA_ARG(lda >= k && ldw >= k && lda % 8 == 0 && ldw % 8 == 0 && ldo >= n);
+    DCA_ARG((out_h != nullptr) == (out_l != nullptr) && (out_h != nullptr || x_out != nullptr));
+    DCA_ARG(((uintptr_t)a_h | (uintptr_t)a_l | (uintptr_t)w_h | (uintptr_t)w_l) % 16 == 0);
+    if (m == 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f16x3_gemm), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS));
+        attr_set = true;
+    }
+    GemmArgs p;
+    p.ah = reinterpret_cast<const _Float16*>(a_h);
+    p.al = reinterpret_cast<const _Float16*>(a_l);
+    p.wh = reinterpret_cast<const _Float16*>(w_h);
+    p.wl = reinterpret_cast<const _Float16*>(w_l);
+    p.col_scale = col_scale;
+    p.bias = bias;
+    p.skip = skip;
+    p.alpha = (float)alpha;
+    p.relu = relu;
+    p.m = m;
+    p.n = n;
+    p.k = k;
+    p.lda = lda;
+    p.ldw = ldw;
+    p.ldo = ldo;
+    p.oh = reinterpret_cast<_Float16*>(out_h);
+    p.ol = reinterpret_cast<_Float16*>(out_l);
+    p.x_out = x_out;
+    p.overflow = overflow;
+    const int64_t nMt = (m + GBM - 1) / GBM;
+    const int64_t nNt = (n + GBN - 1) / GBN;
+    const int64_t blocks = ((nMt + 7) / 8) * 8 * nNt;
+    if (blocks > 0x7FFFFFFFll) {
+        set_error("dca_f16x3_gemm: too many tiles");
+        return DCA_E_BADARG;
+    }
+    hipLaunchKernelGGL(k_f16x3_gemm, dim3((unsigned)blocks), dim3(GTHREADS), GLDS, (hipStream_t)stream, p);
+    return launch_check("k_f16x3_gemm");
+}
+
+int dca_split_planes(const float* x, int64_t m, int64_t n, int64_t ld, void* out_h, void* out_l, int64_t ldo, int* overflow,
+                     void* stream) {
+    DCA_ARG(x && out_h && out_l && m >= 0 && n >= 4 && n % 4 == 0 && ld >= n && ld % 4 == 0 && ldo >= n && ldo % 4 == 0);
+    if (m == 0) return 0;
+    int64_t blocks = (m * (n / 4) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_split_planes, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, m, n, ld,
+                       reinterpret_cast<_Float16*>(out_h), reinterpret_cast<_Float16*>(out_l), ldo, overflow);
+    return launch_check("k_split_planes");
+}
+
+}  // extern "C"

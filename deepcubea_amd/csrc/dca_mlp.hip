@@ -12,8 +12,9 @@
 //     parity mode, P = 2 serves fp16 weights, P = 1 bf16;
 //   * bias + ReLU + the output cast ride in the epilogue.
 //
-// Tiling: a workgroup (8 waves) owns 64 output columns.  Their weights — all P planes, all of K — are staged ONCE
-// into LDS (P*KPAD*128 bytes: 129 KB for cube3 with P = 3) in the exact order the B fragments are read
+// Tiling: a workgroup (8 waves) owns 64 output columns.  Their weights — all P planes — are staged into LDS (cube3:
+// all of K once, 129 KB with P = 3; the sliding puzzles, K up to 2401: 320 one-hot columns at a time, walked per row
+// chunk) in the exact order the B fragments are read
 // ([plane][k/8][column][8] => 512 contiguous bytes per half-wave, conflict-free), then the workgroup walks over row
 // chunks of 512 (64 rows per wave = 2x2 tiles of v_mfma_f32_32x32x16_bf16, 64 accumulator VGPRs).  Per K-step a wave
 // issues 4*P MFMAs for 2 A-fragment rebuilds and 2*P ds_read_b128: the MFMA pipe is the limiter.
@@ -33,7 +34,13 @@ struct L1Geo {
     static constexpr int KSTEPS = (K + 15) / 16;  // MFMA K = 16
     static constexpr int KPAD = KSTEPS * 16;
     static constexpr int KC = KPAD / 8;           // 16-byte weight chunks along K
-    static constexpr int MW = (KPAD + 31) / 32;   // mask words per row
+    // K is walked in chunks whose weights (all planes) fit LDS: the whole of K where it fits in one piece (cube3: 21
+    // steps = 129 KB with 3 planes, staged once per workgroup), else 20 steps = 320 one-hot columns (120 KB) at a time,
+    // re-staged for every 512-row chunk (928 KB of L2 reads against 472 MFLOP of MFMA work for puzzle48: noise)
+    static constexpr int CH_STEPS = KSTEPS <= 21 ? KSTEPS : 20;
+    static constexpr int NCH = (KSTEPS + CH_STEPS - 1) / CH_STEPS;
+    static constexpr int CHKC = CH_STEPS * 2;     // 16-byte weight chunks per LDS chunk and plane
+    static constexpr int MWC = (CH_STEPS * 16 + 31) / 32;  // one-hot mask words per row and chunk
 };
 
 __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
@@ -41,20 +48,29 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
     return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 
-template <int D, int DEPTH, int P, int OUT /*0 f32, 1 f16, 2 bf16, 3 f16x3 split (vh, vl, vh) interleaved*/>
+template <int D, int DEPTH, int P,
+          int OUT /*0 f32, 1 f16, 2 bf16, 3 f16x3 split (vh, vl, vh) interleaved, 4 two fp16 planes (high, then low at +m*ldo)*/>
 __global__ __launch_bounds__(kL1Threads) void k_l1_onehot_gemm(const uint8_t* __restrict__ nn, int64_t m,
                                                         const uint8_t* __restrict__ wt /*[ntile][P][KC][64][8] bf16*/,
                                                         const float* __restrict__ bias, int relu, void* __restrict__ out,
                                                         int64_t ldo, int* __restrict__ overflow) {
     using G = L1Geo<D, DEPTH>;
     extern __shared__ __attribute__((aligned(16))) uint8_t lw[];
-    constexpr int TILE_BYTES = P * G::KC * 64 * 16;
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(wt + (size_t)blockIdx.x * TILE_BYTES);
-        uint4* dst = reinterpret_cast<uint4*>(lw);
-        for (int q = threadIdx.x; q < TILE_BYTES / 16; q += kL1Threads) dst[q] = src[q];
+    // weights of K-chunk ch (all planes) -> LDS, in B-fragment order [plane][k/8][column][8]
+    auto stage = [&](int ch) {
+        const int kc0 = ch * G::CHKC;
+        const int nkc = (G::KC - kc0) < G::CHKC ? (G::KC - kc0) : G::CHKC;
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const uint4* src = reinterpret_cast<const uint4*>(wt) + ((size_t)(blockIdx.x * P + p) * G::KC + kc0) * 64;
+            uint4* dst = reinterpret_cast<uint4*>(lw) + (size_t)p * G::CHKC * 64;
+            for (int q = threadIdx.x; q < nkc * 64; q += kL1Threads) dst[q] = src[q];
+        }
+    };
+    if constexpr (G::NCH == 1) {
+        stage(0);
+        __syncthreads();
     }
-    __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int64_t n0 = (int64_t)blockIdx.x * 64;
@@ -63,28 +79,8 @@ __global__ __launch_bounds__(kL1Threads) void k_l1_onehot_gemm(const uint8_t* __
     bv[1] = bias[n0 + 32 + l31];
     for (int64_t chunk = blockIdx.y; chunk * kL1Rows < m; chunk += gridDim.y) {
         const int64_t rw = chunk * kL1Rows + wv * 64;  // first row of this wave
-        if (rw >= m) continue;
-        // K-bit one-hot mask of this lane's two rows
-        uint32_t mk[2][G::MW];
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-#pragma unroll
-            for (int w = 0; w < G::MW; w++) mk[i][w] = 0;
-            const int64_t r = rw + 32 * i + l31;
-            if (r < m) {
-                const uint8_t* row = nn + r * D;
-#pragma unroll
-                for (int pos = 0; pos < D; pos++) {
-                    const uint32_t c = row[pos];
-                    constexpr int dummy = 0;
-                    (void)dummy;
-                    const int bit0 = pos * DEPTH, w0 = bit0 >> 5, sh = bit0 & 31;
-                    const uint64_t f = (uint64_t)1 << (c + (uint32_t)sh);
-                    mk[i][w0] |= (uint32_t)f;
-                    if (w0 + 1 < G::MW) mk[i][w0 + 1] |= (uint32_t)(f >> 32);
-                }
-            }
-        }
+        // (with K-chunking every wave takes part in the staging barriers, rows or not)
+        if (G::NCH == 1 && rw >= m) continue;
         f32x16 acc[2][2];
 #pragma unroll
         for (int i = 0; i < 2; i++)
@@ -92,26 +88,68 @@ __global__ __launch_bounds__(kL1Threads) void k_l1_onehot_gemm(const uint8_t* __
             for (int jn = 0; jn < 2; jn++)
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[i][jn][e] = 0.f;
-#pragma unroll
-        for (int s = 0; s < G::KSTEPS; s++) {
-            bf16x8 a[2];
+#pragma unroll 1
+        for (int ch = 0; ch < G::NCH; ch++) {
+            if constexpr (G::NCH > 1) {
+                __syncthreads();  // the previous chunk's readers are done with the LDS tile
+                stage(ch);
+                __syncthreads();
+            }
+            const int steps = (G::KSTEPS - ch * G::CH_STEPS) < G::CH_STEPS ? (G::KSTEPS - ch * G::CH_STEPS) : G::CH_STEPS;
+            // one-hot mask of this lane's two rows, restricted to the chunk's columns [k0, k0 + 16*steps)
+            uint32_t mk[2][G::MWC];
 #pragma unroll
             for (int i = 0; i < 2; i++) {
-                const uint32_t byte = (mk[i][s >> 1] >> ((s & 1) * 16 + 8 * h)) & 0xFFu;
-                uint32_t v[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++)  // bits (2j, 2j+1) -> two bf16 ones: spread to bits 0 and 16, scale by 0x3F80
-                    v[j] = ((((byte >> (2 * j)) & 3u) * 0x8001u) & 0x00010001u) * 0x3F80u;
-                __builtin_memcpy(&a[i], v, 16);
+                for (int w = 0; w < G::MWC; w++) mk[i][w] = 0;
+                const int64_t r = rw + 32 * i + l31;
+                if (r < m) {
+                    const uint8_t* row = nn + r * D;
+                    if constexpr (G::NCH == 1) {
+#pragma unroll
+                        for (int pos = 0; pos < D; pos++) {
+                            const uint32_t c = row[pos];
+                            const int bit0 = pos * DEPTH, w0 = bit0 >> 5, sh = bit0 & 31;
+                            const uint64_t f = (uint64_t)1 << (c + (uint32_t)sh);
+                            mk[i][w0] |= (uint32_t)f;
+                            if (w0 + 1 < G::MWC) mk[i][w0 + 1] |= (uint32_t)(f >> 32);
+                        }
+                    } else {
+                        // only the positions whose DEPTH columns overlap the chunk (~ 320 / DEPTH + 2 of them)
+                        const int k0 = ch * G::CH_STEPS * 16, k1 = k0 + steps * 16;
+                        const int p_lo = k0 / DEPTH, p_hi = (k1 - 1) / DEPTH < D - 1 ? (k1 - 1) / DEPTH : D - 1;
+                        for (int pos = p_lo; pos <= p_hi; pos++) {
+                            const int bit = pos * DEPTH + (int)row[pos] - k0;
+                            const uint32_t wsel = (uint32_t)(bit >> 5), bm = 1u << (bit & 31);
+                            const bool in = bit >= 0 && bit < steps * 16;
+#pragma unroll
+                            for (int w = 0; w < G::MWC; w++) mk[i][w] |= (in && wsel == (uint32_t)w) ? bm : 0u;
+                        }
+                    }
+                }
             }
 #pragma unroll
-            for (int p = 0; p < P; p++) {
+            for (int s = 0; s < G::CH_STEPS; s++) {
+                if (G::NCH > 1 && s >= steps) break;
+                bf16x8 a[2];
 #pragma unroll
-                for (int jn = 0; jn < 2; jn++) {
-                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(
-                        lw + ((size_t)((p * G::KC + 2 * s + h) * 64 + jn * 32 + l31)) * 16);
-                    acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b, acc[0][jn], 0, 0, 0);
-                    acc[1][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b, acc[1][jn], 0, 0, 0);
+                for (int i = 0; i < 2; i++) {
+                    const uint32_t byte = (mk[i][s >> 1] >> ((s & 1) * 16 + 8 * h)) & 0xFFu;
+                    uint32_t v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++)  // bits (2j, 2j+1) -> two bf16 ones: spread to bits 0 and 16, scale by 0x3F80
+                        v[j] = ((((byte >> (2 * j)) & 3u) * 0x8001u) & 0x00010001u) * 0x3F80u;
+                    __builtin_memcpy(&a[i], v, 16);
+                }
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+#pragma unroll
+                    for (int jn = 0; jn < 2; jn++) {
+                        const bf16x8 b = *reinterpret_cast<const bf16x8*>(
+                            lw + ((size_t)((p * G::CHKC + 2 * s + h) * 64 + jn * 32 + l31)) * 16);
+                        acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b, acc[0][jn], 0, 0, 0);
+                        acc[1][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b, acc[1][jn], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -133,13 +171,19 @@ __global__ __launch_bounds__(kL1Threads) void k_l1_onehot_gemm(const uint8_t* __
                             reinterpret_cast<_Float16*>(out)[r * ldo + col] = (_Float16)v;
                         else if constexpr (OUT == 2)
                             reinterpret_cast<uint16_t*>(out)[r * ldo + col] = f32_to_bf16_rne(v);
-                        else {  // the next layer's f16x3 A operand directly: 192 contiguous bytes per 32 lanes
+                        else if constexpr (OUT == 3) {  // the library-GEMM f16x3 A operand: 192 contiguous bytes per 32 lanes
                             _Float16* q = reinterpret_cast<_Float16*>(out) + (r * ldo + col) * 3;
                             if (!(fabsf(v) <= 60000.0f) && overflow) *overflow = 1;
                             const _Float16 hh = (_Float16)v;
                             q[0] = hh;
                             q[1] = (_Float16)(v - (float)hh);
                             q[2] = hh;
+                        } else {  // the two fp16 planes dca_f16x3_gemm reads: high halves, then (m*ldo further) low halves
+                            _Float16* q = reinterpret_cast<_Float16*>(out) + r * ldo + col;
+                            if (!(fabsf(v) <= 60000.0f) && overflow) *overflow = 1;
+                            const _Float16 hh = (_Float16)v;
+                            q[0] = hh;
+                            q[m * ldo] = (_Float16)(v - (float)hh);
                         }
                     }
                 }
@@ -151,7 +195,7 @@ template <int D, int DEPTH, int P>
 int launch_l1_out(const uint8_t* nn, int64_t m, const uint8_t* wt, const float* bias, int relu, void* out, int out_dtype,
                   int64_t n_pad, int* overflow, hipStream_t s) {
     using G = L1Geo<D, DEPTH>;
-    constexpr int LDS = P * G::KC * 64 * 16;
+    constexpr int LDS = P * G::CHKC * 64 * 16;
     static_assert(LDS <= 160 * 1024, "weight tile does not fit LDS");
     const int64_t chunks = (m + kL1Rows - 1) / kL1Rows;
     const dim3 grid((unsigned)(n_pad / 64), (unsigned)(chunks < 16 ? (chunks < 1 ? 1 : chunks) : 16)), block(kL1Threads);
@@ -167,8 +211,10 @@ int launch_l1_out(const uint8_t* nn, int64_t m, const uint8_t* wt, const float* 
         DCA_L1_LAUNCH(1);
     else if (out_dtype == DCA_DT_BF16)
         DCA_L1_LAUNCH(2);
-    else
+    else if (out_dtype == DCA_DT_F16X3)
         DCA_L1_LAUNCH(3);
+    else
+        DCA_L1_LAUNCH(4);
 #undef DCA_L1_LAUNCH
     return launch_check("k_l1_onehot_gemm");
 }
@@ -201,7 +247,8 @@ __global__ __launch_bounds__(256) void k_act_split(const float* __restrict__ y, 
                                                    const float* __restrict__ skip, const float* __restrict__ col_scale,
                                                    float alpha, int relu, int64_t m, int64_t n,
                                                    float* __restrict__ x_out /*[m,n] or null*/,
-                                                   _Float16* __restrict__ a3 /*[m,3n]*/, int* __restrict__ overflow) {
+                                                   _Float16* __restrict__ a3 /*[m,3n], or two planes [2][m][n]*/,
+                                                   int planes, int* __restrict__ overflow) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t col = ((int64_t)blockIdx.x * 64 + lane) * 4;
     if (col >= n) return;
@@ -237,7 +284,10 @@ __global__ __launch_bounds__(256) void k_act_split(const float* __restrict__ y, 
             lo[k] = (_Float16)(u - (float)hh);
         }
         if (x_out) *reinterpret_cast<float4*>(x_out + r * n + col) = make_float4(v[0], v[1], v[2], v[3]);
-        if (a3) {  // element k of the row -> halves 3k..3k+2 = (vh, vl, vh): 24 contiguous bytes per lane
+        if (a3 && planes) {  // dca_f16x3_gemm's operand: the high halves [m,n], then the low halves [m,n]
+            *reinterpret_cast<h4*>(a3 + r * n + col) = hi;
+            *reinterpret_cast<h4*>(a3 + (m + r) * n + col) = lo;
+        } else if (a3) {  // element k of the row -> halves 3k..3k+2 = (vh, vl, vh): 24 contiguous bytes per lane
             h4* row = reinterpret_cast<h4*>(a3 + (r * n + col) * 3);
             h4 q0, q1, q2;
             q0[0] = hi[0], q0[1] = lo[0], q0[2] = hi[0], q0[3] = hi[1];
@@ -256,14 +306,16 @@ using namespace dca;
 
 extern "C" {
 
-int dca_l1_supported(int state_dim, int depth) { return (state_dim == 54 && depth == 6) || (state_dim == 16 && depth == 16); }
+int dca_l1_supported(int state_dim, int depth) {
+    return (state_dim == 54 && depth == 6) || (state_dim == depth && (depth == 16 || depth == 25 || depth == 36 || depth == 49));
+}
 
 int64_t dca_l1_kpad(int state_dim, int depth) { return (((int64_t)state_dim * depth + 15) / 16) * 16; }
 
 int dca_l1_onehot_gemm(const uint8_t* nnet_in, int64_t m, int state_dim, int depth, const void* w_tiles, int planes,
                        int64_t n_pad, const float* bias, int relu, void* out, int out_dtype, int* overflow, void* stream) {
     DCA_ARG(nnet_in && w_tiles && bias && out && m >= 0 && planes >= 1 && planes <= 3 && n_pad >= 64 && n_pad % 64 == 0);
-    DCA_ARG(out_dtype >= DCA_DT_F32 && out_dtype <= DCA_DT_F16X3);
+    DCA_ARG(out_dtype >= DCA_DT_F32 && out_dtype <= DCA_DT_F16_PLANES);
     if (!dca_l1_supported(state_dim, depth)) {
         set_error("dca_l1_onehot_gemm: geometry (%d, %d) not instantiated (weight tile must fit LDS)", state_dim, depth);
         return DCA_E_BADARG;
@@ -271,12 +323,17 @@ int dca_l1_onehot_gemm(const uint8_t* nnet_in, int64_t m, int state_dim, int dep
     if (m == 0) return 0;
     const uint8_t* wt = reinterpret_cast<const uint8_t*>(w_tiles);
     hipStream_t s = (hipStream_t)stream;
-    if (state_dim == 54) return launch_l1<54, 6>(planes, nnet_in, m, wt, bias, relu, out, out_dtype, n_pad, overflow, s);
-    return launch_l1<16, 16>(planes, nnet_in, m, wt, bias, relu, out, out_dtype, n_pad, overflow, s);
+    switch (state_dim) {
+        case 54: return launch_l1<54, 6>(planes, nnet_in, m, wt, bias, relu, out, out_dtype, n_pad, overflow, s);
+        case 16: return launch_l1<16, 16>(planes, nnet_in, m, wt, bias, relu, out, out_dtype, n_pad, overflow, s);
+        case 25: return launch_l1<25, 25>(planes, nnet_in, m, wt, bias, relu, out, out_dtype, n_pad, overflow, s);
+        case 36: return launch_l1<36, 36>(planes, nnet_in, m, wt, bias, relu, out, out_dtype, n_pad, overflow, s);
+        default: return launch_l1<49, 49>(planes, nnet_in, m, wt, bias, relu, out, out_dtype, n_pad, overflow, s);
+    }
 }
 
 int dca_act_split(const float* y, const float* bias, const float* skip, const float* col_scale, double alpha, int relu,
-                  int64_t m, int64_t n, float* x_out, void* a3, int* overflow, void* stream) {
+                  int64_t m, int64_t n, float* x_out, void* a3, int a3_planes, int* overflow, void* stream) {
     DCA_ARG(y && (a3 || x_out) && m >= 0 && n >= 4 && n % 4 == 0 && m * n < (1ll << 40));
     if (m == 0) return 0;
     const unsigned gx = (unsigned)((n + 255) / 256);
@@ -285,7 +342,7 @@ int dca_act_split(const float* y, const float* bias, const float* skip, const fl
     if (gy < 1) gy = 1;
     hipLaunchKernelGGL(k_act_split, dim3(gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, y, bias, skip, col_scale,
                        (float)alpha, relu,
-                       m, n, x_out, reinterpret_cast<_Float16*>(a3), overflow);
+                       m, n, x_out, reinterpret_cast<_Float16*>(a3), a3_planes, overflow);
     return launch_check("k_act_split");
 }
 

@@ -164,7 +164,7 @@ class BwasEngine:
         out = (C.c_double * 16)()
         _lib.check(_lib.lib().dca_engine_debug(self._h, out, _lib.stream_ptr()), "dca_engine_debug")
         names = ["front_n", "back_n", "front_cmin", "front_cmax", "back_cmin", "back_cmax", "T", "want", "bstar",
-                 "sel_less", "sel_r", "cand_n", "shift", "spill_bin", "npop", "m"]
+                 "n_ord", "max_bin", "giant_bins_seen", "shift", "spill_bin", "npop", "m"]
         return dict(zip(names, list(out)))
 
     def status(self, instance: int = 0) -> dict:

@@ -179,7 +179,7 @@ class FastResnet(nn.Module):
     network-input rows), or one-hot rows `[M, in_pad]` in `dtype` (row stride `in_pad` >= state_dim*depth, tail zero) as
     written by the engine's pack kernel through `forward_onehot`.  fp32 is the 1e-5 parity mode."""
 
-    def __init__(self, model: ResnetModel, dtype: torch.dtype = torch.float32, split: bool = True):
+    def __init__(self, model: ResnetModel, dtype: torch.dtype = torch.float32, split: bool = True, gemm: str = "hip"):
         super().__init__()
         m = fold_batchnorm(model)
         self.state_dim, self.one_hot_depth = m.state_dim, m.one_hot_depth
@@ -221,10 +221,17 @@ class FastResnet(nn.Module):
         # operands A3[3k..3k+2] = (xh, xl, xh), W3[3k..3k+2] = (wh, wh, wl) (csrc/dca_mlp.hip k_act_split): fp32-accurate, 2.4-2.9x faster
         # than the library's fp32 GEMM.  Weights are pre-scaled by a power of two so their low halves stay normal numbers.
         self.split = bool(split) and dtype == torch.float32
+        # "hip": every dense layer after the first is ONE launch of the hand-written f16x3 kernel (csrc/dca_gemm.hip: operand
+        # planes, the three products per K-step, layer tail in the epilogue); "library": round 1's arrangement — one library
+        # f16 GEMM over the 3x-wide interleaved operand plus the dca_act_split glue kernel per layer (kept for comparison)
+        self.gemm = gemm
+        assert gemm in ("hip", "library")
         # set by the split kernels when a value does not fit fp16 (|v| > 60000): that batch is redone with fp32 GEMMs
         self.register_buffer("_overflow", torch.zeros(1, dtype=torch.int32), persistent=False)
         self.split_fallbacks = 0
         self.split_w = nn.ParameterList()
+        self.split_wh = nn.ParameterList()
+        self.split_wl = nn.ParameterList()
         self.split_b = nn.ParameterList()
         self.split_alpha = nn.ParameterList()  # per-output-unit 1/scale vectors
         self.l1_split_w = nn.ParameterList()
@@ -244,6 +251,8 @@ class FastResnet(nn.Module):
                                                  requires_grad=False))  # W3[:, 3k..3k+2] = (wh, wh, wl)
                 self.split_b.append(nn.Parameter(b.clone(), requires_grad=False))
                 self.split_alpha.append(nn.Parameter(1.0 / sc, requires_grad=False))
+                self.split_wh.append(nn.Parameter(wh.contiguous(), requires_grad=False))  # planes for dca_f16x3_gemm
+                self.split_wl.append(nn.Parameter(wl.contiguous(), requires_grad=False))
         # layer 1 straight from the uint8 rows (csrc/dca_mlp.hip) where the geometry is instantiated: fp32 weights as
         # three bf16 planes (exact), fp16 as two, bf16 as one
         self.l1_planes = {torch.float32: 3, torch.float16: 2, torch.bfloat16: 1}[dtype]
@@ -282,8 +291,9 @@ class FastResnet(nn.Module):
             self._overflow.zero_()
             y = torch.mm(x, self.l1_split_w[0].t(), out_dtype=torch.float32)
             y.add_(torch.mm(x, self.l1_split_w[1].t(), out_dtype=torch.float32))
-            a3, _ = _lib.act_split(y, B[0], None, self.l1_split_alpha, True, False, overflow=self._overflow)
-            out = self._after_l1_split(a3)
+            a3, _ = _lib.act_split(y, B[0], None, self.l1_split_alpha, True, False,
+                                   want_a3="planes" if self.gemm == "hip" else True, overflow=self._overflow)
+            out = self._after_l1_planes(a3) if self.gemm == "hip" else self._after_l1_split(a3)
             if int(self._overflow.item()) == 0:
                 return out
             self.split_fallbacks += 1
@@ -315,8 +325,8 @@ class FastResnet(nn.Module):
         if self.split:  # the layer-1 kernel's epilogue writes the next layer's split operand directly
             self._overflow.zero_()
             a3 = _lib.l1_onehot_gemm(states_nnet, self.one_hot_depth, self.l1_tiles, self.l1_planes, self.l1_bias, True,
-                                     self.dtype, split=True, overflow=self._overflow)
-            out = self._after_l1_split(a3)
+                                     self.dtype, split="planes" if self.gemm == "hip" else True, overflow=self._overflow)
+            out = self._after_l1_planes(a3) if self.gemm == "hip" else self._after_l1_split(a3)
             if int(self._overflow.item()) == 0:
                 return out
             self.split_fallbacks += 1  # some activation beyond fp16 range: same batch again with fp32 GEMMs
@@ -338,4 +348,17 @@ class FastResnet(nn.Module):
             ah, _ = _lib.act_split(y, B[ka], None, A[ka], True, False, overflow=ovf)
             y = torch.mm(ah, W[kb].t(), out_dtype=f32)
             a3, x = _lib.act_split(y, B[kb], x, A[kb], True, True, want_a3=blk + 1 < nblk, overflow=ovf)
+        return x @ self.w_out.t() + self.b_out
+
+    def _after_l1_planes(self, planes: torch.Tensor) -> torch.Tensor:
+        """fp16 planes of relu(layer 1) [2, M, h1_pad] -> [M, out_dim]: one dca_f16x3_gemm launch per dense layer (scale,
+        bias, residual add, ReLU and the split of the result into the next layer's planes ride in its epilogue)."""
+        from .. import _lib
+        Wh, Wl, B, A, ovf = self.split_wh, self.split_wl, self.split_b, self.split_alpha, self._overflow
+        nblk = (len(Wh) - 1) // 2
+        planes, x = _lib.f16x3_gemm(planes, Wh[0], Wl[0], A[0], 1.0, B[0], None, True, nblk > 0, True, ovf)
+        for blk in range(nblk):
+            ka, kb = 1 + 2 * blk, 2 + 2 * blk
+            ph, _ = _lib.f16x3_gemm(planes, Wh[ka], Wl[ka], A[ka], 1.0, B[ka], None, True, True, False, ovf)
+            planes, x = _lib.f16x3_gemm(ph, Wh[kb], Wl[kb], A[kb], 1.0, B[kb], x, True, blk + 1 < nblk, True, ovf)
         return x @ self.w_out.t() + self.b_out

@@ -52,6 +52,7 @@ extern "C" {
 #define DCA_DT_F16 1
 #define DCA_DT_BF16 2
 #define DCA_DT_F16X3 3 /* dca_l1_onehot_gemm only: the f16x3 split operand (vh, vl, vh) per element, [m, 3*n_pad] fp16 */
+#define DCA_DT_F16_PLANES 4 /* dca_l1_onehot_gemm only: dca_f16x3_gemm's operand — [m, n_pad] fp16 high halves, then [m, n_pad] low halves */
 
 /* BWAS semantics: which reference implementation is reproduced */
 #define DCA_SEM_PY 0  /* search_methods/astar.py: f64 cost, FIFO ties, CLOSED starts empty */
@@ -264,7 +265,8 @@ int dca_bn_train_backward(const float* dy, const float* x, const float* y /*need
  * [n_pad/64][planes][k_pad/8][64][8] (k_pad = dca_l1_kpad(state_dim, depth), zero padded; deepcubea_amd/utils/
  * pytorch_models.py:l1_weight_tiles builds it).  out: [m, n_pad] in out_dtype (DCA_DT_*), row stride n_pad; DCA_DT_F16X3
  * writes the next f16x3 layer's A operand [m, 3*n_pad] directly (see dca_act_split).
- * Instantiated for the geometries whose weight tile fits LDS: dca_l1_supported(state_dim, depth) != 0.
+ * K is walked in LDS-sized chunks (cube3: one piece; the sliding puzzles, K up to 2401: 320 one-hot columns at a time).
+ * Instantiated for cube3 (54, 6) and the sliding puzzles (16/25/36/49): dca_l1_supported(state_dim, depth) != 0.
  * ------------------------------------------------------------------------------------------------------------------ */
 int dca_l1_supported(int state_dim, int depth);
 int64_t dca_l1_kpad(int state_dim, int depth);
@@ -279,9 +281,29 @@ int dca_l1_onehot_gemm(const uint8_t* nnet_in /*[m, state_dim]*/, int64_t m, int
  * utils/pytorch_models.py:57-86 computes (BatchNorm folded) to fp32 accuracy.  n % 4 == 0.                            */
 int dca_act_split(const float* y, const float* bias /*[n] or NULL*/, const float* skip /*[m,n] or NULL*/,
                   const float* col_scale /*[n] or NULL: per-output-unit inverse weight scale*/, double alpha, int relu,
-                  int64_t m, int64_t n, float* x_out /*[m,n] or NULL*/, void* a3 /*[m,3n] fp16*/,
+                  int64_t m, int64_t n, float* x_out /*[m,n] or NULL*/, void* a3 /*[m,3n] fp16 or NULL*/,
+                  int a3_planes /*!= 0: write dca_f16x3_gemm's operand instead: [m,n] high halves then [m,n] low halves*/,
                   int* overflow /*device flag, set to 1 if some |v| > 60000 (not splittable into fp16); or NULL*/,
                   void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Heuristic network, dense layers: v = relu?( (x . W^T) * alpha * col_scale + bias (+ skip) ) — one layer
+ * of utils/pytorch_models.py:57-86 with BatchNorm folded — as ONE hand-written MFMA kernel with fp32 accuracy on the f16
+ * matrix pipes ("f16x3": x = xh + xl, w = wh + wl in fp16; x.w = xl.wh + xh.wl + xh.wh accumulated in fp32; csrc/dca_gemm.hip).
+ * Operands are fp16 PLANES: a_h / a_l [m, lda] (high / low halves of the fp32 activations: what this kernel, dca_l1_onehot_gemm
+ * (DCA_DT_F16_PLANES), dca_act_split (a3_planes) and dca_split_planes emit), w_h / w_l [n, ldw] (rows = output units,
+ * pre-scaled by the power of two 1 / col_scale[row]).  k % 64 == 0; lda, ldw % 8 == 0; 16-byte aligned bases.
+ * Outputs (row stride ldo): out_h / out_l — the result's planes, i.e. the NEXT layer's operand — and / or x_out, the fp32
+ * result (the next residual block's skip, or the input of the 1-wide output layer).  overflow: device flag set when a value
+ * does not fit fp16 (|v| > 60000; the caller then redoes the batch with fp32 GEMMs), or NULL.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t lda, const void* w_h, const void* w_l, int n,
+                   int64_t ldw, const float* col_scale /*[n] or NULL*/, double alpha, const float* bias /*[n] or NULL*/,
+                   const float* skip /*[m, ldo] fp32 or NULL*/, int relu, void* out_h, void* out_l, float* x_out, int64_t ldo,
+                   int* overflow, void* stream);
+/* fp32 [m, n] (row stride ld) -> its fp16 planes (row stride ldo); n % 4 == 0 */
+int dca_split_planes(const float* x, int64_t m, int64_t n, int64_t ld, void* out_h, void* out_l, int64_t ldo,
+                     int* overflow /*or NULL*/, void* stream);
 
 #ifdef __cplusplus
 }

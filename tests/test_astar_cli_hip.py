@@ -6,6 +6,8 @@ import sys
 import types
 
 import numpy as np
+
+from deepcubea_amd.utils import data_utils
 import pytest
 import torch
 
@@ -92,7 +94,7 @@ def test_cli_end_to_end(tmp_path, capsys, mode):
                 str(B), "--results_dir", rdir, "--language", "hip", "--nnet_batch_size", "1024", "--max_nodes",
                 str(1 << 20)] + (["--eval_all_children"] if mode == "eval_all_children" else []))
     sys.stdout = sys.__stdout__
-    res = pickle.load(open(os.path.join(rdir, "results.pkl"), "rb"))
+    res = data_utils.load_pickle(os.path.join(rdir, "results.pkl"))
     assert sorted(res.keys()) == ["num_nodes_generated", "paths", "solutions", "states", "times"]  # astar.py:382-397
     log = open(os.path.join(rdir, "output.txt")).read()
     lines = re.findall(r"State: (\d+), SolnCost: ([\d.]+), # Moves: (\d+), # Nodes Gen: ([\d,]+), Time: ([\d.]+)", log)
@@ -172,7 +174,7 @@ def test_cli_instances_per_gpu(tmp_path):
         astar.main(["--states", spath, "--model", "synthetic:11", "--env", "cube3", "--weight", "0.8", "--batch_size",
                     "60", "--results_dir", rdir, "--nnet_batch_size", "1000", "--max_nodes", str(1 << 20),
                     "--instances_per_gpu", str(k), "--debug"])
-        outs[k] = pickle.load(open(os.path.join(rdir, "results.pkl"), "rb"))
+        outs[k] = data_utils.load_pickle(os.path.join(rdir, "results.pkl"))
     for i, root in enumerate(roots):
         for k in (1, 3):
             s = root[None].copy()
@@ -205,7 +207,7 @@ def test_cli_two_ranks_sharded(tmp_path):
            "--nnet_batch_size", "1000", "--max_nodes", str(1 << 20)]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    res = pickle.load(open(os.path.join(rdir, "results.pkl"), "rb"))
+    res = data_utils.load_pickle(os.path.join(rdir, "results.pkl"))
     assert len(res["solutions"]) == 5 and len(res["times"]) == 5 and len(res["num_nodes_generated"]) == 5
     for i, r0 in enumerate(roots):
         s = r0[None].copy()

@@ -1,0 +1,109 @@
+"""GPU tests of the hand-written fp32-accurate dense-layer kernel (csrc/dca_gemm.hip, `dca_f16x3_gemm`): three f16 MFMA
+products per K-step over fp16 operand planes, layer tail (scale, bias, residual add, ReLU, split of the result into the
+next layer's planes) in the epilogue — against float64 evaluations of the same expression."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _split_w(w):
+    from deepcubea_amd.utils.pytorch_models import _pow2_scale, _split_f16
+    sc = _pow2_scale(w)
+    wh, wl = _split_f16(w, sc)
+    return wh.contiguous(), wl.contiguous(), (1.0 / sc).contiguous()
+
+
+def test_identity_activations_with_asymmetric_weights_catch_transposition():
+    """A = I (exactly representable), asymmetric W: the output must be W^T tile for tile — a swapped row/column map of the
+    MFMA accumulator or of the LDS images cannot pass."""
+    from deepcubea_amd import _lib
+    _lib.require_gpu()
+    k = n = 256
+    w = (torch.arange(n * k, dtype=torch.float32).view(n, k) % 251) - 125.0   # integers: exact in fp16
+    w[:, 3] += 7.0
+    wh, wl = w.to(torch.float16).cuda(), torch.zeros(n, k, dtype=torch.float16).cuda()
+    x = torch.eye(k, dtype=torch.float32).cuda()
+    planes = _lib.split_planes(x)
+    assert torch.equal(planes[0].float(), x) and not planes[1].any()
+    _, y = _lib.f16x3_gemm(planes, wh, wl, None, 1.0, None, None, False, False, True)
+    assert torch.equal(y.cpu(), w.t().contiguous())
+    # ragged m: a row subset in a different order
+    idx = torch.tensor([5, 0, 200, 131, 77, 255, 128])
+    _, y2 = _lib.f16x3_gemm(_lib.split_planes(x[idx.cuda()].contiguous()), wh, wl, None, 1.0, None, None, False, False, True)
+    assert torch.equal(y2.cpu(), w.t()[idx])
+
+
+@pytest.mark.parametrize("m", [1, 130, 1000])
+@pytest.mark.parametrize("n,k", [(64, 64), (192, 128), (1024, 1024), (1024, 5120)])
+def test_f16x3_gemm_is_fp32_accurate(m, n, k):
+    from deepcubea_amd import _lib
+    g = torch.Generator().manual_seed(1000 * m + n + k)
+    x = torch.randn(m, k, generator=g) * 3.0
+    x[:, ::7] *= 40.0                       # a spread of magnitudes inside a row
+    w = torch.randn(n, k, generator=g) / np.sqrt(k)
+    w[5] *= 300.0                           # units of very different scale: per-row power-of-two scaling
+    w[7] *= 1e-3
+    b = torch.randn(n, generator=g)
+    skip = torch.randn(m, n, generator=g)
+    wh, wl, inv = _split_w(w)
+    planes = _lib.split_planes(x.cuda())
+    ref = x.double() @ w.double().t()
+    mag = (x.double().abs() @ w.double().abs().t())   # sum |x||w| per output: the natural error scale
+    for bias, sk, relu in ((None, None, False), (b, skip, True), (b, None, True)):
+        pl, y = _lib.f16x3_gemm(planes, wh.cuda(), wl.cuda(), inv.cuda(), 1.0, None if bias is None else bias.cuda(),
+                                None if sk is None else sk.cuda(), relu, True, True)
+        want = ref + (bias.double() if bias is not None else 0) + (sk.double() if sk is not None else 0)
+        if relu:
+            want = torch.relu(want)
+        err = (y.double().cpu() - want).abs()
+        # fp32-GEMM class: a few 2^-22 of sum|x||w| (measured ~2e-7), plus one fp32 rounding of the result
+        assert float((err / (mag * 2.0 ** -19 + want.abs() * 2.0 ** -22 + 1e-30)).max()) <= 1.0, float(err.max())
+        # the planes are exactly the split of the fp32 result
+        hi = y.to(torch.float16)
+        lo = (y - hi.float()).to(torch.float16)
+        assert torch.equal(pl[0], hi) and torch.equal(pl[1], lo)
+    # planes-only and fp32-only calls agree with the combined one
+    pl2, none = _lib.f16x3_gemm(planes, wh.cuda(), wl.cuda(), inv.cuda(), 1.0, b.cuda(), None, True, True, False)
+    assert none is None and torch.equal(pl2, pl)
+
+
+def test_overflow_flag_and_split_planes():
+    from deepcubea_amd import _lib
+    x = torch.randn(300, 128) * 1000.0
+    pl = _lib.split_planes(x.cuda())
+    hi = x.to(torch.float16)
+    assert torch.equal(pl[0].cpu(), hi) and torch.equal(pl[1].cpu(), (x - hi.float()).to(torch.float16))
+    assert float((pl[0].float() + pl[1].float() - x.cuda()).abs().max()) <= float(x.abs().max()) * 2.0 ** -21
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    w = torch.ones(64, 128)
+    wh, wl, inv = _split_w(w)
+    _lib.f16x3_gemm(pl, wh.cuda(), wl.cuda(), inv.cuda(), 1.0, None, None, False, True, True, flag)
+    assert int(flag.item()) == 0
+    big = torch.full((4, 128), 600.0).cuda()   # 128 * 600 = 76800 > fp16 range
+    _lib.f16x3_gemm(_lib.split_planes(big), wh.cuda(), wl.cuda(), inv.cuda(), 1.0, None, None, False, True, True, flag)
+    assert int(flag.item()) == 1
+    flag.zero_()
+    _lib.split_planes(torch.full((4, 8), 7e4).cuda(), flag)
+    assert int(flag.item()) == 1
+
+
+@torch.no_grad()
+def test_hand_written_layers_equal_the_library_arrangement(golden):
+    """FastResnet(gemm="hip") (one dca_f16x3_gemm launch per layer) vs round 1's library f16 GEMM + glue kernel on the same
+    split weights: both fp32-accurate, so they agree to a few fp32 ulps of the activations; both within 1e-5 of the reference."""
+    from deepcubea_amd.utils.pytorch_models import FastResnet, ResnetModel
+    from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
+    full = ResnetModel(54, 6, 5000, 1000, 4, 1, True)
+    load_synthetic_weights(full, 2024)
+    x = torch.tensor(golden["cube3_resnet_seed2024_x"]).cuda()
+    ref = golden["cube3_resnet_seed2024_y"]
+    hip, lib_ = FastResnet(full, gemm="hip").cuda(), FastResnet(full, gemm="library").cuda()
+    yh, yl = hip(x)[:, 0].cpu().numpy(), lib_(x)[:, 0].cpu().numpy()
+    assert np.max(np.abs(yh - ref)) < 1e-5 and np.max(np.abs(yl - ref)) < 1e-5
+    xb = torch.randint(0, 6, (20000, 54), dtype=torch.uint8, device="cuda")
+    assert float((hip(xb) - lib_(xb)).abs().max()) < 1e-5
+    # the one-hot entry (geometries fed with one-hot rows) takes the same layers
+    assert float((hip.forward_onehot(hip.encode(xb[:700])) - hip(xb[:700])).abs().max()) < 1e-5
+    assert hip.split_fallbacks == 0 and lib_.split_fallbacks == 0

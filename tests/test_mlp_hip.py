@@ -7,7 +7,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("D,depth", [(54, 6), (16, 16)])
+@pytest.mark.parametrize("D,depth", [(54, 6), (16, 16), (25, 25), (36, 36), (49, 49)])
 @pytest.mark.parametrize("planes,out_dtype,tol", [(3, torch.float32, 2e-6), (2, torch.float16, 2e-3), (1, torch.bfloat16, 1.5e-2),
                                                   (3, torch.bfloat16, 1e-2), (1, torch.float32, 1e-2)])
 @pytest.mark.parametrize("m", [1, 257, 1500])
@@ -15,7 +15,7 @@ def test_l1_onehot_gemm_matches_float64(D, depth, planes, out_dtype, tol, m):
     from deepcubea_amd import _lib
     from deepcubea_amd.utils.pytorch_models import l1_weight_tiles
     _lib.require_gpu()
-    assert _lib.l1_supported(D, depth) and not _lib.l1_supported(49, 49)
+    assert _lib.l1_supported(D, depth) and not _lib.l1_supported(64, 64)
     g = torch.Generator().manual_seed(D * 1000 + planes * 10 + m)
     K, n_pad = D * depth, 192
     w = torch.randn(n_pad, K, generator=g) * 0.2      # asymmetric, every column different
@@ -148,3 +148,20 @@ def test_f16x3_survives_a_wide_spread_of_unit_scales():
     fo, fnat = FastResnet(net).cuda(), FastResnet(net, split=False).cuda()
     assert torch.equal(fo(x), fnat(x)) and fo.split_fallbacks == 1
     assert torch.equal(fo.forward_onehot(fo.encode(x)), fnat.forward_onehot(fnat.encode(x))) and fo.split_fallbacks == 2
+
+
+@pytest.mark.parametrize("D,depth", [(54, 6), (49, 49)])
+def test_l1_kernel_planes_epilogue_is_the_split_of_its_fp32_output(D, depth):
+    from deepcubea_amd import _lib
+    from deepcubea_amd.utils.pytorch_models import l1_weight_tiles
+    torch.manual_seed(11)
+    m, n_pad = 777, 128
+    w = torch.randn(n_pad, D * depth) * 0.3
+    b = torch.randn(n_pad).cuda()
+    x = torch.stack([torch.randperm(D) for _ in range(m)]).to(torch.uint8).cuda() if depth == D else \
+        torch.randint(0, depth, (m, D), dtype=torch.uint8).cuda()
+    tiles = l1_weight_tiles(w, 3, _lib.l1_kpad(D, depth)).cuda()
+    y = _lib.l1_onehot_gemm(x, depth, tiles, 3, b, True, torch.float32)
+    pl = _lib.l1_onehot_gemm(x, depth, tiles, 3, b, True, torch.float32, split="planes")
+    hi = y.to(torch.float16)
+    assert pl.shape == (2, m, n_pad) and torch.equal(pl[0], hi) and torch.equal(pl[1], (y - hi.float()).to(torch.float16))
