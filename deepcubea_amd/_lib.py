@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "dca_engine_enable_packed", "dca_engine_pop_expand_packed", "dca_engine_commit_packed",
     "dca_engine_profile_builtin", "dca_engine_set_tiers", "dca_engine_debug", "dca_engine_status", "dca_engine_last_children", "dca_engine_solution",
     "dca_bn_workspace_bytes", "dca_bn_train_forward", "dca_bn_train_backward",
-    "dca_l1_supported", "dca_l1_kpad", "dca_l1_onehot_gemm", "dca_act_split", "dca_f16x3_gemm", "dca_split_planes",
+    "dca_l1_supported", "dca_l1_kpad", "dca_l1_onehot_gemm", "dca_act_split", "dca_f16x3_gemm", "dca_split_planes", "dca_f16x3_gemm_variant",
 ]
 
 
@@ -380,3 +380,8 @@ def f16x3_gemm(a_planes: torch.Tensor, w_h: torch.Tensor, w_l: torch.Tensor, col
                                ptr(planes[0]) if want_planes else C.c_void_p(0), ptr(planes[1]) if want_planes else C.c_void_p(0),
                                ptr(x_out), C.c_int64(n), ptr(overflow), stream_ptr()), "dca_f16x3_gemm")
     return planes, x_out
+
+
+def f16x3_gemm_variant(v: int) -> None:
+    """Tuning / test hook: 2 (default) = LDS-DMA 256x256 kernel, 1 = register-staged 128x128 kernel."""
+    check(lib().dca_f16x3_gemm_variant(int(v)), "dca_f16x3_gemm_variant")

@@ -926,8 +926,8 @@ struct RankItem {
     uint32_t off, n, need, src;  // slice [off, off+n) of scratch array `src` (0 tmp, 1 ord); pop rank of its first entry = off
 };
 struct RankShared {
-    uint32_t cnt[NBIN];      // sub-bin counts, then running scatter slots   (direct path: 1024 keys)
-    uint32_t off[NBIN + 1];  // exclusive prefix                              (direct path: ids)
+    uint32_t cnt[NBIN];      // sub-bin counts, then running scatter slots
+    uint32_t off[NBIN + 1];  // exclusive prefix
     uint32_t wsum[16];
     uint64_t red_lo[32], red_hi[32];
     uint64_t vmin_hi, vmin_lo;
@@ -972,137 +972,261 @@ __device__ __forceinline__ uint32_t sub_of(uint64_t k, uint32_t id, u128 vmin, u
     return q < (u128)nsub ? (uint32_t)q : nsub - 1u;
 }
 
-// one work item of a bin's workgroup (see the banner above).  All 1024 threads.
-__device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint32_t nf, uint32_t want, RankItem it) {
+constexpr int RT = 512;                            // threads of a k_rank workgroup (8 waves: up to 256 VGPRs each)
+constexpr int kRegEnt = 16;                        // entries a thread keeps in registers
+constexpr uint32_t kLdsEnt = RT * kRegEnt;         // items up to this size are bucketed entirely in LDS (96 KB)
+
+// exact composite range of the item from per-thread partial min / max -> S.vmin_*, S.bits; also clears the counters
+__device__ __forceinline__ void rank_range(RankShared& S, u128 vmin, u128 vmax) {
     const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    for (int o = 32; o > 0; o >>= 1) {
+        uint64_t ahi = __shfl_xor((uint64_t)(vmin >> 64), o), alo = __shfl_xor((uint64_t)vmin, o);
+        uint64_t bhi = __shfl_xor((uint64_t)(vmax >> 64), o), blo = __shfl_xor((uint64_t)vmax, o);
+        u128 a = ((u128)ahi << 64) | alo, b = ((u128)bhi << 64) | blo;
+        vmin = a < vmin ? a : vmin;
+        vmax = b > vmax ? b : vmax;
+    }
+    if (lane == 0) {
+        S.red_hi[wv] = (uint64_t)(vmin >> 64);
+        S.red_lo[wv] = (uint64_t)vmin;
+        S.red_hi[16 + wv] = (uint64_t)(vmax >> 64);
+        S.red_lo[16 + wv] = (uint64_t)vmax;
+    }
+    for (uint32_t i = t; i < NBIN; i += RT) S.cnt[i] = 0;
+    __syncthreads();
+    if (t == 0) {
+        u128 mn = ~(u128)0, mx = 0;
+        for (int k = 0; k < RT / 64; k++) {
+            u128 a = ((u128)S.red_hi[k] << 64) | S.red_lo[k], b = ((u128)S.red_hi[16 + k] << 64) | S.red_lo[16 + k];
+            mn = a < mn ? a : mn;
+            mx = b > mx ? b : mx;
+        }
+        const u128 range = mx - mn;
+        S.bits = range ? (uint32_t)(128 - clz128(range)) : 0u;
+        S.vmin_hi = (uint64_t)(mn >> 64);
+        S.vmin_lo = (uint64_t)mn;
+    }
+    __syncthreads();
+}
+
+// exclusive prefix of cnt[0..nsub) into off[0..nsub] (2 per thread), the sub-bin holding the need-th entry -> S.tsub,
+// counters back to zero (they become the running scatter slots)
+__device__ __forceinline__ void rank_prefix(RankShared& S, uint32_t nsub, uint32_t need) {
+    constexpr int PER = NBIN / RT;  // counters per thread (4)
+    const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    uint32_t v[PER], s4 = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        v[k] = PER * t + k < nsub ? S.cnt[PER * t + k] : 0u;
+        s4 += v[k];
+    }
+    uint32_t incl = s4;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t u = __shfl_up(incl, o);
+        if (lane >= (uint32_t)o) incl += u;
+    }
+    if (lane == 63) S.wsum[wv] = incl;
+    __syncthreads();
+    uint32_t run = incl - s4;
+    for (uint32_t w = 0; w < wv; w++) run += S.wsum[w];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const uint32_t i = PER * t + k;
+        if (i < nsub) {
+            S.off[i] = run;
+            S.cnt[i] = 0;
+            if (run < need && need <= run + v[k]) S.tsub = i;
+            if (i + 1 == nsub) S.off[nsub] = run + v[k];
+        }
+        run += v[k];
+    }
+    __syncthreads();
+}
+
+// oversized sub-bins of the item just scattered become work items of their own (slice of the OTHER scratch array)
+__device__ __forceinline__ void rank_push(RankShared& S, const RankItem& it, uint32_t tsub, uint32_t need, uint32_t shc) {
+    for (uint32_t sb = threadIdx.x; sb <= tsub; sb += RT) {
+        const uint32_t s0 = S.off[sb], e0 = S.off[sb + 1];
+        if (e0 - s0 > kSubMax && shc > 0) {
+            const uint32_t slot = atomicAdd(&S.sp, 1u);
+            if (slot < (uint32_t)kRankStack)
+                S.stack[slot] = RankItem{it.off + s0, e0 - s0, sb == tsub ? need - s0 : e0 - s0, it.src ^ 1u};
+            else
+                S.fail = 1;
+        }
+    }
+}
+
+// one work item of a bin's workgroup (see the banner above).  All RT threads.  LK / LI: 8192-entry LDS arrays.
+__device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint64_t* LK, uint32_t* LI, uint32_t nf,
+                                       uint32_t want, RankItem it) {
+    const uint32_t t = threadIdx.x;
     const uint64_t* __restrict__ K = (it.src ? E.ord_key : E.tmp_key) + it.off;
     const uint32_t* __restrict__ I = (it.src ? E.ord_id : E.tmp_id) + it.off;
     uint64_t* __restrict__ K2 = (it.src ? E.tmp_key : E.ord_key) + it.off;
     uint32_t* __restrict__ I2 = (it.src ? E.tmp_id : E.ord_id) + it.off;
     const uint32_t n = it.n, need = it.need;
     if (n <= kDirectMax) {
-        // small item: all-pairs out of LDS (keys in S.cnt viewed as u64, ids in S.off)
-        uint64_t* sk = reinterpret_cast<uint64_t*>(S.cnt);
-        uint32_t* si = S.off;
+        // small item: all-pairs out of LDS
         if (t < n) {
-            sk[t] = K[t];
-            si[t] = I[t];
+            LK[t] = K[t];
+            LI[t] = I[t];
         }
         __syncthreads();
         const bool live = t < n;
         uint64_t k = 0;
         uint32_t id = 0, rank = 0;
         if (live) {
-            k = sk[t];
-            id = si[t];
-            for (uint32_t j = 0; j < n; j++) rank += pair_less(sk[j], si[j], k, id) ? 1u : 0u;
+            k = LK[t];
+            id = LI[t];
+            for (uint32_t j = 0; j < n; j++) rank += pair_less(LK[j], LI[j], k, id) ? 1u : 0u;
         }
         emit_ranked(E, c, nf, live, it.off + rank, want, k, id);
         __syncthreads();
         return;
     }
-    // ---- pass 0: exact composite range
-    {
-        u128 vmin = ~(u128)0, vmax = 0;
-        for (uint32_t i = t; i < n; i += 1024) {
-            const u128 v = comp_of(K[i], I[i]);
-            vmin = v < vmin ? v : vmin;
-            vmax = v > vmax ? v : vmax;
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-            uint64_t ahi = __shfl_xor((uint64_t)(vmin >> 64), o), alo = __shfl_xor((uint64_t)vmin, o);
-            uint64_t bhi = __shfl_xor((uint64_t)(vmax >> 64), o), blo = __shfl_xor((uint64_t)vmax, o);
-            u128 a = ((u128)ahi << 64) | alo, b = ((u128)bhi << 64) | blo;
-            vmin = a < vmin ? a : vmin;
-            vmax = b > vmax ? b : vmax;
-        }
-        if (lane == 0) {
-            S.red_hi[wv] = (uint64_t)(vmin >> 64);
-            S.red_lo[wv] = (uint64_t)vmin;
-            S.red_hi[16 + wv] = (uint64_t)(vmax >> 64);
-            S.red_lo[16 + wv] = (uint64_t)vmax;
-        }
-        for (uint32_t i = t; i < NBIN; i += 1024) S.cnt[i] = 0;
-        __syncthreads();
-        if (t == 0) {
-            u128 mn = ~(u128)0, mx = 0;
-            for (int k = 0; k < 16; k++) {
-                u128 a = ((u128)S.red_hi[k] << 64) | S.red_lo[k], b = ((u128)S.red_hi[16 + k] << 64) | S.red_lo[16 + k];
-                mn = a < mn ? a : mn;
-                mx = b > mx ? b : mx;
-            }
-            const u128 range = mx - mn;
-            S.bits = range ? (uint32_t)(128 - clz128(range)) : 0u;
-            S.vmin_hi = (uint64_t)(mn >> 64);
-            S.vmin_lo = (uint64_t)mn;
-        }
-        __syncthreads();
-    }
-    const u128 vmin = ((u128)S.vmin_hi << 64) | S.vmin_lo;
     uint32_t lg = 0;
     while ((8u << lg) <= n && lg < 11) lg++;  // 2^lg <= n / 4, at most NBIN sub-bins
+    if (n <= kLdsEnt) {
+        // ---- the item is read from HBM ONCE (8 entries per thread, kept in registers), bucketed and ranked in LDS
+        uint64_t ek[kRegEnt];
+        uint32_t ei[kRegEnt], es[kRegEnt];
+        u128 vmin = ~(u128)0, vmax = 0;
+#pragma unroll
+        for (int j = 0; j < kRegEnt; j++) {
+            const uint32_t i = t + (uint32_t)RT * j;
+            ek[j] = i < n ? K[i] : ~0ull;
+            ei[j] = i < n ? I[i] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int j = 0; j < kRegEnt; j++)
+            if (t + (uint32_t)RT * j < n) {
+                const u128 v = comp_of(ek[j], ei[j]);
+                vmin = v < vmin ? v : vmin;
+                vmax = v > vmax ? v : vmax;
+            }
+        rank_range(S, vmin, vmax);
+        const u128 base = ((u128)S.vmin_hi << 64) | S.vmin_lo;
+        const uint32_t bits = S.bits;
+        if (lg > bits) lg = bits;  // cannot cut finer than one composite value
+        const uint32_t nsub = 1u << lg, shc = bits - lg;
+#pragma unroll
+        for (int j = 0; j < kRegEnt; j++) {
+            es[j] = 0;
+            if (t + (uint32_t)RT * j < n) {
+                es[j] = sub_of(ek[j], ei[j], base, shc, nsub);
+                atomicAdd(&S.cnt[es[j]], 1u);
+            }
+        }
+        __syncthreads();
+        rank_prefix(S, nsub, need);
+        const uint32_t tsub = S.tsub;
+#pragma unroll
+        for (int j = 0; j < kRegEnt; j++) {
+            const bool live = t + (uint32_t)RT * j < n;
+            if (live && es[j] <= tsub) {
+                const uint32_t p = S.off[es[j]] + atomicAdd(&S.cnt[es[j]], 1u);
+                LK[p] = ek[j];
+                LI[p] = ei[j];
+            }
+            open_append(E, c, nf, live && es[j] > tsub, ek[j], ei[j]);  // the rest of a threshold bin stays in OPEN
+        }
+        __syncthreads();
+        const uint32_t m = S.off[tsub + 1];
+        for (uint32_t p0 = 0; p0 < m; p0 += RT) {
+            const uint32_t p = p0 + t;
+            bool live = p < m;
+            uint64_t k = 0;
+            uint32_t id = 0, rank = 0;
+            if (live) {
+                k = LK[p];
+                id = LI[p];
+                const uint32_t sub = sub_of(k, id, base, shc, nsub);
+                const uint32_t s0 = S.off[sub], e0 = S.off[sub + 1];
+                if (e0 - s0 > kSubMax && shc > 0) {
+                    K2[p] = k;  // refined by the sub-bin's own work item, from the other scratch array
+                    I2[p] = id;
+                    live = false;
+                } else {
+                    rank = s0;
+                    for (uint32_t j = s0; j < e0; j++) rank += pair_less(LK[j], LI[j], k, id) ? 1u : 0u;
+                }
+            }
+            emit_ranked(E, c, nf, live, it.off + rank, want, k, id);
+        }
+        rank_push(S, it, tsub, need, shc);
+        __syncthreads();
+        return;
+    }
+    // ---- larger than LDS: three streaming passes over the slice, 8 loads in flight per thread
+    {
+        u128 vmin = ~(u128)0, vmax = 0;
+        for (uint32_t b0 = 0; b0 < n; b0 += kLdsEnt) {
+            uint64_t ek[kRegEnt];
+            uint32_t ei[kRegEnt];
+#pragma unroll
+            for (int j = 0; j < kRegEnt; j++) {
+                const uint32_t i = b0 + t + (uint32_t)RT * j;
+                ek[j] = i < n ? K[i] : 0;
+                ei[j] = i < n ? I[i] : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < kRegEnt; j++)
+                if (b0 + t + (uint32_t)RT * j < n) {
+                    const u128 v = comp_of(ek[j], ei[j]);
+                    vmin = v < vmin ? v : vmin;
+                    vmax = v > vmax ? v : vmax;
+                }
+        }
+        rank_range(S, vmin, vmax);
+    }
+    const u128 base = ((u128)S.vmin_hi << 64) | S.vmin_lo;
     const uint32_t bits = S.bits;
-    if (lg > bits) lg = bits;                 // cannot cut finer than one composite value
+    if (lg > bits) lg = bits;
     const uint32_t nsub = 1u << lg, shc = bits - lg;
-    // ---- pass 1: sub-bin counts
-    for (uint32_t i = t; i < n; i += 1024) atomicAdd(&S.cnt[sub_of(K[i], I[i], vmin, shc, nsub)], 1u);
-    __syncthreads();
-    {   // exclusive prefix of cnt[0..nsub) into off[0..nsub] (2 per thread), threshold sub-bin, counters back to zero
-        const uint32_t a = 2 * t < nsub ? S.cnt[2 * t] : 0u, b2 = 2 * t + 1 < nsub ? S.cnt[2 * t + 1] : 0u;
-        const uint32_t s2 = a + b2;
-        uint32_t incl = s2;
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t v = __shfl_up(incl, o);
-            if (lane >= (uint32_t)o) incl += v;
+    for (uint32_t b0 = 0; b0 < n; b0 += kLdsEnt) {
+        uint64_t ek[kRegEnt];
+        uint32_t ei[kRegEnt];
+#pragma unroll
+        for (int j = 0; j < kRegEnt; j++) {
+            const uint32_t i = b0 + t + (uint32_t)RT * j;
+            ek[j] = i < n ? K[i] : 0;
+            ei[j] = i < n ? I[i] : 0;
         }
-        if (lane == 63) S.wsum[wv] = incl;
-        __syncthreads();
-        if (t < 16) {
-            uint32_t v = S.wsum[t], acc = v;
-            for (int o = 1; o < 16; o <<= 1) {
-                uint32_t u = __shfl_up(acc, o, 16);
-                if (t >= (uint32_t)o) acc += u;
-            }
-            S.wsum[t] = acc - v;
-        }
-        __syncthreads();
-        const uint32_t excl = incl - s2 + S.wsum[wv];
-        if (2 * t < nsub) {
-            S.off[2 * t] = excl;
-            S.cnt[2 * t] = 0;
-            if (excl < need && need <= excl + a) S.tsub = 2 * t;
-        }
-        if (2 * t + 1 < nsub) {
-            S.off[2 * t + 1] = excl + a;
-            S.cnt[2 * t + 1] = 0;
-            if (excl + a < need && need <= excl + s2) S.tsub = 2 * t + 1;
-        }
-        if (2 * t + 2 == nsub || (nsub == 1 && t == 0)) S.off[nsub] = excl + s2;
-        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kRegEnt; j++)
+            if (b0 + t + (uint32_t)RT * j < n) atomicAdd(&S.cnt[sub_of(ek[j], ei[j], base, shc, nsub)], 1u);
     }
+    __syncthreads();
+    rank_prefix(S, nsub, need);
     const uint32_t tsub = S.tsub;
-    // ---- pass 2: scatter the sub-bins that reach into the batch, hand the rest of a threshold bin back
-    for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
-        const uint32_t i = i0 + t;
-        const bool live = i < n;
-        uint64_t k = 0;
-        uint32_t id = 0, sub = 0;
-        if (live) {
-            k = K[i];
-            id = I[i];
-            sub = sub_of(k, id, vmin, shc, nsub);
-            if (sub <= tsub) {
-                const uint32_t p = S.off[sub] + atomicAdd(&S.cnt[sub], 1u);
-                K2[p] = k;
-                I2[p] = id;
-            }
+    for (uint32_t b0 = 0; b0 < n; b0 += kLdsEnt) {
+        uint64_t ek[kRegEnt];
+        uint32_t ei[kRegEnt];
+#pragma unroll
+        for (int j = 0; j < kRegEnt; j++) {
+            const uint32_t i = b0 + t + (uint32_t)RT * j;
+            ek[j] = i < n ? K[i] : 0;
+            ei[j] = i < n ? I[i] : 0;
         }
-        open_append(E, c, nf, live && sub > tsub, k, id);
+#pragma unroll
+        for (int j = 0; j < kRegEnt; j++) {
+            const bool live = b0 + t + (uint32_t)RT * j < n;
+            uint32_t sub = 0;
+            if (live) {
+                sub = sub_of(ek[j], ei[j], base, shc, nsub);
+                if (sub <= tsub) {
+                    const uint32_t p = S.off[sub] + atomicAdd(&S.cnt[sub], 1u);
+                    K2[p] = ek[j];
+                    I2[p] = ei[j];
+                }
+            }
+            open_append(E, c, nf, live && sub > tsub, ek[j], ei[j]);
+        }
     }
     __syncthreads();
-    // ---- pass 3: rank inside the sub-bin; oversized sub-bins become work items
     const uint32_t m = S.off[tsub + 1];
-    for (uint32_t p0 = 0; p0 < m; p0 += 1024) {
+    for (uint32_t p0 = 0; p0 < m; p0 += RT) {
         const uint32_t p = p0 + t;
         bool live = p < m;
         uint64_t k = 0;
@@ -1110,7 +1234,7 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
         if (live) {
             k = K2[p];
             id = I2[p];
-            const uint32_t sub = sub_of(k, id, vmin, shc, nsub);
+            const uint32_t sub = sub_of(k, id, base, shc, nsub);
             const uint32_t s0 = S.off[sub], e0 = S.off[sub + 1];
             if (e0 - s0 > kSubMax && shc > 0) {
                 live = false;  // ranked by the sub-bin's own work item
@@ -1121,27 +1245,19 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
         }
         emit_ranked(E, c, nf, live, it.off + rank, want, k, id);
     }
-    for (uint32_t sb = t; sb <= tsub; sb += 1024) {
-        const uint32_t s0 = S.off[sb], e0 = S.off[sb + 1];
-        if (e0 - s0 > kSubMax && shc > 0) {
-            const uint32_t slot = atomicAdd(&S.sp, 1u);
-            if (slot < (uint32_t)kRankStack) {
-                const uint32_t nd = sb == tsub ? need - s0 : e0 - s0;
-                S.stack[slot] = RankItem{it.off + s0, e0 - s0, nd, it.src ^ 1u};
-            } else {
-                S.fail = 1;
-            }
-        }
-    }
+    rank_push(S, it, tsub, need, shc);
     __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void k_rank(const Eng* __restrict__ engs) {
+__global__ __launch_bounds__(RT) void k_rank(const Eng* __restrict__ engs) {
     const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
     Stamp stamp(E, P_RANK);
     __shared__ RankShared S;
+    extern __shared__ __attribute__((aligned(16))) uint8_t rank_lds[];  // 8192 keys, then 8192 ids (96 KB)
+    uint64_t* LK = reinterpret_cast<uint64_t*>(rank_lds);
+    uint32_t* LI = reinterpret_cast<uint32_t*>(rank_lds + (size_t)kLdsEnt * 8);
     const uint32_t t = threadIdx.x;
     const uint32_t nf = st_cur(c).cur_f ^ 1, bb = c->cur_b;
     if (blockIdx.x == 0) {
@@ -1164,7 +1280,7 @@ __global__ __launch_bounds__(1024) void k_rank(const Eng* __restrict__ engs) {
         if (t < 4) {
             const int q = (int)t;
             uint64_t r = red[q][0];
-            for (int w = 1; w < 16; w++) r = (q & 1) ? (red[q][w] > r ? red[q][w] : r) : (red[q][w] < r ? red[q][w] : r);
+            for (int w = 1; w < RT / 64; w++) r = (q & 1) ? (red[q][w] > r ? red[q][w] : r) : (red[q][w] < r ? red[q][w] : r);
             const uint32_t buf = q < 2 ? nf : bb;
             // other workgroups append to FRONT' meanwhile (open_append): atomics, not plain stores
             if (q & 1) {
@@ -1195,13 +1311,13 @@ __global__ __launch_bounds__(1024) void k_rank(const Eng* __restrict__ engs) {
             __syncthreads();
             if (t == 0) S.sp = sp - 1;
             __syncthreads();
-            rank_item(E, c, S, nf, want, it);
+            rank_item(E, c, S, LK, LI, nf, want, it);
         }
         if (t == 0 && (S.fail || S.sp != 0)) c->failed = 1;  // (cannot happen: every refinement level narrows the range)
     }
     // ---- bins of at most 64 entries: one wave each
-    const uint32_t gw = blockIdx.x * 16 + (t >> 6);
-    for (uint32_t ti = gw; ti < n_tiny; ti += gridDim.x * 16) {
+    const uint32_t gw = blockIdx.x * (RT / 64) + (t >> 6);
+    for (uint32_t ti = gw; ti < n_tiny; ti += gridDim.x * (RT / 64)) {
         const uint32_t f = E.tiny_list[ti];
         const uint32_t o = E.pre[f];
         rank_tiny_bin(E, c, nf, o, E.pre[f + 1] - o, want);
@@ -1945,6 +2061,8 @@ void launch_probe(const dca_engine* e, hipStream_t s) {
     }
 }
 
+constexpr size_t kRankLdsBytes = (size_t)kLdsEnt * 12;
+
 int enqueue_first_half(dca_engine* e, int heur_id, bool with_refill, hipStream_t s, bool want_oh = true) {
     const Eng* d = e->d_engs;
     if (with_refill) {
@@ -1955,7 +2073,7 @@ int enqueue_first_half(dca_engine* e, int heur_id, bool with_refill, hipStream_t
     hipLaunchKernelGGL(k_sel_hist, gxy(kScanGrid, e), dim3(256), 0, s, d);
     hipLaunchKernelGGL(k_sel_scan, gxy(1, e), dim3(1024), 0, s, d);
     hipLaunchKernelGGL(k_sel_collect, gxy(kCollectBlocks, e), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(k_rank, gxy(kRankBlocks, e), dim3(1024), 0, s, d);
+    hipLaunchKernelGGL(k_rank, gxy(kRankBlocks, e), dim3(RT), kRankLdsBytes, s, d);
     if (int rc = launch_check("select kernels")) return rc;
     return launch_expand(e, heur_id, want_oh, s);
 }
@@ -2117,6 +2235,12 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
     if (!rc) {
         hipError_t err = hipHostMalloc((void**)&e->h_ctl, sizeof(Ctl) + kMaxMoves * sizeof(int32_t) + 512);
         if (err != hipSuccess) rc = hip_fail(err, "hipHostMalloc");
+    }
+    if (!rc) {
+        // k_rank buckets a bin inside 96 KB of dynamic LDS: beyond the default limit
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRankLdsBytes);
+        if (err != hipSuccess) rc = hip_fail(err, "hipFuncSetAttribute(k_rank)");
     }
     if (rc) {
         dca_engine_destroy(e);

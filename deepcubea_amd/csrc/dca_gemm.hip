@@ -49,7 +49,7 @@ struct GemmArgs {
 
 __device__ __forceinline__ uint32_t swz(uint32_t row, uint32_t chunk) { return row * 128u + ((chunk ^ ((row >> 1) & 7u)) << 4); }
 
-__global__ __launch_bounds__(GTHREADS, 2) void k_f16x3_gemm(const GemmArgs p) {
+__global__ __launch_bounds__(GTHREADS, 2) void k_f16x3_gemm_v1(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, h = lane >> 5;
     const int wm = w >> 1, wn = w & 1;
@@ -175,6 +175,140 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_f16x3_gemm(const GemmArgs p) {
     if (ovf && p.overflow) *p.overflow = 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// v2 (default): 256 x 256 outputs per workgroup, 8 waves as 2 (M) x 4 (N), each wave 4 x 2 tiles of 32x32x16 (128
+// accumulator VGPRs, 48 MFMAs per K-step of 32).  The four operand images of a K-step (256 rows x 64 B each = 64 KB) are
+// filled by global_load_lds_dwordx4 — the LDS-DMA path: no staging registers, no ds_write pass — into one of TWO LDS
+// stages, so the loads of step t+1 fly under the MFMAs of step t with a single raw s_barrier per K-step (a counted
+// s_waitcnt in inline asm; __syncthreads() would drain the DMA queue).  An LDS-DMA instruction writes 64 lanes x 16 B
+// linearly, so the image stays linear in LDS and the XOR swizzle that makes the ds_read_b128 fragment reads
+// conflict-free (chunk ^ ((row >> 2) & 3) for 64-byte rows) is applied to each lane's GLOBAL source address instead:
+// the four lanes of a row still read one contiguous 64-byte segment, in permuted order.
+// (v1 above — 128 x 128 tile, register staging, two barriers per K-step — measured 620 TF on the MFMA pipe; it stays as
+// the A/B reference, dca_f16x3_gemm_variant(1).)
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int HBM_T = 256, HBN_T = 256, HBK = 32, HTHREADS = 512;
+constexpr int HIMG = 256 * HBK * 2;   // bytes of one operand image (16 KB)
+constexpr int HSTAGE = 4 * HIMG;      // A high, A low, W high, W low
+constexpr int HLDS = 2 * HSTAGE;      // two stages: 128 KB
+
+__device__ __forceinline__ uint32_t swz64(uint32_t row, uint32_t chunk) { return row * 64u + ((chunk ^ ((row >> 2) & 3u)) << 4); }
+
+__global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v2(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, h = lane >> 5;
+    const int wm = w >> 2, wn = w & 3;
+    const int nNt = (p.n + HBN_T - 1) / HBN_T;
+    const int64_t nMt = (p.m + HBM_T - 1) / HBM_T;
+    const int64_t bid = blockIdx.x;
+    const int64_t slot = bid >> 3;
+    const int64_t mt = (slot / nNt) * 8 + (bid & 7);  // the N tiles of one M tile sit on one XCD
+    const int nt = (int)(slot % nNt);
+    if (mt >= nMt) return;
+    const int64_t m0 = mt * HBM_T;
+    const int n0 = nt * HBN_T;
+
+    // LDS-DMA map: instruction q of wave w fills rows [rb*16, rb*16+16) of image q >> 1, rb = (q & 1) * 8 + w; lane i
+    // lands on row i >> 2, physical chunk i & 3, and therefore fetches logical chunk (i & 3) ^ ((row >> 2) & 3).
+    // Rows past the matrix edge are clamped to the last row: their products are never stored.
+    const _Float16* src[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int img = q >> 1;
+        const uint32_t r = (uint32_t)(((q & 1) * 8 + w) * 16 + (lane >> 2));
+        const uint32_t c = (uint32_t)(lane & 3) ^ ((r >> 2) & 3u);
+        if (img < 2) {
+            int64_t gr = m0 + r;
+            gr = gr < p.m ? gr : p.m - 1;
+            src[q] = (img == 0 ? p.ah : p.al) + gr * p.lda + c * 8;
+        } else {
+            int gn = n0 + (int)r;
+            gn = gn < p.n ? gn : p.n - 1;
+            src[q] = (img == 2 ? p.wh : p.wl) + (int64_t)gn * p.ldw + c * 8;
+        }
+    }
+    auto issue = [&](int stage, int k0) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            uint8_t* dst = lds + stage * HSTAGE + (q >> 1) * HIMG + ((q & 1) * 8 + w) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + k0),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int jn = 0; jn < 2; jn++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][jn][e] = 0.f;
+
+    const int nk = p.k / HBK;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; kt++) {
+        // this wave's DMA of step kt has landed; the barrier makes that true of every wave's — and every wave has
+        // finished reading the other stage, which the next issue overwrites
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + 1 < nk) issue((kt + 1) & 1, (kt + 1) * HBK);
+        const uint8_t* base = lds + (kt & 1) * HSTAGE;
+#pragma unroll
+        for (int s = 0; s < HBK / 16; s++) {
+            const uint32_t c = 2u * s + (uint32_t)h;
+            f16x8 ah[4], al[4], wh[2], wl[2];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t off = swz64((uint32_t)(wm * 128 + i * 32 + l31), c);
+                ah[i] = *reinterpret_cast<const f16x8*>(base + off);
+                al[i] = *reinterpret_cast<const f16x8*>(base + HIMG + off);
+            }
+#pragma unroll
+            for (int jn = 0; jn < 2; jn++) {
+                const uint32_t off = swz64((uint32_t)(wn * 64 + jn * 32 + l31), c);
+                wh[jn] = *reinterpret_cast<const f16x8*>(base + 2 * HIMG + off);
+                wl[jn] = *reinterpret_cast<const f16x8*>(base + 3 * HIMG + off);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int jn = 0; jn < 2; jn++) {
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[jn], acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[jn], acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[jn], acc[i][jn], 0, 0, 0);
+                }
+        }
+    }
+
+    // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    bool ovf = false;
+#pragma unroll
+    for (int jn = 0; jn < 2; jn++) {
+        const int col = n0 + wn * 64 + jn * 32 + l31;
+        if (col >= p.n) continue;
+        const float cs = p.col_scale ? p.alpha * p.col_scale[col] : p.alpha;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const int64_t r = m0 + wm * 128 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (r >= p.m) continue;
+                const int64_t o = r * p.ldo + col;
+                float u = acc[i][jn][reg] * cs + bv;
+                if (p.skip) u += p.skip[o];
+                if (p.relu) u = fmaxf(u, 0.f);
+                if (p.x_out) p.x_out[o] = u;
+                if (p.oh) {
+                    ovf |= !(fabsf(u) <= 60000.0f);  // beyond fp16 (or NaN): the caller redoes the batch in fp32
+                    const _Float16 hh = (_Float16)u;
+                    p.oh[o] = hh;
+                    p.ol[o] = (_Float16)(u - (float)hh);
+                }
+            }
+    }
+    if (ovf && p.overflow) *p.overflow = 1;
+}
+
 // fp32 [m, n] (row stride ld) -> its two fp16 planes (and the overflow flag): the entry into an f16x3 layer for
 // activations that did not come out of an f16x3 epilogue
 __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ x, int64_t m, int64_t n, int64_t ld,
@@ -203,19 +337,29 @@ __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ 
 
 using namespace dca;
 
+static int g_gemm_variant = 2;
+
 extern "C" {
+
+/* tuning / test hook: 1 = the register-staged 128 x 128 kernel, 2 (default) = the LDS-DMA 256 x 256 kernel */
+int dca_f16x3_gemm_variant(int v) {
+    DCA_ARG(v == 1 || v == 2);
+    g_gemm_variant = v;
+    return 0;
+}
 
 int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t lda, const void* w_h, const void* w_l, int n,
                    int64_t ldw, const float* col_scale, double alpha, const float* bias, const float* skip, int relu,
                    void* out_h, void* out_l, float* x_out, int64_t ldo, int* overflow, void* stream) {
-    DCA_ARG(a_h && a_l && w_h && w_l && m >= 0 && n >= 1 && k >= GBK && k % GBK == 0);
+    DCA_ARG(a_h && a_l && w_h && w_l && m >= 0 && n >= 1 && k >= GBK && k % GBK == 0);  // (v2 alone would take k % 32)
     DCA_ARG(lda >= k && ldw >= k && lda % 8 == 0 && ldw % 8 == 0 && ldo >= n);
     DCA_ARG((out_h != nullptr) == (out_l != nullptr) && (out_h != nullptr || x_out != nullptr));
     DCA_ARG(((uintptr_t)a_h | (uintptr_t)a_l | (uintptr_t)w_h | (uintptr_t)w_l) % 16 == 0);
     if (m == 0) return 0;
     static bool attr_set = false;
     if (!attr_set) {
-        DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f16x3_gemm), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS));
+        DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f16x3_gemm_v1), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS));
+        DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f16x3_gemm_v2), hipFuncAttributeMaxDynamicSharedMemorySize, HLDS));
         attr_set = true;
     }
     GemmArgs p;
@@ -238,14 +382,18 @@ int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t l
     p.ol = reinterpret_cast<_Float16*>(out_l);
     p.x_out = x_out;
     p.overflow = overflow;
-    const int64_t nMt = (m + GBM - 1) / GBM;
-    const int64_t nNt = (n + GBN - 1) / GBN;
+    const int bm = g_gemm_variant == 1 ? GBM : HBM_T, bn = g_gemm_variant == 1 ? GBN : HBN_T;
+    const int64_t nMt = (m + bm - 1) / bm;
+    const int64_t nNt = (n + bn - 1) / bn;
     const int64_t blocks = ((nMt + 7) / 8) * 8 * nNt;
     if (blocks > 0x7FFFFFFFll) {
         set_error("dca_f16x3_gemm: too many tiles");
         return DCA_E_BADARG;
     }
-    hipLaunchKernelGGL(k_f16x3_gemm, dim3((unsigned)blocks), dim3(GTHREADS), GLDS, (hipStream_t)stream, p);
+    if (g_gemm_variant == 1)
+        hipLaunchKernelGGL(k_f16x3_gemm_v1, dim3((unsigned)blocks), dim3(GTHREADS), GLDS, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(k_f16x3_gemm_v2, dim3((unsigned)blocks), dim3(HTHREADS), HLDS, (hipStream_t)stream, p);
     return launch_check("k_f16x3_gemm");
 }
 

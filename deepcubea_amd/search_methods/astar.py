@@ -76,17 +76,28 @@ def _load_heuristic(args, env):
     return nnet_utils.get_heuristic_fn_dev(nnet, clip_zero=False, batch_size=_nnet_rows(args), autocast_dtype=ac), None
 
 
+_BUILTIN = {"manhattan": _lib.HEUR_MANHATTAN, "zero": _lib.HEUR_ZERO, "hashu01": _lib.HEUR_HASHU01}
+
+
 def bwas_hip(args, env, states: List) -> Tuple[List[List[int]], List[List], List[float], List[int]]:
     """astar.py:400-454 (bwas_python) with the engine in place of AStar.  Returns
-    (solns, paths, times, num_nodes_gen) for `states`, in order."""
-    heuristic_fn, onehot_stride = _load_heuristic(args, env)
+    (solns, paths, times, num_nodes_gen) for `states`, in order.
+    `--model_dir builtin:manhattan` (or builtin:zero): no network — one of the library's built-in heuristics, evaluated
+    inside the expansion launch, the whole search enqueued without host round trips (admissible, consistent Manhattan
+    distance on the sliding puzzles: with --weight 1 --semantics cpp the solutions are optimal)."""
+    builtin = None
+    if str(args.model_dir).startswith("builtin:"):
+        builtin = _BUILTIN[str(args.model_dir).split(":", 1)[1].lower()]
+        heuristic_fn, onehot_stride = None, None
+    else:
+        heuristic_fn, onehot_stride = _load_heuristic(args, env)
     sem = _lib.SEM_CPP if getattr(args, "semantics", "py") == "cpp" else _lib.SEM_PY
     oh = getattr(args, "_onehot_dtype", None) or {"fp32": torch.float32, "bf16": torch.bfloat16,
                                                    "fp16": torch.float16}[getattr(args, "nnet_dtype", "fp32")]
     K = max(1, int(getattr(args, "instances_per_gpu", 1)))
     eng = BwasEngine(args.env, args.weight, args.batch_size, max_nodes=int(getattr(args, "max_nodes", 1 << 26)),
-                     semantics=sem, onehot_dtype=None if onehot_stride == 0 else oh, num_instances=K,
-                     packed=onehot_stride is not None, onehot_stride=onehot_stride or None)
+                     semantics=sem, onehot_dtype=None if (onehot_stride == 0 or builtin is not None) else oh,
+                     num_instances=K, packed=onehot_stride is not None, onehot_stride=onehot_stride or None)
     world, rank = sharding.world_info()
     local: Dict[int, Tuple[List[int], List, float, int]] = {}
     if getattr(args, "static_shards", False) or world == 1:
@@ -98,8 +109,11 @@ def bwas_hip(args, env, states: List) -> Tuple[List[List[int]], List[List], List
     for group in groups:  # K scrambles stepped together by one engine (one network call per iteration)
         start_time = time.time()
         roots = [np.ascontiguousarray(env._get_arr(states[i]), dtype=np.uint8) for i in group]
-        if K > 1:
-            done_at: Dict[int, float] = {}
+        done_at: Dict[int, float] = {}
+        if builtin is not None:
+            results = eng.solve_many_builtin(roots, builtin, chunk=32, use_graph=True) if K > 1 else \
+                [eng.solve_builtin(roots[0], builtin, chunk=32, use_graph=True)]
+        elif K > 1:
             results = eng.solve_many(roots, heuristic_fn, on_done=lambda i: done_at.setdefault(i, time.time() - start_time))
         else:
             results = [eng.solve(roots[0], heuristic_fn)]
@@ -141,7 +155,8 @@ def build_parser() -> ArgumentParser:
     parser = ArgumentParser()
     # reference flags (astar.py:346-362)
     parser.add_argument('--states', type=str, required=True, help="File containing states to solve")
-    parser.add_argument('--model_dir', type=str, required=True, help="Directory of nnet model, or synthetic:SEED")
+    parser.add_argument('--model_dir', type=str, required=True,
+                        help="Directory of nnet model, or synthetic:SEED, or builtin:manhattan / builtin:zero")
     parser.add_argument('--env', type=str, required=True, help="Environment: cube3, puzzle15, puzzle24, ...")
     parser.add_argument('--batch_size', type=int, default=1, help="Batch size for BWAS")
     parser.add_argument('--weight', type=float, default=1.0, help="Weight of path cost")

@@ -301,6 +301,9 @@ int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t l
                    int64_t ldw, const float* col_scale /*[n] or NULL*/, double alpha, const float* bias /*[n] or NULL*/,
                    const float* skip /*[m, ldo] fp32 or NULL*/, int relu, void* out_h, void* out_l, float* x_out, int64_t ldo,
                    int* overflow, void* stream);
+/* tuning / test hook: 2 (default) = 256 x 256 tiles filled by LDS-DMA, double-buffered; 1 = 128 x 128 tiles staged through
+ * registers (the A/B reference).  Same results to fp32 rounding. */
+int dca_f16x3_gemm_variant(int variant);
 /* fp32 [m, n] (row stride ld) -> its fp16 planes (row stride ldo); n % 4 == 0 */
 int dca_split_planes(const float* x, int64_t m, int64_t n, int64_t ld, void* out_h, void* out_l, int64_t ldo,
                      int* overflow /*or NULL*/, void* stream);

@@ -8,6 +8,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[2, 1], ids=["lds_dma_256", "regstage_128"])
+def variant(request):
+    from deepcubea_amd import _lib
+    _lib.f16x3_gemm_variant(request.param)
+    yield request.param
+    _lib.f16x3_gemm_variant(2)
+
+
 def _split_w(w):
     from deepcubea_amd.utils.pytorch_models import _pow2_scale, _split_f16
     sc = _pow2_scale(w)
@@ -15,7 +23,7 @@ def _split_w(w):
     return wh.contiguous(), wl.contiguous(), (1.0 / sc).contiguous()
 
 
-def test_identity_activations_with_asymmetric_weights_catch_transposition():
+def test_identity_activations_with_asymmetric_weights_catch_transposition(variant):
     """A = I (exactly representable), asymmetric W: the output must be W^T tile for tile — a swapped row/column map of the
     MFMA accumulator or of the LDS images cannot pass."""
     from deepcubea_amd import _lib
@@ -37,7 +45,7 @@ def test_identity_activations_with_asymmetric_weights_catch_transposition():
 
 @pytest.mark.parametrize("m", [1, 130, 1000])
 @pytest.mark.parametrize("n,k", [(64, 64), (192, 128), (1024, 1024), (1024, 5120)])
-def test_f16x3_gemm_is_fp32_accurate(m, n, k):
+def test_f16x3_gemm_is_fp32_accurate(m, n, k, variant):
     from deepcubea_amd import _lib
     g = torch.Generator().manual_seed(1000 * m + n + k)
     x = torch.randn(m, k, generator=g) * 3.0
