@@ -44,7 +44,10 @@
 
 namespace dca {
 
-constexpr int NBIN = 2048;            // radix-select fan-out per level
+constexpr int NBIN = 4096;            // bins of the selection histogram (2048 left 13 000-entry threshold bins in long runs)
+constexpr int kBinsPerThread = NBIN / 1024;  // of the single-workgroup scans
+constexpr int kLgNbin = 12;
+constexpr int kSub = 2048;            // sub-bins of k_rank's per-bin bucketing
 constexpr int kScanBlocks = 256;      // grid of the OPEN scans: few fat blocks (cheap when they early-exit)
 constexpr int kCollectBlocks = 512;   // k_sel_collect: two workgroups per CU keep twice the loads in flight
 constexpr int kRankBlocks = 256;      // k_rank: one 1024-thread workgroup per CU, the bins to order strided over them
@@ -52,6 +55,9 @@ constexpr int kTinyBin = 64;          // bins up to this size are ranked by one 
 constexpr int kSortCap = 8192;        // diagnostics only: bins beyond this many entries are counted as "giant"
 constexpr int kStash = 3072;          // per-workgroup LDS stash of k_sel_collect (entries at or below the threshold bin)
 constexpr uint32_t NIL = 0xFFFFFFFFu;
+// OPEN entries carry "this node is solved" in bit 31 of the id (node ids stay below 2^31): the pop then knows a goal
+// without touching the node pool.  Every compare / index uses the id with the flag masked off.
+constexpr uint32_t ID_MASK = 0x7FFFFFFFu, ID_SOLVED = 0x80000000u;
 constexpr uint64_t EMPTY = ~0ull;
 constexpr uint32_t GINF = 0xFFFFFFFFu;
 constexpr int kMaxMoves = 4096;
@@ -126,10 +132,10 @@ __device__ __forceinline__ double cost_of_key(uint64_t k) {
 __device__ __forceinline__ uint32_t select_shift(uint64_t kmin, uint64_t kmax) {
     uint64_t range = kmax - kmin;
     int bits = range ? 64 - __clzll((long long)range) : 0;
-    return bits > 11 ? (uint32_t)(bits - 11) : 0u;
+    return bits > kLgNbin ? (uint32_t)(bits - kLgNbin) : 0u;
 }
 __device__ __forceinline__ bool pair_less(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib) {
-    return ka < kb || (ka == kb && ia < ib);
+    return ka < kb || (ka == kb && (ia & ID_MASK) < (ib & ID_MASK));
 }
 
 // launch slots of the device-side profile (dca_engine_profile_builtin)
@@ -436,7 +442,7 @@ __global__ void k_reset(Eng E) {
         c->gen = 1;
         uint64_t key = key_of_cost(0.0);
         E.open_key[0][0] = key;
-        E.open_id[0][0] = 0;
+        E.open_id[0][0] = ok ? ID_SOLVED : 0u;
         c->open_n[0].v = 1;
         c->rng[0].kmin = c->rng[0].kmax = key;
     }
@@ -452,7 +458,7 @@ __global__ void k_root_commit(Eng E, const float* h_root) {
     uint64_t key = key_of_cost(cost);
     uint32_t b = st_cur(c).cur_f;
     E.open_key[b][0] = key;
-    E.open_id[b][0] = 0;
+    E.open_id[b][0] = E.solved[0] ? ID_SOLVED : 0u;
     c->open_n[b].v = 1;
     c->rng[b].kmin = c->rng[b].kmax = key;
 }
@@ -499,32 +505,39 @@ __global__ __launch_bounds__(256) void k_refill_hist(const Eng* __restrict__ eng
         if (lh[i]) atomicAdd(&E.hist[i], lh[i]);
 }
 
-// exclusive prefix of the 2048 global bins into pre[0..NBIN] (1024 threads, 2 bins each); zeroes hist
+// exclusive prefix of the NBIN global bins into pre[0..NBIN] (1024 threads, kBinsPerThread bins each); zeroes hist
 __device__ __forceinline__ void scan_bins(const Eng& E, uint32_t* pre, uint32_t* wsum) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    uint32_t a = E.hist[2 * t], b2 = E.hist[2 * t + 1];
-    E.hist[2 * t] = 0;
-    E.hist[2 * t + 1] = 0;
-    uint32_t s = a + b2, incl = s;
+    uint32_t v[kBinsPerThread], s = 0;
+#pragma unroll
+    for (int k = 0; k < kBinsPerThread; k++) {
+        v[k] = E.hist[kBinsPerThread * t + k];
+        E.hist[kBinsPerThread * t + k] = 0;
+        s += v[k];
+    }
+    uint32_t incl = s;
     for (int o = 1; o < 64; o <<= 1) {
-        uint32_t v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
+        uint32_t u = __shfl_up(incl, o);
+        if (lane >= o) incl += u;
     }
     if (lane == 63) wsum[wv] = incl;
     __syncthreads();
     if (t < 16) {
-        uint32_t v = wsum[t], acc = v;
+        uint32_t u = wsum[t], acc = u;
         for (int o = 1; o < 16; o <<= 1) {
-            uint32_t u = __shfl_up(acc, o, 16);
-            if (t >= o) acc += u;
+            uint32_t x = __shfl_up(acc, o, 16);
+            if (t >= o) acc += x;
         }
-        wsum[t] = acc - v;  // exclusive wave offsets
+        wsum[t] = acc - u;  // exclusive wave offsets
     }
     __syncthreads();
-    uint32_t excl = incl - s + wsum[wv];
-    pre[2 * t] = excl;
-    pre[2 * t + 1] = excl + a;
-    if (t == 1023) pre[NBIN] = excl + s;
+    uint32_t run = incl - s + wsum[wv];
+#pragma unroll
+    for (int k = 0; k < kBinsPerThread; k++) {
+        pre[kBinsPerThread * t + k] = run;
+        run += v[k];
+    }
+    if (t == 1023) pre[NBIN] = run;
     __syncthreads();
 }
 
@@ -543,8 +556,8 @@ __global__ __launch_bounds__(1024) void k_refill_scan(const Eng* __restrict__ en
     const int t = threadIdx.x;
     const uint32_t b = c->cur_b, n = c->open_n[b].v - c->back_dead.v;
     const uint32_t target = n < front_keep(E) ? n : front_keep(E);
-    for (int k = 0; k < 2; k++) {
-        int bin = 2 * t + k;
+    for (int k = 0; k < kBinsPerThread; k++) {
+        int bin = kBinsPerThread * t + k;
         if (pre[bin] < target && target <= pre[bin + 1]) c->r_bstar = (uint32_t)bin;  // whole bins move
     }
     __syncthreads();
@@ -698,8 +711,8 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs)
     scan_bins(E, pre, wsum);
     const uint32_t cb = st_cur(c).cur_f, n = c->open_n[cb].v;
     const uint32_t want = n < (uint32_t)E.B ? n : (uint32_t)E.B;
-    for (int k = 0; k < 2; k++) {
-        int bin = 2 * t + k;
+    for (int k = 0; k < kBinsPerThread; k++) {
+        int bin = kBinsPerThread * t + k;
         // threshold bin: first bin with pre[b] < want <= pre[b+1].  Everything at or below it is handed to k_rank
         // grouped by bin (E.pre gives every bin its slice of the scratch array); the overshoot of the threshold
         // bin comes back to FRONT from there.
@@ -714,8 +727,8 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs)
     }
     if (t == 1023) E.pre[NBIN] = pre[NBIN];
     __syncthreads();
-    for (int k = 0; k < 2; k++) {
-        const uint32_t bin = 2 * t + k;
+    for (int k = 0; k < kBinsPerThread; k++) {
+        const uint32_t bin = kBinsPerThread * t + k;
         if (bin <= s_bstar && want != 0) {
             const uint32_t cn = pre[bin + 1] - pre[bin];
             if (cn > 256) atomicMax(&s_maxbin, cn);
@@ -912,7 +925,7 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
 // overshoot of the threshold bin returns to FRONT'.
 // ---------------------------------------------------------------------------------------------
 typedef unsigned __int128 u128;
-__device__ __forceinline__ u128 comp_of(uint64_t key, uint32_t id) { return ((u128)key << 32) | (u128)id; }
+__device__ __forceinline__ u128 comp_of(uint64_t key, uint32_t id) { return ((u128)key << 32) | (u128)(id & ID_MASK); }
 __device__ __forceinline__ int clz128(u128 v) {
     uint64_t hi = (uint64_t)(v >> 64), lo = (uint64_t)v;
     return hi ? __clzll((long long)hi) : 64 + (lo ? __clzll((long long)lo) : 64);
@@ -926,8 +939,8 @@ struct RankItem {
     uint32_t off, n, need, src;  // slice [off, off+n) of scratch array `src` (0 tmp, 1 ord); pop rank of its first entry = off
 };
 struct RankShared {
-    uint32_t cnt[NBIN];      // sub-bin counts, then running scatter slots
-    uint32_t off[NBIN + 1];  // exclusive prefix
+    uint32_t cnt[kSub];      // sub-bin counts, then running scatter slots
+    uint32_t off[kSub + 1];  // exclusive prefix
     uint32_t wsum[16];
     uint64_t red_lo[32], red_hi[32];
     uint64_t vmin_hi, vmin_lo;
@@ -940,11 +953,10 @@ __device__ __forceinline__ void emit_ranked(const Eng& E, Ctl* c, uint32_t nf, b
                                             uint64_t key, uint32_t id) {
     if (live && rank < want) {
         E.pop_key[rank] = key;
-        E.pop_id[rank] = id;
-        E.pop_g[rank] = (uint32_t)E.g[id];
-        if (E.solved[id]) {
+        E.pop_id[rank] = id;  // flag included: k_expand masks it (and writes the parents' path costs, pop_g)
+        if (id & ID_SOLVED) {  // rare: a goal among the popped — nothing else in the pop reads the node pool
             if (E.sem == DCA_SEM_PY)
-                atomicMin(&c->goal_best, ((unsigned long long)(uint32_t)E.g[id] << 32) | rank);
+                atomicMin(&c->goal_best, ((unsigned long long)(uint32_t)E.g[id & ID_MASK] << 32) | rank);
             else
                 atomicMin(&c->first_solved, rank);
         }
@@ -992,7 +1004,7 @@ __device__ __forceinline__ void rank_range(RankShared& S, u128 vmin, u128 vmax) 
         S.red_hi[16 + wv] = (uint64_t)(vmax >> 64);
         S.red_lo[16 + wv] = (uint64_t)vmax;
     }
-    for (uint32_t i = t; i < NBIN; i += RT) S.cnt[i] = 0;
+    for (uint32_t i = t; i < (uint32_t)kSub; i += RT) S.cnt[i] = 0;
     __syncthreads();
     if (t == 0) {
         u128 mn = ~(u128)0, mx = 0;
@@ -1012,7 +1024,7 @@ __device__ __forceinline__ void rank_range(RankShared& S, u128 vmin, u128 vmax) 
 // exclusive prefix of cnt[0..nsub) into off[0..nsub] (2 per thread), the sub-bin holding the need-th entry -> S.tsub,
 // counters back to zero (they become the running scatter slots)
 __device__ __forceinline__ void rank_prefix(RankShared& S, uint32_t nsub, uint32_t need) {
-    constexpr int PER = NBIN / RT;  // counters per thread (4)
+    constexpr int PER = kSub / RT;  // counters per thread (4)
     const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
     uint32_t v[PER], s4 = 0;
 #pragma unroll
@@ -1086,7 +1098,7 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
         return;
     }
     uint32_t lg = 0;
-    while ((8u << lg) <= n && lg < 11) lg++;  // 2^lg <= n / 4, at most NBIN sub-bins
+    while ((8u << lg) <= n && lg < 11) lg++;  // 2^lg <= n / 4, at most kSub sub-bins
     if (n <= kLdsEnt) {
         // ---- the item is read from HBM ONCE (8 entries per thread, kept in registers), bucketed and ranked in LDS
         uint64_t ek[kRegEnt];
@@ -1338,7 +1350,7 @@ __device__ __forceinline__ void close_pop(const Eng& E, Ctl* c, const IterState&
         const unsigned long long gb = c->goal_best;
         if (gb != ~0ull) {
             c->stop_after = 1;
-            c->goal_id = E.pop_id[(uint32_t)(gb & 0xFFFFFFFFull)];
+            c->goal_id = E.pop_id[(uint32_t)(gb & 0xFFFFFFFFull)] & ID_MASK;
         }
     } else {
         // cpp:185-208
@@ -1346,12 +1358,12 @@ __device__ __forceinline__ void close_pop(const Eng& E, Ctl* c, const IterState&
         if (fs != NIL) {
             const float cst = (float)cost_of_key(E.pop_key[fs]);
             if (E.B == 1) {
-                N.best_id = E.pop_id[fs];
+                N.best_id = E.pop_id[fs] & ID_MASK;
                 N.best_cost = cst;
                 N.has_best = 1;
                 c->stop_after = 1;
             } else if (!S0.has_best || S0.best_cost > cst) {
-                N.best_id = E.pop_id[fs];
+                N.best_id = E.pop_id[fs] & ID_MASK;
                 N.best_cost = cst;
                 N.has_best = 1;
             }
@@ -1420,7 +1432,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
         static_assert(WPR <= 16, "row wider than 64 bytes");
         const uint32_t w = threadIdx.x & 15, r = threadIdx.x >> 4;  // 16 lanes per row, 16 rows
         if (r < np && w < WPR) {
-            const uint8_t* row = E.state + (size_t)E.pop_id[r0 + r] * EV::D;
+            const uint8_t* row = E.state + (size_t)(E.pop_id[r0 + r] & ID_MASK) * EV::D;
             uint32_t v = 0;
             // rows start at id*D: read byte-wise only where a word would cross the row end
             if (4 * w + 4 <= EV::D) {
@@ -1477,9 +1489,11 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
             }
         }
         h = hash_final(h);
-        const uint32_t j = j0 + cc, id = base + j, pid = E.pop_id[r0 + r];
+        const uint32_t j = j0 + cc, id = base + j, pid = E.pop_id[r0 + r] & ID_MASK;
+        const uint32_t gp = (uint32_t)E.g[pid];
+        if (a == 0) E.pop_g[r0 + r] = gp;  // the parents' path costs in pop order: what the dedup / push kernels read
         E.child_hash[j] = h;
-        E.g[id] = (int32_t)(E.pop_g[r0 + r] + 1u);  // path cost + unit transition cost (astar.py:125-126 / cpp:219)
+        E.g[id] = (int32_t)(gp + 1u);  // path cost + unit transition cost (astar.py:125-126 / cpp:219)
         E.child_multi[j] = 0;
         E.parent[id] = pid;
         E.move[id] = (uint8_t)a;
@@ -1862,11 +1876,13 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
         if (FUSED && multi && j == first) fix_representative(E, base, slot, id);
     }
     uint64_t key = 0;
+    uint32_t pid_flag = 0;
     if (keep) {
         // the heuristic is only ever needed for the children that survive the CLOSED check
         const float hraw = packed ? E.pk_h[E.kept_pos[j]] : E.child_h[j];
         const float hv = fmaxf(hraw, 0.0f);  // clip_zero (nnet_utils.py:193-194)
         const bool ns = E.solved[id] == 0;
+        pid_flag = ns ? 0u : ID_SOLVED;
         double cost;
         if (E.sem == DCA_SEM_PY) {
             // astar.py:196  weights*path_costs + heuristics*logical_not(is_solved), float64, two roundings
@@ -1885,14 +1901,14 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
     if (tof) {
         if (pos[0] < E.max_nodes) {
             E.open_key[fb][pos[0]] = key;
-            E.open_id[fb][pos[0]] = id;
+            E.open_id[fb][pos[0]] = id | pid_flag;
         } else {
             c->failed = 1;
         }
     } else if (tob) {
         if (pos[1] < E.max_nodes) {
             E.open_key[bb][pos[1]] = key;
-            E.open_id[bb][pos[1]] = id;
+            E.open_id[bb][pos[1]] = id | pid_flag;
         } else {
             c->failed = 1;
         }

@@ -279,34 +279,81 @@ __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v2(const GemmArgs p)
         }
     }
 
-    // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    bool ovf = false;
+    // epilogue.  The accumulator layout (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) would make
+    // every store a 4-byte (fp32) or 2-byte (planes) column access — measured 1.8 ms per layer, more than the K loop.  So
+    // each wave transposes its tile through its own 16 KB of the (now idle) LDS, 32 rows at a time, and leaves with
+    // 16-byte accesses: a lane owns 4 consecutive columns of a row — one float4 skip load, one float4 store, two 8-byte
+    // plane stores; 16 lanes cover a row's 256 contiguous bytes.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the operand stages
+    float* sl = reinterpret_cast<float*>(lds + w * 16384);
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    float cs[2], bv[2];
 #pragma unroll
     for (int jn = 0; jn < 2; jn++) {
         const int col = n0 + wn * 64 + jn * 32 + l31;
-        if (col >= p.n) continue;
-        const float cs = p.col_scale ? p.alpha * p.col_scale[col] : p.alpha;
-        const float bv = p.bias ? p.bias[col] : 0.f;
+        const bool cv = col < p.n;
+        cs[jn] = cv ? (p.col_scale ? p.alpha * p.col_scale[col] : p.alpha) : 0.f;
+        bv[jn] = (cv && p.bias) ? p.bias[col] : 0.f;
+    }
+    const int c4 = (lane & 15) * 4;              // this lane's 4 columns inside the wave's 64
+    const int colg = n0 + wn * 64 + c4;
+    const bool full4 = colg + 3 < p.n;
+    bool ovf = false;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 4; i++) {
 #pragma unroll
-            for (int reg = 0; reg < 16; reg++) {
-                const int64_t r = m0 + wm * 128 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                if (r >= p.m) continue;
-                const int64_t o = r * p.ldo + col;
-                float u = acc[i][jn][reg] * cs + bv;
-                if (p.skip) u += p.skip[o];
-                if (p.relu) u = fmaxf(u, 0.f);
-                if (p.x_out) p.x_out[o] = u;
+        for (int jn = 0; jn < 2; jn++)
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++)
+                sl[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 64 + jn * 32 + l31] = acc[i][jn][reg] * cs[jn] + bv[jn];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private slice: no barrier, just the wave's own writes
+        const int64_t rbase = m0 + wm * 128 + i * 32;
+        float4 sk[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int64_t r = rbase + q * 4 + (lane >> 4);
+            sk[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.skip && r < p.m && full4) sk[q] = *reinterpret_cast<const float4*>(p.skip + r * p.ldo + colg);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int rl = q * 4 + (lane >> 4);
+            const int64_t r = rbase + rl;
+            const float4 v = *reinterpret_cast<const float4*>(sl + rl * 64 + c4);
+            if (r >= p.m) continue;
+            float u[4] = {v.x + sk[q].x, v.y + sk[q].y, v.z + sk[q].z, v.w + sk[q].w};
+            const int64_t o = r * p.ldo + colg;
+            if (full4) {
+                h4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (p.relu) u[e] = fmaxf(u[e], 0.f);
+                    ovf |= !(fabsf(u[e]) <= 60000.0f);
+                    hi[e] = (_Float16)u[e];
+                    lo[e] = (_Float16)(u[e] - (float)hi[e]);
+                }
+                if (p.x_out) *reinterpret_cast<float4*>(p.x_out + o) = make_float4(u[0], u[1], u[2], u[3]);
                 if (p.oh) {
-                    ovf |= !(fabsf(u) <= 60000.0f);  // beyond fp16 (or NaN): the caller redoes the batch in fp32
-                    const _Float16 hh = (_Float16)u;
-                    p.oh[o] = hh;
-                    p.ol[o] = (_Float16)(u - (float)hh);
+                    *reinterpret_cast<h4*>(p.oh + o) = hi;
+                    *reinterpret_cast<h4*>(p.ol + o) = lo;
+                }
+            } else {  // ragged right edge (n not a multiple of 4 columns here): element-wise
+                for (int e = 0; e < 4 && colg + e < p.n; e++) {
+                    float ue = u[e] + (p.skip ? p.skip[o + e] : 0.f);
+                    if (p.relu) ue = fmaxf(ue, 0.f);
+                    ovf |= !(fabsf(ue) <= 60000.0f);
+                    if (p.x_out) p.x_out[o + e] = ue;
+                    if (p.oh) {
+                        const _Float16 hh = (_Float16)ue;
+                        p.oh[o + e] = hh;
+                        p.ol[o + e] = (_Float16)(ue - (float)hh);
+                    }
                 }
             }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slice is rewritten by the next 32 rows
     }
-    if (ovf && p.overflow) *p.overflow = 1;
+    if (ovf && p.oh && p.overflow) *p.overflow = 1;
 }
 
 // fp32 [m, n] (row stride ld) -> its two fp16 planes (and the overflow flag): the entry into an f16x3 layer for
