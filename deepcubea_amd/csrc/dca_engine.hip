@@ -51,7 +51,7 @@ constexpr int kSub = 2048;            // sub-bins of k_rank's per-bin bucketing
 constexpr int kScanBlocks = 256;      // grid of the OPEN scans: few fat blocks (cheap when they early-exit)
 constexpr int kCollectBlocks = 512;   // k_sel_collect: two workgroups per CU keep twice the loads in flight
 constexpr int kRankBlocks = 256;      // k_rank: one 1024-thread workgroup per CU, the bins to order strided over them
-constexpr int kTinyBin = 64;          // bins up to this size are ranked by one wave
+constexpr int kTinyBin = 128;         // bins up to this size are ranked one THREAD per entry (all-pairs inside the bin)
 constexpr int kSortCap = 8192;        // diagnostics only: bins beyond this many entries are counted as "giant"
 constexpr int kStash = 3072;          // per-workgroup LDS stash of k_sel_collect (entries at or below the threshold bin)
 constexpr uint32_t NIL = 0xFFFFFFFFu;
@@ -106,7 +106,7 @@ struct Ctl {
     uint64_t r_kmin;
     uint32_t r_shift;
     // selection
-    uint32_t want, bstar, shift, n_big, n_tiny;
+    uint32_t want, bstar, shift, n_big, n_ord;
     uint64_t sel_kmin;
     // goals
     uint32_t goal_id;
@@ -134,6 +134,14 @@ __device__ __forceinline__ uint32_t select_shift(uint64_t kmin, uint64_t kmax) {
     int bits = range ? 64 - __clzll((long long)range) : 0;
     return bits > kLgNbin ? (uint32_t)(bits - kLgNbin) : 0u;
 }
+// selection bin of a key under the binning (kmin, shift) in force: keys at or below kmin share bin 0, keys past the last
+// bin share bin NBIN - 1 (the binning is only refreshed every kRefillPeriod iterations; children that land outside it
+// meanwhile are still ordered exactly — k_rank works on each bin's own composite range)
+__device__ __forceinline__ uint32_t bin_of(uint64_t k, uint64_t kmin, uint32_t shift) {
+    if (k <= kmin) return 0u;
+    const uint64_t f = (k - kmin) >> shift;
+    return f < (uint64_t)NBIN ? (uint32_t)f : (uint32_t)(NBIN - 1);
+}
 __device__ __forceinline__ bool pair_less(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib) {
     return ka < kb || (ka == kb && (ia & ID_MASK) < (ib & ID_MASK));
 }
@@ -160,14 +168,16 @@ struct Eng {
     uint32_t* open_id[4];
     uint32_t f_keep, f_max;  // FRONT hysteresis: refill/spill down to ~f_keep, spill when above f_max
     uint32_t *hist, *pre, *fill;  // selection histogram, its exclusive prefix [NBIN+1], per-bin fill of the scratch array
+    uint32_t* rhist;              // histogram of BACK (refill), separate: `hist` is maintained across iterations
     uint64_t* part;  // [4][kCollectBlocks] per-block key ranges of k_sel_collect (survivor min/max, spill min/max)
     // scratch of the pop: every FRONT entry at or below the threshold bin, grouped by bin (bin f occupies
     // [pre[f], pre[f+1])), and — only for bins too large for LDS — the single-workgroup sub-bin ordering
     uint64_t* tmp_key;
     uint32_t* tmp_id;
+    uint16_t* tmp_f;   // bin of every scratch entry (k_rank's thread-per-entry pass over the small bins)
     uint64_t* ord_key;
     uint32_t* ord_id;
-    uint32_t *big_list, *tiny_list;  // bins at or below the threshold bin with more than / at most kTinyBin entries
+    uint32_t* big_list;  // bins at or below the threshold bin with more than kTinyBin entries (one workgroup each)
     uint64_t* pop_key;   // the batch in pop order
     uint32_t *pop_id, *pop_g;
     uint64_t* child_hash;
@@ -193,6 +203,16 @@ struct Eng {
 
 __device__ __forceinline__ const IterState& st_cur(const Ctl* c) { return c->S[c->iters & 1]; }
 __device__ __forceinline__ const IterState& st_next(const Ctl* c) { return c->S[(c->iters + 1) & 1]; }
+
+// the binning a rebase iteration installs (k_sel_hist recounts under it, k_sel_scan records it): FRONT's exact key range,
+// its top raised to the tier threshold — no key above T enters FRONT before the next rebase
+__device__ __forceinline__ void fresh_binning(const Ctl* c, uint32_t buf, uint64_t& kmin, uint32_t& shift) {
+    kmin = c->rng[buf].kmin;
+    uint64_t kmax = c->rng[buf].kmax;
+    const uint64_t T = c->T;
+    if (T != ~0ull && T > kmax) kmax = T;
+    shift = kmax > kmin ? select_shift(kmin, kmax) : 0u;
+}
 
 // Device-side profile: thread 0 of every workgroup (instance 0 only) folds its wall-clock start / end into the
 // launch's slot, so the host can read each launch's busy span and the gap to the next one INSIDE a replayed hipGraph.
@@ -502,17 +522,17 @@ __global__ __launch_bounds__(256) void k_refill_hist(const Eng* __restrict__ eng
     }
     __syncthreads();
     for (int i = threadIdx.x; i < NBIN; i += 256)
-        if (lh[i]) atomicAdd(&E.hist[i], lh[i]);
+        if (lh[i]) atomicAdd(&E.rhist[i], lh[i]);
 }
 
-// exclusive prefix of the NBIN global bins into pre[0..NBIN] (1024 threads, kBinsPerThread bins each); zeroes hist
-__device__ __forceinline__ void scan_bins(const Eng& E, uint32_t* pre, uint32_t* wsum) {
+// exclusive prefix of NBIN global bins into pre[0..NBIN] (1024 threads, kBinsPerThread bins each); optionally zeroes them
+__device__ __forceinline__ void scan_bins(uint32_t* __restrict__ hist, bool zero, uint32_t* pre, uint32_t* wsum) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     uint32_t v[kBinsPerThread], s = 0;
 #pragma unroll
     for (int k = 0; k < kBinsPerThread; k++) {
-        v[k] = E.hist[kBinsPerThread * t + k];
-        E.hist[kBinsPerThread * t + k] = 0;
+        v[k] = hist[kBinsPerThread * t + k];
+        if (zero) hist[kBinsPerThread * t + k] = 0;
         s += v[k];
     }
     uint32_t incl = s;
@@ -546,13 +566,16 @@ __global__ __launch_bounds__(1024) void k_refill_scan(const Eng* __restrict__ en
     Ctl* c = E.ctl;
     if (c->done) return;
     Stamp stamp(E, P_REFILL_SCAN);
+    // this launch opens a "rebase" iteration: k_sel_hist recounts FRONT from scratch under a fresh binning right after
+    // the refill, so the incrementally maintained histogram is dropped here
+    for (int k = 0; k < kBinsPerThread; k++) E.hist[kBinsPerThread * threadIdx.x + k] = 0;
     if (!need_refill(E, c)) {
         if (threadIdx.x == 0) c->refill = 0;
         return;
     }
     __shared__ uint32_t pre[NBIN + 1];
     __shared__ uint32_t wsum[16];
-    scan_bins(E, pre, wsum);
+    scan_bins(E.rhist, true, pre, wsum);
     const int t = threadIdx.x;
     const uint32_t b = c->cur_b, n = c->open_n[b].v - c->back_dead.v;
     const uint32_t target = n < front_keep(E) ? n : front_keep(E);
@@ -660,8 +683,9 @@ __global__ __launch_bounds__(256) void k_sel_hist(const Eng* __restrict__ engs) 
     for (int i = threadIdx.x; i < NBIN; i += 256) lh[i] = 0;
     __syncthreads();
     const uint32_t b = st_cur(c).cur_f, n = c->open_n[b].v;
-    const uint64_t kmin = c->rng[b].kmin;
-    const uint32_t shift = select_shift(kmin, c->rng[b].kmax);
+    uint64_t kmin;
+    uint32_t shift;
+    fresh_binning(c, b, kmin, shift);
     const uint64_t* __restrict__ keys = E.open_key[b];
     const uint32_t stride = gridDim.x * 256;
     for (uint32_t i0 = blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 4 * stride) {
@@ -675,8 +699,7 @@ __global__ __launch_bounds__(256) void k_sel_hist(const Eng* __restrict__ engs) 
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             if (!ok[u]) continue;
-            uint64_t f = (k[u] - kmin) >> shift;
-            atomicAdd(&lh[f < NBIN ? (uint32_t)f : NBIN - 1], 1u);
+            atomicAdd(&lh[bin_of(k[u], kmin, shift)], 1u);
         }
     }
     __syncthreads();
@@ -685,20 +708,19 @@ __global__ __launch_bounds__(256) void k_sel_hist(const Eng* __restrict__ engs) 
 }
 
 // S2: one workgroup — prefix over the bins, threshold bin, spill decision, per-iteration counter reset
-__global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs) {
+__global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs, int rebased) {
     const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
     Stamp stamp(E, P_SEL_SCAN);
     __shared__ uint32_t pre[NBIN + 1];
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t s_spill, s_bstar, s_maxbin, s_giant, s_nbig, s_ntiny;
+    __shared__ uint32_t s_spill, s_bstar, s_maxbin, s_giant, s_nbig, s_sp;
     const int t = threadIdx.x;
     if (t == 0) {
         s_maxbin = 0;
         s_giant = 0;
         s_nbig = 0;
-        s_ntiny = 0;
         if (c->refill && c->compact) {  // the compacted copy becomes BACK
             c->cur_b ^= 1;
             c->back_dead.v = 0;
@@ -708,7 +730,9 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs)
         s_spill = NBIN;  // no spill
         s_bstar = 0;
     }
-    scan_bins(E, pre, wsum);
+    // E.hist is FRONT's histogram under the binning in force: recounted by k_sel_hist in a rebase iteration (every
+    // kRefillPeriod-th), maintained incrementally in between (the writeback below + k_commit's pushes)
+    scan_bins(E.hist, false, pre, wsum);
     const uint32_t cb = st_cur(c).cur_f, n = c->open_n[cb].v;
     const uint32_t want = n < (uint32_t)E.B ? n : (uint32_t)E.B;
     for (int k = 0; k < kBinsPerThread; k++) {
@@ -733,23 +757,14 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs)
             const uint32_t cn = pre[bin + 1] - pre[bin];
             if (cn > 256) atomicMax(&s_maxbin, cn);
             if (cn > (uint32_t)kSortCap) atomicAdd(&s_giant, 1u);
-            // work lists of k_rank: one workgroup per bin of more than kTinyBin entries, one wave per smaller bin
-            if (cn > (uint32_t)kTinyBin)
-                E.big_list[atomicAdd(&s_nbig, 1u)] = bin;
-            else if (cn != 0)
-                E.tiny_list[atomicAdd(&s_ntiny, 1u)] = bin;
+            // work list of k_rank: one workgroup per bin of more than kTinyBin entries (smaller bins: a thread per entry)
+            if (cn > (uint32_t)kTinyBin) E.big_list[atomicAdd(&s_nbig, 1u)] = bin;
         }
     }
-    __syncthreads();
     if (t == 0) {
-        c->n_big = s_nbig;
-        c->n_tiny = s_ntiny;
-        c->dbg_nord = want ? pre[s_bstar + 1] : 0;
-        c->dbg_maxbin = s_maxbin;
-        c->dbg_giant = s_giant;
-        c->dbg_giant_seen += s_giant;
-        const uint64_t kmin = c->rng[cb].kmin;
-        const uint32_t shift = select_shift(kmin, c->rng[cb].kmax);
+        uint64_t kmin = c->sel_kmin;
+        uint32_t shift = c->shift;
+        if (rebased) fresh_binning(c, cb, kmin, shift);  // what k_sel_hist just counted under
         c->want = want;
         c->bstar = s_bstar;
         c->sel_kmin = kmin;
@@ -762,6 +777,7 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs)
             sp = NBIN;
         }
         c->spill_bin = sp;  // survivors in bins above it move to BACK
+        s_sp = sp;
         c->open_n[cb ^ 1].v = 0;
         c->rng[cb ^ 1].kmin = ~0ull;
         c->rng[cb ^ 1].kmax = 0;
@@ -771,6 +787,28 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs)
             c->failed = 1;
             c->done = 1;
         }
+    }
+    __syncthreads();
+    // the histogram of what stays in FRONT: bins at or below the threshold bin leave (the threshold bin's overshoot
+    // comes back from k_rank: pre[bstar+1] - want entries), bins above the spill bin move to BACK
+    {
+        const uint32_t bstar = s_bstar, sp = s_sp;
+        for (int k = 0; k < kBinsPerThread; k++) {
+            const uint32_t bin = kBinsPerThread * t + k;
+            if (want == 0) break;
+            if (bin < bstar || bin > sp)
+                E.hist[bin] = 0;
+            else if (bin == bstar)
+                E.hist[bin] = pre[bin + 1] - want;
+        }
+    }
+    if (t == 0) {
+        c->n_big = s_nbig;
+        c->n_ord = want ? pre[s_bstar + 1] : 0;
+        c->dbg_nord = want ? pre[s_bstar + 1] : 0;
+        c->dbg_maxbin = s_maxbin;
+        c->dbg_giant = s_giant;
+        c->dbg_giant_seen += s_giant;
     }
 }
 
@@ -818,8 +856,7 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
         for (uint32_t i = 0; i < ITEMS; i++) {
             const uint32_t idx = tile * TILE + i * 256 + threadIdx.x;
             const bool live = idx < n;
-            const uint64_t f64 = (k[i] - kmin) >> shift;
-            const uint32_t f = f64 < NBIN ? (uint32_t)f64 : NBIN - 1;
+            const uint32_t f = bin_of(k[i], kmin, shift);
             const uint32_t d = !live ? 0u : (f <= bstar ? 1u : (f > spill ? 3u : 2u));
             dest |= d << (2 * i);
             cf += d == 2u ? 1u : 0u;
@@ -830,8 +867,7 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
 #pragma unroll
             for (uint32_t i = 0; i < ITEMS; i++) {
                 if (((dest >> (2 * i)) & 3u) != 1u) continue;
-                const uint64_t f64 = (k[i] - kmin) >> shift;
-                const uint32_t f = f64 < NBIN ? (uint32_t)f64 : NBIN - 1;
+                const uint32_t f = bin_of(k[i], kmin, shift);
                 const uint32_t p = atomicAdd(&st_n, 1u);
                 if (p < kStash) {
                     st_key[p] = k[i];
@@ -840,8 +876,13 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
                     atomicAdd(&lcnt[f], 1u);
                 } else {  // stash full (a workgroup rarely sees this many): place directly
                     const uint32_t pos = E.pre[f] + atomicAdd(&E.fill[f], 1u);
-                    E.tmp_key[pos] = k[i];
-                    E.tmp_id[pos] = id[i];
+                    if (pos < E.pre[f + 1]) {
+                        E.tmp_key[pos] = k[i];
+                        E.tmp_id[pos] = id[i];
+                        E.tmp_f[pos] = (uint16_t)f;
+                    } else {
+                        c->failed = 1;  // histogram and FRONT disagree (cannot happen): refuse to write outside the bin's slice
+                    }
                 }
             }
         }
@@ -879,8 +920,13 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
         for (uint32_t p = threadIdx.x; p < ns; p += 256) {
             const uint32_t f = st_f[p];
             const uint32_t pos = E.pre[f] + atomicAdd(&lcnt[f], 1u);
-            E.tmp_key[pos] = st_key[p];
-            E.tmp_id[pos] = st_id[p];
+            if (pos < E.pre[f + 1]) {
+                E.tmp_key[pos] = st_key[p];
+                E.tmp_id[pos] = st_id[p];
+                E.tmp_f[pos] = (uint16_t)f;
+            } else {
+                c->failed = 1;  // (see above)
+            }
         }
     }
     // key ranges: reduced per block into E.part and folded into the control block by k_rank (four atomics) —
@@ -964,19 +1010,26 @@ __device__ __forceinline__ void emit_ranked(const Eng& E, Ctl* c, uint32_t nf, b
     open_append(E, c, nf, live && rank >= want, key, id);
 }
 
-// a bin of at most 64 entries, by one wave: rank = number of smaller composites, counted through lane shuffles
-__device__ __forceinline__ void rank_tiny_bin(const Eng& E, Ctl* c, uint32_t nf, uint32_t o, uint32_t n, uint32_t want) {
-    const uint32_t lane = threadIdx.x & 63;
-    const bool live = lane < n;
-    const uint64_t k = live ? E.tmp_key[o + lane] : ~0ull;
-    const uint32_t id = live ? E.tmp_id[o + lane] : 0xFFFFFFFFu;
-    uint32_t rank = 0;
-    for (uint32_t j = 0; j < n; j++) {
-        const uint64_t kj = __shfl(k, (int)j);
-        const uint32_t ij = __shfl(id, (int)j);
-        rank += pair_less(kj, ij, k, id) ? 1u : 0u;
+// an entry of a bin of at most kTinyBin entries, by one thread: rank = entries in lower bins + smaller composites inside
+// the bin (its handful of neighbours sit in one or two cache lines).  Wave-collective through emit_ranked.
+__device__ __forceinline__ void rank_small_entry(const Eng& E, Ctl* c, uint32_t nf, uint32_t p, uint32_t n_ord,
+                                                 uint32_t want) {
+    bool live = p < n_ord;
+    uint64_t k = 0;
+    uint32_t id = 0, rank = 0;
+    if (live) {
+        const uint32_t f = E.tmp_f[p];
+        const uint32_t o = E.pre[f], e = E.pre[f + 1];
+        if (e - o > (uint32_t)kTinyBin) {
+            live = false;  // a large bin: ranked by its workgroup
+        } else {
+            k = E.tmp_key[p];
+            id = E.tmp_id[p];
+            rank = o;
+            for (uint32_t j = o; j < e; j++) rank += pair_less(E.tmp_key[j], E.tmp_id[j], k, id) ? 1u : 0u;
+        }
     }
-    emit_ranked(E, c, nf, live, o + rank, want, k, id);
+    emit_ranked(E, c, nf, live, rank, want, k, id);
 }
 
 __device__ __forceinline__ uint32_t sub_of(uint64_t k, uint32_t id, u128 vmin, uint32_t shc, uint32_t nsub) {
@@ -1303,8 +1356,10 @@ __global__ __launch_bounds__(RT) void k_rank(const Eng* __restrict__ engs) {
         }
     }
     const uint32_t bstar = c->bstar, want = c->want;
-    const uint32_t n_big = c->n_big, n_tiny = c->n_tiny;
-    // ---- bins of more than 64 entries: one workgroup each
+    const uint32_t n_big = c->n_big, n_ord = c->n_ord;
+    // ---- entries of small bins (most bins, about half the entries): one thread each, the whole grid at once
+    for (uint32_t p0 = blockIdx.x * RT; p0 < n_ord; p0 += gridDim.x * RT) rank_small_entry(E, c, nf, p0 + t, n_ord, want);
+    // ---- bins of more than kTinyBin entries: one workgroup each
     for (uint32_t bi = blockIdx.x; bi < n_big; bi += gridDim.x) {
         const uint32_t f = E.big_list[bi];
         const uint32_t o = E.pre[f], n = E.pre[f + 1] - o;
@@ -1326,13 +1381,6 @@ __global__ __launch_bounds__(RT) void k_rank(const Eng* __restrict__ engs) {
             rank_item(E, c, S, LK, LI, nf, want, it);
         }
         if (t == 0 && (S.fail || S.sp != 0)) c->failed = 1;  // (cannot happen: every refinement level narrows the range)
-    }
-    // ---- bins of at most 64 entries: one wave each
-    const uint32_t gw = blockIdx.x * (RT / 64) + (t >> 6);
-    for (uint32_t ti = gw; ti < n_tiny; ti += gridDim.x * (RT / 64)) {
-        const uint32_t f = E.tiny_list[ti];
-        const uint32_t o = E.pre[f];
-        rank_tiny_bin(E, c, nf, o, E.pre[f + 1] - o, want);
     }
 }
 
@@ -1422,6 +1470,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
         uint32_t r = r0 + threadIdx.x;
         bool back = threadIdx.x < kTileParents && r >= npop && r < want;
         open_append(E, c, cur_new, back, back ? E.pop_key[r] : 0, back ? E.pop_id[r] : 0);
+        if (back) atomicAdd(&E.hist[bin_of(E.pop_key[r], c->sel_kmin, c->shift)], 1u);  // FRONT's histogram is incremental
     }
     if (r0 >= npop) return;
     const uint32_t np = min((uint32_t)kTileParents, npop - r0);
@@ -1827,6 +1876,7 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
     if (c->done) return;
     Stamp stamp(E, P_COMMIT);
     __shared__ uint32_t sh[3 * 16 + 3];
+    __shared__ uint32_t lh[NBIN];  // this workgroup's pushes into FRONT per selection bin (FRONT's histogram is incremental)
     const IterState& S1 = st_next(c);
     const uint32_t m = S1.m, base = S1.base;
     const uint32_t fb = S1.cur_f, bb = c->cur_b;
@@ -1836,6 +1886,10 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
         commit_ticket(c);
         return;
     }
+    for (int k = 0; k < kBinsPerThread; k++) lh[kBinsPerThread * threadIdx.x + k] = 0;
+    const uint64_t bin_kmin = c->sel_kmin;
+    const uint32_t bin_shift = c->shift;
+    __syncthreads();
     const bool live = j < m;
     const uint32_t id = base + j;
     bool keep = false, is_new = false;
@@ -1894,6 +1948,7 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
         key = key_of_cost(cost);
     }
     const bool tof = keep && key <= T, tob = keep && key > T;
+    if (tof) atomicAdd(&lh[bin_of(key, bin_kmin, bin_shift)], 1u);
     const uint32_t cnt[3] = {tof ? 1u : 0u, tob ? 1u : 0u, is_new ? 1u : 0u};
     uint32_t* const ctr[3] = {&c->open_n[fb].v, &c->open_n[bb].v, &c->closed_n.v};
     uint32_t pos[3];
@@ -1915,6 +1970,11 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
     }
     fold_range(c, fb, tof ? key : ~0ull, tof ? key : 0ull);
     fold_range(c, bb, tob ? key : ~0ull, tob ? key : 0ull);
+    __syncthreads();  // (block_reserveK's barriers already ordered the LDS counts; this one covers the early-out threads)
+    for (int k = 0; k < kBinsPerThread; k++) {
+        const uint32_t v = lh[kBinsPerThread * threadIdx.x + k];
+        if (v) atomicAdd(&E.hist[kBinsPerThread * threadIdx.x + k], v);
+    }
     commit_ticket(c);
 }
 
@@ -2086,8 +2146,10 @@ int enqueue_first_half(dca_engine* e, int heur_id, bool with_refill, hipStream_t
         hipLaunchKernelGGL(k_refill_scan, gxy(1, e), dim3(1024), 0, s, d);
         hipLaunchKernelGGL(k_refill_move, gxy(kScanGrid, e), dim3(256), 0, s, d);
     }
-    hipLaunchKernelGGL(k_sel_hist, gxy(kScanGrid, e), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(k_sel_scan, gxy(1, e), dim3(1024), 0, s, d);
+    // FRONT's selection histogram is recounted only in the refill-check ("rebase") iterations — every kRefillPeriod-th —
+    // and maintained incrementally in between (k_sel_scan's writeback + k_commit's pushes)
+    if (with_refill) hipLaunchKernelGGL(k_sel_hist, gxy(kScanGrid, e), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(k_sel_scan, gxy(1, e), dim3(1024), 0, s, d, with_refill ? 1 : 0);
     hipLaunchKernelGGL(k_sel_collect, gxy(kCollectBlocks, e), dim3(256), 0, s, d);
     hipLaunchKernelGGL(k_rank, gxy(kRankBlocks, e), dim3(RT), kRankLdsBytes, s, d);
     if (int rc = launch_check("select kernels")) return rc;
@@ -2219,15 +2281,16 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
             ALLOC(open_id[b], N);
         }
         ALLOC(hist, NBIN);
+        ALLOC(rhist, NBIN);
         ALLOC(pre, NBIN + 8);
         ALLOC(fill, NBIN);
         ALLOC(part, 4 * 1024);
         ALLOC(tmp_key, N);
         ALLOC(tmp_id, N);
+        ALLOC(tmp_f, N);
         ALLOC(ord_key, N);
         ALLOC(ord_id, N);
         ALLOC(big_list, NBIN);
-        ALLOC(tiny_list, NBIN);
         ALLOC(pop_key, Bz);
         ALLOC(pop_id, Bz);
         ALLOC(pop_g, Bz);
@@ -2243,6 +2306,7 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
 #undef ALLOC
         if (!rc) {
             (void)hipMemset(E.hist, 0, NBIN * sizeof(uint32_t));
+            (void)hipMemset(E.rhist, 0, NBIN * sizeof(uint32_t));
             (void)hipMemset(E.fill, 0, NBIN * sizeof(uint32_t));
             (void)hipMemset(E.child_multi, 0, M);
             (void)hipMemset(E.ctl, 0, sizeof(Ctl));
@@ -2309,7 +2373,7 @@ int dca_engine_reset_instance(dca_engine* e, int inst, const uint8_t* root, void
     hipLaunchKernelGGL(k_init_table, dim3(4096), dim3(256), 0, s, E.tab, E.tab_cap);
     hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, s, E);
     e->phase = 0;
-    if (inst == 0) e->host_iter = 0;
+    e->host_iter = 0;  // the next iteration is a rebase iteration (full histogram) for every instance
     return launch_check("k_reset");
 }
 int dca_engine_reset(dca_engine* e, const uint8_t* root, void* stream) {

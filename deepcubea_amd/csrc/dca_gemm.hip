@@ -429,7 +429,12 @@ int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t l
     p.ol = reinterpret_cast<_Float16*>(out_l);
     p.x_out = x_out;
     p.overflow = overflow;
-    const int bm = g_gemm_variant == 1 ? GBM : HBM_T, bn = g_gemm_variant == 1 ? GBN : HBN_T;
+    // the LDS-DMA kernel leaves with 16-byte row segments: it needs 4-column-aligned outputs (every layer of the network
+    // has them); anything else takes the register-staged kernel
+    const bool wide_ok = ldo % 4 == 0 && ((uintptr_t)out_h | (uintptr_t)out_l) % 8 == 0 &&
+                         ((uintptr_t)x_out | (uintptr_t)skip) % 16 == 0;
+    const int variant = (g_gemm_variant == 2 && wide_ok) ? 2 : 1;
+    const int bm = variant == 1 ? GBM : HBM_T, bn = variant == 1 ? GBN : HBN_T;
     const int64_t nMt = (m + bm - 1) / bm;
     const int64_t nNt = (n + bn - 1) / bn;
     const int64_t blocks = ((nMt + 7) / 8) * 8 * nNt;
@@ -437,7 +442,7 @@ int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t l
         set_error("dca_f16x3_gemm: too many tiles");
         return DCA_E_BADARG;
     }
-    if (g_gemm_variant == 1)
+    if (variant == 1)
         hipLaunchKernelGGL(k_f16x3_gemm_v1, dim3((unsigned)blocks), dim3(GTHREADS), GLDS, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(k_f16x3_gemm_v2, dim3((unsigned)blocks), dim3(HTHREADS), HLDS, (hipStream_t)stream, p);
