@@ -1010,18 +1010,39 @@ __device__ __forceinline__ void emit_ranked(const Eng& E, Ctl* c, uint32_t nf, b
     open_append(E, c, nf, live && rank >= want, key, id);
 }
 
-// an entry of a bin of at most kTinyBin entries, by one thread: rank = entries in lower bins + smaller composites inside
-// the bin (its handful of neighbours sit in one or two cache lines).  Wave-collective through emit_ranked.
-__device__ __forceinline__ void rank_small_entry(const Eng& E, Ctl* c, uint32_t nf, uint32_t p, uint32_t n_ord,
-                                                 uint32_t want) {
+// Entries of the bins of at most kTinyBin entries, a thread per entry: rank = entries in lower bins + smaller composites
+// inside the bin.  A workgroup takes RT consecutive scratch positions; the bins they belong to form one contiguous
+// range of the scratch array (it is grouped by bin), which is staged into LDS once — together with the bins' offsets —
+// so the all-pairs loops run out of LDS.  Falls back to global loads when the range does not fit.
+__device__ __forceinline__ void rank_small_entries(const Eng& E, Ctl* c, RankShared& S, uint64_t* LK, uint32_t* LI,
+                                                   uint32_t nf, uint32_t p0, uint32_t n_ord, uint32_t want) {
+    const uint32_t t = threadIdx.x;
+    const uint32_t plast = (p0 + RT - 1 < n_ord ? p0 + RT - 1 : n_ord - 1);
+    const uint32_t f_lo = E.tmp_f[p0], f_hi = E.tmp_f[plast];
+    const uint32_t lo = E.pre[f_lo], hi = E.pre[f_hi + 1];
+    const bool staged = hi - lo <= kLdsEnt && f_hi - f_lo + 2 <= (uint32_t)kSub;
+    if (staged) {
+        for (uint32_t i = t; i < hi - lo; i += RT) {
+            LK[i] = E.tmp_key[lo + i];
+            LI[i] = E.tmp_id[lo + i];
+        }
+        for (uint32_t i = t; i < f_hi - f_lo + 2; i += RT) S.off[i] = E.pre[f_lo + i];
+    }
+    __syncthreads();
+    const uint32_t p = p0 + t;
     bool live = p < n_ord;
     uint64_t k = 0;
     uint32_t id = 0, rank = 0;
     if (live) {
         const uint32_t f = E.tmp_f[p];
-        const uint32_t o = E.pre[f], e = E.pre[f + 1];
+        const uint32_t o = staged ? S.off[f - f_lo] : E.pre[f], e = staged ? S.off[f - f_lo + 1] : E.pre[f + 1];
         if (e - o > (uint32_t)kTinyBin) {
             live = false;  // a large bin: ranked by its workgroup
+        } else if (staged) {
+            k = LK[p - lo];
+            id = LI[p - lo];
+            rank = o;
+            for (uint32_t j = o - lo; j < e - lo; j++) rank += pair_less(LK[j], LI[j], k, id) ? 1u : 0u;
         } else {
             k = E.tmp_key[p];
             id = E.tmp_id[p];
@@ -1030,6 +1051,7 @@ __device__ __forceinline__ void rank_small_entry(const Eng& E, Ctl* c, uint32_t 
         }
     }
     emit_ranked(E, c, nf, live, rank, want, k, id);
+    __syncthreads();
 }
 
 __device__ __forceinline__ uint32_t sub_of(uint64_t k, uint32_t id, u128 vmin, uint32_t shc, uint32_t nsub) {
@@ -1358,9 +1380,11 @@ __global__ __launch_bounds__(RT) void k_rank(const Eng* __restrict__ engs) {
     const uint32_t bstar = c->bstar, want = c->want;
     const uint32_t n_big = c->n_big, n_ord = c->n_ord;
     // ---- entries of small bins (most bins, about half the entries): one thread each, the whole grid at once
-    for (uint32_t p0 = blockIdx.x * RT; p0 < n_ord; p0 += gridDim.x * RT) rank_small_entry(E, c, nf, p0 + t, n_ord, want);
-    // ---- bins of more than kTinyBin entries: one workgroup each
-    for (uint32_t bi = blockIdx.x; bi < n_big; bi += gridDim.x) {
+    for (uint32_t p0 = blockIdx.x * RT; p0 < n_ord; p0 += gridDim.x * RT)
+        rank_small_entries(E, c, S, LK, LI, nf, p0, n_ord, want);
+    // ---- bins of more than kTinyBin entries: one workgroup each.  The first n_ord / RT workgroups are busy with the pass
+    // above, so the large bins start at workgroup 64
+    for (uint32_t bi = (blockIdx.x + gridDim.x - 64u) % gridDim.x; bi < n_big; bi += gridDim.x) {
         const uint32_t f = E.big_list[bi];
         const uint32_t o = E.pre[f], n = E.pre[f + 1] - o;
         __syncthreads();
@@ -1664,7 +1688,7 @@ __global__ __launch_bounds__(256) void k_probe(const Eng* __restrict__ engs) {
     }
     bool inserted = false;
     uint32_t slot = (uint32_t)h & E.tab_mask;
-    uint32_t v0 = GINF;
+    uint32_t v0 = GINF, rep_id = 0;
     for (uint32_t probes = 0;; probes++) {
         // look first, claim second (a compare-and-swap on every probed slot — one round trip instead of two for a new
         // state — was measured and lost badly: 61 us vs 26 us per launch; returning atomics are that much dearer here).
@@ -1698,7 +1722,10 @@ __global__ __launch_bounds__(256) void k_probe(const Eng* __restrict__ engs) {
                 }
                 diff |= v ^ mine[k];
             }
-            if (diff == 0) break;
+            if (diff == 0) {
+                rep_id = (uint32_t)e;
+                break;
+            }
         }
         slot = (slot + 1) & E.tab_mask;
         if (probes > E.tab_mask) {  // table full (cannot happen while pool <= cap/2)
@@ -1706,15 +1733,24 @@ __global__ __launch_bounds__(256) void k_probe(const Eng* __restrict__ engs) {
             break;
         }
     }
-    const uint32_t old_head = atomicExch(&E.tab[slot].head, id);
-    const bool chained = old_head >= base;  // another child of this batch already sits on the slot
-    E.child_next[j] = chained ? old_head - base : NIL;
+    // chain hook.  The child that just claimed an empty slot needs none: its id IS the slot's entry, and the next child
+    // of this batch to land here finds it there (entry id >= base) when its own exchange returns a stale head — which
+    // spares most children (new states are ~85 % on cube3) their second atomic.
+    uint32_t prev = NIL;  // the child chained in front of this one (batch-relative index)
+    if (!inserted) {
+        const uint32_t old_head = atomicExch(&E.tab[slot].head, id);
+        if (old_head >= base)
+            prev = old_head - base;
+        else if (rep_id >= base)
+            prev = rep_id - base;  // first to follow the child that inserted the slot in this very batch
+    }
+    E.child_next[j] = prev;
     E.child_slot[j] = slot;
     E.child_v0[j] = v0;
     E.child_flags[j] = inserted ? F_NEW : 0;  // counted in k_commit (one atomic per block there)
-    if (chained) {  // both ends of the link learn that their chain has company (k_expand cleared the marks)
+    if (prev != NIL) {  // both ends of the link learn that their chain has company (k_expand cleared the marks)
         E.child_multi[j] = 1;
-        E.child_multi[old_head - base] = 1;
+        E.child_multi[prev] = 1;
     }
 }
 
