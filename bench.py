@@ -282,8 +282,9 @@ def run_astar(args, world, rank):
                       "K-step regions (device_ms_per_step)" % args.profile_iters,
             "launch_span_ms": {k: round(v, 5) for k, v in span.items()},
             "launch_gap_ms": {k: round(v, 5) for k, v in gap.items()},
-            "sum_span_ms": sum(span.values()), "sum_gap_ms": sum(gap.values()),
-            "launches_per_iteration": len([k for k in span if not k.startswith("refill")]),
+            "sum_span_ms": sum(v for k, v in span.items() if not k.startswith("rank_")),
+            "sum_gap_ms": sum(v for k, v in gap.items() if not k.startswith("rank_")),
+            "launches_per_iteration": len([k for k in span if not k.startswith(("refill", "rank_"))]),
         }
     it_bytes = alg["per_expansion_8d"] * B
     res["roofline_iteration"] = {"bound": "hbm", "what": "whole BWAS iteration: SURVEY §8(d) bytes per expansion "

@@ -149,7 +149,7 @@ __device__ __forceinline__ bool pair_less(uint64_t ka, uint32_t ia, uint64_t kb,
 // launch slots of the device-side profile (dca_engine_profile_builtin)
 enum {
     P_REFILL_HIST = 0, P_REFILL_SCAN, P_REFILL_MOVE, P_SEL_HIST, P_SEL_SCAN, P_SEL_COLLECT, P_RANK, P_EXPAND, P_PROBE,
-    P_DECIDE, P_PACK, P_COMMIT, P_COUNT
+    P_DECIDE, P_PACK, P_COMMIT, P_RANK_SMALL, P_RANK_BIG, P_COUNT
 };
 constexpr int kProfSlots = 1024;
 
@@ -977,6 +977,9 @@ __device__ __forceinline__ int clz128(u128 v) {
     return hi ? __clzll((long long)hi) : 64 + (lo ? __clzll((long long)lo) : 64);
 }
 
+constexpr int RT = 512;                            // threads of a k_rank workgroup (8 waves: up to 256 VGPRs each)
+constexpr int kRegEnt = 16;                        // entries a thread keeps in registers
+constexpr uint32_t kLdsEnt = RT * kRegEnt;         // items up to this size are bucketed entirely in LDS (96 KB)
 constexpr int kRankStack = 512;    // pending oversized sub-bins of one bin
 constexpr uint32_t kDirectMax = 512;  // items up to this size are ranked all-pairs out of LDS
 constexpr uint32_t kSubMax = 512;     // sub-bins up to this size are ranked in place, larger ones are refined again
@@ -1059,9 +1062,6 @@ __device__ __forceinline__ uint32_t sub_of(uint64_t k, uint32_t id, u128 vmin, u
     return q < (u128)nsub ? (uint32_t)q : nsub - 1u;
 }
 
-constexpr int RT = 512;                            // threads of a k_rank workgroup (8 waves: up to 256 VGPRs each)
-constexpr int kRegEnt = 16;                        // entries a thread keeps in registers
-constexpr uint32_t kLdsEnt = RT * kRegEnt;         // items up to this size are bucketed entirely in LDS (96 KB)
 
 // exact composite range of the item from per-thread partial min / max -> S.vmin_*, S.bits; also clears the counters
 __device__ __forceinline__ void rank_range(RankShared& S, u128 vmin, u128 vmax) {
@@ -1380,8 +1380,12 @@ __global__ __launch_bounds__(RT) void k_rank(const Eng* __restrict__ engs) {
     const uint32_t bstar = c->bstar, want = c->want;
     const uint32_t n_big = c->n_big, n_ord = c->n_ord;
     // ---- entries of small bins (most bins, about half the entries): one thread each, the whole grid at once
-    for (uint32_t p0 = blockIdx.x * RT; p0 < n_ord; p0 += gridDim.x * RT)
-        rank_small_entries(E, c, S, LK, LI, nf, p0, n_ord, want);
+    {
+        Stamp sub(E, P_RANK_SMALL);  // (profile only: the two halves of this launch get their own slots)
+        for (uint32_t p0 = blockIdx.x * RT; p0 < n_ord; p0 += gridDim.x * RT)
+            rank_small_entries(E, c, S, LK, LI, nf, p0, n_ord, want);
+    }
+    Stamp sub2(E, P_RANK_BIG);
     // ---- bins of more than kTinyBin entries: one workgroup each.  The first n_ord / RT workgroups are busy with the pass
     // above, so the large bins start at workgroup 64
     for (uint32_t bi = (blockIdx.x + gridDim.x - 64u) % gridDim.x; bi < n_big; bi += gridDim.x) {

@@ -141,7 +141,7 @@ class BwasEngine:
                                                      _lib.stream_ptr()), "dca_engine_run_builtin")
 
     PROF_SLOTS = ["refill_hist", "refill_scan", "refill_move", "sel_hist", "sel_scan", "sel_collect", "rank", "expand",
-                  "probe", "decide", "pack", "commit"]
+                  "probe", "decide", "pack", "commit", "rank_small", "rank_big"]
 
     def profile_builtin(self, heur_id: int, iters: int, use_graph: bool = True) -> dict:
         """Device-side profile of `iters` built-in iterations (graph replays by default): per launch the busy span

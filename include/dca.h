@@ -219,11 +219,11 @@ int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph,
  * the previous launch's end as the gap in front of it — measured INSIDE the replayed hipGraph, which HIP events between
  * eager launches cannot do.  span_ms / gap_ms: host float[DCA_PROF_SLOTS], summed milliseconds over the iterations
  * (gap_ms may be NULL).  Slots: 0 refill_hist 1 refill_scan 2 refill_move (every 8th iteration) 3 sel_hist 4 sel_scan
- * 5 sel_collect 6 rank 7 expand 8 probe 9 decide 10 pack (dedup-first stepping only) 11 commit.  Synchronises every
- * iteration.                                                                                                          */
-#define DCA_PROF_SLOTS 12
-int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, int use_graph, float* span_ms /*host [12]*/,
-                               float* gap_ms /*host [12] or NULL*/, void* stream);
+ * 5 sel_collect 6 rank 7 expand 8 probe 9 decide 10 pack (dedup-first stepping only) 11 commit; 12 / 13 = the two halves of
+ * the rank launch (small-bin pass, large-bin workgroups) for tuning.  Synchronises every iteration.                                                                                                          */
+#define DCA_PROF_SLOTS 14
+int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, int use_graph, float* span_ms /*host [DCA_PROF_SLOTS]*/,
+                               float* gap_ms /*host [DCA_PROF_SLOTS] or NULL*/, void* stream);
 /* synchronises the stream */
 int dca_engine_status(dca_engine* e, dca_status* out, void* stream);
 int dca_engine_status_instance(dca_engine* e, int inst, dca_status* out, void* stream);

@@ -52,6 +52,8 @@ with torch.no_grad():
         f = FastResnet(model, dt).cuda()
         ohd = torch.nn.functional.pad(oh, (0, f.in_pad - 324)).to(dt).contiguous()
         ms_lib, _ = t(lambda: torch._addmm_activation(f.biases[0], ohd, f.weights[0].t()))
+        if f.l1_tiles is None:
+            continue
         ms_k, _ = t(lambda: _lib.l1_onehot_gemm(x, 6, f.l1_tiles, f.l1_planes, f.l1_bias, True, dt))
         ms_all, yk = t(lambda: f(x)[:, 0])
         fl = 2 * 324 * 5000 * M
