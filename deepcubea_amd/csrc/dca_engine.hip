@@ -994,23 +994,59 @@ struct RankShared {
     uint64_t red_lo[32], red_hi[32];
     uint64_t vmin_hi, vmin_lo;
     uint32_t bits, tsub, sp, fail;
+    uint32_t ret_base, ret_cnt;            // one reservation in FRONT' per work item for the entries it hands back
+    unsigned long long ret_min, ret_max;   // their key range
     RankItem stack[kRankStack];
 };
 
-// one ranked entry: into the batch (pop order) or back to FRONT'.  Wave-collective (open_append).
+// one entry of the batch at its pop rank
+__device__ __forceinline__ void emit_pop(const Eng& E, Ctl* c, uint32_t rank, uint64_t key, uint32_t id) {
+    E.pop_key[rank] = key;
+    E.pop_id[rank] = id;  // flag included: k_expand masks it (and writes the parents' path costs, pop_g)
+    if (id & ID_SOLVED) {  // rare: a goal among the popped — nothing else in the pop reads the node pool
+        if (E.sem == DCA_SEM_PY)
+            atomicMin(&c->goal_best, ((unsigned long long)(uint32_t)E.g[id & ID_MASK] << 32) | rank);
+        else
+            atomicMin(&c->first_solved, rank);
+    }
+}
+// one ranked entry: into the batch (pop order) or back to FRONT'.  Wave-collective (open_append: one returning global
+// atomic per wave) — fine once per thread (the small-bin pass), NOT inside a loop: the large-bin path uses ret_put.
 __device__ __forceinline__ void emit_ranked(const Eng& E, Ctl* c, uint32_t nf, bool live, uint32_t rank, uint32_t want,
                                             uint64_t key, uint32_t id) {
-    if (live && rank < want) {
-        E.pop_key[rank] = key;
-        E.pop_id[rank] = id;  // flag included: k_expand masks it (and writes the parents' path costs, pop_g)
-        if (id & ID_SOLVED) {  // rare: a goal among the popped — nothing else in the pop reads the node pool
-            if (E.sem == DCA_SEM_PY)
-                atomicMin(&c->goal_best, ((unsigned long long)(uint32_t)E.g[id & ID_MASK] << 32) | rank);
-            else
-                atomicMin(&c->first_solved, rank);
-        }
-    }
+    if (live && rank < want) emit_pop(E, c, rank, key, id);
     open_append(E, c, nf, live && rank >= want, key, id);
+}
+// The entries a work item hands back to FRONT' (the rest of a threshold bin) take slots of ONE reservation made for the
+// whole item; their positions come from an LDS counter.  (An open_append per loop round — a returning global atomic
+// per wave each time, sixteen rounds deep — was what made this path take 20-45 us.)
+__device__ __forceinline__ void ret_begin(Ctl* c, RankShared& S, uint32_t nf, uint32_t count) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        S.ret_base = count ? atomicAdd(&c->open_n[nf].v, count) : 0u;
+        S.ret_cnt = 0;
+        S.ret_min = ~0ull;
+        S.ret_max = 0ull;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void ret_put(const Eng& E, Ctl* c, RankShared& S, uint32_t nf, uint64_t key, uint32_t id) {
+    const uint32_t pos = S.ret_base + atomicAdd(&S.ret_cnt, 1u);
+    if (pos < E.max_nodes) {
+        E.open_key[nf][pos] = key;
+        E.open_id[nf][pos] = id;
+    } else {
+        c->failed = 1;
+    }
+    atomicMin(&S.ret_min, (unsigned long long)key);
+    atomicMax(&S.ret_max, (unsigned long long)key);
+}
+__device__ __forceinline__ void ret_end(Ctl* c, RankShared& S, uint32_t nf) {
+    __syncthreads();
+    if (threadIdx.x == 0 && S.ret_cnt != 0) {
+        atomicMin((unsigned long long*)&c->rng[nf].kmin, S.ret_min);
+        atomicMax((unsigned long long*)&c->rng[nf].kmax, S.ret_max);
+    }
 }
 
 // Entries of the bins of at most kTinyBin entries, a thread per entry: rank = entries in lower bins + smaller composites
@@ -1160,15 +1196,18 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
             LI[t] = I[t];
         }
         __syncthreads();
-        const bool live = t < n;
-        uint64_t k = 0;
-        uint32_t id = 0, rank = 0;
-        if (live) {
-            k = LK[t];
-            id = LI[t];
+        ret_begin(c, S, nf, n - need);
+        if (t < n) {
+            const uint64_t k = LK[t];
+            const uint32_t id = LI[t];
+            uint32_t rank = 0;
             for (uint32_t j = 0; j < n; j++) rank += pair_less(LK[j], LI[j], k, id) ? 1u : 0u;
+            if (rank < need)
+                emit_pop(E, c, it.off + rank, k, id);
+            else
+                ret_put(E, c, S, nf, k, id);
         }
-        emit_ranked(E, c, nf, live, it.off + rank, want, k, id);
+        ret_end(c, S, nf);
         __syncthreads();
         return;
     }
@@ -1208,15 +1247,21 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
         __syncthreads();
         rank_prefix(S, nsub, need);
         const uint32_t tsub = S.tsub;
+        const bool tsub_pushed = S.off[tsub + 1] - S.off[tsub] > kSubMax && shc > 0;
+        // what THIS item hands back: everything above the threshold sub-bin, plus that sub-bin's overshoot unless the
+        // sub-bin is refined by a work item of its own (which then reserves for itself)
+        ret_begin(c, S, nf, (n - S.off[tsub + 1]) + (tsub_pushed ? 0u : S.off[tsub + 1] - need));
 #pragma unroll
         for (int j = 0; j < kRegEnt; j++) {
-            const bool live = t + (uint32_t)RT * j < n;
-            if (live && es[j] <= tsub) {
-                const uint32_t p = S.off[es[j]] + atomicAdd(&S.cnt[es[j]], 1u);
-                LK[p] = ek[j];
-                LI[p] = ei[j];
+            if (t + (uint32_t)RT * j < n) {
+                if (es[j] <= tsub) {
+                    const uint32_t p = S.off[es[j]] + atomicAdd(&S.cnt[es[j]], 1u);
+                    LK[p] = ek[j];
+                    LI[p] = ei[j];
+                } else {
+                    ret_put(E, c, S, nf, ek[j], ei[j]);  // the rest of a threshold bin stays in OPEN
+                }
             }
-            open_append(E, c, nf, live && es[j] > tsub, ek[j], ei[j]);  // the rest of a threshold bin stays in OPEN
         }
         __syncthreads();
         const uint32_t m = S.off[tsub + 1];
@@ -1233,15 +1278,18 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
                 if (e0 - s0 > kSubMax && shc > 0) {
                     K2[p] = k;  // refined by the sub-bin's own work item, from the other scratch array
                     I2[p] = id;
-                    live = false;
                 } else {
                     rank = s0;
                     for (uint32_t j = s0; j < e0; j++) rank += pair_less(LK[j], LI[j], k, id) ? 1u : 0u;
+                    if (rank < need)
+                        emit_pop(E, c, it.off + rank, k, id);
+                    else
+                        ret_put(E, c, S, nf, k, id);
                 }
             }
-            emit_ranked(E, c, nf, live, it.off + rank, want, k, id);
         }
         rank_push(S, it, tsub, need, shc);
+        ret_end(c, S, nf);
         __syncthreads();
         return;
     }
@@ -1287,6 +1335,8 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
     __syncthreads();
     rank_prefix(S, nsub, need);
     const uint32_t tsub = S.tsub;
+    const bool tsub_pushed = S.off[tsub + 1] - S.off[tsub] > kSubMax && shc > 0;
+    ret_begin(c, S, nf, (n - S.off[tsub + 1]) + (tsub_pushed ? 0u : S.off[tsub + 1] - need));
     for (uint32_t b0 = 0; b0 < n; b0 += kLdsEnt) {
         uint64_t ek[kRegEnt];
         uint32_t ei[kRegEnt];
@@ -1298,17 +1348,16 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
         }
 #pragma unroll
         for (int j = 0; j < kRegEnt; j++) {
-            const bool live = b0 + t + (uint32_t)RT * j < n;
-            uint32_t sub = 0;
-            if (live) {
-                sub = sub_of(ek[j], ei[j], base, shc, nsub);
+            if (b0 + t + (uint32_t)RT * j < n) {
+                const uint32_t sub = sub_of(ek[j], ei[j], base, shc, nsub);
                 if (sub <= tsub) {
                     const uint32_t p = S.off[sub] + atomicAdd(&S.cnt[sub], 1u);
                     K2[p] = ek[j];
                     I2[p] = ei[j];
+                } else {
+                    ret_put(E, c, S, nf, ek[j], ei[j]);
                 }
             }
-            open_append(E, c, nf, live && sub > tsub, ek[j], ei[j]);
         }
     }
     __syncthreads();
@@ -1323,16 +1372,18 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
             id = I2[p];
             const uint32_t sub = sub_of(k, id, base, shc, nsub);
             const uint32_t s0 = S.off[sub], e0 = S.off[sub + 1];
-            if (e0 - s0 > kSubMax && shc > 0) {
-                live = false;  // ranked by the sub-bin's own work item
-            } else {
+            if (!(e0 - s0 > kSubMax && shc > 0)) {  // (else: ranked by the sub-bin's own work item)
                 rank = s0;
                 for (uint32_t j = s0; j < e0; j++) rank += pair_less(K2[j], I2[j], k, id) ? 1u : 0u;
+                if (rank < need)
+                    emit_pop(E, c, it.off + rank, k, id);
+                else
+                    ret_put(E, c, S, nf, k, id);
             }
         }
-        emit_ranked(E, c, nf, live, it.off + rank, want, k, id);
     }
     rank_push(S, it, tsub, need, shc);
+    ret_end(c, S, nf);
     __syncthreads();
 }
 
