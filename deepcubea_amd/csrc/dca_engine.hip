@@ -995,7 +995,6 @@ struct RankShared {
     uint64_t vmin_hi, vmin_lo;
     uint32_t bits, tsub, sp, fail;
     uint32_t ret_base, ret_cnt;            // one reservation in FRONT' per work item for the entries it hands back
-    unsigned long long ret_min, ret_max;   // their key range
     RankItem stack[kRankStack];
 };
 
@@ -1025,27 +1024,44 @@ __device__ __forceinline__ void ret_begin(Ctl* c, RankShared& S, uint32_t nf, ui
     if (threadIdx.x == 0) {
         S.ret_base = count ? atomicAdd(&c->open_n[nf].v, count) : 0u;
         S.ret_cnt = 0;
-        S.ret_min = ~0ull;
-        S.ret_max = 0ull;
     }
     __syncthreads();
 }
-__device__ __forceinline__ void ret_put(const Eng& E, Ctl* c, RankShared& S, uint32_t nf, uint64_t key, uint32_t id) {
-    const uint32_t pos = S.ret_base + atomicAdd(&S.ret_cnt, 1u);
-    if (pos < E.max_nodes) {
-        E.open_key[nf][pos] = key;
-        E.open_id[nf][pos] = id;
-    } else {
-        c->failed = 1;
+struct RetAcc {  // a thread's running key range of what it handed back
+    uint64_t kmn, kmx;
+};
+// wave-collective (call from wave-uniform control flow): the lanes with `pred` take consecutive slots, ONE LDS atomic per
+// wave and call.  (Per-entry atomics on the shared slot counter / key range — all on one LDS address — cost 30-60 us.)
+__device__ __forceinline__ void ret_put(const Eng& E, Ctl* c, RankShared& S, uint32_t nf, bool pred, uint64_t key,
+                                        uint32_t id, RetAcc& acc) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t basep = 0;
+    if (lane == leader) basep = atomicAdd(&S.ret_cnt, (uint32_t)__popcll(mask));
+    basep = __shfl(basep, leader);
+    if (pred) {
+        const uint32_t pos = S.ret_base + basep + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (pos < E.max_nodes) {
+            E.open_key[nf][pos] = key;
+            E.open_id[nf][pos] = id;
+        } else {
+            c->failed = 1;
+        }
+        acc.kmn = key < acc.kmn ? key : acc.kmn;
+        acc.kmx = key > acc.kmx ? key : acc.kmx;
     }
-    atomicMin(&S.ret_min, (unsigned long long)key);
-    atomicMax(&S.ret_max, (unsigned long long)key);
 }
-__device__ __forceinline__ void ret_end(Ctl* c, RankShared& S, uint32_t nf) {
-    __syncthreads();
-    if (threadIdx.x == 0 && S.ret_cnt != 0) {
-        atomicMin((unsigned long long*)&c->rng[nf].kmin, S.ret_min);
-        atomicMax((unsigned long long*)&c->rng[nf].kmax, S.ret_max);
+__device__ __forceinline__ void ret_end(Ctl* c, uint32_t nf, RetAcc acc) {
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t a = __shfl_xor(acc.kmn, o), b = __shfl_xor(acc.kmx, o);
+        acc.kmn = a < acc.kmn ? a : acc.kmn;
+        acc.kmx = b > acc.kmx ? b : acc.kmx;
+    }
+    if ((threadIdx.x & 63) == 0 && acc.kmn != ~0ull) {
+        atomicMin((unsigned long long*)&c->rng[nf].kmin, (unsigned long long)acc.kmn);
+        atomicMax((unsigned long long*)&c->rng[nf].kmax, (unsigned long long)acc.kmx);
     }
 }
 
@@ -1197,17 +1213,18 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
         }
         __syncthreads();
         ret_begin(c, S, nf, n - need);
-        if (t < n) {
-            const uint64_t k = LK[t];
-            const uint32_t id = LI[t];
-            uint32_t rank = 0;
+        RetAcc acc{~0ull, 0ull};
+        const bool live = t < n;
+        uint64_t k = 0;
+        uint32_t id = 0, rank = 0;
+        if (live) {
+            k = LK[t];
+            id = LI[t];
             for (uint32_t j = 0; j < n; j++) rank += pair_less(LK[j], LI[j], k, id) ? 1u : 0u;
-            if (rank < need)
-                emit_pop(E, c, it.off + rank, k, id);
-            else
-                ret_put(E, c, S, nf, k, id);
+            if (rank < need) emit_pop(E, c, it.off + rank, k, id);
         }
-        ret_end(c, S, nf);
+        ret_put(E, c, S, nf, live && rank >= need, k, id, acc);
+        ret_end(c, nf, acc);
         __syncthreads();
         return;
     }
@@ -1251,17 +1268,16 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
         // what THIS item hands back: everything above the threshold sub-bin, plus that sub-bin's overshoot unless the
         // sub-bin is refined by a work item of its own (which then reserves for itself)
         ret_begin(c, S, nf, (n - S.off[tsub + 1]) + (tsub_pushed ? 0u : S.off[tsub + 1] - need));
+        RetAcc acc{~0ull, 0ull};
 #pragma unroll
         for (int j = 0; j < kRegEnt; j++) {
-            if (t + (uint32_t)RT * j < n) {
-                if (es[j] <= tsub) {
-                    const uint32_t p = S.off[es[j]] + atomicAdd(&S.cnt[es[j]], 1u);
-                    LK[p] = ek[j];
-                    LI[p] = ei[j];
-                } else {
-                    ret_put(E, c, S, nf, ek[j], ei[j]);  // the rest of a threshold bin stays in OPEN
-                }
+            const bool live = t + (uint32_t)RT * j < n;
+            if (live && es[j] <= tsub) {
+                const uint32_t p = S.off[es[j]] + atomicAdd(&S.cnt[es[j]], 1u);
+                LK[p] = ek[j];
+                LI[p] = ei[j];
             }
+            ret_put(E, c, S, nf, live && es[j] > tsub, ek[j], ei[j], acc);  // the rest of a threshold bin stays in OPEN
         }
         __syncthreads();
         const uint32_t m = S.off[tsub + 1];
@@ -1278,18 +1294,17 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
                 if (e0 - s0 > kSubMax && shc > 0) {
                     K2[p] = k;  // refined by the sub-bin's own work item, from the other scratch array
                     I2[p] = id;
+                    live = false;
                 } else {
                     rank = s0;
                     for (uint32_t j = s0; j < e0; j++) rank += pair_less(LK[j], LI[j], k, id) ? 1u : 0u;
-                    if (rank < need)
-                        emit_pop(E, c, it.off + rank, k, id);
-                    else
-                        ret_put(E, c, S, nf, k, id);
+                    if (rank < need) emit_pop(E, c, it.off + rank, k, id);
                 }
             }
+            ret_put(E, c, S, nf, live && rank >= need, k, id, acc);
         }
         rank_push(S, it, tsub, need, shc);
-        ret_end(c, S, nf);
+        ret_end(c, nf, acc);
         __syncthreads();
         return;
     }
@@ -1337,6 +1352,7 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
     const uint32_t tsub = S.tsub;
     const bool tsub_pushed = S.off[tsub + 1] - S.off[tsub] > kSubMax && shc > 0;
     ret_begin(c, S, nf, (n - S.off[tsub + 1]) + (tsub_pushed ? 0u : S.off[tsub + 1] - need));
+    RetAcc acc{~0ull, 0ull};
     for (uint32_t b0 = 0; b0 < n; b0 += kLdsEnt) {
         uint64_t ek[kRegEnt];
         uint32_t ei[kRegEnt];
@@ -1348,16 +1364,17 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
         }
 #pragma unroll
         for (int j = 0; j < kRegEnt; j++) {
-            if (b0 + t + (uint32_t)RT * j < n) {
-                const uint32_t sub = sub_of(ek[j], ei[j], base, shc, nsub);
+            const bool live = b0 + t + (uint32_t)RT * j < n;
+            uint32_t sub = 0;
+            if (live) {
+                sub = sub_of(ek[j], ei[j], base, shc, nsub);
                 if (sub <= tsub) {
                     const uint32_t p = S.off[sub] + atomicAdd(&S.cnt[sub], 1u);
                     K2[p] = ek[j];
                     I2[p] = ei[j];
-                } else {
-                    ret_put(E, c, S, nf, ek[j], ei[j]);
                 }
             }
+            ret_put(E, c, S, nf, live && sub > tsub, ek[j], ei[j], acc);
         }
     }
     __syncthreads();
@@ -1372,18 +1389,18 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
             id = I2[p];
             const uint32_t sub = sub_of(k, id, base, shc, nsub);
             const uint32_t s0 = S.off[sub], e0 = S.off[sub + 1];
-            if (!(e0 - s0 > kSubMax && shc > 0)) {  // (else: ranked by the sub-bin's own work item)
+            if (e0 - s0 > kSubMax && shc > 0) {
+                live = false;  // ranked by the sub-bin's own work item
+            } else {
                 rank = s0;
                 for (uint32_t j = s0; j < e0; j++) rank += pair_less(K2[j], I2[j], k, id) ? 1u : 0u;
-                if (rank < need)
-                    emit_pop(E, c, it.off + rank, k, id);
-                else
-                    ret_put(E, c, S, nf, k, id);
+                if (rank < need) emit_pop(E, c, it.off + rank, k, id);
             }
         }
+        ret_put(E, c, S, nf, live && rank >= need, k, id, acc);
     }
     rank_push(S, it, tsub, need, shc);
-    ret_end(c, S, nf);
+    ret_end(c, nf, acc);
     __syncthreads();
 }
 
