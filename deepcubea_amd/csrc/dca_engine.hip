@@ -1235,11 +1235,13 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
         uint64_t ek[kRegEnt];
         uint32_t ei[kRegEnt], es[kRegEnt];
         u128 vmin = ~(u128)0, vmax = 0;
+        // (index clamped, not predicated: a predicated load compiles to branch + wait per element here — sixteen
+        // serialized memory round trips, which is what made this path take 20-45 us)
 #pragma unroll
         for (int j = 0; j < kRegEnt; j++) {
-            const uint32_t i = t + (uint32_t)RT * j;
-            ek[j] = i < n ? K[i] : ~0ull;
-            ei[j] = i < n ? I[i] : 0xFFFFFFFFu;
+            const uint32_t i = t + (uint32_t)RT * j, ic = i < n ? i : n - 1;
+            ek[j] = K[ic];
+            ei[j] = I[ic];
         }
 #pragma unroll
         for (int j = 0; j < kRegEnt; j++)
@@ -1316,9 +1318,9 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
             uint32_t ei[kRegEnt];
 #pragma unroll
             for (int j = 0; j < kRegEnt; j++) {
-                const uint32_t i = b0 + t + (uint32_t)RT * j;
-                ek[j] = i < n ? K[i] : 0;
-                ei[j] = i < n ? I[i] : 0;
+                const uint32_t i = b0 + t + (uint32_t)RT * j, ic = i < n ? i : n - 1;
+                ek[j] = K[ic];
+                ei[j] = I[ic];
             }
 #pragma unroll
             for (int j = 0; j < kRegEnt; j++)
@@ -1339,9 +1341,9 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
         uint32_t ei[kRegEnt];
 #pragma unroll
         for (int j = 0; j < kRegEnt; j++) {
-            const uint32_t i = b0 + t + (uint32_t)RT * j;
-            ek[j] = i < n ? K[i] : 0;
-            ei[j] = i < n ? I[i] : 0;
+            const uint32_t i = b0 + t + (uint32_t)RT * j, ic = i < n ? i : n - 1;
+            ek[j] = K[ic];
+            ei[j] = I[ic];
         }
 #pragma unroll
         for (int j = 0; j < kRegEnt; j++)
@@ -1358,9 +1360,9 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
         uint32_t ei[kRegEnt];
 #pragma unroll
         for (int j = 0; j < kRegEnt; j++) {
-            const uint32_t i = b0 + t + (uint32_t)RT * j;
-            ek[j] = i < n ? K[i] : 0;
-            ei[j] = i < n ? I[i] : 0;
+            const uint32_t i = b0 + t + (uint32_t)RT * j, ic = i < n ? i : n - 1;
+            ek[j] = K[ic];
+            ei[j] = I[ic];
         }
 #pragma unroll
         for (int j = 0; j < kRegEnt; j++) {
