@@ -59,6 +59,7 @@ constexpr uint32_t NIL = 0xFFFFFFFFu;
 // without touching the node pool.  Every compare / index uses the id with the flag masked off.
 constexpr uint32_t ID_MASK = 0x7FFFFFFFu, ID_SOLVED = 0x80000000u;
 constexpr uint64_t EMPTY = ~0ull;
+constexpr uint64_t DEAD = ~0ull;  // tombstone key of an OPEN entry that left its tier (BACK -> FRONT, FRONT -> batch / BACK)
 constexpr uint32_t GINF = 0xFFFFFFFFu;
 constexpr int kMaxMoves = 4096;
 
@@ -86,7 +87,6 @@ struct alignas(128) Rng {
 // current by incrementing `iters`.
 struct IterState {
     uint32_t pool_n;        // node ids handed out
-    uint32_t cur_f;         // live FRONT buffer (0/1)
     uint32_t npop, m, base; // batch of the iteration that produced this state
     uint32_t best_id;       // cpp: cheapest solved node popped so far
     int32_t has_best;
@@ -97,9 +97,11 @@ struct Ctl {
     int32_t done, failed, stop_after, pad0;
     int64_t iters, gen, expanded;
     IterState S[2];
-    // OPEN is two tiers of (key,id) arrays.  FRONT (buffers 0/1, ping-pong) holds every entry with
-    // key <= T, BACK (buffer 2/3) the rest; pops only ever look at FRONT, so an iteration costs
-    // O(|FRONT| + children), independent of |OPEN|.
+    // OPEN is two tiers of (key,id) arrays.  FRONT holds every entry with key <= T, BACK (buffer 2/3) the rest; pops
+    // only ever look at FRONT, so an iteration costs O(|FRONT| + children), independent of |OPEN|.  FRONT is edited IN
+    // PLACE: a pop tombstones the entries it takes (key = DEAD), pushes append; every kRefillPeriod-th iteration a
+    // rebase pass squeezes the tombstones out into the other FRONT buffer (and recounts the selection histogram).
+    uint32_t cur_f;         // the live FRONT buffer (0/1); the other one is the target of the next compaction
     uint32_t cur_b;         // the BACK buffer (2/3)
     uint64_t T;             // tier threshold key (inclusive upper bound of FRONT)
     uint32_t refill, compact, r_bstar, spill_bin;
@@ -115,7 +117,7 @@ struct Ctl {
     uint32_t dbg_nord, dbg_maxbin, dbg_giant, dbg_giant_seen;
     // ---- hot words -----------------------------------------------------------------------------
     Cnt open_n[4];   // physical entries per OPEN buffer (0/1 FRONT ping-pong, 2/3 BACK + its compaction target)
-    Cnt closed_n, back_dead, ticket_a;
+    Cnt closed_n, back_dead, front_dead, ret_n, ticket_a;  // *_dead: tombstones (key == DEAD) inside the tier's buffer
     Rng rng[4];      // running key range per OPEN buffer
     alignas(128) unsigned long long goal_best;  // PY: min over solved popped of (g << 32 | pop rank)
     alignas(128) uint32_t first_solved;         // CPP: smallest pop rank holding a solved node
@@ -158,6 +160,7 @@ struct Eng {
     double w;
     float wf;
     uint32_t max_nodes, M, tab_cap, tab_mask;
+    uint32_t front_cap;  // entries a FRONT buffer holds: max_nodes + room for the tombstones of kRefillPeriod iterations
     uint8_t* state;
     int32_t* g;
     uint32_t* parent;
@@ -169,12 +172,13 @@ struct Eng {
     uint32_t f_keep, f_max;  // FRONT hysteresis: refill/spill down to ~f_keep, spill when above f_max
     uint32_t *hist, *pre, *fill;  // selection histogram, its exclusive prefix [NBIN+1], per-bin fill of the scratch array
     uint32_t* rhist;              // histogram of BACK (refill), separate: `hist` is maintained across iterations
-    uint64_t* part;  // [4][kCollectBlocks] per-block key ranges of k_sel_collect (survivor min/max, spill min/max)
+    uint64_t* part;  // [2][kCollectBlocks] per-block key ranges (min, max) of the entries k_front_rebase kept
     // scratch of the pop: every FRONT entry at or below the threshold bin, grouped by bin (bin f occupies
     // [pre[f], pre[f+1])), and — only for bins too large for LDS — the single-workgroup sub-bin ordering
     uint64_t* tmp_key;
     uint32_t* tmp_id;
     uint16_t* tmp_f;   // bin of every scratch entry (k_rank's thread-per-entry pass over the small bins)
+    uint32_t* tmp_idx;  // FRONT position each scratch entry was taken from (k_rank hands entries back into those slots)
     uint64_t* ord_key;
     uint32_t* ord_id;
     uint32_t* big_list;  // bins at or below the threshold bin with more than kTinyBin entries (one workgroup each)
@@ -204,7 +208,7 @@ struct Eng {
 __device__ __forceinline__ const IterState& st_cur(const Ctl* c) { return c->S[c->iters & 1]; }
 __device__ __forceinline__ const IterState& st_next(const Ctl* c) { return c->S[(c->iters + 1) & 1]; }
 
-// the binning a rebase iteration installs (k_sel_hist recounts under it, k_sel_scan records it): FRONT's exact key range,
+// the binning a rebase iteration installs (k_front_rebase recounts under it, k_sel_scan records it): FRONT's exact key range,
 // its top raised to the tier threshold — no key above T enters FRONT before the next rebase
 __device__ __forceinline__ void fresh_binning(const Ctl* c, uint32_t buf, uint64_t& kmin, uint32_t& shift) {
     kmin = c->rng[buf].kmin;
@@ -259,7 +263,7 @@ __device__ __forceinline__ void open_append(const Eng& E, Ctl* c, uint32_t buf, 
     basep = __shfl(basep, leader);
     if (pred) {
         uint32_t pos = basep + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        if (pos < E.max_nodes) {
+        if (pos < (buf < 2 ? E.front_cap : E.max_nodes)) {
             E.open_key[buf][pos] = key;
             E.open_id[buf][pos] = id;
         } else {
@@ -441,10 +445,8 @@ __global__ void k_reset(Eng E) {
     E.parent[0] = NIL;
     E.move[0] = 0xFF;
     E.solved[0] = ok ? 1 : 0;
-    for (int p = 0; p < 2; p++) {
-        c->S[p].pool_n = 1;
-        c->S[p].cur_f = 0;
-    }
+    for (int p = 0; p < 2; p++) c->S[p].pool_n = 1;
+    c->cur_f = 0;
     c->goal_best = ~0ull;
     c->first_solved = NIL;
     for (int b = 0; b < 4; b++) {
@@ -471,12 +473,12 @@ __global__ void k_reset(Eng E) {
 __global__ void k_root_commit(Eng E, const float* h_root) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Ctl* c = E.ctl;
-    if (E.sem != DCA_SEM_PY || c->open_n[st_cur(c).cur_f].v != 0) return;
+    if (E.sem != DCA_SEM_PY || c->open_n[c->cur_f].v != 0) return;
     // astar.py:246-249,196: cost = w*0.0 + max(h,0)*!solved   (float64)
     double hv = fmax((double)h_root[0], 0.0);
     double cost = __dadd_rn(__dmul_rn(E.w, 0.0), __dmul_rn(hv, E.solved[0] ? 0.0 : 1.0));
     uint64_t key = key_of_cost(cost);
-    uint32_t b = st_cur(c).cur_f;
+    uint32_t b = c->cur_f;
     E.open_key[b][0] = key;
     E.open_id[b][0] = E.solved[0] ? ID_SOLVED : 0u;
     c->open_n[b].v = 1;
@@ -498,9 +500,8 @@ __device__ __forceinline__ uint32_t front_keep(const Eng& E) {
 }
 __device__ __forceinline__ bool need_refill(const Eng& E, const Ctl* c) {
     return c->open_n[c->cur_b].v != c->back_dead.v &&
-           c->open_n[st_cur(c).cur_f].v < (uint32_t)(kRefillPeriod + 1) * (uint32_t)E.B;
+           c->open_n[c->cur_f].v - c->front_dead.v < (uint32_t)(kRefillPeriod + 1) * (uint32_t)E.B;
 }
-constexpr uint64_t DEAD = ~0ull;  // tombstone key of a BACK entry that moved to FRONT
 
 __global__ __launch_bounds__(256) void k_refill_hist(const Eng* __restrict__ engs) {
     const Eng& E = engs[blockIdx.y];
@@ -566,9 +567,10 @@ __global__ __launch_bounds__(1024) void k_refill_scan(const Eng* __restrict__ en
     Ctl* c = E.ctl;
     if (c->done) return;
     Stamp stamp(E, P_REFILL_SCAN);
-    // this launch opens a "rebase" iteration: k_sel_hist recounts FRONT from scratch under a fresh binning right after
+    // this launch opens a "rebase" iteration: k_front_rebase compacts and recounts FRONT from scratch under a fresh binning right after
     // the refill, so the incrementally maintained histogram is dropped here
     for (int k = 0; k < kBinsPerThread; k++) E.hist[kBinsPerThread * threadIdx.x + k] = 0;
+    if (threadIdx.x == 0) c->open_n[c->cur_f ^ 1].v = 0;  // the rebase pass compacts FRONT into the other buffer
     if (!need_refill(E, c)) {
         if (threadIdx.x == 0) c->refill = 0;
         return;
@@ -615,7 +617,7 @@ __global__ __launch_bounds__(256) void k_refill_move(const Eng* __restrict__ eng
     if (c->done || !c->refill) return;
     Stamp stamp(E, P_REFILL_MOVE);
     __shared__ uint32_t sh[2 * 4 + 2];
-    const uint32_t sb = c->cur_b, fb = st_cur(c).cur_f, db = sb ^ 1;  // BACK buffers are 2 and 3
+    const uint32_t sb = c->cur_b, fb = c->cur_f, db = sb ^ 1;  // BACK buffers are 2 and 3
     const bool compact = c->compact != 0;  // also squeeze the tombstones out into the other BACK buffer
     const uint32_t n = c->open_n[sb].v;
     const uint64_t kmin = c->r_kmin;
@@ -632,8 +634,8 @@ __global__ __launch_bounds__(256) void k_refill_move(const Eng* __restrict__ eng
 #pragma unroll
         for (uint32_t i = 0; i < ITEMS; i++) {
             uint32_t idx = tile * TILE + i * 256 + threadIdx.x;
-            bool live = idx < n;
-            k[i] = live ? keys[idx] : DEAD;
+            k[i] = keys[idx < n ? idx : n - 1];  // unconditional (index-clamped) load: all eight stay in flight
+            if (idx >= n) k[i] = DEAD;
             uint64_t f = (k[i] - kmin) >> shift;
             bool alive = k[i] != DEAD;
             bool front = alive && (f < NBIN ? (uint32_t)f : NBIN - 1) <= bstar;
@@ -647,7 +649,7 @@ __global__ __launch_bounds__(256) void k_refill_move(const Eng* __restrict__ eng
         for (uint32_t i = 0; i < ITEMS; i++) {
             uint32_t idx = tile * TILE + i * 256 + threadIdx.x;
             if ((tof >> i) & 1u) {
-                if (p.a < E.max_nodes) {
+                if (p.a < E.front_cap) {
                     E.open_key[fb][p.a] = k[i];
                     E.open_id[fb][p.a] = ids[idx];
                 }
@@ -674,37 +676,81 @@ __global__ __launch_bounds__(256) void k_refill_move(const Eng* __restrict__ eng
 // pop: exact top-B of FRONT by (cost key, node id)
 // ---------------------------------------------------------------------------------------------
 // S1: histogram of (key - kmin) >> shift over FRONT, 2048 bins, LDS-privatised
-__global__ __launch_bounds__(256) void k_sel_hist(const Eng* __restrict__ engs) {
+__global__ __launch_bounds__(256) void k_front_rebase(const Eng* __restrict__ engs) {
+    // every kRefillPeriod-th iteration: squeeze FRONT's tombstones out (live entries -> the other FRONT buffer, one
+    // reservation per 2048-entry tile), recount the selection histogram under a fresh binning and take the exact key
+    // range of what is left (the next rebase bins by it)
     const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
     Stamp stamp(E, P_SEL_HIST);
     __shared__ uint32_t lh[NBIN];
+    __shared__ uint32_t sh[2 * 4 + 2];
     for (int i = threadIdx.x; i < NBIN; i += 256) lh[i] = 0;
     __syncthreads();
-    const uint32_t b = st_cur(c).cur_f, n = c->open_n[b].v;
+    const uint32_t b = c->cur_f, nb = b ^ 1, n = c->open_n[b].v;
     uint64_t kmin;
     uint32_t shift;
     fresh_binning(c, b, kmin, shift);
     const uint64_t* __restrict__ keys = E.open_key[b];
-    const uint32_t stride = gridDim.x * 256;
-    for (uint32_t i0 = blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 4 * stride) {
-        uint64_t k[4];
-        bool ok[4];
+    const uint32_t* __restrict__ ids = E.open_id[b];
+    constexpr uint32_t ITEMS = 8, TILE = 256 * ITEMS;
+    uint64_t fmn = ~0ull, fmx = 0;
+    const uint32_t ntiles = (n + TILE - 1) / TILE;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint64_t k[ITEMS];
+        uint32_t id[ITEMS];
+        uint32_t cl = 0;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {  // 4 loads in flight per lane
-            ok[u] = i0 + u * stride < n;
-            k[u] = ok[u] ? keys[i0 + u * stride] : 0;
+        for (uint32_t i = 0; i < ITEMS; i++) {
+            const uint32_t idx = tile * TILE + i * 256 + threadIdx.x, ic = idx < n ? idx : n - 1;
+            k[i] = keys[ic];
+            id[i] = ids[ic];
+            if (idx >= n) k[i] = DEAD;
+            cl += k[i] != DEAD ? 1u : 0u;
         }
+        Pos2 p = block_reserve2<256>(cl, 0u, &c->open_n[nb].v, &c->open_n[nb].v, sh);
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (!ok[u]) continue;
-            atomicAdd(&lh[bin_of(k[u], kmin, shift)], 1u);
+        for (uint32_t i = 0; i < ITEMS; i++) {
+            if (k[i] == DEAD) continue;
+            if (p.a < E.front_cap) {
+                E.open_key[nb][p.a] = k[i];
+                E.open_id[nb][p.a] = id[i];
+            } else {
+                c->failed = 1;
+            }
+            p.a++;
+            atomicAdd(&lh[bin_of(k[i], kmin, shift)], 1u);
+            fmn = k[i] < fmn ? k[i] : fmn;
+            fmx = k[i] > fmx ? k[i] : fmx;
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < NBIN; i += 256)
         if (lh[i]) atomicAdd(&E.hist[i], lh[i]);
+    {
+        __shared__ uint64_t red[2][4];
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint64_t a = __shfl_xor(fmn, o), z = __shfl_xor(fmx, o);
+            fmn = a < fmn ? a : fmn;
+            fmx = z > fmx ? z : fmx;
+        }
+        if (lane == 0) {
+            red[0][wv] = fmn;
+            red[1][wv] = fmx;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t mn = red[0][0], mx = red[1][0];
+            for (int w = 1; w < 4; w++) {
+                mn = red[0][w] < mn ? red[0][w] : mn;
+                mx = red[1][w] > mx ? red[1][w] : mx;
+            }
+            E.part[blockIdx.x] = mn;
+            E.part[kCollectBlocks + blockIdx.x] = mx;
+        }
+    }
 }
 
 // S2: one workgroup — prefix over the bins, threshold bin, spill decision, per-iteration counter reset
@@ -716,8 +762,40 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
     __shared__ uint32_t pre[NBIN + 1];
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t s_spill, s_bstar, s_maxbin, s_giant, s_nbig, s_sp;
+    __shared__ uint64_t s_red[2][16];
     const int t = threadIdx.x;
+    uint32_t cb = c->cur_f;
+    uint64_t new_kmin = c->sel_kmin;
+    uint32_t new_shift = c->shift;
+    if (rebased) {
+        // k_front_rebase compacted FRONT into the other buffer, counted E.hist under this binning and left per-block
+        // key ranges of the live entries in E.part
+        fresh_binning(c, cb, new_kmin, new_shift);
+        uint64_t mn = t < kCollectBlocks ? E.part[t] : ~0ull, mx = t < kCollectBlocks ? E.part[kCollectBlocks + t] : 0ull;
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint64_t a = __shfl_xor(mn, o), z = __shfl_xor(mx, o);
+            mn = a < mn ? a : mn;
+            mx = z > mx ? z : mx;
+        }
+        if ((t & 63) == 0) {
+            s_red[0][t >> 6] = mn;
+            s_red[1][t >> 6] = mx;
+        }
+        cb ^= 1;
+    }
+    __syncthreads();
     if (t == 0) {
+        if (rebased) {
+            uint64_t mn = ~0ull, mx = 0;
+            for (int w = 0; w < 16; w++) {
+                mn = s_red[0][w] < mn ? s_red[0][w] : mn;
+                mx = s_red[1][w] > mx ? s_red[1][w] : mx;
+            }
+            c->cur_f = cb;
+            c->front_dead.v = 0;
+            c->rng[cb].kmin = mn;
+            c->rng[cb].kmax = mx;
+        }
         s_maxbin = 0;
         s_giant = 0;
         s_nbig = 0;
@@ -730,10 +808,10 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
         s_spill = NBIN;  // no spill
         s_bstar = 0;
     }
-    // E.hist is FRONT's histogram under the binning in force: recounted by k_sel_hist in a rebase iteration (every
+    // E.hist is FRONT's histogram under the binning in force: recounted by k_front_rebase in a rebase iteration (every
     // kRefillPeriod-th), maintained incrementally in between (the writeback below + k_commit's pushes)
     scan_bins(E.hist, false, pre, wsum);
-    const uint32_t cb = st_cur(c).cur_f, n = c->open_n[cb].v;
+    const uint32_t n = c->open_n[cb].v - (rebased ? 0u : c->front_dead.v);  // live entries
     const uint32_t want = n < (uint32_t)E.B ? n : (uint32_t)E.B;
     for (int k = 0; k < kBinsPerThread; k++) {
         int bin = kBinsPerThread * t + k;
@@ -762,9 +840,8 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
         }
     }
     if (t == 0) {
-        uint64_t kmin = c->sel_kmin;
-        uint32_t shift = c->shift;
-        if (rebased) fresh_binning(c, cb, kmin, shift);  // what k_sel_hist just counted under
+        const uint64_t kmin = new_kmin;
+        const uint32_t shift = new_shift;
         c->want = want;
         c->bstar = s_bstar;
         c->sel_kmin = kmin;
@@ -778,9 +855,6 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
         }
         c->spill_bin = sp;  // survivors in bins above it move to BACK
         s_sp = sp;
-        c->open_n[cb ^ 1].v = 0;
-        c->rng[cb ^ 1].kmin = ~0ull;
-        c->rng[cb ^ 1].kmax = 0;
         c->goal_best = ~0ull;
         c->first_solved = NIL;
         if (want == 0) {  // OPEN ran empty: no solution reachable
@@ -805,6 +879,10 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
     if (t == 0) {
         c->n_big = s_nbig;
         c->n_ord = want ? pre[s_bstar + 1] : 0;
+        // k_sel_collect tombstones what leaves FRONT: the bins handed to k_rank — which puts the overshoot of the threshold
+        // bin back into the same slots, so only the batch itself stays dead — and the bins that spill to BACK
+        c->ret_n.v = 0;
+        if (want) c->front_dead.v += want + (s_sp < NBIN ? pre[NBIN] - pre[s_sp + 1] : 0u);
         c->dbg_nord = want ? pre[s_bstar + 1] : 0;
         c->dbg_maxbin = s_maxbin;
         c->dbg_giant = s_giant;
@@ -812,10 +890,10 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
     }
 }
 
-// S3: scatter FRONT — at or below the threshold bin: into the scratch array, grouped by bin (k_rank orders each
-// bin); above: survivors -> the other FRONT buffer, or BACK when a spill lowered T.  One atomic per array per tile
-// for the survivors; the few entries bound for the scratch array are stashed in LDS and placed with one global
-// atomic per (workgroup, bin).
+// S3: take the batch's bins out of FRONT, in place.  Only the keys are read (8 bytes an entry); an entry at or below
+// the threshold bin is stashed in LDS (key + position), tombstoned, and placed — with its id, gathered then — into the
+// scratch array grouped by bin (k_rank orders each bin): one global atomic per (workgroup, bin).  When a spill lowered T,
+// the bins above the spill bin move to BACK the same way (one reservation per tile).
 __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ engs) {
     const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
@@ -823,43 +901,38 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
     Stamp stamp(E, P_SEL_COLLECT);
     __shared__ uint32_t sh[2 * 4 + 2];
     __shared__ uint64_t st_key[kStash];
-    __shared__ uint32_t st_id[kStash];
+    __shared__ uint32_t st_idx[kStash];
     __shared__ uint16_t st_f[kStash];
     __shared__ uint32_t lcnt[NBIN];
     __shared__ uint32_t st_n;
-    const uint32_t b = st_cur(c).cur_f, nf = b ^ 1, bb = c->cur_b;
+    const uint32_t b = c->cur_f, bb = c->cur_b;
     const uint32_t n = c->open_n[b].v;
     const uint64_t kmin = c->sel_kmin;
     const uint32_t shift = c->shift, bstar = c->bstar, spill = c->spill_bin;
-    const uint64_t* __restrict__ keys = E.open_key[b];
+    uint64_t* __restrict__ keys = E.open_key[b];
     const uint32_t* __restrict__ ids = E.open_id[b];
     constexpr uint32_t ITEMS = 8, TILE = 256 * ITEMS;
-    uint64_t fmn = ~0ull, fmx = 0, bmn = ~0ull, bmx = 0;
+    uint64_t bmn = ~0ull, bmx = 0;
     const uint32_t ntiles = (n + TILE - 1) / TILE;
     for (int i = threadIdx.x; i < NBIN; i += 256) lcnt[i] = 0;
     if (threadIdx.x == 0) st_n = 0;
     __syncthreads();
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint64_t k[ITEMS];
-        uint32_t id[ITEMS];
-        uint32_t dest = 0;  // 2 bits per item: 0 dead, 1 scratch (ordered by k_rank), 2 FRONT', 3 BACK
-        uint32_t cf = 0, cb = 0;
-        // all 16 loads of the tile first (nothing with a side effect in this loop: they stay in flight together) ...
+        uint32_t dest = 0;  // 2 bits per item: 0 stays (or dead), 1 scratch (ordered by k_rank), 3 BACK
+        // all loads of the tile first (unconditional, index-clamped: they stay in flight together) ...
 #pragma unroll
         for (uint32_t i = 0; i < ITEMS; i++) {
-            const uint32_t idx = tile * TILE + i * 256 + threadIdx.x;
-            const bool live = idx < n;
-            k[i] = live ? keys[idx] : 0;
-            id[i] = live ? ids[idx] : 0;
+            const uint32_t idx = tile * TILE + i * 256 + threadIdx.x, ic = idx < n ? idx : n - 1;
+            k[i] = keys[ic];
+            if (idx >= n) k[i] = DEAD;
         }
+        uint32_t cb = 0;
 #pragma unroll
         for (uint32_t i = 0; i < ITEMS; i++) {
-            const uint32_t idx = tile * TILE + i * 256 + threadIdx.x;
-            const bool live = idx < n;
             const uint32_t f = bin_of(k[i], kmin, shift);
-            const uint32_t d = !live ? 0u : (f <= bstar ? 1u : (f > spill ? 3u : 2u));
+            const uint32_t d = k[i] == DEAD ? 0u : (f <= bstar ? 1u : (f > spill ? 3u : 0u));
             dest |= d << (2 * i);
-            cf += d == 2u ? 1u : 0u;
             cb += d == 3u ? 1u : 0u;
         }
         // ... then the few entries bound for the scratch array (about one in seventy)
@@ -867,40 +940,41 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
 #pragma unroll
             for (uint32_t i = 0; i < ITEMS; i++) {
                 if (((dest >> (2 * i)) & 3u) != 1u) continue;
+                const uint32_t idx = tile * TILE + i * 256 + threadIdx.x;
                 const uint32_t f = bin_of(k[i], kmin, shift);
                 const uint32_t p = atomicAdd(&st_n, 1u);
+                keys[idx] = DEAD;
                 if (p < kStash) {
                     st_key[p] = k[i];
-                    st_id[p] = id[i];
+                    st_idx[p] = idx;
                     st_f[p] = (uint16_t)f;
                     atomicAdd(&lcnt[f], 1u);
                 } else {  // stash full (a workgroup rarely sees this many): place directly
                     const uint32_t pos = E.pre[f] + atomicAdd(&E.fill[f], 1u);
                     if (pos < E.pre[f + 1]) {
                         E.tmp_key[pos] = k[i];
-                        E.tmp_id[pos] = id[i];
+                        E.tmp_id[pos] = ids[idx];
                         E.tmp_f[pos] = (uint16_t)f;
+                        E.tmp_idx[pos] = idx;
                     } else {
                         c->failed = 1;  // histogram and FRONT disagree (cannot happen): refuse to write outside the bin's slice
                     }
                 }
             }
         }
-        Pos2 p = block_reserve2<256>(cf, cb, &c->open_n[nf].v, &c->open_n[bb].v, sh);
+        if (spill < NBIN) {  // a spill iteration (FRONT outgrew f_max): rare
+            Pos2 p = block_reserve2<256>(0u, cb, &c->open_n[bb].v, &c->open_n[bb].v, sh);
 #pragma unroll
-        for (uint32_t i = 0; i < ITEMS; i++) {
-            uint32_t d = (dest >> (2 * i)) & 3u;
-            if (d == 2u) {
-                E.open_key[nf][p.a] = k[i];
-                E.open_id[nf][p.a] = id[i];
-                p.a++;
-                fmn = k[i] < fmn ? k[i] : fmn;
-                fmx = k[i] > fmx ? k[i] : fmx;
-            } else if (d == 3u) {
+            for (uint32_t i = 0; i < ITEMS; i++) {
+                if (((dest >> (2 * i)) & 3u) != 3u) continue;
+                const uint32_t idx = tile * TILE + i * 256 + threadIdx.x;
                 if (p.b < E.max_nodes) {
                     E.open_key[bb][p.b] = k[i];
-                    E.open_id[bb][p.b] = id[i];
+                    E.open_id[bb][p.b] = ids[idx];
+                } else {
+                    c->failed = 1;
                 }
+                keys[idx] = DEAD;
                 p.b++;
                 bmn = k[i] < bmn ? k[i] : bmn;
                 bmx = k[i] > bmx ? k[i] : bmx;
@@ -919,39 +993,19 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
         __syncthreads();
         for (uint32_t p = threadIdx.x; p < ns; p += 256) {
             const uint32_t f = st_f[p];
+            const uint32_t id = ids[st_idx[p]];
             const uint32_t pos = E.pre[f] + atomicAdd(&lcnt[f], 1u);
             if (pos < E.pre[f + 1]) {
                 E.tmp_key[pos] = st_key[p];
-                E.tmp_id[pos] = st_id[p];
+                E.tmp_id[pos] = id;
                 E.tmp_f[pos] = (uint16_t)f;
+                E.tmp_idx[pos] = st_idx[p];
             } else {
                 c->failed = 1;  // (see above)
             }
         }
     }
-    // key ranges: reduced per block into E.part and folded into the control block by k_rank (four atomics) —
-    // a thousand waves doing atomicMin/Max on two words cost as much as the whole scatter
-    {
-        __shared__ uint64_t red[4][4];
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        uint64_t v[4] = {fmn, fmx, bmn, bmx};
-        for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                uint64_t u = __shfl_xor(v[q], o);
-                v[q] = (q & 1) ? (u > v[q] ? u : v[q]) : (u < v[q] ? u : v[q]);
-            }
-        }
-        if (lane == 0)
-            for (int q = 0; q < 4; q++) red[q][wv] = v[q];
-        __syncthreads();
-        if (threadIdx.x < 4) {
-            const int q = threadIdx.x;
-            uint64_t r = red[q][0];
-            for (int w = 1; w < 4; w++) r = (q & 1) ? (red[q][w] > r ? red[q][w] : r) : (red[q][w] < r ? red[q][w] : r);
-            E.part[q * kCollectBlocks + blockIdx.x] = r;
-        }
-    }
+    if (spill < NBIN) fold_range(c, bb, bmn, bmx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1009,29 +1063,42 @@ __device__ __forceinline__ void emit_pop(const Eng& E, Ctl* c, uint32_t rank, ui
             atomicMin(&c->first_solved, rank);
     }
 }
-// one ranked entry: into the batch (pop order) or back to FRONT'.  Wave-collective (open_append: one returning global
-// atomic per wave) — fine once per thread (the small-bin pass), NOT inside a loop: the large-bin path uses ret_put.
+// What k_rank does not pop (the overshoot of the threshold bin) goes back into FRONT — into the slots k_sel_collect
+// tombstoned: return number r (a global counter, at most n_ord - want of them) takes the slot scratch entry r came from
+// (E.tmp_idx[r]; any one-to-one assignment will do).  FRONT's physical size and key range do not change.
+// One ranked entry: into the batch (pop order) or back to FRONT.  Wave-collective (one returning global atomic per
+// wave) — fine once per thread (the small-bin pass), NOT inside a loop: the large-bin path uses ret_put.
 __device__ __forceinline__ void emit_ranked(const Eng& E, Ctl* c, uint32_t nf, bool live, uint32_t rank, uint32_t want,
                                             uint64_t key, uint32_t id) {
     if (live && rank < want) emit_pop(E, c, rank, key, id);
-    open_append(E, c, nf, live && rank >= want, key, id);
+    const bool back = live && rank >= want;
+    const unsigned long long mask = __ballot(back);
+    if (mask == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t basep = 0;
+    if (lane == leader) basep = atomicAdd(&c->ret_n.v, (uint32_t)__popcll(mask));
+    basep = __shfl(basep, leader);
+    if (back) {
+        const uint32_t slot = E.tmp_idx[basep + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))];
+        E.open_key[nf][slot] = key;
+        E.open_id[nf][slot] = id;
+    }
 }
-// The entries a work item hands back to FRONT' (the rest of a threshold bin) take slots of ONE reservation made for the
-// whole item; their positions come from an LDS counter.  (An open_append per loop round — a returning global atomic
-// per wave each time, sixteen rounds deep — was what made this path take 20-45 us.)
+// The entries a work item hands back take return numbers of ONE reservation made for the whole item; their positions
+// inside it come from an LDS counter.  (A returning global atomic per wave and loop round, sixteen rounds deep, was what
+// made this path take 20-45 us.)
 __device__ __forceinline__ void ret_begin(Ctl* c, RankShared& S, uint32_t nf, uint32_t count) {
     __syncthreads();
     if (threadIdx.x == 0) {
-        S.ret_base = count ? atomicAdd(&c->open_n[nf].v, count) : 0u;
+        S.ret_base = count ? atomicAdd(&c->ret_n.v, count) : 0u;
         S.ret_cnt = 0;
     }
     __syncthreads();
 }
-struct RetAcc {  // a thread's running key range of what it handed back
-    uint64_t kmn, kmx;
-};
-// wave-collective (call from wave-uniform control flow): the lanes with `pred` take consecutive slots, ONE LDS atomic per
-// wave and call.  (Per-entry atomics on the shared slot counter / key range — all on one LDS address — cost 30-60 us.)
+struct RetAcc {};  // (nothing to accumulate: an entry that goes back was inside FRONT's key range before)
+// wave-collective (call from wave-uniform control flow): the lanes with `pred` take consecutive return numbers, ONE LDS
+// atomic per wave and call.  (Per-entry atomics on the shared counter — all on one LDS address — cost 30-60 us.)
 __device__ __forceinline__ void ret_put(const Eng& E, Ctl* c, RankShared& S, uint32_t nf, bool pred, uint64_t key,
                                         uint32_t id, RetAcc& acc) {
     const unsigned long long mask = __ballot(pred);
@@ -1042,28 +1109,12 @@ __device__ __forceinline__ void ret_put(const Eng& E, Ctl* c, RankShared& S, uin
     if (lane == leader) basep = atomicAdd(&S.ret_cnt, (uint32_t)__popcll(mask));
     basep = __shfl(basep, leader);
     if (pred) {
-        const uint32_t pos = S.ret_base + basep + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        if (pos < E.max_nodes) {
-            E.open_key[nf][pos] = key;
-            E.open_id[nf][pos] = id;
-        } else {
-            c->failed = 1;
-        }
-        acc.kmn = key < acc.kmn ? key : acc.kmn;
-        acc.kmx = key > acc.kmx ? key : acc.kmx;
+        const uint32_t slot = E.tmp_idx[S.ret_base + basep + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))];
+        E.open_key[nf][slot] = key;
+        E.open_id[nf][slot] = id;
     }
 }
-__device__ __forceinline__ void ret_end(Ctl* c, uint32_t nf, RetAcc acc) {
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint64_t a = __shfl_xor(acc.kmn, o), b = __shfl_xor(acc.kmx, o);
-        acc.kmn = a < acc.kmn ? a : acc.kmn;
-        acc.kmx = b > acc.kmx ? b : acc.kmx;
-    }
-    if ((threadIdx.x & 63) == 0 && acc.kmn != ~0ull) {
-        atomicMin((unsigned long long*)&c->rng[nf].kmin, (unsigned long long)acc.kmn);
-        atomicMax((unsigned long long*)&c->rng[nf].kmax, (unsigned long long)acc.kmx);
-    }
-}
+__device__ __forceinline__ void ret_end(Ctl* c, uint32_t nf, RetAcc acc) {}
 
 // Entries of the bins of at most kTinyBin entries, a thread per entry: rank = entries in lower bins + smaller composites
 // inside the bin.  A workgroup takes RT consecutive scratch positions; the bins they belong to form one contiguous
@@ -1213,7 +1264,7 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
         }
         __syncthreads();
         ret_begin(c, S, nf, n - need);
-        RetAcc acc{~0ull, 0ull};
+        RetAcc acc{};
         const bool live = t < n;
         uint64_t k = 0;
         uint32_t id = 0, rank = 0;
@@ -1270,7 +1321,7 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
         // what THIS item hands back: everything above the threshold sub-bin, plus that sub-bin's overshoot unless the
         // sub-bin is refined by a work item of its own (which then reserves for itself)
         ret_begin(c, S, nf, (n - S.off[tsub + 1]) + (tsub_pushed ? 0u : S.off[tsub + 1] - need));
-        RetAcc acc{~0ull, 0ull};
+        RetAcc acc{};
 #pragma unroll
         for (int j = 0; j < kRegEnt; j++) {
             const bool live = t + (uint32_t)RT * j < n;
@@ -1354,7 +1405,7 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
     const uint32_t tsub = S.tsub;
     const bool tsub_pushed = S.off[tsub + 1] - S.off[tsub] > kSubMax && shc > 0;
     ret_begin(c, S, nf, (n - S.off[tsub + 1]) + (tsub_pushed ? 0u : S.off[tsub + 1] - need));
-    RetAcc acc{~0ull, 0ull};
+    RetAcc acc{};
     for (uint32_t b0 = 0; b0 < n; b0 += kLdsEnt) {
         uint64_t ek[kRegEnt];
         uint32_t ei[kRegEnt];
@@ -1416,37 +1467,7 @@ __global__ __launch_bounds__(RT) void k_rank(const Eng* __restrict__ engs) {
     uint64_t* LK = reinterpret_cast<uint64_t*>(rank_lds);
     uint32_t* LI = reinterpret_cast<uint32_t*>(rank_lds + (size_t)kLdsEnt * 8);
     const uint32_t t = threadIdx.x;
-    const uint32_t nf = st_cur(c).cur_f ^ 1, bb = c->cur_b;
-    if (blockIdx.x == 0) {
-        // fold k_sel_collect's per-block key ranges (survivors -> the new FRONT buffer, spills -> BACK)
-        __shared__ uint64_t red[4][16];
-        const int lane = t & 63, wv = t >> 6;
-        uint64_t v[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) v[q] = t < (uint32_t)kCollectBlocks ? E.part[q * kCollectBlocks + t] : ((q & 1) ? 0ull : ~0ull);
-        for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                uint64_t u = __shfl_xor(v[q], o);
-                v[q] = (q & 1) ? (u > v[q] ? u : v[q]) : (u < v[q] ? u : v[q]);
-            }
-        }
-        if (lane == 0)
-            for (int q = 0; q < 4; q++) red[q][wv] = v[q];
-        __syncthreads();
-        if (t < 4) {
-            const int q = (int)t;
-            uint64_t r = red[q][0];
-            for (int w = 1; w < RT / 64; w++) r = (q & 1) ? (red[q][w] > r ? red[q][w] : r) : (red[q][w] < r ? red[q][w] : r);
-            const uint32_t buf = q < 2 ? nf : bb;
-            // other workgroups append to FRONT' meanwhile (open_append): atomics, not plain stores
-            if (q & 1) {
-                if (r != 0ull) atomicMax((unsigned long long*)&c->rng[buf].kmax, (unsigned long long)r);
-            } else {
-                if (r != ~0ull) atomicMin((unsigned long long*)&c->rng[buf].kmin, (unsigned long long)r);
-            }
-        }
-    }
+    const uint32_t nf = c->cur_f;  // what the batch does not take goes back where it came from
     const uint32_t bstar = c->bstar, want = c->want;
     const uint32_t n_big = c->n_big, n_ord = c->n_ord;
     // ---- entries of small bins (most bins, about half the entries): one thread each, the whole grid at once
@@ -1488,7 +1509,7 @@ __global__ __launch_bounds__(RT) void k_rank(const Eng* __restrict__ engs) {
 // The pop's single-thread epilogue (thread 0 of the expansion's workgroup 0): goal bookkeeping and the state the rest
 // of the iteration — and the next one — starts from.
 __device__ __forceinline__ void close_pop(const Eng& E, Ctl* c, const IterState& S0, uint32_t it, uint32_t want,
-                                          uint32_t npop, uint32_t base, bool fail, uint32_t cur_new) {
+                                          uint32_t npop, uint32_t base, bool fail) {
     IterState N = S0;
     if (E.sem == DCA_SEM_PY) {
         // astar.py:73,421: any solved node among the popped ends the search after this iteration;
@@ -1526,7 +1547,6 @@ __device__ __forceinline__ void close_pop(const Eng& E, Ctl* c, const IterState&
     N.m = m;
     N.base = base;
     N.pool_n = base + m;
-    N.cur_f = cur_new;
     c->S[(it + 1) & 1] = N;
     c->gen += (int64_t)m;
     c->expanded += npop;
@@ -1559,8 +1579,8 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
     }
     const uint32_t base = (S0.pool_n + 15u) & ~15u;  // 16-aligned ids => 16-byte aligned child rows for every D
     const bool fail = (uint64_t)base + (uint64_t)npop * (uint64_t)EV::A > (uint64_t)E.max_nodes;
-    const uint32_t cur_new = S0.cur_f ^ 1;  // the survivors' buffer becomes FRONT; children are appended to it
-    if (blockIdx.x == 0 && threadIdx.x == 0) close_pop(E, c, S0, it, want, npop, base, fail, cur_new);
+    const uint32_t cur_new = c->cur_f;  // FRONT is edited in place: put-backs and children are appended to it
+    if (blockIdx.x == 0 && threadIdx.x == 0) close_pop(E, c, S0, it, want, npop, base, fail);
     if (fail) return;
     const uint32_t r0 = blockIdx.x * kTileParents;
     if (E.sem == DCA_SEM_CPP && r0 + kTileParents > npop) {
@@ -1989,7 +2009,7 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
     __shared__ uint32_t lh[NBIN];  // this workgroup's pushes into FRONT per selection bin (FRONT's histogram is incremental)
     const IterState& S1 = st_next(c);
     const uint32_t m = S1.m, base = S1.base;
-    const uint32_t fb = S1.cur_f, bb = c->cur_b;
+    const uint32_t fb = c->cur_f, bb = c->cur_b;
     const uint64_t T = c->T;
     const uint32_t j = blockIdx.x * 1024 + threadIdx.x;
     if (blockIdx.x * 1024 >= m) {
@@ -2064,7 +2084,7 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
     uint32_t pos[3];
     block_reserveK<1024, 3>(cnt, ctr, pos, sh);
     if (tof) {
-        if (pos[0] < E.max_nodes) {
+        if (pos[0] < E.front_cap) {
             E.open_key[fb][pos[0]] = key;
             E.open_id[fb][pos[0]] = id | pid_flag;
         } else {
@@ -2258,7 +2278,7 @@ int enqueue_first_half(dca_engine* e, int heur_id, bool with_refill, hipStream_t
     }
     // FRONT's selection histogram is recounted only in the refill-check ("rebase") iterations — every kRefillPeriod-th —
     // and maintained incrementally in between (k_sel_scan's writeback + k_commit's pushes)
-    if (with_refill) hipLaunchKernelGGL(k_sel_hist, gxy(kScanGrid, e), dim3(256), 0, s, d);
+    if (with_refill) hipLaunchKernelGGL(k_front_rebase, gxy(kCollectBlocks, e), dim3(256), 0, s, d);
     hipLaunchKernelGGL(k_sel_scan, gxy(1, e), dim3(1024), 0, s, d, with_refill ? 1 : 0);
     hipLaunchKernelGGL(k_sel_collect, gxy(kCollectBlocks, e), dim3(256), 0, s, d);
     hipLaunchKernelGGL(k_rank, gxy(kRankBlocks, e), dim3(RT), kRankLdsBytes, s, d);
@@ -2386,9 +2406,10 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
         ALLOC(move, N);
         ALLOC(solved, N);
         ALLOC(tab, (size_t)cap);
-        for (int b = 0; b < 4; b++) {  // FRONT ping-pong (0/1) + BACK and its compaction target (2/3)
-            ALLOC(open_key[b], N);
-            ALLOC(open_id[b], N);
+        E.front_cap = (uint32_t)(N + (size_t)(2 * kRefillPeriod) * Bz);
+        for (int b = 0; b < 4; b++) {  // FRONT and its compaction target (0/1) + BACK and its compaction target (2/3)
+            ALLOC(open_key[b], b < 2 ? (size_t)E.front_cap : N);
+            ALLOC(open_id[b], b < 2 ? (size_t)E.front_cap : N);
         }
         ALLOC(hist, NBIN);
         ALLOC(rhist, NBIN);
@@ -2398,6 +2419,7 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
         ALLOC(tmp_key, N);
         ALLOC(tmp_id, N);
         ALLOC(tmp_f, N);
+        ALLOC(tmp_idx, N);
         ALLOC(ord_key, N);
         ALLOC(ord_id, N);
         ALLOC(big_list, NBIN);
@@ -2737,7 +2759,7 @@ int dca_engine_status_instance(dca_engine* e, int inst, dca_status* out, void* s
     out->iterations = c.iters;
     out->nodes_generated = c.gen;
     out->nodes_expanded = c.expanded;
-    out->open_size = (int64_t)c.open_n[S.cur_f].v + (int64_t)c.open_n[c.cur_b].v - (int64_t)c.back_dead.v;
+    out->open_size = (int64_t)c.open_n[c.cur_f].v - (int64_t)c.front_dead.v + (int64_t)c.open_n[c.cur_b].v - (int64_t)c.back_dead.v;
     out->closed_size = c.closed_n.v;
     out->pool_size = S.pool_n;
     out->best_cost = S.has_best ? (double)S.best_cost : __builtin_nan("");
@@ -2758,10 +2780,10 @@ int dca_engine_debug(dca_engine* e, double* out, void* stream) {
         return d;
     };
     const IterState& S = c.S[(c.iters + (e->phase != 0 ? 1 : 0)) & 1];
-    out[0] = c.open_n[S.cur_f].v;
+    out[0] = (double)c.open_n[c.cur_f].v - (double)c.front_dead.v;
     out[1] = (double)c.open_n[c.cur_b].v - (double)c.back_dead.v;
-    out[2] = cost(c.rng[S.cur_f].kmin);
-    out[3] = cost(c.rng[S.cur_f].kmax);
+    out[2] = cost(c.rng[c.cur_f].kmin);
+    out[3] = cost(c.rng[c.cur_f].kmax);
     out[4] = cost(c.rng[c.cur_b].kmin);
     out[5] = cost(c.rng[c.cur_b].kmax);
     out[6] = cost(c.T);
