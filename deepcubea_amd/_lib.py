@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "dca_engine_root_nnet_in", "dca_engine_root_nnet_in_instance", "dca_engine_status_instance",
     "dca_engine_solution_instance", "dca_engine_pop_expand", "dca_engine_commit", "dca_engine_run_builtin",
     "dca_engine_enable_packed", "dca_engine_pop_expand_packed", "dca_engine_commit_packed",
-    "dca_engine_profile_builtin", "dca_engine_set_tiers", "dca_engine_debug", "dca_engine_status", "dca_engine_last_children", "dca_engine_solution",
+    "dca_engine_profile_builtin", "dca_engine_set_tiers", "dca_engine_debug", "dca_debug_tune", "dca_engine_status", "dca_engine_last_children", "dca_engine_solution",
     "dca_bn_workspace_bytes", "dca_bn_train_forward", "dca_bn_train_backward",
     "dca_l1_supported", "dca_l1_kpad", "dca_l1_onehot_gemm", "dca_act_split", "dca_f16x3_gemm", "dca_split_planes", "dca_f16x3_gemm_variant",
 ]

@@ -114,7 +114,7 @@ struct Ctl {
     uint32_t goal_id;
     // diagnostics of the last pop (dca_engine_debug): entries handed to k_rank, largest bin among them, bins beyond
     // the LDS sort capacity (those take the refinement path)
-    uint32_t dbg_nord, dbg_maxbin, dbg_giant, dbg_giant_seen;
+    uint32_t dbg_nord, dbg_maxbin, dbg_giant, dbg_giant_seen, dbg_maxsub;
     // ---- hot words -----------------------------------------------------------------------------
     Cnt open_n[4];   // physical entries per OPEN buffer (0/1 FRONT ping-pong, 2/3 BACK + its compaction target)
     Cnt closed_n, back_dead, front_dead, ret_n, ticket_a;  // *_dead: tombstones (key == DEAD) inside the tier's buffer
@@ -151,9 +151,11 @@ __device__ __forceinline__ bool pair_less(uint64_t ka, uint32_t ia, uint64_t kb,
 // launch slots of the device-side profile (dca_engine_profile_builtin)
 enum {
     P_REFILL_HIST = 0, P_REFILL_SCAN, P_REFILL_MOVE, P_SEL_HIST, P_SEL_SCAN, P_SEL_COLLECT, P_RANK, P_EXPAND, P_PROBE,
-    P_DECIDE, P_PACK, P_COMMIT, P_RANK_SMALL, P_RANK_BIG, P_COUNT
+    P_DECIDE, P_PACK, P_COMMIT, P_RANK_SMALL, P_RANK_BIG, P_RB_LOAD, P_RB_COUNT, P_RB_SCATTER, P_RB_ORDER, P_COUNT
 };
 constexpr int kProfSlots = 1024;
+// diagnostics: knobs a tuning run can flip without a rebuild (dca_debug_tune); 0 = the shipped behaviour
+__device__ int g_tune[8];
 
 struct Eng {
     int env, dim, D, A, B, sem, oh_dtype, depth;
@@ -237,6 +239,16 @@ struct Stamp {
         }
     }
 };
+
+// phase marks inside a launch (same slots; profile only)
+__device__ __forceinline__ void prof_begin(const Eng& E, int kid) {
+    if (E.prof != nullptr && threadIdx.x == 0 && blockIdx.y == 0)
+        atomicMin(E.prof + ((size_t)kid * kProfSlots + (blockIdx.x & (kProfSlots - 1))) * 2, (unsigned long long)wall_clock64());
+}
+__device__ __forceinline__ void prof_end(const Eng& E, int kid) {
+    if (E.prof != nullptr && threadIdx.x == 0 && blockIdx.y == 0)
+        atomicMax(E.prof + ((size_t)kid * kProfSlots + (blockIdx.x & (kProfSlots - 1))) * 2 + 1, (unsigned long long)wall_clock64());
+}
 
 // ---------------------------------------------------------------------------------------------
 // wave-aggregated append to the live OPEN buffer (+ running min/max of its keys)
@@ -394,6 +406,25 @@ __device__ __forceinline__ void block_reserveK(const uint32_t (&cnt)[K], uint32_
 #pragma unroll
     for (int k = 0; k < K; k++) pos[k] = sh[K * NW + k] + sh[k * NW + wv] + inc[k] - cnt[k];
     __syncthreads();
+}
+
+// One count per lane with `pred` into an LDS histogram.  Keys tie heavily (integer-valued heuristics give a few dozen
+// distinct costs), and sixty-four lanes adding to one LDS word are served one after the other: the first rounds pick a
+// lane, let every lane with the same bin ride along (ballot) and add the group with ONE atomic; whatever is left after
+// four rounds — distinct bins, mostly — goes the plain way.  Wave-collective.
+__device__ __forceinline__ void hist_add_wave(uint32_t* lh, uint32_t bin, bool pred) {
+    unsigned long long todo = __ballot(pred);
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (todo == 0) break;
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t b = __shfl(bin, leader);
+        const unsigned long long same = __ballot(pred && bin == b) & todo;
+        if (lane == leader) atomicAdd(&lh[b], (uint32_t)__popcll(same));
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1ull) atomicAdd(&lh[bin], 1u);
 }
 
 // fold a thread's running key range into a buffer's kmin/kmax (one atomic per wave, only if it helps)
@@ -712,7 +743,9 @@ __global__ __launch_bounds__(256) void k_front_rebase(const Eng* __restrict__ en
         Pos2 p = block_reserve2<256>(cl, 0u, &c->open_n[nb].v, &c->open_n[nb].v, sh);
 #pragma unroll
         for (uint32_t i = 0; i < ITEMS; i++) {
-            if (k[i] == DEAD) continue;
+            const bool lv = k[i] != DEAD;
+            hist_add_wave(lh, bin_of(k[i], kmin, shift), lv);
+            if (!lv) continue;
             if (p.a < E.front_cap) {
                 E.open_key[nb][p.a] = k[i];
                 E.open_id[nb][p.a] = id[i];
@@ -720,7 +753,6 @@ __global__ __launch_bounds__(256) void k_front_rebase(const Eng* __restrict__ en
                 c->failed = 1;
             }
             p.a++;
-            atomicAdd(&lh[bin_of(k[i], kmin, shift)], 1u);
             fmn = k[i] < fmn ? k[i] : fmn;
             fmx = k[i] > fmx ? k[i] : fmx;
         }
@@ -882,6 +914,7 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
         // k_sel_collect tombstones what leaves FRONT: the bins handed to k_rank — which puts the overshoot of the threshold
         // bin back into the same slots, so only the batch itself stays dead — and the bins that spill to BACK
         c->ret_n.v = 0;
+        c->dbg_maxsub = 0;
         if (want) c->front_dead.v += want + (s_sp < NBIN ? pre[NBIN] - pre[s_sp + 1] : 0u);
         c->dbg_nord = want ? pre[s_bstar + 1] : 0;
         c->dbg_maxbin = s_maxbin;
@@ -936,29 +969,34 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
             cb += d == 3u ? 1u : 0u;
         }
         // ... then the few entries bound for the scratch array (about one in seventy)
-        if (dest & 0x5555u & ~(dest >> 1)) {
 #pragma unroll
-            for (uint32_t i = 0; i < ITEMS; i++) {
-                if (((dest >> (2 * i)) & 3u) != 1u) continue;
-                const uint32_t idx = tile * TILE + i * 256 + threadIdx.x;
-                const uint32_t f = bin_of(k[i], kmin, shift);
-                const uint32_t p = atomicAdd(&st_n, 1u);
-                keys[idx] = DEAD;
-                if (p < kStash) {
-                    st_key[p] = k[i];
-                    st_idx[p] = idx;
-                    st_f[p] = (uint16_t)f;
-                    atomicAdd(&lcnt[f], 1u);
-                } else {  // stash full (a workgroup rarely sees this many): place directly
-                    const uint32_t pos = E.pre[f] + atomicAdd(&E.fill[f], 1u);
-                    if (pos < E.pre[f + 1]) {
-                        E.tmp_key[pos] = k[i];
-                        E.tmp_id[pos] = ids[idx];
-                        E.tmp_f[pos] = (uint16_t)f;
-                        E.tmp_idx[pos] = idx;
-                    } else {
-                        c->failed = 1;  // histogram and FRONT disagree (cannot happen): refuse to write outside the bin's slice
-                    }
+        for (uint32_t i = 0; i < ITEMS; i++) {
+            const bool take = ((dest >> (2 * i)) & 3u) == 1u;
+            const unsigned long long mk = __ballot(take);
+            if (mk == 0) continue;  // (wave-uniform)
+            // one stash reservation per wave and item, one LDS count per group of equal bins (hist_add_wave)
+            const int lane = threadIdx.x & 63, leader = __ffsll((long long)mk) - 1;
+            uint32_t p = 0;
+            if (lane == leader) p = atomicAdd(&st_n, (uint32_t)__popcll(mk));
+            p = __shfl(p, leader) + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
+            const uint32_t idx = tile * TILE + i * 256 + threadIdx.x;
+            const uint32_t f = bin_of(k[i], kmin, shift);
+            hist_add_wave(lcnt, f, take && p < kStash);
+            if (!take) continue;
+            keys[idx] = DEAD;
+            if (p < kStash) {
+                st_key[p] = k[i];
+                st_idx[p] = idx;
+                st_f[p] = (uint16_t)f;
+            } else {  // stash full (a workgroup rarely sees this many): place directly
+                const uint32_t pos = E.pre[f] + atomicAdd(&E.fill[f], 1u);
+                if (pos < E.pre[f + 1]) {
+                    E.tmp_key[pos] = k[i];
+                    E.tmp_id[pos] = ids[idx];
+                    E.tmp_f[pos] = (uint16_t)f;
+                    E.tmp_idx[pos] = idx;
+                } else {
+                    c->failed = 1;  // histogram and FRONT disagree (cannot happen): refuse to write outside the bin's slice
                 }
             }
         }
@@ -1036,13 +1074,14 @@ constexpr int kRegEnt = 16;                        // entries a thread keeps in 
 constexpr uint32_t kLdsEnt = RT * kRegEnt;         // items up to this size are bucketed entirely in LDS (96 KB)
 constexpr int kRankStack = 512;    // pending oversized sub-bins of one bin
 constexpr uint32_t kDirectMax = 512;  // items up to this size are ranked all-pairs out of LDS
-constexpr uint32_t kSubMax = 512;     // sub-bins up to this size are ranked in place, larger ones are refined again
+constexpr uint32_t kSubMaxDefault = 512;  // sub-bins up to this size are ranked in place, larger ones are refined again
+#define kSubMax ((uint32_t)(g_tune[1] ? g_tune[1] : (int)kSubMaxDefault))
 
 struct RankItem {
     uint32_t off, n, need, src;  // slice [off, off+n) of scratch array `src` (0 tmp, 1 ord); pop rank of its first entry = off
 };
 struct RankShared {
-    uint32_t cnt[kSub];      // sub-bin counts, then running scatter slots
+    uint32_t cnt[kSub + 64];  // sub-bin counts, then running scatter slots (+ one idle word per lane, see the LDS path)
     uint32_t off[kSub + 1];  // exclusive prefix
     uint32_t wsum[16];
     uint64_t red_lo[32], red_hi[32];
@@ -1115,6 +1154,38 @@ __device__ __forceinline__ void ret_put(const Eng& E, Ctl* c, RankShared& S, uin
     }
 }
 __device__ __forceinline__ void ret_end(Ctl* c, uint32_t nf, RetAcc acc) {}
+// NJ entries of one thread handed back at once (bit j of `preds`): one LDS atomic per wave for all of them, their slot
+// numbers fetched with unconditional (index-clamped) loads — all in flight together — then predicated stores.  A
+// ret_put per entry made every round wait for its own E.tmp_idx round trip.  Wave-collective.
+template <int NJ>
+__device__ __forceinline__ void ret_put_many(const Eng& E, RankShared& S, uint32_t nf, uint32_t n_ord, uint32_t preds,
+                                             const uint64_t* key, const uint32_t* id) {
+    const uint32_t cnt = (uint32_t)__popc(preds);
+    const int lane = threadIdx.x & 63;
+    uint32_t incl = cnt;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = __shfl_up(incl, o);
+        if (lane >= o) incl += u;
+    }
+    const uint32_t total = __shfl(incl, 63);
+    if (total == 0) return;
+    uint32_t basep = 0;
+    if (lane == 63) basep = atomicAdd(&S.ret_cnt, total);
+    basep = __shfl(basep, 63);
+    uint32_t r = S.ret_base + basep + incl - cnt;
+    uint32_t slot[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        slot[j] = E.tmp_idx[r < n_ord ? r : n_ord - 1];
+        r += (preds >> j) & 1u;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+        if ((preds >> j) & 1u) {
+            E.open_key[nf][slot[j]] = key[j];
+            E.open_id[nf][slot[j]] = id[j];
+        }
+}
 
 // Entries of the bins of at most kTinyBin entries, a thread per entry: rank = entries in lower bins + smaller composites
 // inside the bin.  A workgroup takes RT consecutive scratch positions; the bins they belong to form one contiguous
@@ -1281,6 +1352,7 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
     }
     uint32_t lg = 0;
     while ((8u << lg) <= n && lg < 11) lg++;  // 2^lg <= n / 4, at most kSub sub-bins
+    lg = lg + (uint32_t)g_tune[0] < 11u ? lg + (uint32_t)g_tune[0] : 11u;
     if (n <= kLdsEnt) {
         // ---- the item is read from HBM ONCE (8 entries per thread, kept in registers), bucketed and ranked in LDS
         uint64_t ek[kRegEnt];
@@ -1288,6 +1360,7 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
         u128 vmin = ~(u128)0, vmax = 0;
         // (index clamped, not predicated: a predicated load compiles to branch + wait per element here — sixteen
         // serialized memory round trips, which is what made this path take 20-45 us)
+        prof_begin(E, P_RB_LOAD);
 #pragma unroll
         for (int j = 0; j < kRegEnt; j++) {
             const uint32_t i = t + (uint32_t)RT * j, ic = i < n ? i : n - 1;
@@ -1302,6 +1375,8 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
                 vmax = v > vmax ? v : vmax;
             }
         rank_range(S, vmin, vmax);
+        prof_end(E, P_RB_LOAD);
+        prof_begin(E, P_RB_COUNT);
         const u128 base = ((u128)S.vmin_hi << 64) | S.vmin_lo;
         const uint32_t bits = S.bits;
         if (lg > bits) lg = bits;  // cannot cut finer than one composite value
@@ -1316,49 +1391,92 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
         }
         __syncthreads();
         rank_prefix(S, nsub, need);
+        prof_end(E, P_RB_COUNT);
+        prof_begin(E, P_RB_SCATTER);
+        if (E.prof != nullptr) {  // (diagnostic) largest sub-bin
+            uint32_t mx = 0;
+            for (uint32_t sb = t; sb < nsub; sb += RT) mx = max(mx, S.off[sb + 1] - S.off[sb]);
+            if (mx > 16) atomicMax(&c->dbg_maxsub, mx);
+        }
         const uint32_t tsub = S.tsub;
         const bool tsub_pushed = S.off[tsub + 1] - S.off[tsub] > kSubMax && shc > 0;
         // what THIS item hands back: everything above the threshold sub-bin, plus that sub-bin's overshoot unless the
         // sub-bin is refined by a work item of its own (which then reserves for itself)
         ret_begin(c, S, nf, (n - S.off[tsub + 1]) + (tsub_pushed ? 0u : S.off[tsub + 1] - need));
-        RetAcc acc{};
+        const uint32_t n_ord = c->n_ord;
+        {
+            // Nothing conditional around the LDS reads / returning atomics (a branch per entry means a wait per entry): an
+            // entry that does not take part adds zero to an idle word of its own lane.
+            uint32_t inm = 0, retm = 0, so[kRegEnt], sl[kRegEnt];
 #pragma unroll
-        for (int j = 0; j < kRegEnt; j++) {
-            const bool live = t + (uint32_t)RT * j < n;
-            if (live && es[j] <= tsub) {
-                const uint32_t p = S.off[es[j]] + atomicAdd(&S.cnt[es[j]], 1u);
-                LK[p] = ek[j];
-                LI[p] = ei[j];
+            for (int j = 0; j < kRegEnt; j++) {
+                const bool live = t + (uint32_t)RT * j < n, in = live && es[j] <= tsub;
+                inm |= (in ? 1u : 0u) << j;
+                retm |= (live && !in ? 1u : 0u) << j;  // the rest of a threshold bin stays in OPEN
+                so[j] = S.off[in ? es[j] : 0u];
+                sl[j] = atomicAdd(&S.cnt[in ? es[j] : (uint32_t)kSub + (t & 63u)], in ? 1u : 0u);
             }
-            ret_put(E, c, S, nf, live && es[j] > tsub, ek[j], ei[j], acc);  // the rest of a threshold bin stays in OPEN
+#pragma unroll
+            for (int j = 0; j < kRegEnt; j++)
+                if ((inm >> j) & 1u) {
+                    LK[so[j] + sl[j]] = ek[j];
+                    LI[so[j] + sl[j]] = ei[j];
+                }
+            ret_put_many<kRegEnt>(E, S, nf, n_ord, retm, ek, ei);
         }
         __syncthreads();
+        prof_end(E, P_RB_SCATTER);
+        prof_begin(E, P_RB_ORDER);
         const uint32_t m = S.off[tsub + 1];
-        for (uint32_t p0 = 0; p0 < m; p0 += RT) {
-            const uint32_t p = p0 + t;
-            bool live = p < m;
-            uint64_t k = 0;
-            uint32_t id = 0, rank = 0;
-            if (live) {
-                k = LK[p];
-                id = LI[p];
-                const uint32_t sub = sub_of(k, id, base, shc, nsub);
-                const uint32_t s0 = S.off[sub], e0 = S.off[sub + 1];
-                if (e0 - s0 > kSubMax && shc > 0) {
-                    K2[p] = k;  // refined by the sub-bin's own work item, from the other scratch array
-                    I2[p] = id;
-                    live = false;
-                } else {
-                    rank = s0;
-                    for (uint32_t j = s0; j < e0; j++) rank += pair_less(LK[j], LI[j], k, id) ? 1u : 0u;
-                    if (rank < need) emit_pop(E, c, it.off + rank, k, id);
+        constexpr int U = 8;  // entries a thread ranks side by side: their LDS reads overlap instead of queueing up
+        for (uint32_t p0 = 0; p0 < m; p0 += RT * U) {
+            uint64_t k[U];
+            uint32_t id[U], s0[U], cn[U], rank[U], livem = 0, bigm = 0, trip = 0;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t p = p0 + (uint32_t)u * RT + t;
+                livem |= (p < m ? 1u : 0u) << u;
+                k[u] = LK[p < m ? p : m - 1];
+                id[u] = LI[p < m ? p : m - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t sub = sub_of(k[u], id[u], base, shc, nsub);
+                s0[u] = S.off[sub];
+                cn[u] = S.off[sub + 1] - s0[u];
+                rank[u] = s0[u];
+                if (!((livem >> u) & 1u)) cn[u] = 0;
+                if (cn[u] > kSubMax && shc > 0) {  // refined by the sub-bin's own work item, from the other scratch array
+                    bigm |= 1u << u;
+                    cn[u] = 0;
+                }
+                trip = cn[u] > trip ? cn[u] : trip;
+            }
+            for (uint32_t jj = 0; jj < trip; jj++) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint32_t j = s0[u] + (jj < cn[u] ? jj : 0u);
+                    const bool less = pair_less(LK[j], LI[j], k[u], id[u]);
+                    rank[u] += (jj < cn[u] && less) ? 1u : 0u;
                 }
             }
-            ret_put(E, c, S, nf, live && rank >= need, k, id, acc);
+            uint32_t retm = 0;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t p = p0 + (uint32_t)u * RT + t;
+                if ((bigm >> u) & 1u) {
+                    K2[p] = k[u];
+                    I2[p] = id[u];
+                } else if ((livem >> u) & 1u) {
+                    if (rank[u] < need) emit_pop(E, c, it.off + rank[u], k[u], id[u]);
+                    else retm |= 1u << u;
+                }
+            }
+            ret_put_many<U>(E, S, nf, n_ord, retm, k, id);
         }
         rank_push(S, it, tsub, need, shc);
-        ret_end(c, nf, acc);
         __syncthreads();
+        prof_end(E, P_RB_ORDER);
         return;
     }
     // ---- larger than LDS: three streaming passes over the slice, 8 loads in flight per thread
@@ -1540,6 +1658,7 @@ __device__ __forceinline__ void close_pop(const Eng& E, Ctl* c, const IterState&
     if (fail) {  // node pool exhausted
         c->failed = 1;
         c->done = 1;
+        c->front_dead.v -= want;  // the pop is void: OPEN's reported size stays that of the last complete iteration
         return;
     }
     const uint32_t m = npop * (uint32_t)E.A;
@@ -1550,7 +1669,6 @@ __device__ __forceinline__ void close_pop(const Eng& E, Ctl* c, const IterState&
     c->S[(it + 1) & 1] = N;
     c->gen += (int64_t)m;
     c->expanded += npop;
-    (void)want;
 }
 
 constexpr int kEngTile = 16;  // parents per workgroup: a 20 000-parent batch then fills the chip (1250 workgroups)
@@ -2078,7 +2196,7 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
         key = key_of_cost(cost);
     }
     const bool tof = keep && key <= T, tob = keep && key > T;
-    if (tof) atomicAdd(&lh[bin_of(key, bin_kmin, bin_shift)], 1u);
+    hist_add_wave(lh, bin_of(key, bin_kmin, bin_shift), tof);
     const uint32_t cnt[3] = {tof ? 1u : 0u, tob ? 1u : 0u, is_new ? 1u : 0u};
     uint32_t* const ctr[3] = {&c->open_n[fb].v, &c->open_n[bb].v, &c->closed_n.v};
     uint32_t pos[3];
@@ -2736,6 +2854,13 @@ int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, int use_gr
     return rc;
 }
 
+int dca_debug_tune(int knob, int value) {
+    // diagnostics: 0 extra log2 of sub-bins per large bin, 1 sub-bin size above which a sub-bin is refined on its own
+    DCA_ARG(knob >= 0 && knob < 8);
+    DCA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tune), &value, sizeof(int), (size_t)knob * sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+}
+
 int dca_engine_set_tiers(dca_engine* e, int64_t front_keep, int64_t front_max) {
     // test / tuning hook: FRONT hysteresis in entries (defaults 32*B and 96*B).  Search results never depend on it.
     DCA_ARG(e != nullptr && front_keep >= 1 && front_max >= front_keep && front_max < (1ll << 31));
@@ -2792,7 +2917,7 @@ int dca_engine_debug(dca_engine* e, double* out, void* stream) {
     out[9] = c.dbg_nord;
     out[10] = c.dbg_maxbin;
     out[11] = c.dbg_giant_seen;
-    out[12] = c.shift;
+    out[12] = c.dbg_maxsub;
     out[13] = c.spill_bin;
     out[14] = S.npop;
     out[15] = S.m;

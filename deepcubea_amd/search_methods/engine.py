@@ -141,7 +141,8 @@ class BwasEngine:
                                                      _lib.stream_ptr()), "dca_engine_run_builtin")
 
     PROF_SLOTS = ["refill_hist", "refill_scan", "refill_move", "sel_hist", "sel_scan", "sel_collect", "rank", "expand",
-                  "probe", "decide", "pack", "commit", "rank_small", "rank_big"]
+                  "probe", "decide", "pack", "commit", "rank_small", "rank_big", "rank_big_load", "rank_big_count",
+                  "rank_big_scatter", "rank_big_order"]
 
     def profile_builtin(self, heur_id: int, iters: int, use_graph: bool = True) -> dict:
         """Device-side profile of `iters` built-in iterations (graph replays by default): per launch the busy span
@@ -164,7 +165,7 @@ class BwasEngine:
         out = (C.c_double * 16)()
         _lib.check(_lib.lib().dca_engine_debug(self._h, out, _lib.stream_ptr()), "dca_engine_debug")
         names = ["front_n", "back_n", "front_cmin", "front_cmax", "back_cmin", "back_cmax", "T", "want", "bstar",
-                 "n_ord", "max_bin", "giant_bins_seen", "shift", "spill_bin", "npop", "m"]
+                 "n_ord", "max_bin", "giant_bins_seen", "max_sub", "spill_bin", "npop", "m"]
         return dict(zip(names, list(out)))
 
     def status(self, instance: int = 0) -> dict:

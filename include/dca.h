@@ -221,7 +221,7 @@ int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph,
  * (gap_ms may be NULL).  Slots: 0 refill_hist 1 refill_scan 2 refill_move (every 8th iteration) 3 sel_hist 4 sel_scan
  * 5 sel_collect 6 rank 7 expand 8 probe 9 decide 10 pack (dedup-first stepping only) 11 commit; 12 / 13 = the two halves of
  * the rank launch (small-bin pass, large-bin workgroups) for tuning.  Synchronises every iteration.                                                                                                          */
-#define DCA_PROF_SLOTS 14
+#define DCA_PROF_SLOTS 18
 int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, int use_graph, float* span_ms /*host [DCA_PROF_SLOTS]*/,
                                float* gap_ms /*host [DCA_PROF_SLOTS] or NULL*/, void* stream);
 /* synchronises the stream */
@@ -231,6 +231,8 @@ int dca_engine_status_instance(dca_engine* e, int inst, dca_status* out, void* s
 int dca_engine_set_tiers(dca_engine* e, int64_t front_keep, int64_t front_max);
 /* internals of the last iteration for diagnostics (host double[16]; layout in dca_engine.hip); synchronises */
 int dca_engine_debug(dca_engine* e, double* out /*host [16]*/, void* stream);
+/* diagnostics: flips a tuning knob of the engine kernels process-wide (0 = shipped behaviour); never needed in production */
+int dca_debug_tune(int knob, int value);
 /* child rows of the last pop_expand straight from the node pool (device [m_live, D]); synchronises */
 int dca_engine_last_children(dca_engine* e, const uint8_t** states, int64_t* m_live, void* stream);
 /* root->goal move list (astar.py:213-229 get_path / cpp:336-341).  synchronises.                 */

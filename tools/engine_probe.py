@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-iteration view of the engine at the bench geometry: pop diagnostics (bins handed to k_rank, largest bin, FRONT
-size) next to the device-side launch spans of the same iteration.  python tools/engine_probe.py [env] [B] [warm] [n]"""
+size) next to the device-side launch spans of the same iteration.  python tools/engine_probe.py [env] [B] [warm] [n] [knob=value ...]"""
 import json
 import os
 import sys
@@ -17,6 +17,9 @@ env = sys.argv[1] if len(sys.argv) > 1 else "cube3"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 warm = int(sys.argv[3]) if len(sys.argv) > 3 else 60
 n = int(sys.argv[4]) if len(sys.argv) > 4 else 24
+for kv in sys.argv[5:]:  # knob=value pairs for dca_debug_tune (diagnostics)
+    k, v = kv.split("=")
+    _lib.check(_lib.lib().dca_debug_tune(int(k), int(v)), "dca_debug_tune")
 A = 12 if env == "cube3" else 4
 g = np.load(os.path.join(ROOT, "tests", "golden", "golden.npz"))
 root = np.ascontiguousarray(g[env + "_test_states"][0])
@@ -28,7 +31,7 @@ for it in range(n):
     prof = eng.profile_builtin(2, 1, use_graph=True)
     d = eng.debug()
     row = {"it": warm + it, "front_n": int(d["front_n"]), "back_n": int(d["back_n"]), "bstar": int(d["bstar"]),
-           "n_ord": int(d["n_ord"]), "max_bin": int(d["max_bin"]), "giant_seen": int(d["giant_bins_seen"]),
+           "n_ord": int(d["n_ord"]), "max_bin": int(d["max_bin"]), "max_sub": int(d["max_sub"]),
            "span_us": {k: round(v * 1e3, 1) for k, v in prof["span_ms"].items()},
            "gap_us": {k: round(v * 1e3, 1) for k, v in prof["gap_ms"].items()}}
     print(json.dumps(row))
