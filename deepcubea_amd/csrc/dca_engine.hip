@@ -1352,11 +1352,18 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
     }
     uint32_t lg = 0;
     while ((8u << lg) <= n && lg < 11) lg++;  // 2^lg <= n / 4, at most kSub sub-bins
-    lg = lg + (uint32_t)g_tune[0] < 11u ? lg + (uint32_t)g_tune[0] : 11u;
+    {  // one step finer than n / 4 (shorter ranking loops), tunable for experiments
+        const uint32_t lgx = lg + 1u + (uint32_t)g_tune[0];
+        lg = lgx < 11u ? lgx : 11u;
+    }
     if (n <= kLdsEnt) {
-        // ---- the item is read from HBM ONCE (8 entries per thread, kept in registers), bucketed and ranked in LDS
+        // ---- the item is read from HBM ONCE (kRegEnt entries per thread, kept in registers), bucketed and ranked in LDS.
+        // Inside the item every (key,id) composite is held as its 64-bit offset from the item's smallest composite: one
+        // LDS word to read and one compare per pair in the ranking loop, shifts instead of 128-bit arithmetic for the
+        // sub-bin.  (An item whose composites span more than 64 bits — a large bin of widely spread keys — takes the
+        // streaming path below, which works on full composites.)
         uint64_t ek[kRegEnt];
-        uint32_t ei[kRegEnt], es[kRegEnt];
+        uint32_t ei[kRegEnt];
         u128 vmin = ~(u128)0, vmax = 0;
         // (index clamped, not predicated: a predicated load compiles to branch + wait per element here — sixteen
         // serialized memory round trips, which is what made this path take 20-45 us)
@@ -1376,110 +1383,117 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
             }
         rank_range(S, vmin, vmax);
         prof_end(E, P_RB_LOAD);
-        prof_begin(E, P_RB_COUNT);
-        const u128 base = ((u128)S.vmin_hi << 64) | S.vmin_lo;
         const uint32_t bits = S.bits;
-        if (lg > bits) lg = bits;  // cannot cut finer than one composite value
-        const uint32_t nsub = 1u << lg, shc = bits - lg;
-#pragma unroll
-        for (int j = 0; j < kRegEnt; j++) {
-            es[j] = 0;
-            if (t + (uint32_t)RT * j < n) {
-                es[j] = sub_of(ek[j], ei[j], base, shc, nsub);
-                atomicAdd(&S.cnt[es[j]], 1u);
-            }
-        }
-        __syncthreads();
-        rank_prefix(S, nsub, need);
-        prof_end(E, P_RB_COUNT);
-        prof_begin(E, P_RB_SCATTER);
-        if (E.prof != nullptr) {  // (diagnostic) largest sub-bin
-            uint32_t mx = 0;
-            for (uint32_t sb = t; sb < nsub; sb += RT) mx = max(mx, S.off[sb + 1] - S.off[sb]);
-            if (mx > 16) atomicMax(&c->dbg_maxsub, mx);
-        }
-        const uint32_t tsub = S.tsub;
-        const bool tsub_pushed = S.off[tsub + 1] - S.off[tsub] > kSubMax && shc > 0;
-        // what THIS item hands back: everything above the threshold sub-bin, plus that sub-bin's overshoot unless the
-        // sub-bin is refined by a work item of its own (which then reserves for itself)
-        ret_begin(c, S, nf, (n - S.off[tsub + 1]) + (tsub_pushed ? 0u : S.off[tsub + 1] - need));
-        const uint32_t n_ord = c->n_ord;
-        {
-            // Nothing conditional around the LDS reads / returning atomics (a branch per entry means a wait per entry): an
-            // entry that does not take part adds zero to an idle word of its own lane.
-            uint32_t inm = 0, retm = 0, so[kRegEnt], sl[kRegEnt];
+        if (bits <= 64) {
+            prof_begin(E, P_RB_COUNT);
+            const u128 base = ((u128)S.vmin_hi << 64) | S.vmin_lo;
+            if (lg > bits) lg = bits;  // cannot cut finer than one composite value
+            const uint32_t nsub = 1u << lg, shc = bits - lg;  // (shc <= 63: bits == 64 comes with lg >= 1)
+            // the composites' offsets from `base` replace the keys (registers are short here: no spills wanted)
 #pragma unroll
             for (int j = 0; j < kRegEnt; j++) {
-                const bool live = t + (uint32_t)RT * j < n, in = live && es[j] <= tsub;
-                inm |= (in ? 1u : 0u) << j;
-                retm |= (live && !in ? 1u : 0u) << j;  // the rest of a threshold bin stays in OPEN
-                so[j] = S.off[in ? es[j] : 0u];
-                sl[j] = atomicAdd(&S.cnt[in ? es[j] : (uint32_t)kSub + (t & 63u)], in ? 1u : 0u);
-            }
-#pragma unroll
-            for (int j = 0; j < kRegEnt; j++)
-                if ((inm >> j) & 1u) {
-                    LK[so[j] + sl[j]] = ek[j];
-                    LI[so[j] + sl[j]] = ei[j];
+                ek[j] = (uint64_t)(comp_of(ek[j], ei[j]) - base);
+                if (t + (uint32_t)RT * j < n) {
+                    const uint64_t q = ek[j] >> shc;
+                    atomicAdd(&S.cnt[q < nsub ? (uint32_t)q : nsub - 1u], 1u);
                 }
-            ret_put_many<kRegEnt>(E, S, nf, n_ord, retm, ek, ei);
-        }
-        __syncthreads();
-        prof_end(E, P_RB_SCATTER);
-        prof_begin(E, P_RB_ORDER);
-        const uint32_t m = S.off[tsub + 1];
-        constexpr int U = 8;  // entries a thread ranks side by side: their LDS reads overlap instead of queueing up
-        for (uint32_t p0 = 0; p0 < m; p0 += RT * U) {
-            uint64_t k[U];
-            uint32_t id[U], s0[U], cn[U], rank[U], livem = 0, bigm = 0, trip = 0;
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint32_t p = p0 + (uint32_t)u * RT + t;
-                livem |= (p < m ? 1u : 0u) << u;
-                k[u] = LK[p < m ? p : m - 1];
-                id[u] = LI[p < m ? p : m - 1];
             }
+            __syncthreads();
+            rank_prefix(S, nsub, need);
+            prof_end(E, P_RB_COUNT);
+            prof_begin(E, P_RB_SCATTER);
+            if (E.prof != nullptr) {  // (diagnostic) largest sub-bin
+                uint32_t mx = 0;
+                for (uint32_t sb = t; sb < nsub; sb += RT) mx = max(mx, S.off[sb + 1] - S.off[sb]);
+                if (mx > 16) atomicMax(&c->dbg_maxsub, mx);
+            }
+            const uint32_t tsub = S.tsub;
+            const bool tsub_pushed = S.off[tsub + 1] - S.off[tsub] > kSubMax && shc > 0;
+            // what THIS item hands back: everything above the threshold sub-bin, plus that sub-bin's overshoot unless the
+            // sub-bin is refined by a work item of its own (which then reserves for itself)
+            ret_begin(c, S, nf, (n - S.off[tsub + 1]) + (tsub_pushed ? 0u : S.off[tsub + 1] - need));
+            const uint32_t n_ord = c->n_ord;
+            {
+                // Nothing conditional around the LDS reads / returning atomics (a branch per entry means a wait per
+                // entry): an entry that does not take part adds zero to an idle word of its own lane.
+                uint32_t inm = 0, retm = 0, pos[kRegEnt];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint32_t sub = sub_of(k[u], id[u], base, shc, nsub);
-                s0[u] = S.off[sub];
-                cn[u] = S.off[sub + 1] - s0[u];
-                rank[u] = s0[u];
-                if (!((livem >> u) & 1u)) cn[u] = 0;
-                if (cn[u] > kSubMax && shc > 0) {  // refined by the sub-bin's own work item, from the other scratch array
-                    bigm |= 1u << u;
-                    cn[u] = 0;
+                for (int j = 0; j < kRegEnt; j++) {
+                    const uint64_t q = ek[j] >> shc;
+                    const uint32_t sub = q < nsub ? (uint32_t)q : nsub - 1u;
+                    const bool live = t + (uint32_t)RT * j < n, in = live && sub <= tsub;
+                    inm |= (in ? 1u : 0u) << j;
+                    retm |= (live && !in ? 1u : 0u) << j;  // the rest of a threshold bin stays in OPEN
+                    pos[j] = S.off[in ? sub : 0u] + atomicAdd(&S.cnt[in ? sub : (uint32_t)kSub + (t & 63u)], in ? 1u : 0u);
                 }
-                trip = cn[u] > trip ? cn[u] : trip;
+#pragma unroll
+                for (int j = 0; j < kRegEnt; j++) {
+                    if ((inm >> j) & 1u) {
+                        LK[pos[j]] = ek[j];
+                        LI[pos[j]] = ei[j];
+                    }
+                    ek[j] = (uint64_t)((base + (u128)ek[j]) >> 32);  // the key back from the offset
+                }
+                ret_put_many<kRegEnt>(E, S, nf, n_ord, retm, ek, ei);
             }
-            for (uint32_t jj = 0; jj < trip; jj++) {
+            __syncthreads();
+            prof_end(E, P_RB_SCATTER);
+            prof_begin(E, P_RB_ORDER);
+            const uint32_t m = S.off[tsub + 1];
+            constexpr int U = 4;  // entries a thread ranks side by side: their LDS reads overlap instead of queueing up
+            for (uint32_t p0 = 0; p0 < m; p0 += RT * U) {
+                uint64_t o[U], k[U];
+                uint32_t id[U], s0[U], cn[U], rank[U], livem = 0, bigm = 0, trip = 0;
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    const uint32_t j = s0[u] + (jj < cn[u] ? jj : 0u);
-                    const bool less = pair_less(LK[j], LI[j], k[u], id[u]);
-                    rank[u] += (jj < cn[u] && less) ? 1u : 0u;
+                    const uint32_t p = p0 + (uint32_t)u * RT + t;
+                    livem |= (p < m ? 1u : 0u) << u;
+                    o[u] = LK[p < m ? p : m - 1];
+                    id[u] = LI[p < m ? p : m - 1];
                 }
-            }
-            uint32_t retm = 0;
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint32_t p = p0 + (uint32_t)u * RT + t;
-                if ((bigm >> u) & 1u) {
-                    K2[p] = k[u];
-                    I2[p] = id[u];
-                } else if ((livem >> u) & 1u) {
-                    if (rank[u] < need) emit_pop(E, c, it.off + rank[u], k[u], id[u]);
-                    else retm |= 1u << u;
+                for (int u = 0; u < U; u++) {
+                    const uint64_t q = o[u] >> shc;
+                    const uint32_t sub = q < nsub ? (uint32_t)q : nsub - 1u;
+                    s0[u] = S.off[sub];
+                    cn[u] = S.off[sub + 1] - s0[u];
+                    rank[u] = s0[u];
+                    if (!((livem >> u) & 1u)) cn[u] = 0;
+                    if (cn[u] > kSubMax && shc > 0) {  // refined by the sub-bin's own work item, from the other scratch array
+                        bigm |= 1u << u;
+                        cn[u] = 0;
+                    }
+                    trip = cn[u] > trip ? cn[u] : trip;
                 }
+                for (uint32_t jj = 0; jj < trip; jj++) {
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const uint64_t other = LK[s0[u] + (jj < cn[u] ? jj : 0u)];
+                        rank[u] += (jj < cn[u] && other < o[u]) ? 1u : 0u;
+                    }
+                }
+                uint32_t retm = 0;
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint32_t p = p0 + (uint32_t)u * RT + t;
+                    k[u] = (uint64_t)((base + (u128)o[u]) >> 32);  // the key back from the offset
+                    if ((bigm >> u) & 1u) {
+                        K2[p] = k[u];
+                        I2[p] = id[u];
+                    } else if ((livem >> u) & 1u) {
+                        if (rank[u] < need) emit_pop(E, c, it.off + rank[u], k[u], id[u]);
+                        else retm |= 1u << u;
+                    }
+                }
+                ret_put_many<U>(E, S, nf, n_ord, retm, k, id);
             }
-            ret_put_many<U>(E, S, nf, n_ord, retm, k, id);
+            rank_push(S, it, tsub, need, shc);
+            __syncthreads();
+            prof_end(E, P_RB_ORDER);
+            return;
         }
-        rank_push(S, it, tsub, need, shc);
-        __syncthreads();
-        prof_end(E, P_RB_ORDER);
-        return;
     }
-    // ---- larger than LDS: three streaming passes over the slice, 8 loads in flight per thread
+    // ---- larger than LDS (or composites wider than 64 bits): three streaming passes over the slice, 8 loads in flight per thread
     {
         u128 vmin = ~(u128)0, vmax = 0;
         for (uint32_t b0 = 0; b0 < n; b0 += kLdsEnt) {
