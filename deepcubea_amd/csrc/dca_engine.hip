@@ -53,6 +53,9 @@ constexpr int kCollectBlocks = 512;   // k_sel_collect: two workgroups per CU ke
 constexpr int kRankBlocks = 256;      // k_rank: one 1024-thread workgroup per CU, the bins to order strided over them
 constexpr int kTinyBin = 128;         // bins up to this size are ranked one THREAD per entry (all-pairs inside the bin)
 constexpr int kSortCap = 8192;        // diagnostics only: bins beyond this many entries are counted as "giant"
+constexpr int RT = 512;                            // threads of a k_rank workgroup (8 waves: up to 256 VGPRs each)
+constexpr int kRegEnt = 16;                        // entries a thread keeps in registers
+constexpr uint32_t kLdsEnt = RT * kRegEnt;         // items up to this size are bucketed entirely in LDS (96 KB)
 constexpr int kStash = 3072;          // per-workgroup LDS stash of k_sel_collect (entries at or below the threshold bin)
 constexpr uint32_t NIL = 0xFFFFFFFFu;
 // OPEN entries carry "this node is solved" in bit 31 of the id (node ids stay below 2^31): the pop then knows a goal
@@ -183,7 +186,8 @@ struct Eng {
     uint32_t* tmp_idx;  // FRONT position each scratch entry was taken from (k_rank hands entries back into those slots)
     uint64_t* ord_key;
     uint32_t* ord_id;
-    uint32_t* big_list;  // bins at or below the threshold bin with more than kTinyBin entries (one workgroup each)
+    uint32_t* big_list;  // work units of k_rank's large-bin pass: the bins at or below the threshold bin with more than kTinyBin
+                         // entries, one unit per workgroup that shares the bin (bin | share << 12 | shares << 16)
     uint64_t* pop_key;   // the batch in pop order
     uint32_t *pop_id, *pop_g;
     uint64_t* child_hash;
@@ -868,7 +872,13 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
             if (cn > 256) atomicMax(&s_maxbin, cn);
             if (cn > (uint32_t)kSortCap) atomicAdd(&s_giant, 1u);
             // work list of k_rank: one workgroup per bin of more than kTinyBin entries (smaller bins: a thread per entry)
-            if (cn > (uint32_t)kTinyBin) E.big_list[atomicAdd(&s_nbig, 1u)] = bin;
+            if (cn > (uint32_t)kTinyBin) {
+                // a bin that fits k_rank's LDS path is shared between up to eight workgroups (about a thousand entries each)
+                uint32_t G = cn <= (uint32_t)kLdsEnt ? (cn + 1023u) / 1024u : 1u;
+                G = G > 8u ? 8u : G;
+                const uint32_t at = atomicAdd(&s_nbig, G);
+                for (uint32_t g = 0; g < G; g++) E.big_list[at + g] = bin | (g << 12) | (G << 16);
+            }
         }
     }
     if (t == 0) {
@@ -1069,9 +1079,6 @@ __device__ __forceinline__ int clz128(u128 v) {
     return hi ? __clzll((long long)hi) : 64 + (lo ? __clzll((long long)lo) : 64);
 }
 
-constexpr int RT = 512;                            // threads of a k_rank workgroup (8 waves: up to 256 VGPRs each)
-constexpr int kRegEnt = 16;                        // entries a thread keeps in registers
-constexpr uint32_t kLdsEnt = RT * kRegEnt;         // items up to this size are bucketed entirely in LDS (96 KB)
 constexpr int kRankStack = 512;    // pending oversized sub-bins of one bin
 constexpr uint32_t kDirectMax = 512;  // items up to this size are ranked all-pairs out of LDS
 constexpr uint32_t kSubMaxDefault = 512;  // sub-bins up to this size are ranked in place, larger ones are refined again
@@ -1079,6 +1086,11 @@ constexpr uint32_t kSubMaxDefault = 512;  // sub-bins up to this size are ranked
 
 struct RankItem {
     uint32_t off, n, need, src;  // slice [off, off+n) of scratch array `src` (0 tmp, 1 ord); pop rank of its first entry = off
+    uint32_t g, G;               // this workgroup does share g of G of the item (a large bin is split between workgroups)
+    // Refining a sub-bin ping-pongs between the two scratch arrays; the second hop writes into the FIRST array — which
+    // the other workgroups of a shared bin may still be reading.  Descendants of a shared item therefore never refine
+    // again (an oversized sub-bin of theirs is ranked in place: slow, rare, exact).
+    uint32_t nopush;
 };
 struct RankShared {
     uint32_t cnt[kSub + 64];  // sub-bin counts, then running scatter slots (+ one idle word per lane, see the LDS path)
@@ -1086,6 +1098,8 @@ struct RankShared {
     uint32_t wsum[16];
     uint64_t red_lo[32], red_hi[32];
     uint64_t vmin_hi, vmin_lo;
+    uint64_t kmin, kspan;  // LDS path: the item's smallest key and key span,
+    uint32_t imin, ispan;  // and the same for its (masked) ids
     uint32_t bits, tsub, sp, fail;
     uint32_t ret_base, ret_cnt;            // one reservation in FRONT' per work item for the entries it hands back
     RankItem stack[kRankStack];
@@ -1270,6 +1284,42 @@ __device__ __forceinline__ void rank_range(RankShared& S, u128 vmin, u128 vmax) 
     __syncthreads();
 }
 
+// the LDS path's range: smallest key / id and their spans from per-thread partials -> S.kmin, S.kspan, S.imin, S.ispan;
+// also clears the counters
+__device__ __forceinline__ void rank_range64(RankShared& S, uint64_t kmn, uint64_t kmx, uint32_t imn, uint32_t imx) {
+    const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t a = __shfl_xor(kmn, o), b = __shfl_xor(kmx, o);
+        const uint32_t x = __shfl_xor(imn, o), y = __shfl_xor(imx, o);
+        kmn = a < kmn ? a : kmn;
+        kmx = b > kmx ? b : kmx;
+        imn = x < imn ? x : imn;
+        imx = y > imx ? y : imx;
+    }
+    if (lane == 0) {
+        S.red_lo[wv] = kmn;
+        S.red_lo[16 + wv] = kmx;
+        S.red_hi[wv] = imn;
+        S.red_hi[16 + wv] = imx;
+    }
+    for (uint32_t i = t; i < (uint32_t)kSub; i += RT) S.cnt[i] = 0;
+    __syncthreads();
+    if (t == 0) {
+        uint64_t a = ~0ull, b = 0, x = ~0ull, y = 0;
+        for (int k = 0; k < RT / 64; k++) {
+            a = S.red_lo[k] < a ? S.red_lo[k] : a;
+            b = S.red_lo[16 + k] > b ? S.red_lo[16 + k] : b;
+            x = S.red_hi[k] < x ? S.red_hi[k] : x;
+            y = S.red_hi[16 + k] > y ? S.red_hi[16 + k] : y;
+        }
+        S.kmin = a;
+        S.kspan = b - a;
+        S.imin = (uint32_t)x;
+        S.ispan = (uint32_t)(y - x);
+    }
+    __syncthreads();
+}
+
 // exclusive prefix of cnt[0..nsub) into off[0..nsub] (2 per thread), the sub-bin holding the need-th entry -> S.tsub,
 // counters back to zero (they become the running scatter slots)
 __device__ __forceinline__ void rank_prefix(RankShared& S, uint32_t nsub, uint32_t need) {
@@ -1305,13 +1355,15 @@ __device__ __forceinline__ void rank_prefix(RankShared& S, uint32_t nsub, uint32
 }
 
 // oversized sub-bins of the item just scattered become work items of their own (slice of the OTHER scratch array)
-__device__ __forceinline__ void rank_push(RankShared& S, const RankItem& it, uint32_t tsub, uint32_t need, uint32_t shc) {
-    for (uint32_t sb = threadIdx.x; sb <= tsub; sb += RT) {
+__device__ __forceinline__ void rank_push(RankShared& S, const RankItem& it, uint32_t tsub, uint32_t need, bool refinable,
+                                          uint32_t lo = 0u, uint32_t hi = ~0u) {
+    for (uint32_t sb = lo + threadIdx.x; sb <= tsub && sb < hi; sb += RT) {
         const uint32_t s0 = S.off[sb], e0 = S.off[sb + 1];
-        if (e0 - s0 > kSubMax && shc > 0) {
+        if (e0 - s0 > kSubMax && refinable) {
             const uint32_t slot = atomicAdd(&S.sp, 1u);
             if (slot < (uint32_t)kRankStack)
-                S.stack[slot] = RankItem{it.off + s0, e0 - s0, sb == tsub ? need - s0 : e0 - s0, it.src ^ 1u};
+                S.stack[slot] = RankItem{it.off + s0, e0 - s0, sb == tsub ? need - s0 : e0 - s0, it.src ^ 1u, 0u, 1u,
+                                         (it.G > 1u || it.nopush) ? 1u : 0u};
             else
                 S.fail = 1;
         }
@@ -1358,13 +1410,13 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
     }
     if (n <= kLdsEnt) {
         // ---- the item is read from HBM ONCE (kRegEnt entries per thread, kept in registers), bucketed and ranked in LDS.
-        // Inside the item every (key,id) composite is held as its 64-bit offset from the item's smallest composite: one
-        // LDS word to read and one compare per pair in the ranking loop, shifts instead of 128-bit arithmetic for the
-        // sub-bin.  (An item whose composites span more than 64 bits — a large bin of widely spread keys — takes the
-        // streaming path below, which works on full composites.)
+        // Inside the item an entry is held as a 64-bit offset — key minus the item's smallest key; or, when all keys of
+        // the item are equal (a tie group), id minus its smallest id — so the sub-bin is a shift, not 128-bit
+        // arithmetic, and stays monotone in the (key,id) order; pairs inside a sub-bin compare (offset, id).
+        // A bin of several thousand entries is shared between it.G workgroups: every one of them reads and counts the
+        // whole bin (cheap), then scatters, ranks and emits only its own run of sub-bins.
         uint64_t ek[kRegEnt];
         uint32_t ei[kRegEnt];
-        u128 vmin = ~(u128)0, vmax = 0;
         // (index clamped, not predicated: a predicated load compiles to branch + wait per element here — sixteen
         // serialized memory round trips, which is what made this path take 20-45 us)
         prof_begin(E, P_RB_LOAD);
@@ -1374,126 +1426,133 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
             ek[j] = K[ic];
             ei[j] = I[ic];
         }
+        {
+            uint64_t kmn = ~0ull, kmx = 0;
+            uint32_t imn = ~0u, imx = 0;
 #pragma unroll
-        for (int j = 0; j < kRegEnt; j++)
-            if (t + (uint32_t)RT * j < n) {
-                const u128 v = comp_of(ek[j], ei[j]);
-                vmin = v < vmin ? v : vmin;
-                vmax = v > vmax ? v : vmax;
+            for (int j = 0; j < kRegEnt; j++) {  // (clamped duplicates change nothing)
+                const uint32_t im = ei[j] & ID_MASK;
+                kmn = ek[j] < kmn ? ek[j] : kmn;
+                kmx = ek[j] > kmx ? ek[j] : kmx;
+                imn = im < imn ? im : imn;
+                imx = im > imx ? im : imx;
             }
-        rank_range(S, vmin, vmax);
+            rank_range64(S, kmn, kmx, imn, imx);
+        }
         prof_end(E, P_RB_LOAD);
-        const uint32_t bits = S.bits;
-        if (bits <= 64) {
-            prof_begin(E, P_RB_COUNT);
-            const u128 base = ((u128)S.vmin_hi << 64) | S.vmin_lo;
-            if (lg > bits) lg = bits;  // cannot cut finer than one composite value
-            const uint32_t nsub = 1u << lg, shc = bits - lg;  // (shc <= 63: bits == 64 comes with lg >= 1)
-            // the composites' offsets from `base` replace the keys (registers are short here: no spills wanted)
+        prof_begin(E, P_RB_COUNT);
+        const bool idmode = S.kspan == 0;
+        const uint64_t kbase = S.kmin, span = idmode ? (uint64_t)S.ispan : S.kspan;
+        const uint32_t ibase = S.imin;
+        const uint32_t bits = span ? (uint32_t)(64 - __clzll((long long)span)) : 0u;
+        if (lg > bits) lg = bits;  // cannot cut finer than one value
+        const uint32_t nsub = 1u << lg, shc = bits - lg;  // (shc <= 63: bits == 64 comes with lg >= 1)
+        // a sub-bin too large to rank in place is refined by a work item of its own — unless it cannot be cut further
+        // (one id value per sub-bin; in key mode a one-key sub-bin comes back as a tie group, cut by id)
+        const bool refinable = (shc > 0 || !idmode) && !it.nopush;
+        const uint32_t lo_sub = (uint32_t)((uint64_t)nsub * it.g / it.G), hi_sub = (uint32_t)((uint64_t)nsub * (it.g + 1u) / it.G);
+#pragma unroll
+        for (int j = 0; j < kRegEnt; j++) {  // offsets replace the keys (registers are short here: no spills wanted)
+            ek[j] = idmode ? (uint64_t)((ei[j] & ID_MASK) - ibase) : ek[j] - kbase;
+            if (t + (uint32_t)RT * j < n) atomicAdd(&S.cnt[(uint32_t)(ek[j] >> shc)], 1u);
+        }
+        __syncthreads();
+        rank_prefix(S, nsub, need);
+        prof_end(E, P_RB_COUNT);
+        prof_begin(E, P_RB_SCATTER);
+        if (E.prof != nullptr) {  // (diagnostic) largest sub-bin
+            uint32_t mx = 0;
+            for (uint32_t sb = t; sb < nsub; sb += RT) mx = max(mx, S.off[sb + 1] - S.off[sb]);
+            if (mx > 16) atomicMax(&c->dbg_maxsub, mx);
+        }
+        const uint32_t tsub = S.tsub;
+        const bool tsub_pushed = S.off[tsub + 1] - S.off[tsub] > kSubMax && refinable;
+        const uint32_t in_hi = hi_sub < tsub + 1u ? hi_sub : tsub + 1u;          // my sub-bins [lo_sub, in_hi) are ranked,
+        const uint32_t ret_lo = lo_sub > tsub + 1u ? lo_sub : tsub + 1u;         // [ret_lo, hi_sub) go back to OPEN
+        // what THIS workgroup hands back: its sub-bins above the threshold sub-bin, plus that sub-bin's overshoot if it is
+        // one of them — unless the sub-bin is refined by a work item of its own (which then reserves for itself)
+        ret_begin(c, S, nf, (ret_lo < hi_sub ? S.off[hi_sub] - S.off[ret_lo] : 0u) +
+                                ((tsub >= lo_sub && tsub < hi_sub && !tsub_pushed) ? S.off[tsub + 1] - need : 0u));
+        const uint32_t n_ord = c->n_ord;
+        {
+            // Nothing conditional around the LDS reads / returning atomics (a branch per entry means a wait per
+            // entry): an entry that does not take part adds zero to an idle word of its own lane.
+            uint32_t inm = 0, retm = 0, pos[kRegEnt];
 #pragma unroll
             for (int j = 0; j < kRegEnt; j++) {
-                ek[j] = (uint64_t)(comp_of(ek[j], ei[j]) - base);
-                if (t + (uint32_t)RT * j < n) {
-                    const uint64_t q = ek[j] >> shc;
-                    atomicAdd(&S.cnt[q < nsub ? (uint32_t)q : nsub - 1u], 1u);
-                }
+                const uint32_t sub = (uint32_t)(ek[j] >> shc);
+                const bool live = t + (uint32_t)RT * j < n, in = live && sub >= lo_sub && sub < in_hi;
+                inm |= (in ? 1u : 0u) << j;
+                retm |= (live && sub >= ret_lo && sub < hi_sub ? 1u : 0u) << j;  // the rest of a threshold bin stays in OPEN
+                pos[j] = S.off[in ? sub : 0u] + atomicAdd(&S.cnt[in ? sub : (uint32_t)kSub + (t & 63u)], in ? 1u : 0u);
             }
-            __syncthreads();
-            rank_prefix(S, nsub, need);
-            prof_end(E, P_RB_COUNT);
-            prof_begin(E, P_RB_SCATTER);
-            if (E.prof != nullptr) {  // (diagnostic) largest sub-bin
-                uint32_t mx = 0;
-                for (uint32_t sb = t; sb < nsub; sb += RT) mx = max(mx, S.off[sb + 1] - S.off[sb]);
-                if (mx > 16) atomicMax(&c->dbg_maxsub, mx);
+#pragma unroll
+            for (int j = 0; j < kRegEnt; j++) {
+                if ((inm >> j) & 1u) {
+                    LK[pos[j]] = ek[j];
+                    LI[pos[j]] = ei[j];
+                }
+                ek[j] = idmode ? kbase : kbase + ek[j];  // the key back from the offset
             }
-            const uint32_t tsub = S.tsub;
-            const bool tsub_pushed = S.off[tsub + 1] - S.off[tsub] > kSubMax && shc > 0;
-            // what THIS item hands back: everything above the threshold sub-bin, plus that sub-bin's overshoot unless the
-            // sub-bin is refined by a work item of its own (which then reserves for itself)
-            ret_begin(c, S, nf, (n - S.off[tsub + 1]) + (tsub_pushed ? 0u : S.off[tsub + 1] - need));
-            const uint32_t n_ord = c->n_ord;
-            {
-                // Nothing conditional around the LDS reads / returning atomics (a branch per entry means a wait per
-                // entry): an entry that does not take part adds zero to an idle word of its own lane.
-                uint32_t inm = 0, retm = 0, pos[kRegEnt];
-#pragma unroll
-                for (int j = 0; j < kRegEnt; j++) {
-                    const uint64_t q = ek[j] >> shc;
-                    const uint32_t sub = q < nsub ? (uint32_t)q : nsub - 1u;
-                    const bool live = t + (uint32_t)RT * j < n, in = live && sub <= tsub;
-                    inm |= (in ? 1u : 0u) << j;
-                    retm |= (live && !in ? 1u : 0u) << j;  // the rest of a threshold bin stays in OPEN
-                    pos[j] = S.off[in ? sub : 0u] + atomicAdd(&S.cnt[in ? sub : (uint32_t)kSub + (t & 63u)], in ? 1u : 0u);
-                }
-#pragma unroll
-                for (int j = 0; j < kRegEnt; j++) {
-                    if ((inm >> j) & 1u) {
-                        LK[pos[j]] = ek[j];
-                        LI[pos[j]] = ei[j];
-                    }
-                    ek[j] = (uint64_t)((base + (u128)ek[j]) >> 32);  // the key back from the offset
-                }
-                ret_put_many<kRegEnt>(E, S, nf, n_ord, retm, ek, ei);
-            }
-            __syncthreads();
-            prof_end(E, P_RB_SCATTER);
-            prof_begin(E, P_RB_ORDER);
-            const uint32_t m = S.off[tsub + 1];
-            constexpr int U = 4;  // entries a thread ranks side by side: their LDS reads overlap instead of queueing up
-            for (uint32_t p0 = 0; p0 < m; p0 += RT * U) {
-                uint64_t o[U], k[U];
-                uint32_t id[U], s0[U], cn[U], rank[U], livem = 0, bigm = 0, trip = 0;
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const uint32_t p = p0 + (uint32_t)u * RT + t;
-                    livem |= (p < m ? 1u : 0u) << u;
-                    o[u] = LK[p < m ? p : m - 1];
-                    id[u] = LI[p < m ? p : m - 1];
-                }
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const uint64_t q = o[u] >> shc;
-                    const uint32_t sub = q < nsub ? (uint32_t)q : nsub - 1u;
-                    s0[u] = S.off[sub];
-                    cn[u] = S.off[sub + 1] - s0[u];
-                    rank[u] = s0[u];
-                    if (!((livem >> u) & 1u)) cn[u] = 0;
-                    if (cn[u] > kSubMax && shc > 0) {  // refined by the sub-bin's own work item, from the other scratch array
-                        bigm |= 1u << u;
-                        cn[u] = 0;
-                    }
-                    trip = cn[u] > trip ? cn[u] : trip;
-                }
-                for (uint32_t jj = 0; jj < trip; jj++) {
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        const uint64_t other = LK[s0[u] + (jj < cn[u] ? jj : 0u)];
-                        rank[u] += (jj < cn[u] && other < o[u]) ? 1u : 0u;
-                    }
-                }
-                uint32_t retm = 0;
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const uint32_t p = p0 + (uint32_t)u * RT + t;
-                    k[u] = (uint64_t)((base + (u128)o[u]) >> 32);  // the key back from the offset
-                    if ((bigm >> u) & 1u) {
-                        K2[p] = k[u];
-                        I2[p] = id[u];
-                    } else if ((livem >> u) & 1u) {
-                        if (rank[u] < need) emit_pop(E, c, it.off + rank[u], k[u], id[u]);
-                        else retm |= 1u << u;
-                    }
-                }
-                ret_put_many<U>(E, S, nf, n_ord, retm, k, id);
-            }
-            rank_push(S, it, tsub, need, shc);
-            __syncthreads();
-            prof_end(E, P_RB_ORDER);
-            return;
+            ret_put_many<kRegEnt>(E, S, nf, n_ord, retm, ek, ei);
         }
+        __syncthreads();
+        prof_end(E, P_RB_SCATTER);
+        prof_begin(E, P_RB_ORDER);
+        const uint32_t p_lo = S.off[lo_sub], p_hi = in_hi > lo_sub ? S.off[in_hi] : p_lo;
+        constexpr int U = 4;  // entries a thread ranks side by side: their LDS reads overlap instead of queueing up
+        for (uint32_t p0 = p_lo; p0 < p_hi; p0 += RT * U) {
+            uint64_t o[U];
+            uint32_t id[U], s0[U], cn[U], rank[U], livem = 0, bigm = 0, trip = 0;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t p = p0 + (uint32_t)u * RT + t;
+                livem |= (p < p_hi ? 1u : 0u) << u;
+                o[u] = LK[p < p_hi ? p : p_hi - 1];
+                id[u] = LI[p < p_hi ? p : p_hi - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t sub = (uint32_t)(o[u] >> shc);
+                s0[u] = S.off[sub];
+                cn[u] = S.off[sub + 1] - s0[u];
+                rank[u] = s0[u];
+                if (!((livem >> u) & 1u)) cn[u] = 0;
+                if (cn[u] > kSubMax && refinable) {  // refined by the sub-bin's own work item, from the other scratch array
+                    bigm |= 1u << u;
+                    cn[u] = 0;
+                }
+                trip = cn[u] > trip ? cn[u] : trip;
+            }
+            for (uint32_t jj = 0; jj < trip; jj++) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint32_t j = s0[u] + (jj < cn[u] ? jj : 0u);
+                    const bool less = pair_less(LK[j], LI[j], o[u], id[u]);
+                    rank[u] += (jj < cn[u] && less) ? 1u : 0u;
+                }
+            }
+            uint32_t retm = 0;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t p = p0 + (uint32_t)u * RT + t;
+                o[u] = idmode ? kbase : kbase + o[u];  // the key back from the offset
+                if ((bigm >> u) & 1u) {
+                    K2[p] = o[u];
+                    I2[p] = id[u];
+                } else if ((livem >> u) & 1u) {
+                    if (rank[u] < need) emit_pop(E, c, it.off + rank[u], o[u], id[u]);
+                    else retm |= 1u << u;
+                }
+            }
+            ret_put_many<U>(E, S, nf, n_ord, retm, o, id);
+        }
+        rank_push(S, it, tsub, need, refinable, lo_sub, in_hi);
+        __syncthreads();
+        prof_end(E, P_RB_ORDER);
+        return;
     }
-    // ---- larger than LDS (or composites wider than 64 bits): three streaming passes over the slice, 8 loads in flight per thread
+    // ---- larger than LDS: three streaming passes over the slice, 8 loads in flight per thread
     {
         u128 vmin = ~(u128)0, vmax = 0;
         for (uint32_t b0 = 0; b0 < n; b0 += kLdsEnt) {
@@ -1584,7 +1643,7 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
         }
         ret_put(E, c, S, nf, live && rank >= need, k, id, acc);
     }
-    rank_push(S, it, tsub, need, shc);
+    rank_push(S, it, tsub, need, shc > 0);
     ret_end(c, nf, acc);
     __syncthreads();
 }
@@ -1612,12 +1671,13 @@ __global__ __launch_bounds__(RT) void k_rank(const Eng* __restrict__ engs) {
     // ---- bins of more than kTinyBin entries: one workgroup each.  The first n_ord / RT workgroups are busy with the pass
     // above, so the large bins start at workgroup 64
     for (uint32_t bi = (blockIdx.x + gridDim.x - 64u) % gridDim.x; bi < n_big; bi += gridDim.x) {
-        const uint32_t f = E.big_list[bi];
+        const uint32_t unit = E.big_list[bi];  // bin | share << 12 | shares << 16
+        const uint32_t f = unit & (NBIN - 1u);
         const uint32_t o = E.pre[f], n = E.pre[f + 1] - o;
         __syncthreads();
         if (t == 0) {
             // entries of this bin that belong to the batch: all of it below the threshold bin
-            S.stack[0] = RankItem{o, n, (f == bstar) ? want - o : n, 0u};
+            S.stack[0] = RankItem{o, n, (f == bstar) ? want - o : n, 0u, (unit >> 12) & 15u, unit >> 16, 0u};
             S.sp = 1;
             S.fail = 0;
         }
@@ -2554,7 +2614,7 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
         ALLOC(tmp_idx, N);
         ALLOC(ord_key, N);
         ALLOC(ord_id, N);
-        ALLOC(big_list, NBIN);
+        ALLOC(big_list, 8 * NBIN);
         ALLOC(pop_key, Bz);
         ALLOC(pop_id, Bz);
         ALLOC(pop_g, Bz);
