@@ -17,9 +17,13 @@ env = sys.argv[1] if len(sys.argv) > 1 else "cube3"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 warm = int(sys.argv[3]) if len(sys.argv) > 3 else 60
 n = int(sys.argv[4]) if len(sys.argv) > 4 else 24
-for kv in sys.argv[5:]:  # knob=value pairs for dca_debug_tune (diagnostics)
-    k, v = kv.split("=")
-    _lib.check(_lib.lib().dca_debug_tune(int(k), int(v)), "dca_debug_tune")
+late = []
+for kv in sys.argv[5:]:  # knob=value pairs for dca_debug_tune (diagnostics); @knob=value: only after the warm-up
+    k, v = kv.lstrip("@").split("=")
+    if kv.startswith("@"):
+        late.append((int(k), int(v)))
+    else:
+        _lib.check(_lib.lib().dca_debug_tune(int(k), int(v)), "dca_debug_tune")
 A = 12 if env == "cube3" else 4
 g = np.load(os.path.join(ROOT, "tests", "golden", "golden.npz"))
 root = np.ascontiguousarray(g[env + "_test_states"][0])
@@ -27,6 +31,8 @@ eng = BwasEngine(env, 0.8, B, max_nodes=(warm + n + 40) * B * A + (1 << 16))
 eng.reset(root)
 eng.root_commit(_lib.heuristic_builtin(2, torch.from_numpy(root[None].copy()).cuda()))
 eng.run_builtin(2, warm, use_graph=True)
+for k, v in late:
+    _lib.check(_lib.lib().dca_debug_tune(k, v), "dca_debug_tune")
 for it in range(n):
     prof = eng.profile_builtin(2, 1, use_graph=True)
     d = eng.debug()
