@@ -105,6 +105,7 @@ struct Ctl {
     // PLACE: a pop tombstones the entries it takes (key = DEAD), pushes append; every kRefillPeriod-th iteration a
     // rebase pass squeezes the tombstones out into the other FRONT buffer (and recounts the selection histogram).
     uint32_t cur_f;         // the live FRONT buffer (0/1); the other one is the target of the next compaction
+    uint32_t hbin;          // E.hist is kept up to date below this bin only (see k_sel_scan)
     uint32_t cur_b;         // the BACK buffer (2/3)
     uint64_t T;             // tier threshold key (inclusive upper bound of FRONT)
     uint32_t refill, compact, r_bstar, spill_bin;
@@ -410,25 +411,6 @@ __device__ __forceinline__ void block_reserveK(const uint32_t (&cnt)[K], uint32_
 #pragma unroll
     for (int k = 0; k < K; k++) pos[k] = sh[K * NW + k] + sh[k * NW + wv] + inc[k] - cnt[k];
     __syncthreads();
-}
-
-// One count per lane with `pred` into an LDS histogram.  Keys tie heavily (integer-valued heuristics give a few dozen
-// distinct costs), and sixty-four lanes adding to one LDS word are served one after the other: the first rounds pick a
-// lane, let every lane with the same bin ride along (ballot) and add the group with ONE atomic; whatever is left after
-// four rounds — distinct bins, mostly — goes the plain way.  Wave-collective.
-__device__ __forceinline__ void hist_add_wave(uint32_t* lh, uint32_t bin, bool pred) {
-    unsigned long long todo = __ballot(pred);
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        if (todo == 0) break;
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t b = __shfl(bin, leader);
-        const unsigned long long same = __ballot(pred && bin == b) & todo;
-        if (lane == leader) atomicAdd(&lh[b], (uint32_t)__popcll(same));
-        todo &= ~same;
-    }
-    if ((todo >> lane) & 1ull) atomicAdd(&lh[bin], 1u);
 }
 
 // fold a thread's running key range into a buffer's kmin/kmax (one atomic per wave, only if it helps)
@@ -748,8 +730,8 @@ __global__ __launch_bounds__(256) void k_front_rebase(const Eng* __restrict__ en
 #pragma unroll
         for (uint32_t i = 0; i < ITEMS; i++) {
             const bool lv = k[i] != DEAD;
-            if (g_tune[3]) hist_add_wave(lh, bin_of(k[i], kmin, shift), lv);
-            else if (lv) atomicAdd(&lh[bin_of(k[i], kmin, shift)], 1u);
+            // (grouping equal bins of a wave by ballot before the LDS atomic measured slower: 33 vs 29 us)
+            if (lv) atomicAdd(&lh[bin_of(k[i], kmin, shift)], 1u);
             if (!lv) continue;
             if (p.a < E.front_cap) {
                 E.open_key[nb][p.a] = k[i];
@@ -798,7 +780,7 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
     Stamp stamp(E, P_SEL_SCAN);
     __shared__ uint32_t pre[NBIN + 1];
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t s_spill, s_bstar, s_maxbin, s_giant, s_nbig, s_sp;
+    __shared__ uint32_t s_spill, s_bstar, s_maxbin, s_giant, s_nbig, s_sp, s_hbin;
     __shared__ uint64_t s_red[2][16];
     const int t = threadIdx.x;
     uint32_t cb = c->cur_f;
@@ -844,12 +826,14 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
         c->refill = 0;
         s_spill = NBIN;  // no spill
         s_bstar = 0;
+        s_hbin = NBIN;
     }
     // E.hist is FRONT's histogram under the binning in force: recounted by k_front_rebase in a rebase iteration (every
     // kRefillPeriod-th), maintained incrementally in between (the writeback below + k_commit's pushes)
     scan_bins(E.hist, false, pre, wsum);
     const uint32_t n = c->open_n[cb].v - (rebased ? 0u : c->front_dead.v);  // live entries
     const uint32_t want = n < (uint32_t)E.B ? n : (uint32_t)E.B;
+    const uint32_t hwant = (uint32_t)(kRefillPeriod + 2) * (uint32_t)E.B;
     for (int k = 0; k < kBinsPerThread; k++) {
         int bin = kBinsPerThread * t + k;
         // threshold bin: first bin with pre[b] < want <= pre[b+1].  Everything at or below it is handed to k_rank
@@ -857,10 +841,15 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
         // bin comes back to FRONT from there.
         if (pre[bin] < want && want <= pre[bin + 1]) s_bstar = (uint32_t)bin;
         // spill: FRONT grew past f_max -> keep the bins that hold the batch plus ~f_keep more
-        if (n > E.f_max) {
+        if (rebased && n > E.f_max) {
             const uint32_t keepn = want + front_keep(E);
             if (pre[bin] < keepn && keepn <= pre[bin + 1]) s_spill = (uint32_t)bin;
         }
+        // Between two rebase iterations the histogram is only maintained below `hbin`, the first bin under which FRONT
+        // holds (kRefillPeriod + 2) batches now: the next kRefillPeriod pops take at most kRefillPeriod batches from the
+        // bottom and pushes only add, so every threshold bin until the next recount lies below it — and k_commit need not
+        // count the bulk of the children, which land higher (a global atomic per child and bin was a third of its time).
+        if (rebased && pre[bin] < hwant && hwant <= pre[bin + 1]) s_hbin = (uint32_t)bin + 1u;
         E.pre[bin] = pre[bin];
         E.fill[bin] = 0;
     }
@@ -887,6 +876,7 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
         const uint32_t shift = new_shift;
         c->want = want;
         c->bstar = s_bstar;
+        if (rebased) c->hbin = s_hbin;
         c->sel_kmin = kmin;
         c->shift = shift;
         uint32_t sp = s_spill;
@@ -2268,11 +2258,11 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
         key = key_of_cost(cost);
     }
     const bool tof = keep && key <= T, tob = keep && key > T;
-    if (g_tune[2] == 0) {
-        if (tof) atomicAdd(&lh[bin_of(key, bin_kmin, bin_shift)], 1u);
-    } else if (g_tune[2] == 1) {
-        hist_add_wave(lh, bin_of(key, bin_kmin, bin_shift), tof);
-    }  // (2: what-if timing run without the histogram)
+    const uint32_t hbin = c->hbin;
+    if (tof) {
+        const uint32_t f = bin_of(key, bin_kmin, bin_shift);
+        if (f < hbin) atomicAdd(&lh[f], 1u);
+    }
     const uint32_t cnt[3] = {tof ? 1u : 0u, tob ? 1u : 0u, is_new ? 1u : 0u};
     uint32_t* const ctr[3] = {&c->open_n[fb].v, &c->open_n[bb].v, &c->closed_n.v};
     uint32_t pos[3];
@@ -2295,7 +2285,7 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
     fold_range(c, fb, tof ? key : ~0ull, tof ? key : 0ull);
     fold_range(c, bb, tob ? key : ~0ull, tob ? key : 0ull);
     __syncthreads();  // (block_reserveK's barriers already ordered the LDS counts; this one covers the early-out threads)
-    if (g_tune[2] != 2)
+    if (kBinsPerThread * threadIdx.x < hbin)
         for (int k = 0; k < kBinsPerThread; k++) {
             const uint32_t v = lh[kBinsPerThread * threadIdx.x + k];
             if (v) atomicAdd(&E.hist[kBinsPerThread * threadIdx.x + k], v);
@@ -2932,7 +2922,7 @@ int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, int use_gr
 }
 
 int dca_debug_tune(int knob, int value) {
-    // diagnostics: 0 extra log2 of sub-bins per large bin, 1 sub-bin size above which a sub-bin is refined on its own
+    // diagnostics: 0 extra log2 of sub-bins per large bin, 1 sub-bin size above which a sub-bin is refined on its own (2-7 unused)
     DCA_ARG(knob >= 0 && knob < 8);
     DCA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tune), &value, sizeof(int), (size_t)knob * sizeof(int), hipMemcpyHostToDevice));
     return 0;
