@@ -106,6 +106,7 @@ struct Ctl {
     // rebase pass squeezes the tombstones out into the other FRONT buffer (and recounts the selection histogram).
     uint32_t cur_f;         // the live FRONT buffer (0/1); the other one is the target of the next compaction
     uint32_t hbin;          // E.hist is kept up to date below this bin only (see k_sel_scan)
+    uint32_t front_above;   // FRONT entries above T since the last spill: they leave for BACK in the next rebase pass
     uint32_t cur_b;         // the BACK buffer (2/3)
     uint64_t T;             // tier threshold key (inclusive upper bound of FRONT)
     uint32_t refill, compact, r_bstar, spill_bin;
@@ -517,7 +518,7 @@ __device__ __forceinline__ uint32_t front_keep(const Eng& E) {
 }
 __device__ __forceinline__ bool need_refill(const Eng& E, const Ctl* c) {
     return c->open_n[c->cur_b].v != c->back_dead.v &&
-           c->open_n[c->cur_f].v - c->front_dead.v < (uint32_t)(kRefillPeriod + 1) * (uint32_t)E.B;
+           c->open_n[c->cur_f].v - c->front_dead.v - c->front_above < (uint32_t)(kRefillPeriod + 1) * (uint32_t)E.B;
 }
 
 __global__ __launch_bounds__(256) void k_refill_hist(const Eng* __restrict__ engs) {
@@ -706,29 +707,46 @@ __global__ __launch_bounds__(256) void k_front_rebase(const Eng* __restrict__ en
     for (int i = threadIdx.x; i < NBIN; i += 256) lh[i] = 0;
     __syncthreads();
     const uint32_t b = c->cur_f, nb = b ^ 1, n = c->open_n[b].v;
+    // entries above the tier threshold leave for BACK on the way (a spill lowers T and leaves the move to this pass; a
+    // BACK compaction in flight — k_refill_move — continues in the other BACK buffer, which k_sel_scan makes current)
+    const uint32_t bb = (c->refill && c->compact) ? c->cur_b ^ 1u : c->cur_b;
+    const uint64_t T = c->T;
     uint64_t kmin;
     uint32_t shift;
     fresh_binning(c, b, kmin, shift);
     const uint64_t* __restrict__ keys = E.open_key[b];
     const uint32_t* __restrict__ ids = E.open_id[b];
     constexpr uint32_t ITEMS = 8, TILE = 256 * ITEMS;
-    uint64_t fmn = ~0ull, fmx = 0;
+    uint64_t fmn = ~0ull, fmx = 0, bmn = ~0ull, bmx = 0;
     const uint32_t ntiles = (n + TILE - 1) / TILE;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint64_t k[ITEMS];
         uint32_t id[ITEMS];
-        uint32_t cl = 0;
+        uint32_t cl = 0, ce = 0;
 #pragma unroll
         for (uint32_t i = 0; i < ITEMS; i++) {
             const uint32_t idx = tile * TILE + i * 256 + threadIdx.x, ic = idx < n ? idx : n - 1;
             k[i] = keys[ic];
             id[i] = ids[ic];
             if (idx >= n) k[i] = DEAD;
-            cl += k[i] != DEAD ? 1u : 0u;
+            cl += (k[i] != DEAD && k[i] <= T) ? 1u : 0u;
+            ce += (k[i] != DEAD && k[i] > T) ? 1u : 0u;
         }
-        Pos2 p = block_reserve2<256>(cl, 0u, &c->open_n[nb].v, &c->open_n[nb].v, sh);
+        Pos2 p = block_reserve2<256>(cl, ce, &c->open_n[nb].v, &c->open_n[bb].v, sh);
 #pragma unroll
         for (uint32_t i = 0; i < ITEMS; i++) {
+            if (k[i] != DEAD && k[i] > T) {
+                if (p.b < E.max_nodes) {
+                    E.open_key[bb][p.b] = k[i];
+                    E.open_id[bb][p.b] = id[i];
+                } else {
+                    c->failed = 1;
+                }
+                p.b++;
+                bmn = k[i] < bmn ? k[i] : bmn;
+                bmx = k[i] > bmx ? k[i] : bmx;
+                continue;
+            }
             const bool lv = k[i] != DEAD;
             // (grouping equal bins of a wave by ballot before the LDS atomic measured slower: 33 vs 29 us)
             if (lv) atomicAdd(&lh[bin_of(k[i], kmin, shift)], 1u);
@@ -747,6 +765,7 @@ __global__ __launch_bounds__(256) void k_front_rebase(const Eng* __restrict__ en
     __syncthreads();
     for (int i = threadIdx.x; i < NBIN; i += 256)
         if (lh[i]) atomicAdd(&E.hist[i], lh[i]);
+    if (T != ~0ull) fold_range(c, bb, bmn, bmx);
     {
         __shared__ uint64_t red[2][4];
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -831,7 +850,8 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
     // E.hist is FRONT's histogram under the binning in force: recounted by k_front_rebase in a rebase iteration (every
     // kRefillPeriod-th), maintained incrementally in between (the writeback below + k_commit's pushes)
     scan_bins(E.hist, false, pre, wsum);
-    const uint32_t n = c->open_n[cb].v - (rebased ? 0u : c->front_dead.v);  // live entries
+    // live entries at or below T (a rebase pass has just dropped the tombstones and moved what was above T to BACK)
+    const uint32_t n = c->open_n[cb].v - (rebased ? 0u : c->front_dead.v + c->front_above);
     const uint32_t want = n < (uint32_t)E.B ? n : (uint32_t)E.B;
     const uint32_t hwant = (uint32_t)(kRefillPeriod + 2) * (uint32_t)E.B;
     for (int k = 0; k < kBinsPerThread; k++) {
@@ -886,7 +906,8 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
         } else {
             sp = NBIN;
         }
-        c->spill_bin = sp;  // survivors in bins above it move to BACK
+        if (rebased) c->front_above = sp < NBIN ? pre[NBIN] - pre[sp + 1] : 0u;
+        c->spill_bin = sp;  // T was lowered to the top of this bin: the entries above it leave for BACK in the next rebase pass
         s_sp = sp;
         c->goal_best = ~0ull;
         c->first_solved = NIL;
@@ -913,10 +934,10 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
         c->n_big = s_nbig;
         c->n_ord = want ? pre[s_bstar + 1] : 0;
         // k_sel_collect tombstones what leaves FRONT: the bins handed to k_rank — which puts the overshoot of the threshold
-        // bin back into the same slots, so only the batch itself stays dead — and the bins that spill to BACK
+        // bin back into the same slots, so only the batch itself stays dead
         c->ret_n.v = 0;
         c->dbg_maxsub = 0;
-        if (want) c->front_dead.v += want + (s_sp < NBIN ? pre[NBIN] - pre[s_sp + 1] : 0u);
+        if (want) c->front_dead.v += want;
         c->dbg_nord = want ? pre[s_bstar + 1] : 0;
         c->dbg_maxbin = s_maxbin;
         c->dbg_giant = s_giant;
@@ -926,34 +947,31 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
 
 // S3: take the batch's bins out of FRONT, in place.  Only the keys are read (8 bytes an entry); an entry at or below
 // the threshold bin is stashed in LDS (key + position), tombstoned, and placed — with its id, gathered then — into the
-// scratch array grouped by bin (k_rank orders each bin): one global atomic per (workgroup, bin).  When a spill lowered T,
-// the bins above the spill bin move to BACK the same way (one reservation per tile).
+// scratch array grouped by bin (k_rank orders each bin): one global atomic per (workgroup, bin).
 __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ engs) {
     const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
     Stamp stamp(E, P_SEL_COLLECT);
-    __shared__ uint32_t sh[2 * 4 + 2];
     __shared__ uint64_t st_key[kStash];
     __shared__ uint32_t st_idx[kStash];
     __shared__ uint16_t st_f[kStash];
     __shared__ uint32_t lcnt[NBIN];
     __shared__ uint32_t st_n;
-    const uint32_t b = c->cur_f, bb = c->cur_b;
+    const uint32_t b = c->cur_f;
     const uint32_t n = c->open_n[b].v;
     const uint64_t kmin = c->sel_kmin;
-    const uint32_t shift = c->shift, bstar = c->bstar, spill = c->spill_bin;
+    const uint32_t shift = c->shift, bstar = c->bstar;
     uint64_t* __restrict__ keys = E.open_key[b];
     const uint32_t* __restrict__ ids = E.open_id[b];
     constexpr uint32_t ITEMS = 8, TILE = 256 * ITEMS;
-    uint64_t bmn = ~0ull, bmx = 0;
     const uint32_t ntiles = (n + TILE - 1) / TILE;
     for (int i = threadIdx.x; i < NBIN; i += 256) lcnt[i] = 0;
     if (threadIdx.x == 0) st_n = 0;
     __syncthreads();
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint64_t k[ITEMS];
-        uint32_t dest = 0;  // 2 bits per item: 0 stays (or dead), 1 scratch (ordered by k_rank), 3 BACK
+        uint32_t dest = 0;  // 2 bits per item: 0 stays (or dead), 1 scratch (ordered by k_rank)
         // all loads of the tile first (unconditional, index-clamped: they stay in flight together) ...
 #pragma unroll
         for (uint32_t i = 0; i < ITEMS; i++) {
@@ -961,15 +979,12 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
             k[i] = keys[ic];
             if (idx >= n) k[i] = DEAD;
         }
-        uint32_t cb = 0;
 #pragma unroll
         for (uint32_t i = 0; i < ITEMS; i++) {
             const uint32_t f = bin_of(k[i], kmin, shift);
-            const uint32_t d = k[i] == DEAD ? 0u : (f <= bstar ? 1u : (f > spill ? 3u : 0u));
+            const uint32_t d = (k[i] != DEAD && f <= bstar) ? 1u : 0u;
             dest |= d << (2 * i);
-            cb += d == 3u ? 1u : 0u;
         }
-        // ... then the few entries bound for the scratch array (about one in seventy)
         // ... then the few entries bound for the scratch array (about one in seventy).  (Wave-aggregating the two LDS
         // atomics — one reservation per wave, one count per group of equal bins — measured slower: 17.5 vs 13.6 us.)
         if (dest & 0x5555u & ~(dest >> 1)) {
@@ -998,24 +1013,6 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
                 }
             }
         }
-        if (spill < NBIN) {  // a spill iteration (FRONT outgrew f_max): rare
-            Pos2 p = block_reserve2<256>(0u, cb, &c->open_n[bb].v, &c->open_n[bb].v, sh);
-#pragma unroll
-            for (uint32_t i = 0; i < ITEMS; i++) {
-                if (((dest >> (2 * i)) & 3u) != 3u) continue;
-                const uint32_t idx = tile * TILE + i * 256 + threadIdx.x;
-                if (p.b < E.max_nodes) {
-                    E.open_key[bb][p.b] = k[i];
-                    E.open_id[bb][p.b] = ids[idx];
-                } else {
-                    c->failed = 1;
-                }
-                keys[idx] = DEAD;
-                p.b++;
-                bmn = k[i] < bmn ? k[i] : bmn;
-                bmx = k[i] > bmx ? k[i] : bmx;
-            }
-        }
     }
     __syncthreads();
     {
@@ -1041,7 +1038,6 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
             }
         }
     }
-    if (spill < NBIN) fold_range(c, bb, bmn, bmx);
 }
 
 // ---------------------------------------------------------------------------------------------
