@@ -544,6 +544,38 @@ __global__ __launch_bounds__(256) void k_refill_hist(const Eng* __restrict__ eng
         if (lh[i]) atomicAdd(&E.rhist[i], lh[i]);
 }
 
+// exclusive prefix of NBIN bin counts held kBinsPerThread per thread (1024 threads) into pre[0..NBIN]
+__device__ __forceinline__ void scan_vals(const uint32_t (&v)[kBinsPerThread], uint32_t* pre, uint32_t* wsum) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kBinsPerThread; k++) s += v[k];
+    uint32_t incl = s;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t u = __shfl_up(incl, o);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    if (t < 16) {
+        uint32_t u = wsum[t], acc = u;
+        for (int o = 1; o < 16; o <<= 1) {
+            uint32_t x = __shfl_up(acc, o, 16);
+            if (t >= o) acc += x;
+        }
+        wsum[t] = acc - u;  // exclusive wave offsets
+    }
+    __syncthreads();
+    uint32_t run = incl - s + wsum[wv];
+#pragma unroll
+    for (int k = 0; k < kBinsPerThread; k++) {
+        pre[kBinsPerThread * t + k] = run;
+        run += v[k];
+    }
+    if (t == 1023) pre[NBIN] = run;
+    __syncthreads();
+}
+
 // exclusive prefix of NBIN global bins into pre[0..NBIN] (1024 threads, kBinsPerThread bins each); optionally zeroes them
 __device__ __forceinline__ void scan_bins(uint32_t* __restrict__ hist, bool zero, uint32_t* pre, uint32_t* wsum) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -795,21 +827,40 @@ __global__ __launch_bounds__(256) void k_front_rebase(const Eng* __restrict__ en
 __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs, int rebased) {
     const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
-    if (c->done) return;
-    Stamp stamp(E, P_SEL_SCAN);
     __shared__ uint32_t pre[NBIN + 1];
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t s_spill, s_bstar, s_maxbin, s_giant, s_nbig, s_sp, s_hbin;
     __shared__ uint64_t s_red[2][16];
     const int t = threadIdx.x;
-    uint32_t cb = c->cur_f;
-    uint64_t new_kmin = c->sel_kmin;
-    uint32_t new_shift = c->shift;
+    // Everything this launch reads from the control block, the histogram and (rebase) the per-block key ranges is
+    // requested here, in one batch: a read that waits for an earlier one costs a trip to memory each (the launch is a
+    // single workgroup: nothing else hides it), and there used to be six such trips in a row.
+    const uint32_t done = c->done;
+    const uint32_t cur0 = c->cur_f, old_shift = c->shift, refill = c->refill, compact = c->compact;
+    const uint64_t old_kmin = c->sel_kmin, T0 = c->T;
+    const uint32_t on0 = c->open_n[0].v, on1 = c->open_n[1].v, dead0 = c->front_dead.v, above0 = c->front_above;
+    const uint64_t r0min = c->rng[0].kmin, r0max = c->rng[0].kmax, r1min = c->rng[1].kmin, r1max = c->rng[1].kmax;
+    const uint32_t giant_seen = c->dbg_giant_seen;
+    uint32_t hv[kBinsPerThread];
+#pragma unroll
+    for (int k = 0; k < kBinsPerThread; k++) hv[k] = E.hist[kBinsPerThread * t + k];
+    uint64_t mn = ~0ull, mx = 0;
+    if (rebased && t < kCollectBlocks) {
+        mn = E.part[t];
+        mx = E.part[kCollectBlocks + t];
+    }
+    if (done) return;
+    Stamp stamp(E, P_SEL_SCAN);
+    uint32_t cb = cur0;
+    uint64_t new_kmin = old_kmin;
+    uint32_t new_shift = old_shift;
     if (rebased) {
-        // k_front_rebase compacted FRONT into the other buffer, counted E.hist under this binning and left per-block
-        // key ranges of the live entries in E.part
-        fresh_binning(c, cb, new_kmin, new_shift);
-        uint64_t mn = t < kCollectBlocks ? E.part[t] : ~0ull, mx = t < kCollectBlocks ? E.part[kCollectBlocks + t] : 0ull;
+        // k_front_rebase compacted FRONT into the other buffer, counted E.hist under this binning (fresh_binning of the
+        // old buffer's key range) and left per-block key ranges of the entries it kept in E.part
+        new_kmin = cur0 ? r1min : r0min;
+        uint64_t kmax = cur0 ? r1max : r0max;
+        if (T0 != ~0ull && T0 > kmax) kmax = T0;
+        new_shift = kmax > new_kmin ? select_shift(new_kmin, kmax) : 0u;
         for (int o = 32; o > 0; o >>= 1) {
             const uint64_t a = __shfl_xor(mn, o), z = __shfl_xor(mx, o);
             mn = a < mn ? a : mn;
@@ -821,37 +872,19 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
         }
         cb ^= 1;
     }
-    __syncthreads();
     if (t == 0) {
-        if (rebased) {
-            uint64_t mn = ~0ull, mx = 0;
-            for (int w = 0; w < 16; w++) {
-                mn = s_red[0][w] < mn ? s_red[0][w] : mn;
-                mx = s_red[1][w] > mx ? s_red[1][w] : mx;
-            }
-            c->cur_f = cb;
-            c->front_dead.v = 0;
-            c->rng[cb].kmin = mn;
-            c->rng[cb].kmax = mx;
-        }
         s_maxbin = 0;
         s_giant = 0;
         s_nbig = 0;
-        if (c->refill && c->compact) {  // the compacted copy becomes BACK
-            c->cur_b ^= 1;
-            c->back_dead.v = 0;
-            c->compact = 0;
-        }
-        c->refill = 0;
         s_spill = NBIN;  // no spill
         s_bstar = 0;
         s_hbin = NBIN;
     }
     // E.hist is FRONT's histogram under the binning in force: recounted by k_front_rebase in a rebase iteration (every
     // kRefillPeriod-th), maintained incrementally in between (the writeback below + k_commit's pushes)
-    scan_bins(E.hist, false, pre, wsum);
+    scan_vals(hv, pre, wsum);
     // live entries at or below T (a rebase pass has just dropped the tombstones and moved what was above T to BACK)
-    const uint32_t n = c->open_n[cb].v - (rebased ? 0u : c->front_dead.v + c->front_above);
+    const uint32_t n = rebased ? (cb ? on1 : on0) : (cb ? on1 : on0) - dead0 - above0;
     const uint32_t want = n < (uint32_t)E.B ? n : (uint32_t)E.B;
     const uint32_t hwant = (uint32_t)(kRefillPeriod + 2) * (uint32_t)E.B;
     for (int k = 0; k < kBinsPerThread; k++) {
@@ -892,17 +925,33 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
         }
     }
     if (t == 0) {
-        const uint64_t kmin = new_kmin;
-        const uint32_t shift = new_shift;
+        if (rebased) {
+            uint64_t fmn = ~0ull, fmx = 0;
+            for (int w = 0; w < 16; w++) {
+                fmn = s_red[0][w] < fmn ? s_red[0][w] : fmn;
+                fmx = s_red[1][w] > fmx ? s_red[1][w] : fmx;
+            }
+            c->cur_f = cb;
+            c->rng[cb].kmin = fmn;
+            c->rng[cb].kmax = fmx;
+            c->hbin = s_hbin;
+        }
+        if (refill) {
+            if (compact) {  // the compacted copy becomes BACK
+                c->cur_b ^= 1;
+                c->back_dead.v = 0;
+                c->compact = 0;
+            }
+            c->refill = 0;
+        }
         c->want = want;
         c->bstar = s_bstar;
-        if (rebased) c->hbin = s_hbin;
-        c->sel_kmin = kmin;
-        c->shift = shift;
+        c->sel_kmin = new_kmin;
+        c->shift = new_shift;
         uint32_t sp = s_spill;
         if (sp < NBIN - 1) {
-            uint64_t top = kmin + (((uint64_t)sp + 1) << shift) - 1;
-            if (top >= kmin && top < c->T) c->T = top;  else sp = NBIN;
+            const uint64_t top = new_kmin + (((uint64_t)sp + 1) << new_shift) - 1;
+            if (top >= new_kmin && top < T0) c->T = top;  else sp = NBIN;
         } else {
             sp = NBIN;
         }
@@ -915,10 +964,21 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
             c->failed = 1;
             c->done = 1;
         }
+        c->n_big = s_nbig;
+        c->n_ord = want ? pre[s_bstar + 1] : 0;
+        // k_sel_collect tombstones what leaves FRONT: the bins handed to k_rank — which puts the overshoot of the threshold
+        // bin back into the same slots, so only the batch itself stays dead
+        c->ret_n.v = 0;
+        c->dbg_maxsub = 0;
+        c->front_dead.v = (rebased ? 0u : dead0) + want;
+        c->dbg_nord = want ? pre[s_bstar + 1] : 0;
+        c->dbg_maxbin = s_maxbin;
+        c->dbg_giant = s_giant;
+        c->dbg_giant_seen = giant_seen + s_giant;
     }
     __syncthreads();
     // the histogram of what stays in FRONT: bins at or below the threshold bin leave (the threshold bin's overshoot
-    // comes back from k_rank: pre[bstar+1] - want entries), bins above the spill bin move to BACK
+    // comes back from k_rank: pre[bstar+1] - want entries), bins above the spill bin are no longer tracked
     {
         const uint32_t bstar = s_bstar, sp = s_sp;
         for (int k = 0; k < kBinsPerThread; k++) {
@@ -929,19 +989,6 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
             else if (bin == bstar)
                 E.hist[bin] = pre[bin + 1] - want;
         }
-    }
-    if (t == 0) {
-        c->n_big = s_nbig;
-        c->n_ord = want ? pre[s_bstar + 1] : 0;
-        // k_sel_collect tombstones what leaves FRONT: the bins handed to k_rank — which puts the overshoot of the threshold
-        // bin back into the same slots, so only the batch itself stays dead
-        c->ret_n.v = 0;
-        c->dbg_maxsub = 0;
-        if (want) c->front_dead.v += want;
-        c->dbg_nord = want ? pre[s_bstar + 1] : 0;
-        c->dbg_maxbin = s_maxbin;
-        c->dbg_giant = s_giant;
-        c->dbg_giant_seen += s_giant;
     }
 }
 
@@ -957,9 +1004,11 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
     __shared__ uint32_t st_idx[kStash];
     __shared__ uint16_t st_f[kStash];
     __shared__ uint32_t lcnt[NBIN];
-    __shared__ uint32_t st_n;
-    const uint32_t b = c->cur_f;
-    const uint32_t n = c->open_n[b].v;
+    __shared__ uint16_t nzf[kStash];  // the bins this workgroup stashed entries of (each once)
+    __shared__ uint32_t st_n, nz_n;
+    // (both counters requested together with the buffer index: a read that waits for another is a trip to memory)
+    const uint32_t b = c->cur_f, on0 = c->open_n[0].v, on1 = c->open_n[1].v;
+    const uint32_t n = b ? on1 : on0;
     const uint64_t kmin = c->sel_kmin;
     const uint32_t shift = c->shift, bstar = c->bstar;
     uint64_t* __restrict__ keys = E.open_key[b];
@@ -967,7 +1016,10 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
     constexpr uint32_t ITEMS = 8, TILE = 256 * ITEMS;
     const uint32_t ntiles = (n + TILE - 1) / TILE;
     for (int i = threadIdx.x; i < NBIN; i += 256) lcnt[i] = 0;
-    if (threadIdx.x == 0) st_n = 0;
+    if (threadIdx.x == 0) {
+        st_n = 0;
+        nz_n = 0;
+    }
     __syncthreads();
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint64_t k[ITEMS];
@@ -999,7 +1051,7 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
                     st_key[p] = k[i];
                     st_idx[p] = idx;
                     st_f[p] = (uint16_t)f;
-                    atomicAdd(&lcnt[f], 1u);
+                    if (atomicAdd(&lcnt[f], 1u) == 0u) nzf[atomicAdd(&nz_n, 1u)] = (uint16_t)f;
                 } else {  // stash full (a workgroup rarely sees this many): place directly
                     const uint32_t pos = E.pre[f] + atomicAdd(&E.fill[f], 1u);
                     if (pos < E.pre[f + 1]) {
@@ -1018,10 +1070,13 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
     {
         // the stash: one global atomic per bin this workgroup touched reserves its slice of the bin, then every
         // stashed entry takes its slot inside the slice (LDS atomic)
+        // (walking all bins up to the threshold bin here — a returning global atomic, and a wait, per non-empty bin and
+        // loop round — was most of this kernel's time; the list of touched bins is a few dozen long: one round)
         const uint32_t ns = st_n < (uint32_t)kStash ? st_n : (uint32_t)kStash;
-        for (uint32_t f = threadIdx.x; f <= bstar; f += 256) {
-            const uint32_t cn = lcnt[f];
-            if (cn) lcnt[f] = atomicAdd(&E.fill[f], cn);
+        const uint32_t nz = nz_n;
+        for (uint32_t i = threadIdx.x; i < nz; i += 256) {
+            const uint32_t f = nzf[i];
+            lcnt[f] = atomicAdd(&E.fill[f], lcnt[f]);
         }
         __syncthreads();
         for (uint32_t p = threadIdx.x; p < ns; p += 256) {
@@ -2380,6 +2435,7 @@ int dev_alloc(dca_engine* e, T** p, size_t count) {
 }
 
 constexpr int kScanGrid = kScanBlocks;
+static int h_tune[8];  // host copy of the diagnostic knobs (dca_debug_tune)
 
 inline dim3 gxy(unsigned x, const dca_engine* e) { return dim3(x, (unsigned)e->K); }
 
@@ -2461,7 +2517,7 @@ int enqueue_first_half(dca_engine* e, int heur_id, bool with_refill, hipStream_t
     // and maintained incrementally in between (k_sel_scan's writeback + k_commit's pushes)
     if (with_refill) hipLaunchKernelGGL(k_front_rebase, gxy(kCollectBlocks, e), dim3(256), 0, s, d);
     hipLaunchKernelGGL(k_sel_scan, gxy(1, e), dim3(1024), 0, s, d, with_refill ? 1 : 0);
-    hipLaunchKernelGGL(k_sel_collect, gxy(kCollectBlocks, e), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(k_sel_collect, gxy(h_tune[4] > 0 ? h_tune[4] : kCollectBlocks, e), dim3(256), 0, s, d);
     hipLaunchKernelGGL(k_rank, gxy(kRankBlocks, e), dim3(RT), kRankLdsBytes, s, d);
     if (int rc = launch_check("select kernels")) return rc;
     return launch_expand(e, heur_id, want_oh, s);
@@ -2918,6 +2974,7 @@ int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, int use_gr
 }
 
 int dca_debug_tune(int knob, int value) {
+    if (knob >= 0 && knob < 8) h_tune[knob] = value;  // (host-side knobs: 4 = workgroups of k_sel_collect; set before the first step)
     // diagnostics: 0 extra log2 of sub-bins per large bin, 1 sub-bin size above which a sub-bin is refined on its own (2-7 unused)
     DCA_ARG(knob >= 0 && knob < 8);
     DCA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tune), &value, sizeof(int), (size_t)knob * sizeof(int), hipMemcpyHostToDevice));
