@@ -56,7 +56,7 @@ constexpr int kSortCap = 8192;        // diagnostics only: bins beyond this many
 constexpr int RT = 512;                            // threads of a k_rank workgroup (8 waves: up to 256 VGPRs each)
 constexpr int kRegEnt = 16;                        // entries a thread keeps in registers
 constexpr uint32_t kLdsEnt = RT * kRegEnt;         // items up to this size are bucketed entirely in LDS (96 KB)
-constexpr int kStash = 3072;          // per-workgroup LDS stash of k_sel_collect (entries at or below the threshold bin)
+constexpr int kStash = 2560;          // per-workgroup LDS stash of k_sel_collect (entries at or below the threshold bin)
 constexpr uint32_t NIL = 0xFFFFFFFFu;
 // OPEN entries carry "this node is solved" in bit 31 of the id (node ids stay below 2^31): the pop then knows a goal
 // without touching the node pool.  Every compare / index uses the id with the flag masked off.
