@@ -924,6 +924,7 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
             }
         }
     }
+    __syncthreads();  // (s_nbig, s_maxbin, s_giant are complete)
     if (t == 0) {
         if (rebased) {
             uint64_t fmn = ~0ull, fmx = 0;
