@@ -2436,6 +2436,12 @@ int dev_alloc(dca_engine* e, T** p, size_t count) {
 }
 
 constexpr int kScanGrid = kScanBlocks;
+// Rebase iterations: every kRefillPeriod-th — and each of the first kRampIters after a reset.  A search starts from one
+// entry, so the binning taken at iteration 0 (key range = the root's key) puts every child of the next iterations into
+// the last bin: one bin of 10^5..10^6 entries for k_rank to order on a single workgroup (1-2 ms per iteration, measured:
+// k_rank's rocprofv3 maximum).  While OPEN is still growing by a factor of A per iteration a fresh binning each time is cheap.
+constexpr int kRampIters = 12;
+static inline bool rebase_due(long host_iter) { return host_iter < kRampIters || host_iter % kRefillPeriod == 0; }
 static int h_tune[8];  // host copy of the diagnostic knobs (dca_debug_tune)
 
 inline dim3 gxy(unsigned x, const dca_engine* e) { return dim3(x, (unsigned)e->K); }
@@ -2778,7 +2784,7 @@ int dca_engine_pop_expand(dca_engine* e, const uint8_t** nnet_in, const void** o
         set_error("dca_engine_pop_expand called twice without dca_engine_commit");
         return DCA_E_STATE;
     }
-    if (int rc = enqueue_first_half(e, -1, (e->host_iter++ % kRefillPeriod) == 0, (hipStream_t)stream)) return rc;
+    if (int rc = enqueue_first_half(e, -1, rebase_due(e->host_iter++), (hipStream_t)stream)) return rc;
     if (nnet_in) *nnet_in = e->nnet_all;
     if (onehot) *onehot = e->onehot_all;
     if (m_capacity) *m_capacity = (int64_t)e->E[0].M * e->K;
@@ -2848,7 +2854,7 @@ int dca_engine_pop_expand_packed(dca_engine* e, const uint8_t** nnet_in, const v
     }
     hipStream_t s = (hipStream_t)stream;
     DCA_HIP(hipMemsetAsync(e->pk_n, 0, sizeof(uint32_t), s));
-    if (int rc = enqueue_first_half(e, -1, (e->host_iter++ % kRefillPeriod) == 0, s, false)) return rc;
+    if (int rc = enqueue_first_half(e, -1, rebase_due(e->host_iter++), s, false)) return rc;
     if (int rc = enqueue_dedup(e, true, s)) return rc;
     if (int rc = launch_pack(e, s)) return rc;
     DCA_HIP(hipMemcpyAsync(e->h_pk_n, e->pk_n, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -2885,7 +2891,7 @@ int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph,
     hipStream_t s = (hipStream_t)stream;
     if (!use_graph) {
         for (int i = 0; i < iters; i++) {
-            if (int rc = enqueue_first_half(e, heur_id, (e->host_iter++ % kRefillPeriod) == 0, s)) return rc;
+            if (int rc = enqueue_first_half(e, heur_id, rebase_due(e->host_iter++), s)) return rc;
             if (int rc = enqueue_second_half(e, s)) return rc;
         }
         return 0;
@@ -2910,7 +2916,7 @@ int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph,
         e->graph_heur = heur_id;
     }
     for (int i = 0; i < iters; i++)
-        DCA_HIP(hipGraphLaunch(e->graph_exec[(e->host_iter++ % kRefillPeriod) == 0 ? 1 : 0], s));
+        DCA_HIP(hipGraphLaunch(e->graph_exec[rebase_due(e->host_iter++) ? 1 : 0], s));
     return 0;
 }
 
