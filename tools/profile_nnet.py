@@ -1,8 +1,9 @@
 """Workload for rocprofv3: the cube3 cost-to-go network (FastResnet layout) on one dedup-first batch of 204 800 rows,
 fp32 (parity mode) or bf16.  `python tools/profile_nnet.py fp32|bf16 [reps]`"""
+import os
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepcubea_amd.utils import env_utils
 from deepcubea_amd.utils.pytorch_models import FastResnet
 from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
