@@ -13,22 +13,24 @@
 //   CLOSED      open-addressing table of 16-byte slots {tag32|rep32, best g, batch list head},
 //               keyed by the 64-bit state hash, verified against the representative node's state
 //               bytes (exact key equality, like State.__eq__ / NodePointerEq).
-//   OPEN        (cost key u64 = order-preserving bits of the f64 cost, node id u32) arrays in two tiers: FRONT
-//               (entries with key <= T, ping-pong buffers) and BACK (the rest, append-only with tombstones).
-//               pop = exact top-B of FRONT by (cost, id): 2048-bin histogram -> threshold bin -> every entry at or
-//               below the threshold bin is moved, grouped by bin, into a scratch array; one workgroup per bin then
-//               orders its bin exactly on the 96-bit (key,id) composite (bitonic network in LDS; a bin too large for
-//               LDS — massive cost ties — is first cut down by radix refinement on the composite and ordered through
-//               arithmetic sub-bins of its own exact range) and hands the overshoot of the threshold bin back.
-//               FRONT is refilled from / spilled to BACK with hysteresis, so an iteration costs
-//               O(|FRONT| + children), independent of |OPEN|.
+//   OPEN        (cost key u64 = order-preserving bits of the f64 cost, node id u32 | is_solved flag) arrays in two tiers:
+//               FRONT (entries with key <= T, edited IN PLACE: pops tombstone what they take, pushes append) and BACK
+//               (the rest, append-only with tombstones).  pop = exact top-B of FRONT by (cost, id): an incrementally
+//               maintained 4096-bin histogram gives the threshold bin (k_sel_scan); every entry at or below it is
+//               moved, grouped by bin, into a scratch array (k_sel_collect); k_rank orders each bin exactly — small
+//               bins a thread per entry, large ones bucketed in LDS on 64-bit key / id offsets and shared between
+//               workgroups, giant ones (massive cost ties) streamed on the 96-bit (key,id) composite — and puts the
+//               overshoot of the threshold bin back into the slots it came from.  Every 8th ("rebase") iteration one
+//               pass compacts FRONT into its second buffer, evicts what a spill left above T, recounts the histogram
+//               under a fresh binning; refills from BACK and spills to it are decided there, with hysteresis, so an
+//               iteration costs O(|FRONT| + children), independent of |OPEN|.
 //
-// One BWAS iteration = pop -> expand -> heuristic -> dedup -> push in SEVEN launches (hist, scan, collect, rank,
-// expand, probe, commit), all stream-ordered, no host round trip: counts live in a device control block (hot counters
-// on their own cache lines) and every kernel sizes itself from it.  The per-iteration batch geometry is double
-// buffered by iteration parity (IterState), so the expansion launch itself closes the pop (no single-thread kernel
-// in between).  One engine steps K independent instances at once: every kernel takes the device array of instance
-// descriptors and picks its instance with blockIdx.y.
+// One BWAS iteration = pop -> expand -> heuristic -> dedup -> push in SIX launches (scan, collect, rank, expand, probe,
+// commit; four more in a rebase iteration), all stream-ordered, no host round trip: counts live in a device control
+// block (hot counters on their own cache lines) and every kernel sizes itself from it.  The per-iteration batch
+// geometry is double buffered by iteration parity (IterState), so the expansion launch itself closes the pop (no
+// single-thread kernel in between).  One engine steps K independent instances at once: every kernel takes the device
+// array of instance descriptors and picks its instance with blockIdx.y.
 //
 // Sequential-order dedup, done in parallel: children of one batch that hit the same
 // CLOSED slot are chained through the slot's `head`; child j is kept iff g_j < v0 (the slot's value
@@ -50,7 +52,7 @@ constexpr int kLgNbin = 12;
 constexpr int kSub = 2048;            // sub-bins of k_rank's per-bin bucketing
 constexpr int kScanBlocks = 256;      // grid of the OPEN scans: few fat blocks (cheap when they early-exit)
 constexpr int kCollectBlocks = 512;   // k_sel_collect: two workgroups per CU keep twice the loads in flight
-constexpr int kRankBlocks = 256;      // k_rank: one 1024-thread workgroup per CU, the bins to order strided over them
+constexpr int kRankBlocks = 256;      // k_rank: one 512-thread workgroup per CU, the work units strided over them
 constexpr int kTinyBin = 128;         // bins up to this size are ranked one THREAD per entry (all-pairs inside the bin)
 constexpr int kSortCap = 8192;        // diagnostics only: bins beyond this many entries are counted as "giant"
 constexpr int RT = 512;                            // threads of a k_rank workgroup (8 waves: up to 256 VGPRs each)
@@ -121,7 +123,7 @@ struct Ctl {
     // the LDS sort capacity (those take the refinement path)
     uint32_t dbg_nord, dbg_maxbin, dbg_giant, dbg_giant_seen, dbg_maxsub;
     // ---- hot words -----------------------------------------------------------------------------
-    Cnt open_n[4];   // physical entries per OPEN buffer (0/1 FRONT ping-pong, 2/3 BACK + its compaction target)
+    Cnt open_n[4];   // physical entries per OPEN buffer (0/1 FRONT + its compaction target, 2/3 BACK + its compaction target)
     Cnt closed_n, back_dead, front_dead, ret_n, ticket_a;  // *_dead: tombstones (key == DEAD) inside the tier's buffer
     Rng rng[4];      // running key range per OPEN buffer
     alignas(128) unsigned long long goal_best;  // PY: min over solved popped of (g << 32 | pop rank)
@@ -1097,20 +1099,20 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_rank: exact order of the batch.  k_sel_scan listed the non-empty bins at or below the threshold bin: "tiny" ones
-// (<= 64 entries — most of them) are ranked by ONE WAVE each (all-pairs through lane shuffles, no LDS, no barrier),
-// the others by one 1024-thread workgroup each with a streamed bucket sort on the 96-bit (key,id) composite:
-//   pass 0  exact min / max of the bin's composites
-//   pass 1  counts of up to 2048 arithmetic sub-bins of that exact range (LDS atomics); prefix; the sub-bin that holds
-//           the last entry the batch still needs
-//   pass 2  entries in lower-or-equal sub-bins are scattered, grouped by sub-bin, into the bin's slice of the second
-//           scratch array; the rest of a threshold bin goes straight back to FRONT'
-//   pass 3  rank inside the (few-entry) sub-bin = final pop rank; a sub-bin that is still large (ids of a tie group
-//           clustered, a few distinct keys with huge multiplicities) becomes a work item of its own, with its own exact
-//           range, reading the slice the scatter just wrote and scattering back into the first array (ping-pong).
-// Only counters live in LDS, so a bin of any size — a whole OPEN tied on one cost — takes the same path; ranks below
-// `want` are the batch in pop order (which fixes the children's node ids and therefore every later tie-break), the
-// overshoot of the threshold bin returns to FRONT'.
+// k_rank: exact order of the batch.  The scratch array holds every entry at or below the threshold bin, grouped by bin.
+//   * bins of at most kTinyBin entries (most bins, about half the entries): one THREAD per entry, the bins' slice of the
+//     scratch array staged in LDS, rank = entries in lower bins + smaller (key,id) pairs inside the bin;
+//   * larger bins are work units of k_sel_scan's list, one per workgroup (a bin of more than 1024 entries is shared by up
+//     to eight workgroups).  Up to kLdsEnt entries the bin is read ONCE into registers and bucketed + ranked in LDS:
+//       1  smallest key / id and their spans                          2  counts of up to 2048 sub-bins, prefix, the sub-bin
+//       3  scatter of the sub-bins the batch needs into LDS;             holding the last entry the batch still needs
+//          the rest of a threshold bin goes back to FRONT             4  rank inside the (few-entry) sub-bin = pop rank
+//     a sub-bin that is still large (ids of a tie group clustered, a few distinct keys with huge multiplicities) becomes a
+//     work item of its own, reading the slice the scatter wrote to the second scratch array (ping-pong);
+//   * bins beyond kLdsEnt entries (a whole OPEN tied on one cost) stream through the same four passes from HBM on the
+//     96-bit (key,id) composite, only counters in LDS: any size, one workgroup.
+// Ranks below `want` are the batch in pop order (which fixes the children's node ids and therefore every later tie-break);
+// the overshoot of the threshold bin returns to the FRONT slots k_sel_collect took it from.
 // ---------------------------------------------------------------------------------------------
 typedef unsigned __int128 u128;
 __device__ __forceinline__ u128 comp_of(uint64_t key, uint32_t id) { return ((u128)key << 32) | (u128)(id & ID_MASK); }
@@ -1141,7 +1143,7 @@ struct RankShared {
     uint64_t kmin, kspan;  // LDS path: the item's smallest key and key span,
     uint32_t imin, ispan;  // and the same for its (masked) ids
     uint32_t bits, tsub, sp, fail;
-    uint32_t ret_base, ret_cnt;            // one reservation in FRONT' per work item for the entries it hands back
+    uint32_t ret_base, ret_cnt;            // one reservation of return numbers per work item for the entries it hands back
     RankItem stack[kRankStack];
 };
 
