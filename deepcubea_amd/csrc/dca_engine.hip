@@ -1024,6 +1024,40 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
         nz_n = 0;
     }
     __syncthreads();
+    // The stash goes out (workgroup-collective, call after a barrier): one global atomic per bin this workgroup touched
+    // reserves its slice of the bin, then every stashed entry takes its slot inside the slice (LDS atomic).  (Walking all
+    // bins up to the threshold bin instead — a returning global atomic, and a wait, per non-empty bin and loop round — was
+    // most of this kernel's time; the list of touched bins is a few dozen long: one round.)
+    auto flush = [&]() {
+        const uint32_t ns = st_n < (uint32_t)kStash ? st_n : (uint32_t)kStash;
+        const uint32_t nz = nz_n;
+        for (uint32_t i = threadIdx.x; i < nz; i += 256) {
+            const uint32_t f = nzf[i];
+            lcnt[f] = atomicAdd(&E.fill[f], lcnt[f]);
+        }
+        __syncthreads();
+        for (uint32_t p = threadIdx.x; p < ns; p += 256) {
+            const uint32_t f = st_f[p];
+            const uint32_t id = ids[st_idx[p]];
+            const uint32_t pos = E.pre[f] + atomicAdd(&lcnt[f], 1u);
+            if (pos < E.pre[f + 1]) {
+                E.tmp_key[pos] = st_key[p];
+                E.tmp_id[pos] = id;
+                E.tmp_f[pos] = (uint16_t)f;
+                E.tmp_idx[pos] = st_idx[p];
+            } else {
+                c->failed = 1;  // histogram and FRONT disagree (cannot happen): refuse to write outside the bin's slice
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nz; i += 256) lcnt[nzf[i]] = 0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            st_n = 0;
+            nz_n = 0;
+        }
+        __syncthreads();
+    };
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint64_t k[ITEMS];
         uint32_t dest = 0;  // 2 bits per item: 0 stays (or dead), 1 scratch (ordered by k_rank)
@@ -1055,7 +1089,7 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
                     st_idx[p] = idx;
                     st_f[p] = (uint16_t)f;
                     if (atomicAdd(&lcnt[f], 1u) == 0u) nzf[atomicAdd(&nz_n, 1u)] = (uint16_t)f;
-                } else {  // stash full (a workgroup rarely sees this many): place directly
+                } else {  // stash full (cannot happen: it is flushed while a whole tile still fits): place directly
                     const uint32_t pos = E.pre[f] + atomicAdd(&E.fill[f], 1u);
                     if (pos < E.pre[f + 1]) {
                         E.tmp_key[pos] = k[i];
@@ -1068,34 +1102,13 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
                 }
             }
         }
+        // a tile can add up to TILE entries: make room when fewer are left (only ever true when a bin holds a large share
+        // of FRONT — massive cost ties — where placing the overflow entry by entry meant millions of atomics on ONE counter)
+        __syncthreads();
+        if (st_n + TILE > (uint32_t)kStash) flush();
     }
     __syncthreads();
-    {
-        // the stash: one global atomic per bin this workgroup touched reserves its slice of the bin, then every
-        // stashed entry takes its slot inside the slice (LDS atomic)
-        // (walking all bins up to the threshold bin here — a returning global atomic, and a wait, per non-empty bin and
-        // loop round — was most of this kernel's time; the list of touched bins is a few dozen long: one round)
-        const uint32_t ns = st_n < (uint32_t)kStash ? st_n : (uint32_t)kStash;
-        const uint32_t nz = nz_n;
-        for (uint32_t i = threadIdx.x; i < nz; i += 256) {
-            const uint32_t f = nzf[i];
-            lcnt[f] = atomicAdd(&E.fill[f], lcnt[f]);
-        }
-        __syncthreads();
-        for (uint32_t p = threadIdx.x; p < ns; p += 256) {
-            const uint32_t f = st_f[p];
-            const uint32_t id = ids[st_idx[p]];
-            const uint32_t pos = E.pre[f] + atomicAdd(&lcnt[f], 1u);
-            if (pos < E.pre[f + 1]) {
-                E.tmp_key[pos] = st_key[p];
-                E.tmp_id[pos] = id;
-                E.tmp_f[pos] = (uint16_t)f;
-                E.tmp_idx[pos] = st_idx[p];
-            } else {
-                c->failed = 1;  // (see above)
-            }
-        }
-    }
+    flush();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1639,6 +1652,7 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
     const bool tsub_pushed = S.off[tsub + 1] - S.off[tsub] > kSubMax && shc > 0;
     ret_begin(c, S, nf, (n - S.off[tsub + 1]) + (tsub_pushed ? 0u : S.off[tsub + 1] - need));
     RetAcc acc{};
+    const uint32_t n_ord_all = c->n_ord;
     for (uint32_t b0 = 0; b0 < n; b0 += kLdsEnt) {
         uint64_t ek[kRegEnt];
         uint32_t ei[kRegEnt];
@@ -1648,6 +1662,7 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
             ek[j] = K[ic];
             ei[j] = I[ic];
         }
+        uint32_t retm = 0;
 #pragma unroll
         for (int j = 0; j < kRegEnt; j++) {
             const bool live = b0 + t + (uint32_t)RT * j < n;
@@ -1660,8 +1675,11 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
                     I2[p] = ei[j];
                 }
             }
-            ret_put(E, c, S, nf, live && sub > tsub, ek[j], ei[j], acc);
+            retm |= (live && sub > tsub ? 1u : 0u) << j;
         }
+        // (one batched hand-back per chunk: a ret_put per entry waits for its own slot-number load — sixteen memory round
+        // trips per chunk, hundreds of chunks when the bin is a tie group of millions)
+        ret_put_many<kRegEnt>(E, S, nf, n_ord_all, retm, ek, ei);
     }
     __syncthreads();
     const uint32_t m = S.off[tsub + 1];
