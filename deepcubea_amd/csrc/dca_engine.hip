@@ -217,26 +217,6 @@ struct Eng {
 
 __device__ __forceinline__ const IterState& st_cur(const Ctl* c) { return c->S[c->iters & 1]; }
 __device__ __forceinline__ const IterState& st_next(const Ctl* c) { return c->S[(c->iters + 1) & 1]; }
-// Kernel heads: a read that waits for an earlier read is a trip to memory (the control block is cold in every launch —
-// other XCDs wrote it), and `done` -> `iters` -> S[parity] -> ... used to be four of them in a row before a kernel touched
-// its data.  The batch geometry of the iteration in flight, both parities requested together with `iters` and `done`:
-struct Geo {
-    uint32_t done, npop, m, base;
-};
-__device__ __forceinline__ Geo next_geo(const Ctl* c) {
-    const uint32_t done = (uint32_t)c->done, it = (uint32_t)c->iters;
-    const uint32_t n0 = c->S[0].npop, m0 = c->S[0].m, b0 = c->S[0].base;
-    const uint32_t n1 = c->S[1].npop, m1 = c->S[1].m, b1 = c->S[1].base;
-    const bool odd = ((it + 1u) & 1u) != 0u;
-    return Geo{done, odd ? n1 : n0, odd ? m1 : m0, odd ? b1 : b0};
-}
-// ... and the fence that keeps such a batch together: the compiler sinks a load below the `if (done) return` when only
-// the code behind it uses the value (one more wait, one more trip); an empty asm that consumes the values pins them above.
-// (same for the instance descriptor's fields — scalar loads, otherwise issued one by one right in front of their first use)
-#define DCA_PINS12(a, b, c_, d, e, f, g, h, i, j, k, l) \
-    asm volatile("" ::"s"(a), "s"(b), "s"(c_), "s"(d), "s"(e), "s"(f), "s"(g), "s"(h), "s"(i), "s"(j), "s"(k), "s"(l))
-#define DCA_PIN1(a) asm volatile("" ::"v"(a))
-#define DCA_PIN4(a, b, c_, d) asm volatile("" ::"v"(a), "v"(b), "v"(c_), "v"(d))
 
 // the binning a rebase iteration installs (k_front_rebase recounts under it, k_sel_scan records it): FRONT's exact key range,
 // its top raised to the tier threshold — no key above T enters FRONT before the next rebase
@@ -1021,15 +1001,7 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
 __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ engs) {
     const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
-    // (everything read from the control block is requested in one batch, see next_geo)
-    DCA_PINS12(E.open_key[0], E.open_key[1], E.open_id[0], E.open_id[1], E.pre, E.fill, E.tmp_key, E.tmp_id,
-               E.tmp_f, E.tmp_idx, E.prof, E.prof);
-    const uint32_t done = (uint32_t)c->done, b = c->cur_f, on0 = c->open_n[0].v, on1 = c->open_n[1].v;
-    const uint64_t kmin = c->sel_kmin;
-    const uint32_t shift = c->shift, bstar = c->bstar;
-    DCA_PIN4(b, on0, on1, kmin);
-    DCA_PIN4(shift, bstar, done, done);
-    if (done) return;
+    if (c->done) return;
     Stamp stamp(E, P_SEL_COLLECT);
     __shared__ uint64_t st_key[kStash];
     __shared__ uint32_t st_idx[kStash];
@@ -1037,7 +1009,11 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
     __shared__ uint32_t lcnt[NBIN];
     __shared__ uint16_t nzf[kStash];  // the bins this workgroup stashed entries of (each once)
     __shared__ uint32_t st_n, nz_n;
+    // (both counters requested together with the buffer index: a read that waits for another is a trip to memory)
+    const uint32_t b = c->cur_f, on0 = c->open_n[0].v, on1 = c->open_n[1].v;
     const uint32_t n = b ? on1 : on0;
+    const uint64_t kmin = c->sel_kmin;
+    const uint32_t shift = c->shift, bstar = c->bstar;
     uint64_t* __restrict__ keys = E.open_key[b];
     const uint32_t* __restrict__ ids = E.open_id[b];
     constexpr uint32_t ITEMS = 8, TILE = 256 * ITEMS;
@@ -1735,19 +1711,16 @@ __device__ __noinline__ void rank_item(const Eng& E, Ctl* c, RankShared& S, uint
 __global__ __launch_bounds__(RT) void k_rank(const Eng* __restrict__ engs) {
     const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
-    DCA_PINS12(E.tmp_key, E.tmp_id, E.tmp_f, E.tmp_idx, E.pre, E.big_list, E.pop_key, E.pop_id,
-               E.open_key[0], E.open_key[1], E.open_id[0], E.open_id[1]);
-    const uint32_t done = (uint32_t)c->done, nf = c->cur_f;  // what the batch does not take goes back where it came from
-    const uint32_t bstar = c->bstar, want = c->want, n_big = c->n_big, n_ord = c->n_ord;
-    DCA_PIN4(nf, bstar, want, n_big);
-    DCA_PIN1(n_ord);
-    if (done) return;
+    if (c->done) return;
     Stamp stamp(E, P_RANK);
     __shared__ RankShared S;
     extern __shared__ __attribute__((aligned(16))) uint8_t rank_lds[];  // 8192 keys, then 8192 ids (96 KB)
     uint64_t* LK = reinterpret_cast<uint64_t*>(rank_lds);
     uint32_t* LI = reinterpret_cast<uint32_t*>(rank_lds + (size_t)kLdsEnt * 8);
     const uint32_t t = threadIdx.x;
+    const uint32_t nf = c->cur_f;  // what the batch does not take goes back where it came from
+    const uint32_t bstar = c->bstar, want = c->want;
+    const uint32_t n_big = c->n_big, n_ord = c->n_ord;
     // ---- entries of small bins (most bins, about half the entries): one thread each, the whole grid at once
     {
         Stamp sub(E, P_RANK_SMALL);  // (profile only: the two halves of this launch get their own slots)
@@ -1840,30 +1813,25 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
     using TL = Tile<ENV, DIM, kEngTile>;
     constexpr int kTileParents = kEngTile;  // shadows the stand-alone kernels' 64
     Ctl* c = E.ctl;
-    // batch geometry: every workgroup derives it from the state the previous iteration left (S[iters & 1]) and the
-    // pop that k_rank just finished; workgroup 0 also records it for the rest of the iteration (close_pop).  Both
-    // parities of the state are requested together with `iters` (see next_geo).
-    DCA_PINS12(E.pop_id, E.state, E.g, E.pop_g, E.child_hash, E.parent, E.move, E.solved,
-               E.child_multi, E.child_h, E.nnet_in, E.prof);
-    const uint32_t done = (uint32_t)c->done, it = (uint32_t)c->iters;
-    const IterState Sa = c->S[0], Sb = c->S[1];
-    const uint32_t want = c->want, fs = c->first_solved, cur_new = c->cur_f;  // FRONT is edited in place: put-backs and children are appended to it
-    DCA_PIN4(Sa.pool_n, Sa.npop, Sa.m, Sa.base);
-    DCA_PIN4(Sa.best_id, Sa.has_best, Sa.best_cost, it);
-    DCA_PIN4(Sb.pool_n, Sb.npop, Sb.m, Sb.base);
-    DCA_PIN4(Sb.best_id, Sb.has_best, Sb.best_cost, want);
-    DCA_PIN4(fs, cur_new, done, done);
-    if (done) return;
+    if (c->done) return;
     Stamp stamp(E, P_EXPAND);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* lpar = smem;
     uint8_t* ltab = smem + TL::PAR_BYTES;
     uint8_t* lst = smem + TL::LDS_BYTES;  // child rows of the tile, laid out exactly like their HBM destination
-    const IterState S0 = (it & 1u) ? Sb : Sa;
+    // batch geometry: every workgroup derives it from the state the previous iteration left (S[iters & 1]) and the
+    // pop that k_rank just finished; workgroup 0 also records it for the rest of the iteration (close_pop)
+    const uint32_t it = (uint32_t)c->iters;
+    const IterState S0 = c->S[it & 1];
+    const uint32_t want = c->want;
     uint32_t npop = want;
-    if (E.sem == DCA_SEM_CPP && fs != NIL) npop = fs + 1;  // cpp:203 break at the first solved node popped
+    if (E.sem == DCA_SEM_CPP) {
+        const uint32_t fs = c->first_solved;
+        if (fs != NIL) npop = fs + 1;  // cpp:203 break at the first solved node popped
+    }
     const uint32_t base = (S0.pool_n + 15u) & ~15u;  // 16-aligned ids => 16-byte aligned child rows for every D
     const bool fail = (uint64_t)base + (uint64_t)npop * (uint64_t)EV::A > (uint64_t)E.max_nodes;
+    const uint32_t cur_new = c->cur_f;  // FRONT is edited in place: put-backs and children are appended to it
     if (blockIdx.x == 0 && threadIdx.x == 0) close_pop(E, c, S0, it, want, npop, base, fail);
     if (fail) return;
     const uint32_t r0 = blockIdx.x * kTileParents;
@@ -2040,14 +2008,11 @@ template <int D>
 __global__ __launch_bounds__(256) void k_probe(const Eng* __restrict__ engs) {
     const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
-    DCA_PINS12(E.child_hash, E.state, E.tab, E.tab_mask, E.child_next, E.child_slot, E.child_v0, E.child_flags,
-               E.child_multi, E.prof, E.tab_mask, E.tab_mask);
-    const Geo geo = next_geo(c);
-    DCA_PIN4(geo.npop, geo.m, geo.base, geo.done);
-    if (geo.done) return;
+    if (c->done) return;
     Stamp stamp(E, P_PROBE);
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t m = geo.m, base = geo.base;
+    const IterState& S1 = st_next(c);
+    const uint32_t m = S1.m, base = S1.base;
     if (j >= m) return;
     constexpr int NW = (D + 3) / 4;
     const uint32_t id = base + j;
@@ -2290,25 +2255,22 @@ template <bool FUSED>
 __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, int packed) {
     const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
-    DCA_PINS12(E.child_flags, E.pop_g, E.child_slot, E.child_multi, E.child_v0, E.tab, E.child_h, E.solved,
-               E.hist, E.prof, E.A, E.sem);
-    const Geo geo = next_geo(c);
-    const uint32_t fb = c->cur_f, bb = c->cur_b, hbin = c->hbin, bin_shift = c->shift;
-    const uint64_t T = c->T, bin_kmin = c->sel_kmin;
-    DCA_PIN4(geo.npop, geo.m, geo.base, geo.done);
-    DCA_PIN4(fb, bb, hbin, bin_shift);
-    DCA_PIN4(T, bin_kmin, geo.done, geo.done);
-    if (geo.done) return;
+    if (c->done) return;
     Stamp stamp(E, P_COMMIT);
     __shared__ uint32_t sh[3 * 16 + 3];
     __shared__ uint32_t lh[NBIN];  // this workgroup's pushes into FRONT per selection bin (FRONT's histogram is incremental)
-    const uint32_t m = geo.m, base = geo.base;
+    const IterState& S1 = st_next(c);
+    const uint32_t m = S1.m, base = S1.base;
+    const uint32_t fb = c->cur_f, bb = c->cur_b;
+    const uint64_t T = c->T;
     const uint32_t j = blockIdx.x * 1024 + threadIdx.x;
     if (blockIdx.x * 1024 >= m) {
         commit_ticket(c);
         return;
     }
     for (int k = 0; k < kBinsPerThread; k++) lh[kBinsPerThread * threadIdx.x + k] = 0;
+    const uint64_t bin_kmin = c->sel_kmin;
+    const uint32_t bin_shift = c->shift;
     __syncthreads();
     const bool live = j < m;
     const uint32_t id = base + j;
@@ -2368,6 +2330,7 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
         key = key_of_cost(cost);
     }
     const bool tof = keep && key <= T, tob = keep && key > T;
+    const uint32_t hbin = c->hbin;
     if (tof) {
         const uint32_t f = bin_of(key, bin_kmin, bin_shift);
         if (f < hbin) atomicAdd(&lh[f], 1u);
