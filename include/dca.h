@@ -218,9 +218,11 @@ int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph,
  * clock at entry and exit, per launch the host takes max(end) - min(start) as the launch's busy span and the distance to
  * the previous launch's end as the gap in front of it — measured INSIDE the replayed hipGraph, which HIP events between
  * eager launches cannot do.  span_ms / gap_ms: host float[DCA_PROF_SLOTS], summed milliseconds over the iterations
- * (gap_ms may be NULL).  Slots: 0 refill_hist 1 refill_scan 2 refill_move (every 8th iteration) 3 sel_hist 4 sel_scan
- * 5 sel_collect 6 rank 7 expand 8 probe 9 decide 10 pack (dedup-first stepping only) 11 commit; 12 / 13 = the two halves of
- * the rank launch (small-bin pass, large-bin workgroups) for tuning.  Synchronises every iteration.                                                                                                          */
+ * (gap_ms may be NULL).  Slots: 0 refill_hist 1 refill_scan 2 refill_move 3 sel_hist (= the FRONT rebase pass; 0-3 only in
+ * rebase iterations: every 8th, and the first twelve after a reset) 4 sel_scan 5 sel_collect 6 rank 7 expand 8 probe 9 decide
+ * 10 pack (dedup-first stepping only) 11 commit; 12 / 13 = the two halves of the rank launch (small-bin pass, large-bin
+ * workgroups), 14-17 = phases of the large-bin path (load + range, count + prefix, scatter, order) as envelopes over the
+ * workgroups — for tuning.  Synchronises every iteration.                                                            */
 #define DCA_PROF_SLOTS 18
 int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, int use_graph, float* span_ms /*host [DCA_PROF_SLOTS]*/,
                                float* gap_ms /*host [DCA_PROF_SLOTS] or NULL*/, void* stream);
@@ -231,7 +233,9 @@ int dca_engine_status_instance(dca_engine* e, int inst, dca_status* out, void* s
 int dca_engine_set_tiers(dca_engine* e, int64_t front_keep, int64_t front_max);
 /* internals of the last iteration for diagnostics (host double[16]; layout in dca_engine.hip); synchronises */
 int dca_engine_debug(dca_engine* e, double* out /*host [16]*/, void* stream);
-/* diagnostics: flips a tuning knob of the engine kernels process-wide (0 = shipped behaviour); never needed in production */
+/* diagnostics: flips a tuning knob of the engine kernels process-wide (0 = shipped behaviour); never needed in production.
+ * knob 0: extra log2 of sub-bins per large bin in k_rank; 1: sub-bin size above which a sub-bin is refined on its own;
+ * 4: workgroups of k_sel_collect (host side, set before the first step); others unused.                              */
 int dca_debug_tune(int knob, int value);
 /* child rows of the last pop_expand straight from the node pool (device [m_live, D]); synchronises */
 int dca_engine_last_children(dca_engine* e, const uint8_t** states, int64_t* m_live, void* stream);
