@@ -131,15 +131,16 @@ def gather_ranks(x: float, world: int):
 
 def pmc_traffic(kernel: str, env: str, B: int):
     """HBM bytes per launch from the rocprofv3 PMC passes of THIS command (`tools/pmc_summary.py` writes
-    profiles/r02_pmc_traffic.json from `rocprofv3 --pmc ... -- python bench.py`): counters cannot be read from inside
+    profiles/r03_pmc_traffic.json from `rocprofv3 --pmc ... -- python bench.py`): counters cannot be read from inside
     the process, so the entry is matched on kernel, environment and batch size and otherwise left null."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-    except (OSError, ValueError):
-        return None
-    if d.get("env") != env or d.get("batch_size") != B:
-        return None
-    return d.get("kernels", {}).get(kernel)
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        if d.get("env") == env and d.get("batch_size") == B and kernel in d.get("kernels", {}):
+            return d["kernels"][kernel]
+    return None
 
 
 def test_root(idx: int, env: str = "cube3") -> np.ndarray:
@@ -198,7 +199,8 @@ def run_astar_leg(args, world, rank, onehot_dtype, min_timed_s, profile_iters):
     A = 12 if args.env == "cube3" else 4
     fill = 8  # iterations a fresh search needs before every pop is a full batch (12^5 > 20 000)
     warm = max(args.warmup, fill)
-    iters_cap = warm + args.steps + profile_iters + 24
+    profile_iters = min(args.steps, 256) if profile_iters > 0 else 0  # the profile covers the timed window's iterations
+    iters_cap = warm + args.steps + 24
     max_nodes = max(1 << 20, iters_cap * B * A + (1 << 16))
     eng = BwasEngine(args.env, w, B, max_nodes=max_nodes, semantics=sem, onehot_dtype=onehot_dtype)
     graph = not args.no_graph
@@ -236,9 +238,17 @@ def run_astar_leg(args, world, rank, onehot_dtype, min_timed_s, profile_iters):
            "open_size_end": st1["open_size"], "closed_size_end": st1["closed_size"],
            "nodes_generated_timed_rank0": total_gen}
     if profile_iters > 0:
-        # the same graph replays, one at a time, with the device-side stamps switched on (dca.h: profile_builtin)
+        # One more episode of exactly the timed shape — fresh scramble, the same W untimed iterations, then the K iterations
+        # that the timed regions cover (rebase iterations included) — replayed one at a time with the device-side stamps
+        # switched on (dca.h: profile_builtin), so that sum(span) + sum(gap) reconciles with ms_per_step.
+        root = test_root(rank + world * episodes, args.env)
+        eng.reset(root)
+        if sem == _lib.SEM_PY:
+            eng.root_commit(_lib.heuristic_builtin(hid, torch.from_numpy(root[None].copy()).cuda()))
+        eng.run_builtin(hid, warm, use_graph=graph)
         prof = eng.profile_builtin(hid, profile_iters, use_graph=graph)
         res["profile"] = prof
+        res["profile_iters"] = profile_iters
         dbg = eng.debug()
         res["front_n"], res["n_ord"] = dbg["front_n"], dbg["n_ord"]
     eng.close()
@@ -282,12 +292,15 @@ def run_astar(args, world, rank):
             "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("k_" + dom, args.env, B),
             "bytes_per_launch": alg_k[dom], "kernel_ms": span[dom],
             "timing": "device wall-clock stamps written by every workgroup of the launch INSIDE the replayed hipGraph "
-                      "(dca_engine_profile_builtin; max end - min start over %d replays); HIP events bracket the "
-                      "K-step regions (device_ms_per_step)" % args.profile_iters,
+                      "(dca_engine_profile_builtin; max end - min start, averaged over the %d iterations of one "
+                      "more episode of the timed shape: same warm-up, same K iterations, rebase iterations included); HIP "
+                      "events bracket the K-step regions (device_ms_per_step)" % leg["profile_iters"],
             "launch_span_ms": {k: round(v, 5) for k, v in span.items()},
             "launch_gap_ms": {k: round(v, 5) for k, v in gap.items()},
             "sum_span_ms": sum(v for k, v in span.items() if not k.startswith("rank_")),
             "sum_gap_ms": sum(v for k, v in gap.items() if not k.startswith("rank_")),
+            "unprofiled_ms": leg["ms_per_step"] - sum(v for k, v in span.items() if not k.startswith("rank_"))
+            - sum(v for k, v in gap.items() if not k.startswith("rank_")),  # iteration-to-iteration hand-over inside the graph chain
             "launches_per_iteration": len([k for k in span if not k.startswith(("refill", "rank_", "sel_hist"))]),
             "launches_every_8th_iteration_extra": 4,
             "note": "k_%s is the longest launch of the iteration; it is bound by dependent memory round trips (hash-table "
@@ -301,7 +314,7 @@ def run_astar(args, world, rank):
                                  "frac": it_bytes / (leg["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
     res["per_rank_value"] = per_rank
     if args.onehot_leg:
-        oh = run_astar_leg(args, world, rank, torch.float32, 0.1, min(args.profile_iters, 8))
+        oh = run_astar_leg(args, world, rank, torch.float32, MIN_TIMED_S, args.profile_iters)
         algo = engine_bytes(args.env, B, 4)
         ob = algo["per_expansion_8d"] * B
         leg_o = {"value": oh["value"], "unit": "nodes expanded/s", "ms_per_step": oh["ms_per_step"], "episodes": oh["episodes"],
@@ -327,39 +340,44 @@ def run_astar(args, world, rank):
 
 
 def run_sharded_queue(args, world, rank):
-    """BASELINE configs[3] in miniature: `--queue-states` x world test-set scrambles drawn from the shared work queue
-    (search_methods/sharding.WorkQueue: an atomic counter in the process group's store, no collective), each searched
-    for a fixed budget of iterations with the built-in heuristic.  Measures the sharding path the CLI uses at N > 1."""
+    """BASELINE configs[3]'s sharding path at a size that means something: `--queue-states` x world shipped puzzle15 test
+    scrambles drawn from the shared work queue (search_methods/sharding.WorkQueue: an atomic counter in the process
+    group's store, no collective), each searched TO COMPLETION with the built-in Manhattan heuristic (batch 10 000,
+    weight 0.8): per-state cost varies ~50x (1e6 .. 7e7 nodes), which is what the queue is there to balance (the
+    published cube3 searches vary 40x, results/cube3/output.txt).  value = nodes expanded by all ranks / wall time,
+    resets, ramp-up and the tie-heavy integer-cost f-levels included."""
     from deepcubea_amd import _lib
     from deepcubea_amd.search_methods import sharding
     from deepcubea_amd.search_methods.engine import BwasEngine
-    B, w = args.batch_size, args.weight
+    env, B, w, hid = "puzzle15", 10000, 0.8, _lib.HEUR_MANHATTAN
     n_states = args.queue_states * world
-    iters = args.queue_iters
-    eng = BwasEngine("cube3", w, B, max_nodes=max(1 << 20, (iters + 8) * B * 12 + (1 << 16)))
+    eng = BwasEngine(env, w, B, max_nodes=1 << 27)
     queue = sharding.WorkQueue(n_states, world, rank, key="dca_bench_queue")
     barrier(world)
     t0 = time.perf_counter()
-    mine, expanded = 0, 0
+    mine, expanded, generated, lens = 0, 0, 0, 0
     while True:
         nxt = queue.next(1)
         if not nxt:
             break
-        root = test_root(nxt[0])
-        eng.reset(root)
-        eng.root_commit(_lib.heuristic_builtin(_lib.HEUR_HASHU01, torch.from_numpy(root[None].copy()).cuda()))
-        eng.run_builtin(_lib.HEUR_HASHU01, iters, use_graph=not args.no_graph)
-        expanded += eng.status()["nodes_expanded"]
+        res = eng.solve_builtin(test_root(nxt[0], env), hid, chunk=32, use_graph=not args.no_graph)
+        assert res["solved"], res
+        expanded += res["nodes_expanded"]
+        generated += res["nodes_generated"]
+        lens += len(res["moves"])
         mine += 1
     barrier(world)
     wall = reduce_ranks(time.perf_counter() - t0, world, "max")
     total = reduce_ranks(float(expanded), world, "sum")
+    total_gen = reduce_ranks(float(generated), world, "sum")
     counts = gather_ranks(float(mine), world)
     eng.close()
     torch.cuda.empty_cache()
-    return {"value": total / wall, "unit": "nodes expanded/s", "states": n_states, "iterations_per_state": iters,
-            "states_per_rank": counts, "seconds": wall,
-            "how": "per-instance sharding through the shared work queue, resets and ramp-up included"}
+    return {"value": total / wall, "unit": "nodes expanded/s", "nodes_generated_per_s": total_gen / wall, "states": n_states,
+            "env": env, "batch_size": B, "weight": w, "heuristic": "built-in Manhattan distance", "states_per_rank": counts,
+            "seconds": wall, "mean_solution_length": reduce_ranks(float(lens), world, "sum") / max(n_states, 1),
+            "how": "per-instance sharding through the shared work queue; every search runs to completion (resets, ramp-up, "
+                   "refills, tie groups included)"}
 
 
 def run_astar_concurrent(args, world, rank, sem, hid):
@@ -407,14 +425,15 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
     from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
     from deepcubea_amd.utils import env_utils
     B, w = args.batch_size, args.weight
-    steps, warm = args.nnet_steps, 2
+    steps, warm = args.nnet_steps, 2  # `steps` timed iterations per round, rounds repeated until MIN_TIMED_S were timed
     env = env_utils.get_environment(args.env)
     A = env.get_num_moves()
     model = env.get_nnet_model()  # cube3: ResnetModel(54, 6, 5000, 1000, 4, 1, True)
     load_synthetic_weights(model, 2024)
     macs = sum(m.in_features * m.out_features for m in model.modules() if isinstance(m, torch.nn.Linear))
     dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[dtype_name]
-    cap = max(1 << 20, (steps + warm + 12) * B * A + 64 * B * A // 2)
+    max_rounds = 64
+    cap = max(1 << 20, (steps * max_rounds + warm + 12) * B * A + 64 * B * A // 2)
     if eval_all_children:
         model = fold_batchnorm(model).cuda().eval()
         hfn = nnet_utils.get_heuristic_fn_dev(model, clip_zero=False, batch_size=args.nnet_batch_size,
@@ -440,22 +459,28 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
         eng.step(hfn)
     st0 = eng.status()
     rows0 = eng.rows_evaluated
-    barrier(world)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        eng.step(hfn)
-    barrier(world)
-    wall = time.perf_counter() - t0
+    wall, rounds = 0.0, 0
+    while True:  # (every rank takes the same decision: `wall` is the max over ranks)
+        barrier(world)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.step(hfn)
+        barrier(world)
+        wall += reduce_ranks(time.perf_counter() - t0, world, "max")
+        rounds += 1
+        if wall >= MIN_TIMED_S or rounds >= max_rounds:
+            break
     st1 = eng.status()
+    assert not st1["failed"] and not st1["done"], "benchmark search ended early: %r" % (st1,)
+    steps = steps * rounds
     expanded = st1["nodes_expanded"] - st0["nodes_expanded"]
     rows = (eng.rows_evaluated - rows0) / steps
-    wall = reduce_ranks(wall, world, "max")
     total_exp = reduce_ranks(float(expanded), world, "sum")
     flops = 2.0 * macs * rows
     eng.close()
     torch.cuda.empty_cache()
     return {"value": total_exp / wall, "unit": "nodes expanded/s", "ms_per_step": wall / steps * 1e3,
-            "steps": steps, "heuristic_dtype": dtype_name, "weights": "synthetic (numpy PCG64 seed 2024, BN folded)",
+            "steps": steps, "timed_s": wall, "heuristic_dtype": dtype_name, "weights": "synthetic (numpy PCG64 seed 2024, BN folded)",
             "order": "eval_all_children (reference order)" if eval_all_children else "dedup_first (CLI default)",
             "layer1": "library GEMM on one-hot rows" if eval_all_children or not fast.uses_l1_kernel
             else "dca_l1_onehot_gemm (hand-written MFMA, %d bf16 plane(s))" % fast.l1_planes,
@@ -675,9 +700,9 @@ def main():
     ap.add_argument("--no-onehot-leg", dest="onehot_leg", action="store_false",
                     help="astar: skip the engine leg with the fused fp32 one-hot rows")
     ap.add_argument("--concurrent", type=int, default=4, help="astar: also time k concurrent instances per GPU (0/1 = skip)")
-    ap.add_argument("--queue-states", type=int, default=4,
-                    help="astar: scrambles per rank drawn from the shared work queue in the sharded leg (0 = skip)")
-    ap.add_argument("--queue-iters", type=int, default=64, help="astar: iteration budget per scramble of the sharded leg")
+    ap.add_argument("--queue-states", type=int, default=32,
+                    help="astar: puzzle15 test scrambles per rank drawn from the shared work queue and searched to completion "
+                         "in the sharded leg (0 = skip)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -721,6 +746,11 @@ def main():
             line["cpu_baseline"] = cpu_baseline_expand()
         elif args.env == "cube3":
             line["cpu_baseline"] = cpu_baseline_astar(args)
+            # the REFERENCE's own compiled code beside it (oracle/_ref = cpp/environments.cpp built where it lies): the
+            # expansion half of the iteration only — the reference's search core needs boost and cannot be built here
+            ref = cpu_baseline_expand(seconds_budget=5.0)
+            if ref["kind"] == "reference":
+                line["cpu_baseline"]["reference_expand"] = ref
     if rank == 0:
         print(json.dumps(line))
     if world > 1:

@@ -111,7 +111,7 @@ struct Ctl {
     uint32_t front_above;   // FRONT entries above T since the last spill: they leave for BACK in the next rebase pass
     uint32_t cur_b;         // the BACK buffer (2/3)
     uint64_t T;             // tier threshold key (inclusive upper bound of FRONT)
-    uint32_t refill, compact, r_bstar, spill_bin;
+    uint32_t refill, compact, r_bstar, spill_bin, r_move;
     uint64_t r_kmin;
     uint32_t r_shift;
     // selection
@@ -624,7 +624,23 @@ __global__ __launch_bounds__(1024) void k_refill_scan(const Eng* __restrict__ en
     for (int k = 0; k < kBinsPerThread; k++) E.hist[kBinsPerThread * threadIdx.x + k] = 0;
     if (threadIdx.x == 0) c->open_n[c->cur_f ^ 1].v = 0;  // the rebase pass compacts FRONT into the other buffer
     if (!need_refill(E, c)) {
-        if (threadIdx.x == 0) c->refill = 0;
+        if (threadIdx.x == 0) {
+            // Nothing to move over — but spills (k_front_rebase) and pushes (k_commit) keep appending to BACK while its
+            // tombstones stay: when the buffer nears its physical end, squeeze them out now (a compaction-only pass of
+            // k_refill_move) instead of failing a search whose OPEN would fit.
+            const uint32_t b = c->cur_b, phys = c->open_n[b].v, dead = c->back_dead.v;
+            // (g_tune[2]: test hook — squeeze once BACK holds more than max_nodes * v / 1024 physical entries)
+            const uint32_t mark = g_tune[2] > 0 ? (uint32_t)(((uint64_t)E.max_nodes * (uint32_t)g_tune[2]) >> 10) : (E.max_nodes / 8) * 7;
+            const bool squeeze = dead != 0 && phys > mark;
+            c->refill = squeeze ? 1u : 0u;
+            c->compact = squeeze ? 1u : 0u;
+            c->r_move = 0;
+            if (squeeze) {
+                c->open_n[b ^ 1].v = 0;
+                c->rng[b ^ 1].kmin = c->rng[b].kmin;
+                c->rng[b ^ 1].kmax = c->rng[b].kmax;
+            }
+        }
         return;
     }
     __shared__ uint32_t pre[NBIN + 1];
@@ -642,6 +658,7 @@ __global__ __launch_bounds__(1024) void k_refill_scan(const Eng* __restrict__ en
         const uint64_t kmin = c->rng[b].kmin;
         const uint32_t shift = select_shift(kmin, c->rng[b].kmax);
         c->refill = 1;
+        c->r_move = 1;
         c->r_kmin = kmin;
         c->r_shift = shift;
         // new tier threshold = top key of the last bin that moves (the final bin also absorbs overflow)
@@ -674,6 +691,7 @@ __global__ __launch_bounds__(256) void k_refill_move(const Eng* __restrict__ eng
     const uint32_t n = c->open_n[sb].v;
     const uint64_t kmin = c->r_kmin;
     const uint32_t shift = c->r_shift, bstar = c->r_bstar;
+    const bool move = c->r_move != 0;  // (false: compaction-only pass, nothing crosses over to FRONT)
     uint64_t* __restrict__ keys = E.open_key[sb];
     const uint32_t* __restrict__ ids = E.open_id[sb];
     constexpr uint32_t ITEMS = 8, TILE = 256 * ITEMS;
@@ -690,7 +708,7 @@ __global__ __launch_bounds__(256) void k_refill_move(const Eng* __restrict__ eng
             if (idx >= n) k[i] = DEAD;
             uint64_t f = (k[i] - kmin) >> shift;
             bool alive = k[i] != DEAD;
-            bool front = alive && (f < NBIN ? (uint32_t)f : NBIN - 1) <= bstar;
+            bool front = alive && move && (f < NBIN ? (uint32_t)f : NBIN - 1) <= bstar;
             tof |= (front ? 1u : 0u) << i;
             stay |= ((alive && !front && compact) ? 1u : 0u) << i;
             cf += front ? 1u : 0u;
@@ -3002,7 +3020,8 @@ int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, int use_gr
 
 int dca_debug_tune(int knob, int value) {
     if (knob >= 0 && knob < 8) h_tune[knob] = value;  // (host-side knobs: 4 = workgroups of k_sel_collect; set before the first step)
-    // diagnostics: 0 extra log2 of sub-bins per large bin, 1 sub-bin size above which a sub-bin is refined on its own (2-7 unused)
+    // diagnostics: 0 extra log2 of sub-bins per large bin, 1 sub-bin size above which a sub-bin is refined on its own,
+    // 2 BACK squeeze mark in 1/1024ths of max_nodes (3-7 unused)
     DCA_ARG(knob >= 0 && knob < 8);
     DCA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tune), &value, sizeof(int), (size_t)knob * sizeof(int), hipMemcpyHostToDevice));
     return 0;

@@ -20,6 +20,8 @@
 // with (row >> 1) & 7: every ds_read_b128 lane group then touches each LDS bank exactly once.  Two workgroups per CU
 // (2 x 64 KB LDS, <= 256 VGPRs) overlap one group's staging with the other's MFMAs.  Workgroup ids are remapped so that
 // the N tiles sharing an A tile run on ONE XCD (its L2 then reads the A tile from HBM once).
+#include <atomic>
+
 #include "dca_common.h"
 
 namespace dca {
@@ -249,7 +251,9 @@ __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v2(const GemmArgs p)
     for (int kt = 0; kt < nk; kt++) {
         // this wave's DMA of step kt has landed; the barrier makes that true of every wave's — and every wave has
         // finished reading the other stage, which the next issue overwrites
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        // (lgkmcnt too: the fragment reads of step kt-1 must have RETURNED before any wave's next issue overwrites their
+        // stage — their consumers are MFMAs, register-only, which the compiler may schedule below this point)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (kt + 1 < nk) issue((kt + 1) & 1, (kt + 1) * HBK);
         const uint8_t* base = lds + (kt & 1) * HSTAGE;
 #pragma unroll
@@ -403,11 +407,16 @@ int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t l
     DCA_ARG((out_h != nullptr) == (out_l != nullptr) && (out_h != nullptr || x_out != nullptr));
     DCA_ARG(((uintptr_t)a_h | (uintptr_t)a_l | (uintptr_t)w_h | (uintptr_t)w_l) % 16 == 0);
     if (m == 0) return 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f16x3_gemm_v1), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS));
-        DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f16x3_gemm_v2), hipFuncAttributeMaxDynamicSharedMemorySize, HLDS));
-        attr_set = true;
+    {   // the dynamic-LDS limit is a per-device function attribute: set it once for every device this process uses
+        static std::atomic<uint64_t> attr_devs{0};
+        int dev = 0;
+        DCA_HIP(hipGetDevice(&dev));
+        const uint64_t bit = 1ull << (dev & 63);
+        if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
+            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f16x3_gemm_v1), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS));
+            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f16x3_gemm_v2), hipFuncAttributeMaxDynamicSharedMemorySize, HLDS));
+            attr_devs.fetch_or(bit, std::memory_order_release);
+        }
     }
     GemmArgs p;
     p.ah = reinterpret_cast<const _Float16*>(a_h);

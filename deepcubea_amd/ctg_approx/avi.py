@@ -182,6 +182,9 @@ def main(argv=None):
             cnt = torch.tensor([outputs.shape[0]], dtype=torch.int64, device=device)
             torch.distributed.all_reduce(cnt, op=torch.distributed.ReduceOp.MIN)
             n_common = int(cnt.item())
+            if n_common == 0:
+                raise RuntimeError("update %d: a rank ended up with no training examples (states_per_update %d over %d "
+                                   "ranks) - nothing to train on" % (update_num, args_dict['states_per_update'], world))
             if n_common < outputs.shape[0]:
                 states_nnet, outputs = states_nnet[:n_common], outputs[:n_common]
         num_train_itrs = int(args_dict['epochs_per_update'] * np.ceil(outputs.shape[0] / local_batch))

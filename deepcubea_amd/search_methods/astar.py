@@ -76,6 +76,16 @@ def _load_heuristic(args, env):
     return nnet_utils.get_heuristic_fn_dev(nnet, clip_zero=False, batch_size=_nnet_rows(args), autocast_dtype=ac), None
 
 
+def _max_nodes(args, instances: int) -> int:
+    """`--max_nodes N` or `auto` (default): every generated child takes a node id, and the published cube3 searches reach
+    6.1e7 nodes (results/cube3/output.txt) — so the pool is sized from the HBM that is free on this rank's GPU (288 GB on an
+    MI355X: ~1e9 ids), not from a constant."""
+    v = getattr(args, "max_nodes", "auto")
+    if str(v).lower() != "auto":
+        return int(v)
+    return BwasEngine.auto_max_nodes(args.env, args.batch_size, instances)
+
+
 _BUILTIN = {"manhattan": _lib.HEUR_MANHATTAN, "zero": _lib.HEUR_ZERO, "hashu01": _lib.HEUR_HASHU01}
 
 
@@ -87,7 +97,13 @@ def bwas_hip(args, env, states: List) -> Tuple[List[List[int]], List[List], List
     distance on the sliding puzzles: with --weight 1 --semantics cpp the solutions are optimal)."""
     builtin = None
     if str(args.model_dir).startswith("builtin:"):
-        builtin = _BUILTIN[str(args.model_dir).split(":", 1)[1].lower()]
+        name = str(args.model_dir).split(":", 1)[1].lower()
+        if name not in _BUILTIN:
+            raise ValueError("Unknown built-in heuristic %r (have: %s)" % (name, ", ".join(sorted(_BUILTIN))))
+        if name == "manhattan" and not str(args.env).startswith("puzzle"):
+            raise ValueError("builtin:manhattan is defined for the sliding puzzles only (it is 0 on %s: "
+                             "the search would silently become uniform-cost search)" % args.env)
+        builtin = _BUILTIN[name]
         heuristic_fn, onehot_stride = None, None
     else:
         heuristic_fn, onehot_stride = _load_heuristic(args, env)
@@ -95,7 +111,7 @@ def bwas_hip(args, env, states: List) -> Tuple[List[List[int]], List[List], List
     oh = getattr(args, "_onehot_dtype", None) or {"fp32": torch.float32, "bf16": torch.bfloat16,
                                                    "fp16": torch.float16}[getattr(args, "nnet_dtype", "fp32")]
     K = max(1, int(getattr(args, "instances_per_gpu", 1)))
-    eng = BwasEngine(args.env, args.weight, args.batch_size, max_nodes=int(getattr(args, "max_nodes", 1 << 26)),
+    eng = BwasEngine(args.env, args.weight, args.batch_size, max_nodes=_max_nodes(args, K),
                      semantics=sem, onehot_dtype=None if (onehot_stride == 0 or builtin is not None) else oh,
                      num_instances=K, packed=onehot_stride is not None, onehot_stride=onehot_stride or None)
     world, rank = sharding.world_info()
@@ -111,8 +127,9 @@ def bwas_hip(args, env, states: List) -> Tuple[List[List[int]], List[List], List
         roots = [np.ascontiguousarray(env._get_arr(states[i]), dtype=np.uint8) for i in group]
         done_at: Dict[int, float] = {}
         if builtin is not None:
-            results = eng.solve_many_builtin(roots, builtin, chunk=32, use_graph=True) if K > 1 else \
-                [eng.solve_builtin(roots[0], builtin, chunk=32, use_graph=True)]
+            results = eng.solve_many_builtin(roots, builtin, chunk=32, use_graph=True,
+                                             on_done=lambda i: done_at.setdefault(i, time.time() - start_time)) \
+                if K > 1 else [eng.solve_builtin(roots[0], builtin, chunk=32, use_graph=True)]
         elif K > 1:
             results = eng.solve_many(roots, heuristic_fn, on_done=lambda i: done_at.setdefault(i, time.time() - start_time))
         else:
@@ -171,7 +188,8 @@ def build_parser() -> ArgumentParser:
     # engine options
     parser.add_argument('--semantics', type=str, default="py", choices=["py", "cpp"],
                         help="which reference search core to reproduce (astar.py vs parallel_weighted_astar.cpp)")
-    parser.add_argument('--max_nodes', type=int, default=1 << 26, help="node pool capacity (ids per search)")
+    parser.add_argument('--max_nodes', type=str, default="auto",
+                        help="node pool capacity (ids per search): a number, or auto = sized from the GPU's free HBM")
     parser.add_argument('--instances_per_gpu', type=int, default=1,
                         help="scrambles stepped together by one engine (finer per-instance sharding inside a GPU)")
     parser.add_argument('--nnet_dtype', type=str, default="fp32", choices=["fp32", "bf16", "fp16"],

@@ -58,6 +58,24 @@ class BwasEngine:
                        "dca_engine_enable_packed")
             self.packed_capacity = (self.m_capacity + 1023) // 1024 * 1024
 
+    @staticmethod
+    def bytes_per_node(env_name: str) -> int:
+        """Device bytes one node id costs (dca_engine_create_multi's allocations): state row + g/parent/move/solved, the
+        CLOSED table (16-byte slots, power of two >= 2 ids per id: up to 4 slots), four OPEN buffers of (key, id), the
+        pop's scratch arrays (tmp key/id/bin/idx, ord key/id)."""
+        D = _lib.env_ids(env_name)[2]
+        return D + 10 + 4 * 16 + 4 * 12 + 18 + 12
+
+    @staticmethod
+    def auto_max_nodes(env_name: str, batch_size: int, num_instances: int = 1, fraction: float = 0.8) -> int:
+        """Largest node pool that fits `fraction` of the HBM currently free on this device (288 GB on an MI355X), split
+        between the engine's instances; capped by the 31-bit node id."""
+        _lib.require_gpu()
+        free, _total = torch.cuda.mem_get_info()
+        n = int(free * fraction) // (BwasEngine.bytes_per_node(env_name) * max(1, int(num_instances)))
+        floor = int(batch_size) * _lib.env_ids(env_name)[3] * 4 + 64
+        return max(floor, min(n, 0x7FFFFF00 // 2))  # (the CLOSED table's slot index is 32-bit: 2 slots per id)
+
     def close(self):
         if self._h:
             _lib.lib().dca_engine_destroy(self._h)
@@ -230,8 +248,9 @@ class BwasEngine:
 
     # ---- K instances at once (per-instance sharding inside one GPU) ---------------------------
     def solve_many_builtin(self, roots, heur_id: int, max_iters: int = 1 << 30, chunk: int = 16,
-                           use_graph: bool = False) -> List[dict]:
-        """len(roots) <= num_instances searches stepped together; returns one result dict per root."""
+                           use_graph: bool = False, on_done=None) -> List[dict]:
+        """len(roots) <= num_instances searches stepped together; returns one result dict per root.  on_done(i) is
+        called once, at the first poll (every `chunk` iterations) that finds instance i finished."""
         k = len(roots)
         assert 1 <= k <= self.num_instances
         for i, root in enumerate(roots):
@@ -240,11 +259,17 @@ class BwasEngine:
                 h0 = _lib.heuristic_builtin(heur_id, torch.from_numpy(np.ascontiguousarray(root, np.uint8)[None]).cuda())
                 self.root_commit(h0, i)
         it = 0
+        finished = [False] * k
         while it < max_iters:
             n = min(chunk, max_iters - it)
             self.run_builtin(heur_id, n, use_graph)
             it += n
-            if all(self.status(i)["done"] for i in range(k)):
+            for i in range(k):
+                if not finished[i] and self.status(i)["done"]:
+                    finished[i] = True
+                    if on_done is not None:
+                        on_done(i)
+            if all(finished):
                 break
         return [self._result(i) for i in range(k)]
 
