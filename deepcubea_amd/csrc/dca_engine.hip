@@ -59,6 +59,14 @@ constexpr int RT = 512;                            // threads of a k_rank workgr
 constexpr int kRegEnt = 16;                        // entries a thread keeps in registers
 constexpr uint32_t kLdsEnt = RT * kRegEnt;         // items up to this size are bucketed entirely in LDS (96 KB)
 constexpr int kStash = 2560;          // per-workgroup LDS stash of k_sel_collect (entries at or below the threshold bin)
+// Segments k_rank may see: the selection bins; in "giant" iterations (the threshold bin holds more entries than k_rank can
+// bucket in LDS — massive cost ties) k_sel_collect refines that bin across the whole grid first and hands over, in its
+// place, the part that is certainly in the batch (segment bstar) and the last refinement level's sub-bins up to the one
+// holding the batch's last entry (segments bstar+1 ...).
+constexpr int kSegs = NBIN + 1 + kSub;
+constexpr uint32_t kGiantBinDefault = 8192;   // = kLdsEnt: larger threshold bins are refined by the grid, not by one workgroup
+constexpr int kMaxLevels = 9;                 // 96 composite bits / 11 bits per level
+constexpr unsigned long long kBarrierTimeout = 200000000ull;  // 2 s of the 100 MHz wall clock: a stuck grid barrier fails the search
 constexpr uint32_t NIL = 0xFFFFFFFFu;
 // OPEN entries carry "this node is solved" in bit 31 of the id (node ids stay below 2^31): the pop then knows a goal
 // without touching the node pool.  Every compare / index uses the id with the flag masked off.
@@ -81,6 +89,11 @@ struct Slot {
 struct alignas(128) Cnt {
     uint32_t v;
     uint32_t pad[31];
+};
+struct alignas(128) GRange {
+    uint64_t kmin, kmax;
+    uint32_t imin, imax;
+    uint32_t pad[26];
 };
 struct alignas(128) Rng {
     uint64_t kmin, kmax;
@@ -116,6 +129,8 @@ struct Ctl {
     uint32_t r_shift;
     // selection
     uint32_t want, bstar, shift, n_big, n_ord;
+    uint32_t giant;   // this pop's threshold bin is refined across the grid by k_sel_collect (set by k_sel_scan)
+    uint32_t tseg;    // the segment holding the batch's last entry (= bstar unless giant)
     uint64_t sel_kmin;
     // goals
     uint32_t goal_id;
@@ -125,6 +140,8 @@ struct Ctl {
     // ---- hot words -----------------------------------------------------------------------------
     Cnt open_n[4];   // physical entries per OPEN buffer (0/1 FRONT + its compaction target, 2/3 BACK + its compaction target)
     Cnt closed_n, back_dead, front_dead, ret_n, ticket_a;  // *_dead: tombstones (key == DEAD) inside the tier's buffer
+    Cnt gbar;        // arrivals at k_sel_collect's grid barrier (giant iterations; zeroed by k_sel_scan)
+    GRange grange;   // key / id range of the giant threshold bin (atomics from every workgroup of k_sel_collect)
     Rng rng[4];      // running key range per OPEN buffer
     alignas(128) unsigned long long goal_best;  // PY: min over solved popped of (g << 32 | pop rank)
     alignas(128) uint32_t first_solved;         // CPP: smallest pop rank holding a solved node
@@ -181,6 +198,8 @@ struct Eng {
     uint32_t f_keep, f_max;  // FRONT hysteresis: refill/spill down to ~f_keep, spill when above f_max
     uint32_t *hist, *pre, *fill;  // selection histogram, its exclusive prefix [NBIN+1], per-bin fill of the scratch array
     uint32_t* rhist;              // histogram of BACK (refill), separate: `hist` is maintained across iterations
+    uint32_t* subhist;            // [kMaxLevels][kSub] sub-bin counts of a giant threshold bin, one array per refinement level
+    int coop;                     // k_sel_collect's grid is fully resident (single-instance engine): grid barriers allowed
     uint64_t* part;  // [2][kCollectBlocks] per-block key ranges (min, max) of the entries k_front_rebase kept
     // scratch of the pop: every FRONT entry at or below the threshold bin, grouped by bin (bin f occupies
     // [pre[f], pre[f+1])), and — only for bins too large for LDS — the single-workgroup sub-bin ordering
@@ -190,8 +209,8 @@ struct Eng {
     uint32_t* tmp_idx;  // FRONT position each scratch entry was taken from (k_rank hands entries back into those slots)
     uint64_t* ord_key;
     uint32_t* ord_id;
-    uint32_t* big_list;  // work units of k_rank's large-bin pass: the bins at or below the threshold bin with more than kTinyBin
-                         // entries, one unit per workgroup that shares the bin (bin | share << 12 | shares << 16)
+    uint32_t* big_list;  // work units of k_rank's large-bin pass: the segments at or below the threshold with more than kTinyBin
+                         // entries, one unit per workgroup that shares the segment (segment | share << 16 | shares << 20)
     uint64_t* pop_key;   // the batch in pop order
     uint32_t *pop_id, *pop_g;
     uint64_t* child_hash;
@@ -926,21 +945,30 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
         E.pre[bin] = pre[bin];
         E.fill[bin] = 0;
     }
+    for (int i = NBIN + t; i < kSegs; i += 1024) E.fill[i] = 0;  // (segments of a giant iteration)
     if (t == 1023) E.pre[NBIN] = pre[NBIN];
     __syncthreads();
+    // A threshold bin too large for k_rank's LDS bucketing (massive cost ties: an integer-valued heuristic makes every
+    // f-level one tie group of up to millions of entries) is not handed to k_rank whole: k_sel_collect refines it across
+    // the grid first ("giant" iteration) and k_rank only sees the few thousand entries around the batch's end.
+    const uint32_t giant_limit = g_tune[3] > 0 ? (uint32_t)g_tune[3] : kGiantBinDefault;
+    const bool giant = E.coop && want != 0 && pre[s_bstar + 1] - pre[s_bstar] > giant_limit;
+    if (giant)
+        for (int i = t; i < kMaxLevels * kSub; i += 1024) E.subhist[i] = 0;
     for (int k = 0; k < kBinsPerThread; k++) {
         const uint32_t bin = kBinsPerThread * t + k;
         if (bin <= s_bstar && want != 0) {
             const uint32_t cn = pre[bin + 1] - pre[bin];
             if (cn > 256) atomicMax(&s_maxbin, cn);
             if (cn > (uint32_t)kSortCap) atomicAdd(&s_giant, 1u);
-            // work list of k_rank: one workgroup per bin of more than kTinyBin entries (smaller bins: a thread per entry)
-            if (cn > (uint32_t)kTinyBin) {
+            // work list of k_rank: one workgroup per bin of more than kTinyBin entries (smaller bins: a thread per entry);
+            // the segments that replace a giant threshold bin are listed by k_sel_collect
+            if (cn > (uint32_t)kTinyBin && !(giant && bin == s_bstar)) {
                 // a bin that fits k_rank's LDS path is shared between up to eight workgroups (about a thousand entries each)
                 uint32_t G = cn <= (uint32_t)kLdsEnt ? (cn + 1023u) / 1024u : 1u;
                 G = G > 8u ? 8u : G;
                 const uint32_t at = atomicAdd(&s_nbig, G);
-                for (uint32_t g = 0; g < G; g++) E.big_list[at + g] = bin | (g << 12) | (G << 16);
+                for (uint32_t g = 0; g < G; g++) E.big_list[at + g] = bin | (g << 16) | (G << 20);
             }
         }
     }
@@ -967,6 +995,13 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
         }
         c->want = want;
         c->bstar = s_bstar;
+        c->tseg = s_bstar;
+        c->giant = giant ? 1u : 0u;
+        c->gbar.v = 0;
+        c->grange.kmin = ~0ull;
+        c->grange.kmax = 0;
+        c->grange.imin = ~0u;
+        c->grange.imax = 0;
         c->sel_kmin = new_kmin;
         c->shift = new_shift;
         uint32_t sp = s_spill;
@@ -1013,20 +1048,346 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
     }
 }
 
+// the (cost key, node id) composite: the total order of OPEN (astar.py:64-67: cost, then push count)
+typedef unsigned __int128 u128;
+__device__ __forceinline__ u128 comp_of(uint64_t key, uint32_t id) { return ((u128)key << 32) | (u128)(id & ID_MASK); }
+__device__ __forceinline__ int clz128(u128 v) {
+    uint64_t hi = (uint64_t)(v >> 64), lo = (uint64_t)v;
+    return hi ? __clzll((long long)hi) : 64 + (lo ? __clzll((long long)lo) : 64);
+}
+
 // S3: take the batch's bins out of FRONT, in place.  Only the keys are read (8 bytes an entry); an entry at or below
 // the threshold bin is stashed in LDS (key + position), tombstoned, and placed — with its id, gathered then — into the
 // scratch array grouped by bin (k_rank orders each bin): one global atomic per (workgroup, bin).
+//
+// Giant iterations (c->giant: the threshold bin is a cost-tie group of tens of thousands to millions of entries).  Moving
+// the whole bin to the scratch array and letting ONE workgroup of k_rank cut it down (what round 2 did: 1-15 ms per pop)
+// is replaced by a radix selection on the (key, id) composite carried out by this launch's whole grid, in place:
+//   A  range of the bin's keys and ids (one pass over FRONT, four global atomics per workgroup)         | grid barrier
+//   B  per level: 2048 sub-bins over the current composite range, counted per workgroup in LDS and      | grid barrier
+//      added to the level's global array; every workgroup then finds the sub-bin holding the batch's
+//      last entry and, while that sub-bin is still larger than k_rank's LDS capacity, descends into it
+//   D  collection: bins below the threshold bin as usual; of the threshold bin the part below the last level's range
+//      (certainly in the batch: segment bstar) and the last level's sub-bins up to the threshold one (segments
+//      bstar+1+s); everything else is left untouched in FRONT — not even tombstoned.
+// Workgroup 0 publishes the segments' offsets, the threshold segment and k_rank's work units.  The grid barrier is a
+// counter in the control block (agent-scope release before the arrival, relaxed polling, one acquire after; every spin
+// bounded): the launch is sized to be fully resident (2 workgroups per CU; single-instance engines only).
+struct CollectLds {
+    uint64_t st_key[kStash];
+    uint32_t st_idx[kStash];
+    uint32_t lcnt[kSegs + 3];
+    uint32_t subpre[kSub + 4];   // giant: exclusive prefix of the last level's sub-bin counts
+    uint16_t st_f[kStash];
+    uint16_t nzf[kStash];        // the segments this workgroup stashed entries of (each once)
+    uint64_t red64[2][4];
+    uint32_t red32[2][4];
+    uint32_t wsum[4];
+    uint32_t st_n, nz_n, ok, tsub, nb;
+};
+static_assert(sizeof(CollectLds) <= 80 * 1024, "two workgroups of k_sel_collect must fit one CU's LDS");
+
+// all threads of the workgroup; false = the barrier timed out or another workgroup gave up (the search is failed)
+__device__ __forceinline__ bool collect_grid_barrier(Ctl* c, CollectLds& L, uint32_t target) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave's stores / atomics have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(&c->gbar.v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = true;
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(&c->gbar.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (__hip_atomic_load(&c->failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                wall_clock64() - t0 > kBarrierTimeout) {
+                ok = false;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (!ok) {  // not every workgroup is resident (or one of them died): refuse to continue with half a selection
+            __hip_atomic_store(&c->failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&c->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        L.ok = ok ? 1u : 0u;
+    }
+    __syncthreads();
+    return L.ok != 0;
+}
+
+__device__ __noinline__ void collect_giant(const Eng& E, Ctl* c, CollectLds& L) {
+    const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint32_t b = c->cur_f, n = c->open_n[b].v;
+    const uint64_t bkmin = c->sel_kmin;
+    const uint32_t shift = c->shift, bstar = c->bstar, want = c->want;
+    const uint32_t pre_b = E.pre[bstar];
+    uint64_t* __restrict__ keys = E.open_key[b];
+    const uint32_t* __restrict__ ids = E.open_id[b];
+    constexpr uint32_t ITEMS = 8, TILE = 256 * ITEMS;
+    const uint32_t ntiles = (n + TILE - 1) / TILE;
+    uint32_t phase = 0;
+    // ---- A: key / id range of the threshold bin
+    {
+        uint64_t kmn = ~0ull, kmx = 0;
+        uint32_t imn = ~0u, imx = 0;
+        for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            uint64_t k[ITEMS];
+            uint32_t id[ITEMS];
+#pragma unroll
+            for (uint32_t i = 0; i < ITEMS; i++) {
+                const uint32_t idx = tile * TILE + i * 256 + t, ic = idx < n ? idx : n - 1;
+                k[i] = keys[ic];
+                id[i] = ids[ic] & ID_MASK;
+                if (idx >= n) k[i] = DEAD;
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < ITEMS; i++) {
+                const bool in = k[i] != DEAD && bin_of(k[i], bkmin, shift) == bstar;
+                kmn = in && k[i] < kmn ? k[i] : kmn;
+                kmx = in && k[i] > kmx ? k[i] : kmx;
+                imn = in && id[i] < imn ? id[i] : imn;
+                imx = in && id[i] > imx ? id[i] : imx;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint64_t a = __shfl_xor(kmn, o), z = __shfl_xor(kmx, o);
+            const uint32_t x = __shfl_xor(imn, o), y = __shfl_xor(imx, o);
+            kmn = a < kmn ? a : kmn;
+            kmx = z > kmx ? z : kmx;
+            imn = x < imn ? x : imn;
+            imx = y > imx ? y : imx;
+        }
+        if (lane == 0) {
+            L.red64[0][wv] = kmn;
+            L.red64[1][wv] = kmx;
+            L.red32[0][wv] = imn;
+            L.red32[1][wv] = imx;
+        }
+        __syncthreads();
+        if (t == 0) {
+            for (int w = 1; w < 4; w++) {
+                kmn = L.red64[0][w] < kmn ? L.red64[0][w] : kmn;
+                kmx = L.red64[1][w] > kmx ? L.red64[1][w] : kmx;
+                imn = L.red32[0][w] < imn ? L.red32[0][w] : imn;
+                imx = L.red32[1][w] > imx ? L.red32[1][w] : imx;
+            }
+            if (kmn <= kmx) {  // (this workgroup saw entries of the bin)
+                atomicMin((unsigned long long*)&c->grange.kmin, (unsigned long long)kmn);
+                atomicMax((unsigned long long*)&c->grange.kmax, (unsigned long long)kmx);
+                atomicMin(&c->grange.imin, imn);
+                atomicMax(&c->grange.imax, imx);
+            }
+        }
+    }
+    if (!collect_grid_barrier(c, L, ++phase * gridDim.x)) return;
+    const uint64_t gkmin = __hip_atomic_load(&c->grange.kmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t gkmax = __hip_atomic_load(&c->grange.kmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t gimin = __hip_atomic_load(&c->grange.imin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t gimax = __hip_atomic_load(&c->grange.imax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- B: radix selection on the composite, level by level.  An entry's offset is comp(key, id) - V0, in [0, span].
+    u128 V0 = ((u128)gkmin << 32) + (u128)gimin;
+    u128 span = ((u128)(gkmax - gkmin) << 32) + (u128)(gimax - gimin);  // (upper bound: ids of the top key are <= imax)
+    uint32_t need = want - pre_b, below = 0, shc = 0, tsub = 0;
+    const uint32_t giant_limit = g_tune[3] > 0 ? (uint32_t)g_tune[3] : kGiantBinDefault;
+    uint32_t* lh = reinterpret_cast<uint32_t*>(L.st_key);  // (the stash is idle until the collection pass)
+    for (int lvl = 0;; lvl++) {
+        const uint32_t bits = span ? (uint32_t)(128 - clz128(span)) : 0u;
+        shc = bits > 11u ? bits - 11u : 0u;
+        for (uint32_t i = t; i < (uint32_t)kSub; i += 256) lh[i] = 0;
+        __syncthreads();
+        for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            uint64_t k[ITEMS];
+            uint32_t id[ITEMS];
+#pragma unroll
+            for (uint32_t i = 0; i < ITEMS; i++) {
+                const uint32_t idx = tile * TILE + i * 256 + t, ic = idx < n ? idx : n - 1;
+                k[i] = keys[ic];
+                id[i] = ids[ic];
+                if (idx >= n) k[i] = DEAD;
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < ITEMS; i++) {
+                if (k[i] == DEAD || bin_of(k[i], bkmin, shift) != bstar) continue;
+                const u128 v = comp_of(k[i], id[i]);
+                if (v < V0 || v - V0 > span) continue;
+                atomicAdd(&lh[(uint32_t)((v - V0) >> shc)], 1u);
+            }
+        }
+        __syncthreads();
+        uint32_t* gh = E.subhist + (size_t)lvl * kSub;
+        for (uint32_t i = t; i < (uint32_t)kSub; i += 256)
+            if (lh[i]) atomicAdd(&gh[i], lh[i]);
+        if (!collect_grid_barrier(c, L, ++phase * gridDim.x)) return;
+        // every workgroup: prefix over the level's counts, the sub-bin holding the need-th entry
+        constexpr int PER = kSub / 256;
+        uint32_t v[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            v[k] = __hip_atomic_load(&gh[PER * t + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sum += v[k];
+        }
+        uint32_t incl = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = __shfl_up(incl, o);
+            if (lane >= (uint32_t)o) incl += u;
+        }
+        if (lane == 63) L.wsum[wv] = incl;
+        if (t == 0) L.tsub = ~0u;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (uint32_t w = 0; w < wv; w++) run += L.wsum[w];
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            L.subpre[PER * t + k] = run;
+            if (run < need && need <= run + v[k]) L.tsub = PER * t + k;
+            run += v[k];
+        }
+        if (t == 255) L.subpre[kSub] = run;
+        __syncthreads();
+        tsub = L.tsub;
+        if (tsub == ~0u) {  // counts and FRONT disagree (cannot happen)
+            if (t == 0) c->failed = 1, c->done = 1;
+            return;
+        }
+        const uint32_t cn = L.subpre[tsub + 1] - L.subpre[tsub];
+        if (cn <= giant_limit || shc == 0 || lvl + 1 >= kMaxLevels) break;
+        // descend into the threshold sub-bin: everything below it is certainly in the batch
+        below += L.subpre[tsub];
+        need -= L.subpre[tsub];
+        V0 += (u128)tsub << shc;
+        span = ((u128)1 << shc) - 1;
+        __syncthreads();  // (subpre / tsub are rewritten by the next level)
+    }
+    // ---- publish (workgroup 0): segment offsets, threshold segment, k_rank's work units
+    const uint32_t seg0 = bstar + 1u;  // segment of the last level's sub-bin 0; segment bstar = the part below V0
+    if (blockIdx.x == 0) {
+        if (t == 0) {
+            L.nb = c->n_big;
+            E.pre[bstar + 1] = pre_b + below;
+            c->tseg = seg0 + tsub;
+            c->n_ord = pre_b + below + L.subpre[tsub + 1];
+            c->dbg_nord = pre_b + below + L.subpre[tsub + 1];
+        }
+        __syncthreads();
+        for (uint32_t sg = t; sg <= tsub + 1u; sg += 256) {  // sg 0 = the below part, sg 1 + s = sub-bin s
+            const uint32_t cn = sg == 0 ? below : L.subpre[sg] - L.subpre[sg - 1];
+            if (sg > 0) E.pre[seg0 + sg] = pre_b + below + L.subpre[sg];
+            if (cn > (uint32_t)kTinyBin) {
+                uint32_t G = cn <= (uint32_t)kLdsEnt ? (cn + 1023u) / 1024u : 1u;
+                G = G > 8u ? 8u : G;
+                const uint32_t at = atomicAdd(&L.nb, G);
+                for (uint32_t g = 0; g < G; g++) E.big_list[at + g] = (bstar + sg) | (g << 16) | (G << 20);
+            }
+        }
+        __syncthreads();
+        if (t == 0) c->n_big = L.nb;
+    }
+    // ---- D: collection
+    for (uint32_t i = t; i < (uint32_t)(kSegs + 3); i += 256) L.lcnt[i] = 0;
+    if (t == 0) {
+        L.st_n = 0;
+        L.nz_n = 0;
+    }
+    __syncthreads();
+    auto seg_base = [&](uint32_t f) -> uint32_t {
+        return f < bstar ? E.pre[f] : f == bstar ? pre_b : pre_b + below + L.subpre[f - seg0];
+    };
+    auto seg_end = [&](uint32_t f) -> uint32_t {
+        return f < bstar ? E.pre[f + 1] : f == bstar ? pre_b + below : pre_b + below + L.subpre[f - seg0 + 1];
+    };
+    auto flush = [&]() {
+        const uint32_t ns = L.st_n < (uint32_t)kStash ? L.st_n : (uint32_t)kStash;
+        const uint32_t nz = L.nz_n;
+        for (uint32_t i = t; i < nz; i += 256) {
+            const uint32_t f = L.nzf[i];
+            L.lcnt[f] = atomicAdd(&E.fill[f], L.lcnt[f]);
+        }
+        __syncthreads();
+        for (uint32_t p = t; p < ns; p += 256) {
+            const uint32_t f = L.st_f[p];
+            const uint32_t id = ids[L.st_idx[p]];
+            const uint32_t pos = seg_base(f) + atomicAdd(&L.lcnt[f], 1u);
+            if (pos < seg_end(f)) {
+                E.tmp_key[pos] = L.st_key[p];
+                E.tmp_id[pos] = id;
+                E.tmp_f[pos] = (uint16_t)f;
+                E.tmp_idx[pos] = L.st_idx[p];
+            } else {
+                c->failed = 1;  // counts and FRONT disagree (cannot happen): refuse to write outside the segment's slice
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = t; i < nz; i += 256) L.lcnt[L.nzf[i]] = 0;
+        __syncthreads();
+        if (t == 0) {
+            L.st_n = 0;
+            L.nz_n = 0;
+        }
+        __syncthreads();
+    };
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint64_t k[ITEMS];
+        uint32_t id[ITEMS];
+#pragma unroll
+        for (uint32_t i = 0; i < ITEMS; i++) {
+            const uint32_t idx = tile * TILE + i * 256 + t, ic = idx < n ? idx : n - 1;
+            k[i] = keys[ic];
+            id[i] = ids[ic];
+            if (idx >= n) k[i] = DEAD;
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < ITEMS; i++) {
+            if (k[i] == DEAD) continue;
+            uint32_t f = bin_of(k[i], bkmin, shift);
+            if (f > bstar) continue;
+            if (f == bstar) {
+                const u128 v = comp_of(k[i], id[i]);
+                if (v >= V0) {
+                    if (v - V0 > span) continue;
+                    const uint32_t sub = (uint32_t)((v - V0) >> shc);
+                    if (sub > tsub) continue;  // stays in FRONT, untouched
+                    f = seg0 + sub;
+                }
+            }
+            const uint32_t idx = tile * TILE + i * 256 + t;
+            const uint32_t p = atomicAdd(&L.st_n, 1u);
+            keys[idx] = DEAD;
+            if (p < (uint32_t)kStash) {
+                L.st_key[p] = k[i];
+                L.st_idx[p] = idx;
+                L.st_f[p] = (uint16_t)f;
+                if (atomicAdd(&L.lcnt[f], 1u) == 0u) L.nzf[atomicAdd(&L.nz_n, 1u)] = (uint16_t)f;
+            } else {  // stash full (cannot happen: it is flushed while a whole tile still fits): place directly
+                const uint32_t pos = seg_base(f) + atomicAdd(&E.fill[f], 1u);
+                if (pos < seg_end(f)) {
+                    E.tmp_key[pos] = k[i];
+                    E.tmp_id[pos] = id[i];
+                    E.tmp_f[pos] = (uint16_t)f;
+                    E.tmp_idx[pos] = idx;
+                } else {
+                    c->failed = 1;
+                }
+            }
+        }
+        __syncthreads();
+        if (L.st_n + TILE > (uint32_t)kStash) flush();
+    }
+    __syncthreads();
+    flush();
+}
+
 __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ engs) {
     const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
     if (c->done) return;
     Stamp stamp(E, P_SEL_COLLECT);
-    __shared__ uint64_t st_key[kStash];
-    __shared__ uint32_t st_idx[kStash];
-    __shared__ uint16_t st_f[kStash];
-    __shared__ uint32_t lcnt[NBIN];
-    __shared__ uint16_t nzf[kStash];  // the bins this workgroup stashed entries of (each once)
-    __shared__ uint32_t st_n, nz_n;
+    extern __shared__ __attribute__((aligned(16))) uint8_t collect_lds[];
+    CollectLds& L = *reinterpret_cast<CollectLds*>(collect_lds);
+    if (c->giant) {
+        collect_giant(E, c, L);
+        return;
+    }
     // (both counters requested together with the buffer index: a read that waits for another is a trip to memory)
     const uint32_t b = c->cur_f, on0 = c->open_n[0].v, on1 = c->open_n[1].v;
     const uint32_t n = b ? on1 : on0;
@@ -1036,10 +1397,10 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
     const uint32_t* __restrict__ ids = E.open_id[b];
     constexpr uint32_t ITEMS = 8, TILE = 256 * ITEMS;
     const uint32_t ntiles = (n + TILE - 1) / TILE;
-    for (int i = threadIdx.x; i < NBIN; i += 256) lcnt[i] = 0;
+    for (int i = threadIdx.x; i < NBIN; i += 256) L.lcnt[i] = 0;
     if (threadIdx.x == 0) {
-        st_n = 0;
-        nz_n = 0;
+        L.st_n = 0;
+        L.nz_n = 0;
     }
     __syncthreads();
     // The stash goes out (workgroup-collective, call after a barrier): one global atomic per bin this workgroup touched
@@ -1047,32 +1408,32 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
     // bins up to the threshold bin instead — a returning global atomic, and a wait, per non-empty bin and loop round — was
     // most of this kernel's time; the list of touched bins is a few dozen long: one round.)
     auto flush = [&]() {
-        const uint32_t ns = st_n < (uint32_t)kStash ? st_n : (uint32_t)kStash;
-        const uint32_t nz = nz_n;
+        const uint32_t ns = L.st_n < (uint32_t)kStash ? L.st_n : (uint32_t)kStash;
+        const uint32_t nz = L.nz_n;
         for (uint32_t i = threadIdx.x; i < nz; i += 256) {
-            const uint32_t f = nzf[i];
-            lcnt[f] = atomicAdd(&E.fill[f], lcnt[f]);
+            const uint32_t f = L.nzf[i];
+            L.lcnt[f] = atomicAdd(&E.fill[f], L.lcnt[f]);
         }
         __syncthreads();
         for (uint32_t p = threadIdx.x; p < ns; p += 256) {
-            const uint32_t f = st_f[p];
-            const uint32_t id = ids[st_idx[p]];
-            const uint32_t pos = E.pre[f] + atomicAdd(&lcnt[f], 1u);
+            const uint32_t f = L.st_f[p];
+            const uint32_t id = ids[L.st_idx[p]];
+            const uint32_t pos = E.pre[f] + atomicAdd(&L.lcnt[f], 1u);
             if (pos < E.pre[f + 1]) {
-                E.tmp_key[pos] = st_key[p];
+                E.tmp_key[pos] = L.st_key[p];
                 E.tmp_id[pos] = id;
                 E.tmp_f[pos] = (uint16_t)f;
-                E.tmp_idx[pos] = st_idx[p];
+                E.tmp_idx[pos] = L.st_idx[p];
             } else {
                 c->failed = 1;  // histogram and FRONT disagree (cannot happen): refuse to write outside the bin's slice
             }
         }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < nz; i += 256) lcnt[nzf[i]] = 0;
+        for (uint32_t i = threadIdx.x; i < nz; i += 256) L.lcnt[L.nzf[i]] = 0;
         __syncthreads();
         if (threadIdx.x == 0) {
-            st_n = 0;
-            nz_n = 0;
+            L.st_n = 0;
+            L.nz_n = 0;
         }
         __syncthreads();
     };
@@ -1100,13 +1461,13 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
                 if (((dest >> (2 * i)) & 3u) != 1u) continue;
                 const uint32_t idx = tile * TILE + i * 256 + threadIdx.x;
                 const uint32_t f = bin_of(k[i], kmin, shift);
-                const uint32_t p = atomicAdd(&st_n, 1u);
+                const uint32_t p = atomicAdd(&L.st_n, 1u);
                 keys[idx] = DEAD;
                 if (p < kStash) {
-                    st_key[p] = k[i];
-                    st_idx[p] = idx;
-                    st_f[p] = (uint16_t)f;
-                    if (atomicAdd(&lcnt[f], 1u) == 0u) nzf[atomicAdd(&nz_n, 1u)] = (uint16_t)f;
+                    L.st_key[p] = k[i];
+                    L.st_idx[p] = idx;
+                    L.st_f[p] = (uint16_t)f;
+                    if (atomicAdd(&L.lcnt[f], 1u) == 0u) L.nzf[atomicAdd(&L.nz_n, 1u)] = (uint16_t)f;
                 } else {  // stash full (cannot happen: it is flushed while a whole tile still fits): place directly
                     const uint32_t pos = E.pre[f] + atomicAdd(&E.fill[f], 1u);
                     if (pos < E.pre[f + 1]) {
@@ -1123,7 +1484,7 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
         // a tile can add up to TILE entries: make room when fewer are left (only ever true when a bin holds a large share
         // of FRONT — massive cost ties — where placing the overflow entry by entry meant millions of atomics on ONE counter)
         __syncthreads();
-        if (st_n + TILE > (uint32_t)kStash) flush();
+        if (L.st_n + TILE > (uint32_t)kStash) flush();
     }
     __syncthreads();
     flush();
@@ -1145,12 +1506,6 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
 // Ranks below `want` are the batch in pop order (which fixes the children's node ids and therefore every later tie-break);
 // the overshoot of the threshold bin returns to the FRONT slots k_sel_collect took it from.
 // ---------------------------------------------------------------------------------------------
-typedef unsigned __int128 u128;
-__device__ __forceinline__ u128 comp_of(uint64_t key, uint32_t id) { return ((u128)key << 32) | (u128)(id & ID_MASK); }
-__device__ __forceinline__ int clz128(u128 v) {
-    uint64_t hi = (uint64_t)(v >> 64), lo = (uint64_t)v;
-    return hi ? __clzll((long long)hi) : 64 + (lo ? __clzll((long long)lo) : 64);
-}
 
 constexpr int kRankStack = 512;    // pending oversized sub-bins of one bin
 constexpr uint32_t kDirectMax = 512;  // items up to this size are ranked all-pairs out of LDS
@@ -1737,7 +2092,7 @@ __global__ __launch_bounds__(RT) void k_rank(const Eng* __restrict__ engs) {
     uint32_t* LI = reinterpret_cast<uint32_t*>(rank_lds + (size_t)kLdsEnt * 8);
     const uint32_t t = threadIdx.x;
     const uint32_t nf = c->cur_f;  // what the batch does not take goes back where it came from
-    const uint32_t bstar = c->bstar, want = c->want;
+    const uint32_t tseg = c->tseg, want = c->want;  // (tseg: the segment holding the batch's last entry — the threshold bin)
     const uint32_t n_big = c->n_big, n_ord = c->n_ord;
     // ---- entries of small bins (most bins, about half the entries): one thread each, the whole grid at once
     {
@@ -1749,13 +2104,13 @@ __global__ __launch_bounds__(RT) void k_rank(const Eng* __restrict__ engs) {
     // ---- bins of more than kTinyBin entries: one workgroup each.  The first n_ord / RT workgroups are busy with the pass
     // above, so the large bins start at workgroup 64
     for (uint32_t bi = (blockIdx.x + gridDim.x - 64u) % gridDim.x; bi < n_big; bi += gridDim.x) {
-        const uint32_t unit = E.big_list[bi];  // bin | share << 12 | shares << 16
-        const uint32_t f = unit & (NBIN - 1u);
+        const uint32_t unit = E.big_list[bi];  // segment | share << 16 | shares << 20
+        const uint32_t f = unit & 0xFFFFu;
         const uint32_t o = E.pre[f], n = E.pre[f + 1] - o;
         __syncthreads();
         if (t == 0) {
             // entries of this bin that belong to the batch: all of it below the threshold bin
-            S.stack[0] = RankItem{o, n, (f == bstar) ? want - o : n, 0u, (unit >> 12) & 15u, unit >> 16, 0u};
+            S.stack[0] = RankItem{o, n, (f == tseg) ? want - o : n, 0u, (unit >> 16) & 15u, unit >> 20, 0u};
             S.sp = 1;
             S.fail = 0;
         }
@@ -1837,6 +2192,8 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
     uint8_t* lpar = smem;
     uint8_t* ltab = smem + TL::PAR_BYTES;
     uint8_t* lst = smem + TL::LDS_BYTES;  // child rows of the tile, laid out exactly like their HBM destination
+    __shared__ uint32_t l_pid[kEngTile], l_g[kEngTile];
+    static_assert((EV::D + 3) / 4 < 16, "no spare lane per row for the parent's path cost");
     // batch geometry: every workgroup derives it from the state the previous iteration left (S[iters & 1]) and the
     // pop that k_rank just finished; workgroup 0 also records it for the rest of the iteration (close_pop)
     const uint32_t it = (uint32_t)c->iters;
@@ -1868,6 +2225,13 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
         constexpr int WPR = (EV::D + 3) / 4;  // words per row (<= 14)
         static_assert(WPR <= 16, "row wider than 64 bytes");
         const uint32_t w = threadIdx.x & 15, r = threadIdx.x >> 4;  // 16 lanes per row, 16 rows
+        // (a spare lane of every row fetches the parent's path cost in the same round trip as the row itself: the
+        // per-child loop below used to wait for it — a dependent random access — before it could write anything)
+        if (r < np && w == WPR) {
+            const uint32_t pid = E.pop_id[r0 + r] & ID_MASK;
+            l_pid[r] = pid;
+            l_g[r] = (uint32_t)E.g[pid];
+        }
         if (r < np && w < WPR) {
             const uint8_t* row = E.state + (size_t)(E.pop_id[r0 + r] & ID_MASK) * EV::D;
             uint32_t v = 0;
@@ -1926,8 +2290,8 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
             }
         }
         h = hash_final(h);
-        const uint32_t j = j0 + cc, id = base + j, pid = E.pop_id[r0 + r] & ID_MASK;
-        const uint32_t gp = (uint32_t)E.g[pid];
+        const uint32_t j = j0 + cc, id = base + j, pid = l_pid[r];
+        const uint32_t gp = l_g[r];
         if (a == 0) E.pop_g[r0 + r] = gp;  // the parents' path costs in pop order: what the dedup / push kernels read
         E.child_hash[j] = h;
         E.g[id] = (int32_t)(gp + 1u);  // path cost + unit transition cost (astar.py:125-126 / cpp:219)
@@ -2444,6 +2808,7 @@ struct dca_engine {
     float* pk_h;
     int64_t pk_rows;       // rows packed by the last dca_engine_pop_expand_packed
     int phase;             // 0 idle, 1 between pop_expand and commit, 2 between pop_expand_packed and commit_packed
+    unsigned collect_blocks;  // grid of k_sel_collect: two workgroups per CU, all resident (its giant-bin path barriers across it)
     hipGraph_t graph[2];   // [0] iteration without / [1] with the refill check
     hipGraphExec_t graph_exec[2];
     int graph_heur;
@@ -2562,7 +2927,7 @@ int enqueue_first_half(dca_engine* e, int heur_id, bool with_refill, hipStream_t
     // and maintained incrementally in between (k_sel_scan's writeback + k_commit's pushes)
     if (with_refill) hipLaunchKernelGGL(k_front_rebase, gxy(kCollectBlocks, e), dim3(256), 0, s, d);
     hipLaunchKernelGGL(k_sel_scan, gxy(1, e), dim3(1024), 0, s, d, with_refill ? 1 : 0);
-    hipLaunchKernelGGL(k_sel_collect, gxy(h_tune[4] > 0 ? h_tune[4] : kCollectBlocks, e), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(k_sel_collect, gxy(e->collect_blocks, e), dim3(256), sizeof(CollectLds), s, d);
     hipLaunchKernelGGL(k_rank, gxy(kRankBlocks, e), dim3(RT), kRankLdsBytes, s, d);
     if (int rc = launch_check("select kernels")) return rc;
     return launch_expand(e, heur_id, want_oh, s);
@@ -2650,6 +3015,15 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
     if (!e) return DCA_E_NOMEM;
     memset(e, 0, sizeof(*e));
     e->K = num_instances;
+    {
+        // k_sel_collect's giant-bin path runs grid barriers: every workgroup must be resident.  Two 256-thread workgroups
+        // (74 KB of LDS each) fit a CU; a device that exposes fewer CUs (partition modes) gets a smaller grid.
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        e->collect_blocks = (unsigned)(2 * cus < kCollectBlocks ? 2 * cus : kCollectBlocks);
+        if (h_tune[4] > 0 && h_tune[4] < (int)e->collect_blocks) e->collect_blocks = (unsigned)h_tune[4];
+    }
     const size_t K = (size_t)num_instances;
     const size_t N = (size_t)max_nodes, M = (size_t)Mll, Bz = (size_t)batch_size + 64;
     int rc = 0;
@@ -2673,6 +3047,7 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
         E.wf = (float)weight;  // cpp:353 (float) atof(argv[2])
         E.max_nodes = (uint32_t)max_nodes;
         E.M = (uint32_t)Mll;
+        E.coop = (num_instances == 1 && h_tune[5] == 0) ? 1 : 0;  // (knob 5: giant-bin path off, round-2 behaviour)
         E.f_keep = (uint32_t)(32 * batch_size > 65536 ? 32 * batch_size : 65536);
         E.f_max = 3 * E.f_keep;
         E.tab_cap = (uint32_t)cap;
@@ -2695,8 +3070,9 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
         }
         ALLOC(hist, NBIN);
         ALLOC(rhist, NBIN);
-        ALLOC(pre, NBIN + 8);
-        ALLOC(fill, NBIN);
+        ALLOC(pre, kSegs + 16);
+        ALLOC(fill, kSegs + 8);
+        ALLOC(subhist, (size_t)kMaxLevels * kSub);
         ALLOC(part, 4 * 1024);
         ALLOC(tmp_key, N);
         ALLOC(tmp_id, N);
@@ -2704,7 +3080,7 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
         ALLOC(tmp_idx, N);
         ALLOC(ord_key, N);
         ALLOC(ord_id, N);
-        ALLOC(big_list, 8 * NBIN);
+        ALLOC(big_list, 8 * kSegs);
         ALLOC(pop_key, Bz);
         ALLOC(pop_id, Bz);
         ALLOC(pop_g, Bz);
@@ -2721,7 +3097,8 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
         if (!rc) {
             (void)hipMemset(E.hist, 0, NBIN * sizeof(uint32_t));
             (void)hipMemset(E.rhist, 0, NBIN * sizeof(uint32_t));
-            (void)hipMemset(E.fill, 0, NBIN * sizeof(uint32_t));
+            (void)hipMemset(E.fill, 0, (kSegs + 8) * sizeof(uint32_t));
+            (void)hipMemset(E.subhist, 0, (size_t)kMaxLevels * kSub * sizeof(uint32_t));
             (void)hipMemset(E.child_multi, 0, M);
             (void)hipMemset(E.ctl, 0, sizeof(Ctl));
         }
@@ -2729,6 +3106,11 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
     if (!rc) {
         hipError_t err = hipHostMalloc((void**)&e->h_ctl, sizeof(Ctl) + kMaxMoves * sizeof(int32_t) + 512);
         if (err != hipSuccess) rc = hip_fail(err, "hipHostMalloc");
+    }
+    if (!rc) {
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sel_collect),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CollectLds));
+        if (err != hipSuccess) rc = hip_fail(err, "hipFuncSetAttribute(k_sel_collect)");
     }
     if (!rc) {
         // k_rank buckets a bin inside 96 KB of dynamic LDS: beyond the default limit
@@ -3021,7 +3403,8 @@ int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, int use_gr
 int dca_debug_tune(int knob, int value) {
     if (knob >= 0 && knob < 8) h_tune[knob] = value;  // (host-side knobs: 4 = workgroups of k_sel_collect; set before the first step)
     // diagnostics: 0 extra log2 of sub-bins per large bin, 1 sub-bin size above which a sub-bin is refined on its own,
-    // 2 BACK squeeze mark in 1/1024ths of max_nodes (3-7 unused)
+    // 2 BACK squeeze mark in 1/1024ths of max_nodes, 3 threshold-bin size above which the grid refines the bin (giant
+    // iterations), 5 (host, before create) giant-bin path off (6-7 unused)
     DCA_ARG(knob >= 0 && knob < 8);
     DCA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tune), &value, sizeof(int), (size_t)knob * sizeof(int), hipMemcpyHostToDevice));
     return 0;

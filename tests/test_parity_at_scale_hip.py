@@ -2,7 +2,7 @@
 configured geometry, followed by the C++ oracle (oracle/dca_oracle.cpp restating astar.py:50-90,180-203,256-333 and
 cpp/parallel_weighted_astar.cpp:169-330) iteration by iteration.
 
- (a) cube3, batch 20 000, weight 0.8 (configs[2]), both search semantics, 150 iterations: FRONT crosses its spill
+ (a) cube3, batch 20 000, weight 0.8 (configs[2]), both search semantics, 160 iterations: FRONT crosses its spill
      mark (96 batches), spills to BACK, refills from it, and the every-8th-iteration rebase runs 18+ times.
  (b) whole searches on shipped puzzle15 test states (1.5-2.8 M nodes), batch 10 000, the built-in Manhattan heuristic
      (integer costs: every f-level is one tie group, ordered by push count like astar.py:64-67): nodes generated,
@@ -33,7 +33,9 @@ def co():
 @pytest.mark.parametrize("sem", ["py", "cpp"])
 def test_cube3_batch_20000_through_spill_refill_rebase(L, co, golden, sem):
     from deepcubea_amd.search_methods.engine import BwasEngine
-    B, w, hid, iters = 20000, 0.8, L.HEUR_HASHU01, 150
+    # KNUTH3: few exact float32 cost ties (what the cpp core's heap order is sensitive to); with it FRONT drains to its
+    # refill mark at iteration ~136 (tools/tier_probe.py), so 160 iterations see the spill AND a refill from BACK
+    B, w, hid, iters = 20000, 0.8, L.HEUR_KNUTH3, 160
     root = np.ascontiguousarray(golden["cube3_test_states"][0])
     semv, osem = (L.SEM_PY, co.SEM_PY) if sem == "py" else (L.SEM_CPP, co.SEM_CPP)
     ref = co.astar("cube3", root, w, B, osem, heur_builtin_id=hid, max_iters=iters, trace_cap=iters, stop_on_goal=False)
@@ -62,9 +64,10 @@ def test_cube3_batch_20000_through_spill_refill_rebase(L, co, golden, sem):
     print("sem=%s  |OPEN| end %d  BACK max %d  tier threshold rose %d times, fell %d times"
           % (sem, tr[-1, 0], back.max(), rises, int((np.diff(thr[finite]) < 0).sum())))
     assert rises >= 1, "no refill from BACK happened"
+    assert len(tr) // 8 >= 18  # rebase iterations (every 8th) behind the ramp
     assert np.array_equal(tr[:, 2], ref["trace"][:, 2])  # nodes generated per iteration: exact in both semantics
     if sem == "py":
-        assert np.array_equal(tr, ref["trace"])  # |OPEN|, |CLOSED| after every one of the 150 iterations
+        assert np.array_equal(tr, ref["trace"])  # |OPEN|, |CLOSED| after every one of the 160 iterations
     else:
         # cpp: equal float32 costs pop in libstdc++'s heap order in the reference, in push order here
         rel = np.abs(tr[:, :2] - ref["trace"][:, :2]) / np.maximum(ref["trace"][:, :2], 1)

@@ -28,7 +28,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 w = sys.argv[3] if len(sys.argv) > 3 else "0.8"
 B = sys.argv[4] if len(sys.argv) > 4 else "10000"
 sem = sys.argv[5] if len(sys.argv) > 5 else "py"
-max_nodes = sys.argv[6] if len(sys.argv) > 6 else str(1 << 27)
+max_nodes = sys.argv[6] if len(sys.argv) > 6 else "auto"
 g = np.load(os.path.join(ROOT, "tests", "golden", "golden.npz"))
 states = g[env + "_test_states"][:n]
 opt = g[env + "_test_opt_len"][:n] if env + "_test_opt_len" in g.files else None
