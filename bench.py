@@ -705,6 +705,7 @@ def main():
                          "in the sharded leg (0 = skip)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune", default="", help="diagnostics: dca_debug_tune knobs, e.g. 6=1,3=16384 (A/B runs; not for the record)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))  # one rank per GPU under torch.distributed.run
@@ -715,6 +716,11 @@ def main():
     world, rank, local = dist_setup(args.dist_backend)
     if world != max(args.gpus, 1):
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    if args.tune:
+        from deepcubea_amd import _lib
+        for kv in args.tune.split(","):
+            k, v = kv.split("=")
+            _lib.check(_lib.lib().dca_debug_tune(int(k), int(v)), "dca_debug_tune")
     res = {"astar": run_astar, "expand": run_expand, "avi": run_avi, "train": run_train,
            "selftest": run_selftest}[args.workload](args, world, rank)
     line = {

@@ -37,6 +37,7 @@ ABI_SYMBOLS = [
     "dca_engine_profile_builtin", "dca_engine_set_tiers", "dca_engine_debug", "dca_debug_tune", "dca_engine_status", "dca_engine_last_children", "dca_engine_solution",
     "dca_bn_workspace_bytes", "dca_bn_train_forward", "dca_bn_train_backward",
     "dca_l1_supported", "dca_l1_kpad", "dca_l1_onehot_gemm", "dca_act_split", "dca_f16x3_gemm", "dca_split_planes", "dca_f16x3_gemm_variant",
+    "dca_gemm16",
 ]
 
 
@@ -380,6 +381,23 @@ def f16x3_gemm(a_planes: torch.Tensor, w_h: torch.Tensor, w_l: torch.Tensor, col
                                ptr(planes[0]) if want_planes else C.c_void_p(0), ptr(planes[1]) if want_planes else C.c_void_p(0),
                                ptr(x_out), C.c_int64(n), ptr(overflow), stream_ptr()), "dca_f16x3_gemm")
     return planes, x_out
+
+
+def gemm16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], skip: Optional[torch.Tensor], relu: bool,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One dense layer in the non-parity 16-bit modes (dca_gemm16): relu?(a . w^T + bias (+ skip)), a [m, k] / w [n, k] /
+    skip [m, n] bf16 or fp16, bias fp32, fp32 accumulation, result in the operands' type.  `out` may be `skip` (in place)."""
+    assert a.dtype in (torch.bfloat16, torch.float16) and w.dtype == a.dtype and a.is_contiguous() and w.is_contiguous()
+    m, k = a.shape
+    n = w.shape[0]
+    assert w.shape[1] == k and (bias is None or (bias.dtype == torch.float32 and bias.numel() == n))
+    assert skip is None or (skip.dtype == a.dtype and skip.shape == (m, n) and skip.is_contiguous())
+    if out is None:
+        out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    assert out.dtype == a.dtype and out.shape == (m, n) and out.is_contiguous() and out.data_ptr() != a.data_ptr()
+    check(lib().dca_gemm16(ptr(a), C.c_int64(m), int(k), C.c_int64(k), ptr(w), int(n), C.c_int64(k), _TORCH_DT[a.dtype],
+                           ptr(bias), ptr(skip), int(relu), ptr(out), C.c_int64(n), stream_ptr()), "dca_gemm16")
+    return out
 
 
 def f16x3_gemm_variant(v: int) -> None:

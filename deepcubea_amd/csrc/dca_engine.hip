@@ -131,6 +131,7 @@ struct Ctl {
     uint32_t want, bstar, shift, n_big, n_ord;
     uint32_t giant;   // this pop's threshold bin is refined across the grid by k_sel_collect (set by k_sel_scan)
     uint32_t tseg;    // the segment holding the batch's last entry (= bstar unless giant)
+    uint32_t pre_b, cn_star;  // entries below the threshold bin / in it (k_rank's histogram writeback)
     uint64_t sel_kmin;
     // goals
     uint32_t goal_id;
@@ -996,6 +997,8 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
         c->want = want;
         c->bstar = s_bstar;
         c->tseg = s_bstar;
+        c->pre_b = pre[s_bstar];
+        c->cn_star = pre[s_bstar + 1] - pre[s_bstar];
         c->giant = giant ? 1u : 0u;
         c->gbar.v = 0;
         c->grange.kmin = ~0ull;
@@ -1073,19 +1076,45 @@ __device__ __forceinline__ int clz128(u128 v) {
 // Workgroup 0 publishes the segments' offsets, the threshold segment and k_rank's work units.  The grid barrier is a
 // counter in the control block (agent-scope release before the arrival, relaxed polling, one acquire after; every spin
 // bounded): the launch is sized to be fully resident (2 workgroups per CU; single-instance engines only).
+constexpr int kStashG = 1536;   // the stash of a giant iteration's collection pass (tiles of 1024 entries there)
 struct CollectLds {
-    uint64_t st_key[kStash];
-    uint32_t st_idx[kStash];
-    uint32_t lcnt[kSegs + 3];
-    uint32_t subpre[kSub + 4];   // giant: exclusive prefix of the last level's sub-bin counts
-    uint16_t st_f[kStash];
-    uint16_t nzf[kStash];        // the segments this workgroup stashed entries of (each once)
+    // exclusive prefix of the selection histogram: computed by EVERY workgroup from E.hist in the iterations that have no
+    // k_sel_scan launch (all but the rebase iterations), copied from E.pre otherwise
+    uint32_t pre[NBIN + 4];
+    uint32_t lcnt[NBIN];  // entries stashed per segment, then the workgroup's slice base; giant: continues in g.lcnt_ext
+    union {
+        struct {
+            uint64_t st_key[kStash];
+            uint32_t st_idx[kStash];
+            uint16_t st_f[kStash];
+            uint16_t nzf[kStash];  // the segments this workgroup stashed entries of (each once)
+        } n;
+        struct {
+            uint32_t lcnt_ext[kSegs - NBIN + 3];
+            uint32_t subpre[kSub + 4];  // exclusive prefix of the last level's sub-bin counts
+            uint64_t st_key[kStashG];   // (doubles as the sub-bin counters of the histogram passes)
+            uint32_t st_idx[kStashG];
+            uint16_t st_f[kStashG];
+            uint16_t nzf[kStashG];
+        } g;
+    } u;
     uint64_t red64[2][4];
     uint32_t red32[2][4];
     uint32_t wsum[4];
-    uint32_t st_n, nz_n, ok, tsub, nb;
+    uint32_t st_n, nz_n, ok, tsub, nb, bstar;
 };
 static_assert(sizeof(CollectLds) <= 80 * 1024, "two workgroups of k_sel_collect must fit one CU's LDS");
+static_assert(offsetof(CollectLds, u) == offsetof(CollectLds, lcnt) + sizeof(uint32_t) * NBIN, "lcnt must run on into lcnt_ext");
+static_assert(sizeof(uint64_t) * kStashG >= sizeof(uint32_t) * kSub, "sub-bin counters alias the giant stash");
+
+// what a pop selects, identical in every workgroup of the launch
+struct SelParams {
+    uint32_t b, n;        // FRONT buffer and its physical size
+    uint64_t kmin;        // binning in force
+    uint32_t shift;
+    uint32_t want, bstar, pre_b, cn_star;
+    bool giant;
+};
 
 // all threads of the workgroup; false = the barrier timed out or another workgroup gave up (the search is failed)
 __device__ __forceinline__ bool collect_grid_barrier(Ctl* c, CollectLds& L, uint32_t target) {
@@ -1116,14 +1145,14 @@ __device__ __forceinline__ bool collect_grid_barrier(Ctl* c, CollectLds& L, uint
     return L.ok != 0;
 }
 
-__device__ __noinline__ void collect_giant(const Eng& E, Ctl* c, CollectLds& L) {
+__device__ __noinline__ void collect_giant(const Eng& E, Ctl* c, CollectLds& L, const SelParams P) {
     const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const uint32_t b = c->cur_f, n = c->open_n[b].v;
-    const uint64_t bkmin = c->sel_kmin;
-    const uint32_t shift = c->shift, bstar = c->bstar, want = c->want;
-    const uint32_t pre_b = E.pre[bstar];
-    uint64_t* __restrict__ keys = E.open_key[b];
-    const uint32_t* __restrict__ ids = E.open_id[b];
+    const uint32_t n = P.n;
+    const uint64_t bkmin = P.kmin;
+    const uint32_t shift = P.shift, bstar = P.bstar, want = P.want;
+    const uint32_t pre_b = P.pre_b;
+    uint64_t* __restrict__ keys = E.open_key[P.b];
+    const uint32_t* __restrict__ ids = E.open_id[P.b];
     constexpr uint32_t ITEMS = 8, TILE = 256 * ITEMS;
     const uint32_t ntiles = (n + TILE - 1) / TILE;
     uint32_t phase = 0;
@@ -1190,7 +1219,8 @@ __device__ __noinline__ void collect_giant(const Eng& E, Ctl* c, CollectLds& L) 
     u128 span = ((u128)(gkmax - gkmin) << 32) + (u128)(gimax - gimin);  // (upper bound: ids of the top key are <= imax)
     uint32_t need = want - pre_b, below = 0, shc = 0, tsub = 0;
     const uint32_t giant_limit = g_tune[3] > 0 ? (uint32_t)g_tune[3] : kGiantBinDefault;
-    uint32_t* lh = reinterpret_cast<uint32_t*>(L.st_key);  // (the stash is idle until the collection pass)
+    uint32_t* lh = reinterpret_cast<uint32_t*>(L.u.g.st_key);  // (the stash is idle until the collection pass)
+    uint32_t* subpre = L.u.g.subpre;
     for (int lvl = 0;; lvl++) {
         const uint32_t bits = span ? (uint32_t)(128 - clz128(span)) : 0u;
         shc = bits > 11u ? bits - 11u : 0u;
@@ -1239,22 +1269,22 @@ __device__ __noinline__ void collect_giant(const Eng& E, Ctl* c, CollectLds& L) 
         for (uint32_t w = 0; w < wv; w++) run += L.wsum[w];
 #pragma unroll
         for (int k = 0; k < PER; k++) {
-            L.subpre[PER * t + k] = run;
+            subpre[PER * t + k] = run;
             if (run < need && need <= run + v[k]) L.tsub = PER * t + k;
             run += v[k];
         }
-        if (t == 255) L.subpre[kSub] = run;
+        if (t == 255) subpre[kSub] = run;
         __syncthreads();
         tsub = L.tsub;
         if (tsub == ~0u) {  // counts and FRONT disagree (cannot happen)
             if (t == 0) c->failed = 1, c->done = 1;
             return;
         }
-        const uint32_t cn = L.subpre[tsub + 1] - L.subpre[tsub];
+        const uint32_t cn = subpre[tsub + 1] - subpre[tsub];
         if (cn <= giant_limit || shc == 0 || lvl + 1 >= kMaxLevels) break;
         // descend into the threshold sub-bin: everything below it is certainly in the batch
-        below += L.subpre[tsub];
-        need -= L.subpre[tsub];
+        below += subpre[tsub];
+        need -= subpre[tsub];
         V0 += (u128)tsub << shc;
         span = ((u128)1 << shc) - 1;
         __syncthreads();  // (subpre / tsub are rewritten by the next level)
@@ -1266,13 +1296,13 @@ __device__ __noinline__ void collect_giant(const Eng& E, Ctl* c, CollectLds& L) 
             L.nb = c->n_big;
             E.pre[bstar + 1] = pre_b + below;
             c->tseg = seg0 + tsub;
-            c->n_ord = pre_b + below + L.subpre[tsub + 1];
-            c->dbg_nord = pre_b + below + L.subpre[tsub + 1];
+            c->n_ord = pre_b + below + subpre[tsub + 1];
+            c->dbg_nord = pre_b + below + subpre[tsub + 1];
         }
         __syncthreads();
         for (uint32_t sg = t; sg <= tsub + 1u; sg += 256) {  // sg 0 = the below part, sg 1 + s = sub-bin s
-            const uint32_t cn = sg == 0 ? below : L.subpre[sg] - L.subpre[sg - 1];
-            if (sg > 0) E.pre[seg0 + sg] = pre_b + below + L.subpre[sg];
+            const uint32_t cn = sg == 0 ? below : subpre[sg] - subpre[sg - 1];
+            if (sg > 0) E.pre[seg0 + sg] = pre_b + below + subpre[sg];
             if (cn > (uint32_t)kTinyBin) {
                 uint32_t G = cn <= (uint32_t)kLdsEnt ? (cn + 1023u) / 1024u : 1u;
                 G = G > 8u ? 8u : G;
@@ -1283,42 +1313,46 @@ __device__ __noinline__ void collect_giant(const Eng& E, Ctl* c, CollectLds& L) 
         __syncthreads();
         if (t == 0) c->n_big = L.nb;
     }
-    // ---- D: collection
-    for (uint32_t i = t; i < (uint32_t)(kSegs + 3); i += 256) L.lcnt[i] = 0;
+    // ---- D: collection (tiles of 1024 entries: the stash is smaller here)
+    uint32_t* lcnt = L.lcnt;  // (runs on into u.g.lcnt_ext: kSegs entries)
+    for (uint32_t i = t; i < (uint32_t)(kSegs + 3); i += 256) lcnt[i] = 0;
     if (t == 0) {
         L.st_n = 0;
         L.nz_n = 0;
     }
     __syncthreads();
+    uint64_t* st_key = L.u.g.st_key;
+    uint32_t* st_idx = L.u.g.st_idx;
+    uint16_t *st_f = L.u.g.st_f, *nzf = L.u.g.nzf;
     auto seg_base = [&](uint32_t f) -> uint32_t {
-        return f < bstar ? E.pre[f] : f == bstar ? pre_b : pre_b + below + L.subpre[f - seg0];
+        return f < bstar ? L.pre[f] : f == bstar ? pre_b : pre_b + below + subpre[f - seg0];
     };
     auto seg_end = [&](uint32_t f) -> uint32_t {
-        return f < bstar ? E.pre[f + 1] : f == bstar ? pre_b + below : pre_b + below + L.subpre[f - seg0 + 1];
+        return f < bstar ? L.pre[f + 1] : f == bstar ? pre_b + below : pre_b + below + subpre[f - seg0 + 1];
     };
     auto flush = [&]() {
-        const uint32_t ns = L.st_n < (uint32_t)kStash ? L.st_n : (uint32_t)kStash;
+        const uint32_t ns = L.st_n < (uint32_t)kStashG ? L.st_n : (uint32_t)kStashG;
         const uint32_t nz = L.nz_n;
         for (uint32_t i = t; i < nz; i += 256) {
-            const uint32_t f = L.nzf[i];
-            L.lcnt[f] = atomicAdd(&E.fill[f], L.lcnt[f]);
+            const uint32_t f = nzf[i];
+            lcnt[f] = atomicAdd(&E.fill[f], lcnt[f]);
         }
         __syncthreads();
         for (uint32_t p = t; p < ns; p += 256) {
-            const uint32_t f = L.st_f[p];
-            const uint32_t id = ids[L.st_idx[p]];
-            const uint32_t pos = seg_base(f) + atomicAdd(&L.lcnt[f], 1u);
+            const uint32_t f = st_f[p];
+            const uint32_t id = ids[st_idx[p]];
+            const uint32_t pos = seg_base(f) + atomicAdd(&lcnt[f], 1u);
             if (pos < seg_end(f)) {
-                E.tmp_key[pos] = L.st_key[p];
+                E.tmp_key[pos] = st_key[p];
                 E.tmp_id[pos] = id;
                 E.tmp_f[pos] = (uint16_t)f;
-                E.tmp_idx[pos] = L.st_idx[p];
+                E.tmp_idx[pos] = st_idx[p];
             } else {
                 c->failed = 1;  // counts and FRONT disagree (cannot happen): refuse to write outside the segment's slice
             }
         }
         __syncthreads();
-        for (uint32_t i = t; i < nz; i += 256) L.lcnt[L.nzf[i]] = 0;
+        for (uint32_t i = t; i < nz; i += 256) lcnt[nzf[i]] = 0;
         __syncthreads();
         if (t == 0) {
             L.st_n = 0;
@@ -1326,57 +1360,72 @@ __device__ __noinline__ void collect_giant(const Eng& E, Ctl* c, CollectLds& L) 
         }
         __syncthreads();
     };
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        uint64_t k[ITEMS];
-        uint32_t id[ITEMS];
+    constexpr uint32_t ITEMS_D = 4, TILE_D = 256 * ITEMS_D;
+    const uint32_t ntiles_d = (n + TILE_D - 1) / TILE_D;
+    // (the same entries as in the passes above: workgroup w owned tiles w, w + grid, ... of 2048 entries = tile pairs here)
+    for (uint32_t tile2 = blockIdx.x; tile2 < ntiles; tile2 += gridDim.x) {
+        for (uint32_t half = 0; half < 2; half++) {
+            const uint32_t tile = tile2 * 2 + half;
+            if (tile < ntiles_d) {  // (uniform)
+                uint64_t k[ITEMS_D];
+                uint32_t id[ITEMS_D];
 #pragma unroll
-        for (uint32_t i = 0; i < ITEMS; i++) {
-            const uint32_t idx = tile * TILE + i * 256 + t, ic = idx < n ? idx : n - 1;
-            k[i] = keys[ic];
-            id[i] = ids[ic];
-            if (idx >= n) k[i] = DEAD;
-        }
+                for (uint32_t i = 0; i < ITEMS_D; i++) {
+                    const uint32_t idx = tile * TILE_D + i * 256 + t, ic = idx < n ? idx : n - 1;
+                    k[i] = keys[ic];
+                    id[i] = ids[ic];
+                    if (idx >= n) k[i] = DEAD;
+                }
 #pragma unroll
-        for (uint32_t i = 0; i < ITEMS; i++) {
-            if (k[i] == DEAD) continue;
-            uint32_t f = bin_of(k[i], bkmin, shift);
-            if (f > bstar) continue;
-            if (f == bstar) {
-                const u128 v = comp_of(k[i], id[i]);
-                if (v >= V0) {
-                    if (v - V0 > span) continue;
-                    const uint32_t sub = (uint32_t)((v - V0) >> shc);
-                    if (sub > tsub) continue;  // stays in FRONT, untouched
-                    f = seg0 + sub;
+                for (uint32_t i = 0; i < ITEMS_D; i++) {
+                    if (k[i] == DEAD) continue;
+                    uint32_t f = bin_of(k[i], bkmin, shift);
+                    if (f > bstar) continue;
+                    if (f == bstar) {
+                        const u128 v = comp_of(k[i], id[i]);
+                        if (v >= V0) {
+                            if (v - V0 > span) continue;
+                            const uint32_t sub = (uint32_t)((v - V0) >> shc);
+                            if (sub > tsub) continue;  // stays in FRONT, untouched
+                            f = seg0 + sub;
+                        }
+                    }
+                    const uint32_t idx = tile * TILE_D + i * 256 + t;
+                    const uint32_t p = atomicAdd(&L.st_n, 1u);
+                    keys[idx] = DEAD;
+                    if (p < (uint32_t)kStashG) {
+                        st_key[p] = k[i];
+                        st_idx[p] = idx;
+                        st_f[p] = (uint16_t)f;
+                        if (atomicAdd(&lcnt[f], 1u) == 0u) nzf[atomicAdd(&L.nz_n, 1u)] = (uint16_t)f;
+                    } else {  // stash full (cannot happen: it is flushed while a whole tile still fits): place directly
+                        const uint32_t pos = seg_base(f) + atomicAdd(&E.fill[f], 1u);
+                        if (pos < seg_end(f)) {
+                            E.tmp_key[pos] = k[i];
+                            E.tmp_id[pos] = id[i];
+                            E.tmp_f[pos] = (uint16_t)f;
+                            E.tmp_idx[pos] = idx;
+                        } else {
+                            c->failed = 1;
+                        }
+                    }
                 }
             }
-            const uint32_t idx = tile * TILE + i * 256 + t;
-            const uint32_t p = atomicAdd(&L.st_n, 1u);
-            keys[idx] = DEAD;
-            if (p < (uint32_t)kStash) {
-                L.st_key[p] = k[i];
-                L.st_idx[p] = idx;
-                L.st_f[p] = (uint16_t)f;
-                if (atomicAdd(&L.lcnt[f], 1u) == 0u) L.nzf[atomicAdd(&L.nz_n, 1u)] = (uint16_t)f;
-            } else {  // stash full (cannot happen: it is flushed while a whole tile still fits): place directly
-                const uint32_t pos = seg_base(f) + atomicAdd(&E.fill[f], 1u);
-                if (pos < seg_end(f)) {
-                    E.tmp_key[pos] = k[i];
-                    E.tmp_id[pos] = id[i];
-                    E.tmp_f[pos] = (uint16_t)f;
-                    E.tmp_idx[pos] = idx;
-                } else {
-                    c->failed = 1;
-                }
-            }
+            __syncthreads();
+            if (L.st_n + TILE_D > (uint32_t)kStashG) flush();
         }
-        __syncthreads();
-        if (L.st_n + TILE > (uint32_t)kStash) flush();
     }
     __syncthreads();
     flush();
 }
 
+// FUSED: this launch opens the iteration — there is no k_sel_scan in front of it.  Every workgroup derives the pop's
+// geometry itself from the selection histogram (16 KB from L2 and a 4096-bin prefix in LDS: cheaper than a single-workgroup
+// launch plus its boundary, which was 7 % of the iteration); workgroup 0 also records it for k_rank.  `want` was left by the
+// previous iteration's k_commit (commit_ticket), the histogram's writeback is done by k_rank (nobody may change it while the
+// workgroups of this launch read it).  Rebase iterations keep k_sel_scan (FUSED = false): it also takes FRONT's new key
+// range, the spill decision and the refill's bookkeeping.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ engs) {
     const Eng& E = engs[blockIdx.y];
     Ctl* c = E.ctl;
@@ -1384,21 +1433,129 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
     Stamp stamp(E, P_SEL_COLLECT);
     extern __shared__ __attribute__((aligned(16))) uint8_t collect_lds[];
     CollectLds& L = *reinterpret_cast<CollectLds*>(collect_lds);
-    if (c->giant) {
-        collect_giant(E, c, L);
+    const uint32_t t = threadIdx.x;
+    SelParams P;
+    {
+        // (everything requested together: a read that waits for another is a trip to memory)
+        const uint32_t b = c->cur_f, on0 = c->open_n[0].v, on1 = c->open_n[1].v;
+        P.b = b;
+        P.n = b ? on1 : on0;
+        P.kmin = c->sel_kmin;
+        P.shift = c->shift;
+        P.want = c->want;
+    }
+    if constexpr (FUSED) {
+        constexpr int PER = NBIN / 256;  // 16 bins per thread
+        const uint32_t lane = t & 63, wv = t >> 6;
+        uint32_t v[PER], sum = 0;
+        {
+            const uint4* h4 = reinterpret_cast<const uint4*>(E.hist + PER * t);
+#pragma unroll
+            for (int q = 0; q < PER / 4; q++) {
+                const uint4 x = h4[q];
+                v[4 * q] = x.x;
+                v[4 * q + 1] = x.y;
+                v[4 * q + 2] = x.z;
+                v[4 * q + 3] = x.w;
+            }
+#pragma unroll
+            for (int k = 0; k < PER; k++) sum += v[k];
+        }
+        uint32_t incl = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = __shfl_up(incl, o);
+            if (lane >= (uint32_t)o) incl += u;
+        }
+        if (lane == 63) L.wsum[wv] = incl;
+        if (t == 0) L.bstar = 0;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (uint32_t w = 0; w < wv; w++) run += L.wsum[w];
+        const uint32_t want = P.want;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            L.pre[PER * t + k] = run;
+            if (run < want && want <= run + v[k]) L.bstar = PER * t + k;
+            run += v[k];
+        }
+        if (t == 255) L.pre[NBIN] = run;
+        __syncthreads();
+        if (want == 0) {  // OPEN ran empty: no solution reachable
+            if (blockIdx.x == 0 && t == 0) {
+                c->failed = 1;
+                c->done = 1;
+            }
+            return;
+        }
+        P.bstar = L.bstar;
+        P.pre_b = L.pre[P.bstar];
+        P.cn_star = L.pre[P.bstar + 1] - P.pre_b;
+        const uint32_t giant_limit = g_tune[3] > 0 ? (uint32_t)g_tune[3] : kGiantBinDefault;
+        P.giant = E.coop && P.cn_star > giant_limit;
+        if (blockIdx.x == 0) {
+            // the record k_rank (and the rest of the iteration) reads — what k_sel_scan writes in a rebase iteration
+            for (uint32_t i = t; i <= (uint32_t)NBIN; i += 256) E.pre[i] = L.pre[i];
+            if (t == 0) {
+                L.nb = 0;
+                L.st_n = 0;  // (borrowed: largest bin / bins beyond the LDS sort capacity, diagnostics)
+                L.nz_n = 0;
+            }
+            __syncthreads();
+            for (uint32_t bin = t; bin <= P.bstar; bin += 256) {
+                const uint32_t cn = L.pre[bin + 1] - L.pre[bin];
+                if (cn > 256) atomicMax(&L.st_n, cn);
+                if (cn > (uint32_t)kSortCap) atomicAdd(&L.nz_n, 1u);
+                if (cn > (uint32_t)kTinyBin && !(P.giant && bin == P.bstar)) {
+                    uint32_t G = cn <= (uint32_t)kLdsEnt ? (cn + 1023u) / 1024u : 1u;
+                    G = G > 8u ? 8u : G;
+                    const uint32_t at = atomicAdd(&L.nb, G);
+                    for (uint32_t g = 0; g < G; g++) E.big_list[at + g] = bin | (g << 16) | (G << 20);
+                }
+            }
+            __syncthreads();
+            if (t == 0) {
+                c->bstar = P.bstar;
+                c->tseg = P.bstar;
+                c->giant = P.giant ? 1u : 0u;
+                c->pre_b = P.pre_b;
+                c->cn_star = P.cn_star;
+                c->spill_bin = NBIN;
+                c->n_big = L.nb;
+                c->n_ord = L.pre[P.bstar + 1];
+                c->front_dead.v += want;  // k_sel_collect tombstones what leaves FRONT; k_rank puts the overshoot back
+                c->dbg_nord = L.pre[P.bstar + 1];
+                c->dbg_maxbin = L.st_n;
+                c->dbg_giant = L.nz_n;
+                c->dbg_giant_seen += L.nz_n;
+                c->dbg_maxsub = 0;
+            }
+            __syncthreads();
+        }
+    } else {
+        P.bstar = c->bstar;
+        P.giant = c->giant != 0;
+        P.pre_b = c->pre_b;
+        P.cn_star = c->cn_star;
+        if (P.want == 0) return;
+        for (uint32_t i = t; i <= P.bstar + 1u; i += 256) L.pre[i] = E.pre[i];
+        __syncthreads();
+    }
+    if (P.giant) {
+        collect_giant(E, c, L, P);
         return;
     }
-    // (both counters requested together with the buffer index: a read that waits for another is a trip to memory)
-    const uint32_t b = c->cur_f, on0 = c->open_n[0].v, on1 = c->open_n[1].v;
-    const uint32_t n = b ? on1 : on0;
-    const uint64_t kmin = c->sel_kmin;
-    const uint32_t shift = c->shift, bstar = c->bstar;
-    uint64_t* __restrict__ keys = E.open_key[b];
-    const uint32_t* __restrict__ ids = E.open_id[b];
+    const uint32_t n = P.n;
+    const uint64_t kmin = P.kmin;
+    const uint32_t shift = P.shift, bstar = P.bstar;
+    uint64_t* __restrict__ keys = E.open_key[P.b];
+    const uint32_t* __restrict__ ids = E.open_id[P.b];
     constexpr uint32_t ITEMS = 8, TILE = 256 * ITEMS;
     const uint32_t ntiles = (n + TILE - 1) / TILE;
-    for (int i = threadIdx.x; i < NBIN; i += 256) L.lcnt[i] = 0;
-    if (threadIdx.x == 0) {
+    uint64_t* st_key = L.u.n.st_key;
+    uint32_t* st_idx = L.u.n.st_idx;
+    uint16_t *st_f = L.u.n.st_f, *nzf = L.u.n.nzf;
+    for (int i = t; i < NBIN; i += 256) L.lcnt[i] = 0;
+    if (t == 0) {
         L.st_n = 0;
         L.nz_n = 0;
     }
@@ -1410,28 +1567,28 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
     auto flush = [&]() {
         const uint32_t ns = L.st_n < (uint32_t)kStash ? L.st_n : (uint32_t)kStash;
         const uint32_t nz = L.nz_n;
-        for (uint32_t i = threadIdx.x; i < nz; i += 256) {
-            const uint32_t f = L.nzf[i];
+        for (uint32_t i = t; i < nz; i += 256) {
+            const uint32_t f = nzf[i];
             L.lcnt[f] = atomicAdd(&E.fill[f], L.lcnt[f]);
         }
         __syncthreads();
-        for (uint32_t p = threadIdx.x; p < ns; p += 256) {
-            const uint32_t f = L.st_f[p];
-            const uint32_t id = ids[L.st_idx[p]];
-            const uint32_t pos = E.pre[f] + atomicAdd(&L.lcnt[f], 1u);
-            if (pos < E.pre[f + 1]) {
-                E.tmp_key[pos] = L.st_key[p];
+        for (uint32_t p = t; p < ns; p += 256) {
+            const uint32_t f = st_f[p];
+            const uint32_t id = ids[st_idx[p]];
+            const uint32_t pos = L.pre[f] + atomicAdd(&L.lcnt[f], 1u);
+            if (pos < L.pre[f + 1]) {
+                E.tmp_key[pos] = st_key[p];
                 E.tmp_id[pos] = id;
                 E.tmp_f[pos] = (uint16_t)f;
-                E.tmp_idx[pos] = L.st_idx[p];
+                E.tmp_idx[pos] = st_idx[p];
             } else {
                 c->failed = 1;  // histogram and FRONT disagree (cannot happen): refuse to write outside the bin's slice
             }
         }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < nz; i += 256) L.lcnt[L.nzf[i]] = 0;
+        for (uint32_t i = t; i < nz; i += 256) L.lcnt[nzf[i]] = 0;
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (t == 0) {
             L.st_n = 0;
             L.nz_n = 0;
         }
@@ -1443,7 +1600,7 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
         // all loads of the tile first (unconditional, index-clamped: they stay in flight together) ...
 #pragma unroll
         for (uint32_t i = 0; i < ITEMS; i++) {
-            const uint32_t idx = tile * TILE + i * 256 + threadIdx.x, ic = idx < n ? idx : n - 1;
+            const uint32_t idx = tile * TILE + i * 256 + t, ic = idx < n ? idx : n - 1;
             k[i] = keys[ic];
             if (idx >= n) k[i] = DEAD;
         }
@@ -1459,18 +1616,18 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
 #pragma unroll
             for (uint32_t i = 0; i < ITEMS; i++) {
                 if (((dest >> (2 * i)) & 3u) != 1u) continue;
-                const uint32_t idx = tile * TILE + i * 256 + threadIdx.x;
+                const uint32_t idx = tile * TILE + i * 256 + t;
                 const uint32_t f = bin_of(k[i], kmin, shift);
                 const uint32_t p = atomicAdd(&L.st_n, 1u);
                 keys[idx] = DEAD;
                 if (p < kStash) {
-                    L.st_key[p] = k[i];
-                    L.st_idx[p] = idx;
-                    L.st_f[p] = (uint16_t)f;
-                    if (atomicAdd(&L.lcnt[f], 1u) == 0u) L.nzf[atomicAdd(&L.nz_n, 1u)] = (uint16_t)f;
+                    st_key[p] = k[i];
+                    st_idx[p] = idx;
+                    st_f[p] = (uint16_t)f;
+                    if (atomicAdd(&L.lcnt[f], 1u) == 0u) nzf[atomicAdd(&L.nz_n, 1u)] = (uint16_t)f;
                 } else {  // stash full (cannot happen: it is flushed while a whole tile still fits): place directly
-                    const uint32_t pos = E.pre[f] + atomicAdd(&E.fill[f], 1u);
-                    if (pos < E.pre[f + 1]) {
+                    const uint32_t pos = L.pre[f] + atomicAdd(&E.fill[f], 1u);
+                    if (pos < L.pre[f + 1]) {
                         E.tmp_key[pos] = k[i];
                         E.tmp_id[pos] = ids[idx];
                         E.tmp_f[pos] = (uint16_t)f;
@@ -2094,6 +2251,19 @@ __global__ __launch_bounds__(RT) void k_rank(const Eng* __restrict__ engs) {
     const uint32_t nf = c->cur_f;  // what the batch does not take goes back where it came from
     const uint32_t tseg = c->tseg, want = c->want;  // (tseg: the segment holding the batch's last entry — the threshold bin)
     const uint32_t n_big = c->n_big, n_ord = c->n_ord;
+    if (blockIdx.x == gridDim.x - 1) {
+        // housekeeping for the launches that read these arrays while every workgroup is looking (k_sel_collect): FRONT's
+        // histogram minus what this pop takes — the bins below the threshold bin leave entirely, the threshold bin keeps
+        // its overshoot (k_commit adds the children later in this iteration) — and the scratch counters back to zero
+        const uint32_t bstar = c->bstar, pre_b = c->pre_b, cn_star = c->cn_star;
+        if (want != 0) {
+            for (uint32_t bin = t; bin < bstar; bin += RT) E.hist[bin] = 0;
+            if (t == 0) E.hist[bstar] = cn_star - (want - pre_b);
+        }
+        for (uint32_t i = t; i < (uint32_t)kSegs; i += RT) E.fill[i] = 0;
+        if (c->giant)
+            for (uint32_t i = t; i < (uint32_t)(kMaxLevels * kSub); i += RT) E.subhist[i] = 0;
+    }
     // ---- entries of small bins (most bins, about half the entries): one thread each, the whole grid at once
     {
         Stamp sub(E, P_RANK_SMALL);  // (profile only: the two halves of this launch get their own slots)
@@ -2620,14 +2790,35 @@ __global__ __launch_bounds__(256) void k_pack(const Eng* __restrict__ engs) {
 
 // the last workgroup of k_commit to finish closes the iteration (astar.py:317 step_num += 1) and thereby makes the
 // state the expansion recorded (S[(iters + 1) & 1]) the current one
-__device__ __forceinline__ void commit_ticket(Ctl* c) {
+// — and leaves what the next iteration's opening launch needs before it can look at FRONT (in all but the rebase
+// iterations that launch is k_sel_collect itself, whose workgroups all read these words and none may write them): the
+// size of the next batch, and the per-pop words reset.
+__device__ __forceinline__ void commit_ticket(const Eng& E, Ctl* c) {
+    // (FRONT's size and tombstone count only ever change through returning device-scope atomics, each waited for by its
+    // workgroup before the barrier below: the last arrival reads them with device-scope loads — no fence needed, and a
+    // release fence per workgroup costs microseconds on the launch's critical path)
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t t = atomicAdd(&c->ticket_a.v, 1u);
         if (t == gridDim.x - 1) {
             c->ticket_a.v = 0;
             c->iters += 1;
-            if (c->stop_after || c->failed) c->done = 1;
+            if (c->stop_after || c->failed) {
+                c->done = 1;
+            } else {
+                const uint32_t fb = c->cur_f;
+                const uint32_t live = __hip_atomic_load(&c->open_n[fb].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                                      __hip_atomic_load(&c->front_dead.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - c->front_above;
+                c->want = live < (uint32_t)E.B ? live : (uint32_t)E.B;
+                c->ret_n.v = 0;
+                c->goal_best = ~0ull;
+                c->first_solved = NIL;
+                c->gbar.v = 0;
+                c->grange.kmin = ~0ull;
+                c->grange.kmax = 0;
+                c->grange.imin = ~0u;
+                c->grange.imax = 0;
+            }
         }
     }
 }
@@ -2647,7 +2838,7 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
     const uint64_t T = c->T;
     const uint32_t j = blockIdx.x * 1024 + threadIdx.x;
     if (blockIdx.x * 1024 >= m) {
-        commit_ticket(c);
+        commit_ticket(E, c);
         return;
     }
     for (int k = 0; k < kBinsPerThread; k++) lh[kBinsPerThread * threadIdx.x + k] = 0;
@@ -2744,7 +2935,7 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
             const uint32_t v = lh[kBinsPerThread * threadIdx.x + k];
             if (v) atomicAdd(&E.hist[kBinsPerThread * threadIdx.x + k], v);
         }
-    commit_ticket(c);
+    commit_ticket(E, c);
 }
 
 __global__ void k_solution(Eng E, int32_t* out /*[0]=len, [1..]=moves root->goal*/, double* path_cost) {
@@ -2809,8 +3000,8 @@ struct dca_engine {
     int64_t pk_rows;       // rows packed by the last dca_engine_pop_expand_packed
     int phase;             // 0 idle, 1 between pop_expand and commit, 2 between pop_expand_packed and commit_packed
     unsigned collect_blocks;  // grid of k_sel_collect: two workgroups per CU, all resident (its giant-bin path barriers across it)
-    hipGraph_t graph[2];   // [0] iteration without / [1] with the refill check
-    hipGraphExec_t graph_exec[2];
+    hipGraph_t graph[3];   // [0] iteration without / [1] with the refill check, [2] a whole period: rebase iteration + 7 plain ones
+    hipGraphExec_t graph_exec[3];
     int graph_heur;
     long host_iter;        // iterations enqueued since the last reset of instance 0 (drives the refill cadence)
     unsigned long long* d_prof;  // [P_COUNT][kProfSlots][2] device wall-clock stamps of the profiled launches
@@ -2843,7 +3034,7 @@ constexpr int kScanGrid = kScanBlocks;
 // entry, so the binning taken at iteration 0 (key range = the root's key) puts every child of the next iterations into
 // the last bin: one bin of 10^5..10^6 entries for k_rank to order on a single workgroup (1-2 ms per iteration, measured:
 // k_rank's rocprofv3 maximum).  While OPEN is still growing by a factor of A per iteration a fresh binning each time is cheap.
-constexpr int kRampIters = 12;
+constexpr int kRampIters = 8;
 static inline bool rebase_due(long host_iter) { return host_iter < kRampIters || host_iter % kRefillPeriod == 0; }
 static int h_tune[8];  // host copy of the diagnostic knobs (dca_debug_tune)
 
@@ -2926,8 +3117,13 @@ int enqueue_first_half(dca_engine* e, int heur_id, bool with_refill, hipStream_t
     // FRONT's selection histogram is recounted only in the refill-check ("rebase") iterations — every kRefillPeriod-th —
     // and maintained incrementally in between (k_sel_scan's writeback + k_commit's pushes)
     if (with_refill) hipLaunchKernelGGL(k_front_rebase, gxy(kCollectBlocks, e), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(k_sel_scan, gxy(1, e), dim3(1024), 0, s, d, with_refill ? 1 : 0);
-    hipLaunchKernelGGL(k_sel_collect, gxy(e->collect_blocks, e), dim3(256), sizeof(CollectLds), s, d);
+    // the iteration's opening launch: k_sel_scan in a rebase iteration, k_sel_collect itself otherwise (FUSED)
+    if (with_refill || h_tune[6] != 0) {  // (knob 6: a k_sel_scan launch in every iteration, round-2 behaviour)
+        hipLaunchKernelGGL(k_sel_scan, gxy(1, e), dim3(1024), 0, s, d, with_refill ? 1 : 0);
+        hipLaunchKernelGGL(k_sel_collect<false>, gxy(e->collect_blocks, e), dim3(256), sizeof(CollectLds), s, d);
+    } else {
+        hipLaunchKernelGGL(k_sel_collect<true>, gxy(e->collect_blocks, e), dim3(256), sizeof(CollectLds), s, d);
+    }
     hipLaunchKernelGGL(k_rank, gxy(kRankBlocks, e), dim3(RT), kRankLdsBytes, s, d);
     if (int rc = launch_check("select kernels")) return rc;
     return launch_expand(e, heur_id, want_oh, s);
@@ -2958,7 +3154,7 @@ int enqueue_second_half(dca_engine* e, hipStream_t s) {
 }
 
 void drop_graphs(dca_engine* e) {
-    for (int g = 0; g < 2; g++) {
+    for (int g = 0; g < 3; g++) {
         if (e->graph_exec[g]) (void)hipGraphExecDestroy(e->graph_exec[g]);
         if (e->graph[g]) (void)hipGraphDestroy(e->graph[g]);
         e->graph_exec[g] = nullptr;
@@ -3108,8 +3304,11 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
         if (err != hipSuccess) rc = hip_fail(err, "hipHostMalloc");
     }
     if (!rc) {
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sel_collect),
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sel_collect<false>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CollectLds));
+        if (err == hipSuccess)
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sel_collect<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CollectLds));
         if (err != hipSuccess) rc = hip_fail(err, "hipFuncSetAttribute(k_sel_collect)");
     }
     if (!rc) {
@@ -3318,14 +3517,19 @@ int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph,
     }
     if (e->graph_exec[0] == nullptr || e->graph_heur != heur_id) {
         drop_graphs(e);
-        for (int g = 0; g < 2; g++) {
+        for (int g = 0; g < 3; g++) {
             hipStream_t cs;
             DCA_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
             hipError_t err = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
             int rc = 0;
             if (err == hipSuccess) {
-                rc = enqueue_first_half(e, heur_id, g == 1, cs);
-                if (!rc) rc = enqueue_second_half(e, cs);
+                // graph 2 = one whole rebase period (the boundary between two graph launches costs ~6 us, the one between
+                // two launches inside a graph ~2: a steady search replays periods, not single iterations)
+                const int n_it = g == 2 ? kRefillPeriod : 1;
+                for (int it = 0; it < n_it && !rc; it++) {
+                    rc = enqueue_first_half(e, heur_id, g == 1 || (g == 2 && it == 0), cs);
+                    if (!rc) rc = enqueue_second_half(e, cs);
+                }
                 err = hipStreamEndCapture(cs, &e->graph[g]);
             }
             (void)hipStreamDestroy(cs);
@@ -3335,8 +3539,16 @@ int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph,
         }
         e->graph_heur = heur_id;
     }
-    for (int i = 0; i < iters; i++)
-        DCA_HIP(hipGraphLaunch(e->graph_exec[rebase_due(e->host_iter++) ? 1 : 0], s));
+    for (int i = 0; i < iters;) {
+        if (h_tune[7] == 0 && e->host_iter >= kRampIters && e->host_iter % kRefillPeriod == 0 && iters - i >= kRefillPeriod) {
+            DCA_HIP(hipGraphLaunch(e->graph_exec[2], s));  // (knob 7: single-iteration graphs only)
+            e->host_iter += kRefillPeriod;
+            i += kRefillPeriod;
+        } else {
+            DCA_HIP(hipGraphLaunch(e->graph_exec[rebase_due(e->host_iter++) ? 1 : 0], s));
+            i++;
+        }
+    }
     return 0;
 }
 
@@ -3404,7 +3616,7 @@ int dca_debug_tune(int knob, int value) {
     if (knob >= 0 && knob < 8) h_tune[knob] = value;  // (host-side knobs: 4 = workgroups of k_sel_collect; set before the first step)
     // diagnostics: 0 extra log2 of sub-bins per large bin, 1 sub-bin size above which a sub-bin is refined on its own,
     // 2 BACK squeeze mark in 1/1024ths of max_nodes, 3 threshold-bin size above which the grid refines the bin (giant
-    // iterations), 5 (host, before create) giant-bin path off (6-7 unused)
+    // iterations), 5 (host, before create) giant-bin path off, 6 (host) k_sel_scan launched in every iteration, 7 (host) single-iteration graphs only
     DCA_ARG(knob >= 0 && knob < 8);
     DCA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tune), &value, sizeof(int), (size_t)knob * sizeof(int), hipMemcpyHostToDevice));
     return 0;

@@ -215,6 +215,8 @@ class FastResnet(nn.Module):
         wo, bo = padw(m.fc_out, m.fc_out.out_features, rp)
         self.weights = nn.ParameterList([nn.Parameter(w.to(dtype), requires_grad=False) for w in ws])
         self.biases = nn.ParameterList([nn.Parameter(b.to(dtype), requires_grad=False) for b in bs])
+        # fp32 copies of the biases for the 16-bit kernels' epilogues (the bias is added to the fp32 accumulator there)
+        self.biases_f32 = nn.ParameterList([nn.Parameter(b.to(dtype).float(), requires_grad=False) for b in bs])
         self.w_out = nn.Parameter(wo.to(dtype), requires_grad=False)
         self.b_out = nn.Parameter(bo.float(), requires_grad=False)
         # fp32 mode on the device: every dense layer after the first as ONE f16 GEMM with fp32 output over the split
@@ -301,8 +303,18 @@ class FastResnet(nn.Module):
         return self._after_l1(torch._addmm_activation(B[0], x, W[0].t()))
 
     def _after_l1(self, x: torch.Tensor) -> torch.Tensor:
-        """fp32 / bf16 / fp16 library GEMMs with fused epilogues."""
+        """bf16 / fp16 on the device (`gemm="hip"`): one dca_gemm16 launch per dense layer — bias, residual add, ReLU and
+        the rounding to 16 bits in its epilogue (csrc/dca_gemm16.hip).  Otherwise (fp32 without the split, the host, or
+        `gemm="library"`): library GEMMs with fused epilogues."""
         W, B = self.weights, self.biases
+        if x.is_cuda and self.gemm == "hip" and self.dtype in (torch.bfloat16, torch.float16) and x.dtype == self.dtype:
+            from .. import _lib
+            Bf = self.biases_f32
+            x = _lib.gemm16(x.contiguous(), W[1], Bf[1], None, True)
+            for k in range(2, len(W), 2):
+                h = _lib.gemm16(x, W[k], Bf[k], None, True)
+                x = _lib.gemm16(h, W[k + 1], None, x, True, out=x)  # (the block's second bias rides in W through h's constant-one unit)
+            return (x @ self.w_out.t()).float() + self.b_out
         x = torch._addmm_activation(B[1], x, W[1].t())
         for k in range(2, len(W), 2):
             h = torch._addmm_activation(B[k], x, W[k].t())

@@ -310,6 +310,16 @@ int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t l
 /* tuning / test hook: 2 (default) = 256 x 256 tiles filled by LDS-DMA, double-buffered; 1 = 128 x 128 tiles staged through
  * registers (the A/B reference).  Same results to fp32 rounding. */
 int dca_f16x3_gemm_variant(int variant);
+
+/* The same layer in the NON-parity 16-bit modes (`--nnet_dtype bf16 | fp16`; replaces the library GEMM + separate clamp pass of
+ * utils/pytorch_models.py:57-86 as PyTorch runs it): out = relu?( a . w^T + bias (+ skip) ), operands and result in `dtype`
+ * (DCA_DT_BF16 or DCA_DT_F16), fp32 accumulation on the 16-bit MFMA pipes, bias fp32, the residual `skip` [m, ldo] in
+ * `dtype`, result rounded to nearest even — bias, residual add, ReLU and rounding ride in the epilogue (csrc/dca_gemm16.hip).
+ * a [m, lda], w [n, ldw] (rows = output units); k % 64 == 0; lda, ldw % 8 == 0; ldo % 4 == 0; a / w 16-byte, out / skip
+ * 8-byte aligned.  `out` may not alias `a`; it may alias `skip`. */
+int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int n, int64_t ldw, int dtype,
+               const float* bias /*[n] or NULL*/, const void* skip /*[m, ldo] or NULL*/, int relu, void* out, int64_t ldo,
+               void* stream);
 /* fp32 [m, n] (row stride ld) -> its fp16 planes (row stride ldo); n % 4 == 0 */
 int dca_split_planes(const float* x, int64_t m, int64_t n, int64_t ld, void* out_h, void* out_l, int64_t ldo,
                      int* overflow /*or NULL*/, void* stream);

@@ -115,3 +115,72 @@ def test_hand_written_layers_equal_the_library_arrangement(golden):
     # the one-hot entry (geometries fed with one-hot rows) takes the same layers
     assert float((hip.forward_onehot(hip.encode(xb[:700])) - hip(xb[:700])).abs().max()) < 1e-5
     assert hip.split_fallbacks == 0 and lib_.split_fallbacks == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# dca_gemm16 (csrc/dca_gemm16.hip): the same layer in the non-parity 16-bit modes, tail in the epilogue
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_gemm16_identity_catches_transposition(dt):
+    from deepcubea_amd import _lib
+    _lib.require_gpu()
+    k = n = 256
+    w = ((torch.arange(n * k, dtype=torch.float32).view(n, k) % 251) - 125.0)  # |v| <= 125: exact in bf16 and fp16
+    w[:, 3] += 2.0
+    x = torch.eye(k, dtype=torch.float32)
+    y = _lib.gemm16(x.to(dt).cuda(), w.to(dt).cuda(), None, None, False)
+    assert torch.equal(y.float().cpu(), w.t().contiguous())
+    perm = torch.tensor([5, 0, 255, 17, 128, 64, 200], dtype=torch.long)
+    y = _lib.gemm16(x[perm].to(dt).cuda().contiguous(), w.to(dt).cuda(), None, None, False)
+    assert torch.equal(y.float().cpu(), w.t()[perm].contiguous())
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("m,n,k", [(1, 4, 64), (300, 200, 128), (257, 1024, 1024), (1000, 1024, 5120), (513, 260, 192)])
+def test_gemm16_layer_tail_against_float64(dt, m, n, k):
+    """relu(a.w^T + bias + skip) rounded to the 16-bit type: the kernel accumulates in fp32, the yardstick in float64 — they
+    may land on opposite sides of a rounding boundary, so one unit in the last place of the output type is allowed (and
+    nothing more); ragged m / n, the in-place residual form (out == skip), no-bias / no-skip / no-ReLU forms."""
+    from deepcubea_amd import _lib
+    _lib.require_gpu()
+    g = torch.Generator().manual_seed(m * 7 + n * 3 + k)
+    a = (torch.randn(m, k, generator=g) * 0.5).to(dt)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(dt)
+    bias = torch.randn(n, generator=g)
+    skip = torch.randn(m, n, generator=g).to(dt)
+    ref64 = a.double() @ w.double().t()
+    ulp = lambda v: torch.maximum(v.abs(), torch.tensor(1e-3, dtype=torch.float64)) * (2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11)
+    for use_b, use_s, relu in ((True, True, True), (True, False, True), (False, True, False), (False, False, False)):
+        want = ref64 + (bias.double() if use_b else 0.0) + (skip.double() if use_s else 0.0)
+        if relu:
+            want = want.clamp_min(0.0)
+        sk = skip.cuda().clone() if use_s else None
+        y = _lib.gemm16(a.cuda(), w.cuda(), bias.cuda() if use_b else None, sk, relu, out=sk if use_s else None)
+        err = (y.double().cpu() - want).abs()
+        assert bool((err <= ulp(want) * 1.01 + 1e-30).all()), (use_b, use_s, relu, float((err / ulp(want)).max()))
+        if relu:
+            assert float(y.float().min()) >= 0.0
+
+
+@torch.no_grad()
+def test_fastresnet_bf16_on_the_hand_written_kernels_matches_the_library_path():
+    """Whole network, bf16 mode: every dense layer on dca_gemm16 (layer 1 on dca_l1_onehot_gemm) vs the same FastResnet on
+    the library GEMMs — both are bf16 evaluations of the same weights; they differ by bf16 rounding of intermediate sums
+    only.  The deviation from the fp32 network is stated (not a parity mode: north star tolerance 1e-5 applies to fp32)."""
+    from deepcubea_amd import _lib
+    from deepcubea_amd.utils.pytorch_models import FastResnet, ResnetModel
+    from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
+    _lib.require_gpu()
+    net = ResnetModel(54, 6, 5000, 1000, 4, 1, True)
+    load_synthetic_weights(net, 2024)
+    net.eval()
+    x = torch.randint(0, 6, (3000, 54), dtype=torch.uint8, generator=torch.Generator().manual_seed(3)).cuda()
+    y32 = FastResnet(net).cuda()(x)[:, 0]
+    hip = FastResnet(net, torch.bfloat16).cuda()
+    libm = FastResnet(net, torch.bfloat16, gemm="library").cuda()
+    yh, yl = hip(x)[:, 0], libm(x)[:, 0]
+    scale = float(y32.abs().max())
+    dev_h, dev_l = float((yh - y32).abs().max()) / scale, float((yl - y32).abs().max()) / scale
+    print("bf16 network vs fp32 network, max deviation / max|h|: hand-written %.3e, library %.3e" % (dev_h, dev_l))
+    assert dev_h < 5e-2 and dev_l < 5e-2          # bf16: 8 mantissa bits through 10 layers
+    assert dev_h < 2.0 * dev_l + 1e-3             # no worse than the library's bf16 evaluation

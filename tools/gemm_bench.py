@@ -64,3 +64,29 @@ for n, k in ((1024, 1024), (1024, 5120)):
     print(json.dumps(row))
     del x, planes, a3, skip
     torch.cuda.empty_cache()
+
+# ---- the 16-bit (non-parity) layer: dca_gemm16 with its tail in the epilogue vs the library's addmm_activation (+ the
+# separate ReLU pass a residual layer needs there)
+for dt, nm in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")):
+    for n, k in ((1024, 1024), (1024, 5120)):
+        g = torch.Generator().manual_seed(n + k)
+        x = (torch.randn(m, k, generator=g) * 0.5).to(dt).cuda()
+        w = (torch.randn(n, k, generator=g) / k ** 0.5).to(dt).cuda()
+        b32 = torch.randn(n, generator=g).cuda()
+        bdt = b32.to(dt)
+        skip = torch.randn(m, n, generator=g).to(dt).cuda()
+        flops = 2.0 * m * n * k
+        row = {"dtype": nm, "m": m, "n": n, "k": k}
+        ms = timed(lambda: _lib.gemm16(x, w, b32, None, True))
+        row["hip_bias_relu_ms"], row["hip_bias_relu_tflops"] = round(ms, 4), round(flops / ms / 1e9, 1)
+        out = skip.clone()
+        ms = timed(lambda: _lib.gemm16(x, w, None, out, True, out=out))
+        row["hip_skip_relu_ms"], row["hip_skip_relu_tflops"] = round(ms, 4), round(flops / ms / 1e9, 1)
+        ms = timed(lambda: torch._addmm_activation(bdt, x, w.t()))
+        row["library_bias_relu_ms"], row["library_bias_relu_tflops"] = round(ms, 4), round(flops / ms / 1e9, 1)
+        out2 = skip.clone()
+        ms = timed(lambda: out2.addmm_(x, w.t()).relu_())
+        row["library_skip_relu_ms"], row["library_skip_relu_tflops"] = round(ms, 4), round(flops / ms / 1e9, 1)
+        print(json.dumps(row))
+        del x, skip, out, out2
+        torch.cuda.empty_cache()
