@@ -413,7 +413,7 @@ def run_astar_concurrent(args, world, rank, sem, hid):
             "how": "one engine, every kernel launched once for all instances (grid.y = instance)"}
 
 
-def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool = False):
+def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool = False, gemm16: str = "library"):
     """Same loop, heuristic = ResNet(54*6 -> 5000 -> 1000 -> 4 res blocks -> 1) on PyTorch-ROCm, synthetic weights
     (numpy PCG64 seed 2024).  Default = the CLI's default path: dedup-first engine stepping (only the children that
     survive the CLOSED check are evaluated — same search, astar.py:272-282) + the padded / epilogue-fused network
@@ -440,7 +440,7 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
                                               autocast_dtype=None if dt == torch.float32 else dt)
         eng = BwasEngine(args.env, w, B, max_nodes=cap, onehot_dtype=dt)
     else:
-        fast = FastResnet(model, dt).cuda()
+        fast = FastResnet(model, dt, gemm16=gemm16).cuda()
         hfn = nnet_utils.get_heuristic_fn_dev(fast, clip_zero=False, batch_size=args.nnet_batch_size)
         if fast.uses_l1_kernel:  # layer 1 = the library's one-hot MFMA kernel on the packed uint8 rows
             eng = BwasEngine(args.env, w, B, max_nodes=cap, packed=True)
@@ -484,6 +484,9 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
             "order": "eval_all_children (reference order)" if eval_all_children else "dedup_first (CLI default)",
             "layer1": "library GEMM on one-hot rows" if eval_all_children or not fast.uses_l1_kernel
             else "dca_l1_onehot_gemm (hand-written MFMA, %d bf16 plane(s))" % fast.l1_planes,
+            "dense_layers": ("library fp32 GEMMs" if eval_all_children else "dca_f16x3_gemm (hand-written MFMA, epilogue-fused)")
+            if dtype_name == "fp32" else ("dca_gemm16 (hand-written MFMA, epilogue-fused)" if gemm16 == "hip"
+                                          else "library (hipBLASLt) GEMMs + clamp pass"),
             "network_rows_per_step": rows, "children_per_step": B * A,
             "heuristic_tflops_per_gpu": flops / (wall / steps) / 1e12,
             # fp32 default path = f16x3 split layers: 3 f16 MFMA flops per useful flop -> ceiling 2500/3 "fp32-equivalent"
@@ -746,6 +749,7 @@ def main():
     if args.workload == "astar" and args.nnet_steps > 0:
         line["end_to_end_nnet"] = {"fp32": run_astar_nnet(args, world, rank, "fp32"),
                                    "bf16": run_astar_nnet(args, world, rank, "bf16"),
+                                   "bf16_hand_written_gemm": run_astar_nnet(args, world, rank, "bf16", gemm16="hip"),
                                    "fp32_eval_all_children": run_astar_nnet(args, world, rank, "fp32", True)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("astar", "expand"):
         if args.workload == "expand":

@@ -179,7 +179,8 @@ class FastResnet(nn.Module):
     network-input rows), or one-hot rows `[M, in_pad]` in `dtype` (row stride `in_pad` >= state_dim*depth, tail zero) as
     written by the engine's pack kernel through `forward_onehot`.  fp32 is the 1e-5 parity mode."""
 
-    def __init__(self, model: ResnetModel, dtype: torch.dtype = torch.float32, split: bool = True, gemm: str = "hip"):
+    def __init__(self, model: ResnetModel, dtype: torch.dtype = torch.float32, split: bool = True, gemm: str = "hip",
+                 gemm16: str = "library"):
         super().__init__()
         m = fold_batchnorm(model)
         self.state_dim, self.one_hot_depth = m.state_dim, m.one_hot_depth
@@ -228,6 +229,11 @@ class FastResnet(nn.Module):
         # f16 GEMM over the 3x-wide interleaved operand plus the dca_act_split glue kernel per layer (kept for comparison)
         self.gemm = gemm
         assert gemm in ("hip", "library")
+        # bf16 / fp16 (non-parity) modes: "library" = hipBLASLt GEMMs with fused bias+ReLU (1.14-1.28 PFLOP/s on the cube3
+        # layers of an MI355X, plus one clamp pass per residual block); "hip" = one dca_gemm16 launch per layer, whole tail in
+        # the epilogue (csrc/dca_gemm16.hip: 0.85-0.88 PFLOP/s measured — slower than the library today, hence not the default)
+        self.gemm16 = gemm16
+        assert gemm16 in ("hip", "library")
         # set by the split kernels when a value does not fit fp16 (|v| > 60000): that batch is redone with fp32 GEMMs
         self.register_buffer("_overflow", torch.zeros(1, dtype=torch.int32), persistent=False)
         self.split_fallbacks = 0
@@ -303,11 +309,11 @@ class FastResnet(nn.Module):
         return self._after_l1(torch._addmm_activation(B[0], x, W[0].t()))
 
     def _after_l1(self, x: torch.Tensor) -> torch.Tensor:
-        """bf16 / fp16 on the device (`gemm="hip"`): one dca_gemm16 launch per dense layer — bias, residual add, ReLU and
-        the rounding to 16 bits in its epilogue (csrc/dca_gemm16.hip).  Otherwise (fp32 without the split, the host, or
-        `gemm="library"`): library GEMMs with fused epilogues."""
+        """bf16 / fp16 on the device with `gemm16="hip"`: one dca_gemm16 launch per dense layer — bias, residual add, ReLU
+        and the rounding to 16 bits in its epilogue (csrc/dca_gemm16.hip).  Otherwise (the default for the 16-bit modes, fp32
+        without the split, the host): library GEMMs with fused epilogues."""
         W, B = self.weights, self.biases
-        if x.is_cuda and self.gemm == "hip" and self.dtype in (torch.bfloat16, torch.float16) and x.dtype == self.dtype:
+        if x.is_cuda and self.gemm16 == "hip" and self.dtype in (torch.bfloat16, torch.float16) and x.dtype == self.dtype:
             from .. import _lib
             Bf = self.biases_f32
             x = _lib.gemm16(x.contiguous(), W[1], Bf[1], None, True)

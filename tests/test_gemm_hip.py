@@ -149,7 +149,9 @@ def test_gemm16_layer_tail_against_float64(dt, m, n, k):
     bias = torch.randn(n, generator=g)
     skip = torch.randn(m, n, generator=g).to(dt)
     ref64 = a.double() @ w.double().t()
-    ulp = lambda v: torch.maximum(v.abs(), torch.tensor(1e-3, dtype=torch.float64)) * (2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11)
+    absdot = a.double().abs() @ w.double().abs().t()
+    # one unit in the last place is at most |v| * 2^-(p-1) for a p-bit significand (8 bits bf16, 11 bits fp16)
+    ulp = lambda v: torch.maximum(v.abs(), torch.tensor(1e-3, dtype=torch.float64)) * (2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10)
     for use_b, use_s, relu in ((True, True, True), (True, False, True), (False, True, False), (False, False, False)):
         want = ref64 + (bias.double() if use_b else 0.0) + (skip.double() if use_s else 0.0)
         if relu:
@@ -157,7 +159,10 @@ def test_gemm16_layer_tail_against_float64(dt, m, n, k):
         sk = skip.cuda().clone() if use_s else None
         y = _lib.gemm16(a.cuda(), w.cuda(), bias.cuda() if use_b else None, sk, relu, out=sk if use_s else None)
         err = (y.double().cpu() - want).abs()
-        assert bool((err <= ulp(want) * 1.01 + 1e-30).all()), (use_b, use_s, relu, float((err / ulp(want)).max()))
+        # ... plus the fp32 accumulation error of the K-long dot product itself (MFMA partial sums, order unspecified):
+        # 16 fp32 epsilons of sum |a_i w_i| — loose against the sqrt(k)-like growth seen in practice, tight against k eps
+        tol = ulp(want) * 1.01 + 16.0 * 2.0 ** -24 * absdot
+        assert bool((err <= tol).all()), (use_b, use_s, relu, float((err / tol).max()))
         if relu:
             assert float(y.float().min()) >= 0.0
 
@@ -176,8 +181,8 @@ def test_fastresnet_bf16_on_the_hand_written_kernels_matches_the_library_path():
     net.eval()
     x = torch.randint(0, 6, (3000, 54), dtype=torch.uint8, generator=torch.Generator().manual_seed(3)).cuda()
     y32 = FastResnet(net).cuda()(x)[:, 0]
-    hip = FastResnet(net, torch.bfloat16).cuda()
-    libm = FastResnet(net, torch.bfloat16, gemm="library").cuda()
+    hip = FastResnet(net, torch.bfloat16, gemm16="hip").cuda()
+    libm = FastResnet(net, torch.bfloat16).cuda()
     yh, yl = hip(x)[:, 0], libm(x)[:, 0]
     scale = float(y32.abs().max())
     dev_h, dev_l = float((yh - y32).abs().max()) / scale, float((yl - y32).abs().max()) / scale

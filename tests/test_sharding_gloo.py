@@ -139,3 +139,43 @@ def test_train_nnet_ddp_two_ranks_equals_full_batch(tmp_path):
     nnet_utils.train_nnet(net, [x], y, torch.device("cpu"), 8, 7, 2, 0.01, 0.95, display=False, batches_idx=batches)
     for k, v in net.state_dict().items():
         assert np.allclose(got[k], v.numpy(), rtol=1e-5, atol=1e-6), k
+
+
+def _queue_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import time
+    from deepcubea_amd.search_methods import sharding
+    w, r = sharding.init_from_env()
+    n = 100
+    # per-state cost varies 40x (results/cube3/output.txt: 1.6e6 .. 6.1e7 nodes): state i "costs" 1 or 40 ticks
+    cost = [40 if i % 9 == 0 else 1 for i in range(n)]
+    queue = sharding.WorkQueue(n, w, r)
+    mine, busy = [], 0.0
+    while True:
+        got = queue.next(1)
+        if not got:
+            break
+        mine += got
+        time.sleep(cost[got[0]] * 0.002)
+        busy += cost[got[0]] * 0.002
+    local = {i: ([i], None, 0.0, i * i) for i in mine}
+    merged = sharding.gather_results(local, n, w, r)
+    np.save(os.path.join(out_dir, "rank%d.npy" % r), np.array([len(mine), int(busy * 1000)], np.int64))
+    if r == 0:
+        assert sorted(merged) == list(range(n)) and all(merged[i][3] == i * i for i in range(n))
+    sharding.finalize()
+
+
+def test_work_queue_world_8_balances_skewed_costs(tmp_path):
+    """The shape of the 8-GPU run (configs[3]: 1000 scrambles over 8 ranks), on 8 gloo ranks: every state is drawn exactly
+    once, rank 0 merges all of them in order, and the queue — unlike `i mod N` — evens out a 40x spread in per-state cost."""
+    world = 8
+    mp.spawn(_queue_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    stats = np.array([np.load(str(tmp_path / ("rank%d.npy" % r))) for r in range(world)])
+    assert stats[:, 0].sum() == 100 and stats[:, 0].min() >= 1
+    busy = stats[:, 1].astype(np.float64)
+    # static round robin would give rank 0 (states 0, 8, 16, ...: five of the expensive ones) ~2.4x the mean; the queue
+    # keeps every rank within one expensive state of the mean
+    assert busy.max() <= busy.mean() + 40 * 2 + 20, busy
