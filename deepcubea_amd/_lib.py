@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdca_hip.so")
 
-ENV_CUBE3, ENV_NPUZZLE = 0, 1
+ENV_CUBE3, ENV_NPUZZLE, ENV_LIGHTSOUT = 0, 1, 2
 DT_F32, DT_F16, DT_BF16, DT_F16X3, DT_F16_PLANES = 0, 1, 2, 3, 4
 SEM_PY, SEM_CPP = 0, 1
 HEUR_MOD97, HEUR_KNUTH3, HEUR_HASHU01, HEUR_ZERO, HEUR_MANHATTAN = 0, 1, 2, 3, 4
@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "dca_engine_profile_builtin", "dca_engine_set_tiers", "dca_engine_debug", "dca_debug_tune", "dca_engine_status", "dca_engine_last_children", "dca_engine_solution",
     "dca_bn_workspace_bytes", "dca_bn_train_forward", "dca_bn_train_backward",
     "dca_l1_supported", "dca_l1_kpad", "dca_l1_onehot_gemm", "dca_act_split", "dca_f16x3_gemm", "dca_split_planes", "dca_f16x3_gemm_variant",
-    "dca_gemm16",
+    "dca_gemm16", "dca_lightsout_next_state", "dca_lightsout_expand_fused",
 ]
 
 
@@ -112,7 +112,19 @@ def env_ids(env_name: str):
         dim = int(math.sqrt(int(m.group(1)) + 1))
         if 4 <= dim <= 7:
             return ENV_NPUZZLE, dim, dim * dim, 4, dim * dim
+    m = re.search(r"lightsout(\d+)", name)
+    if m and int(m.group(1)) == 7:
+        return ENV_LIGHTSOUT, 7, 49, 49, 6
     raise ValueError("No known environment %s" % env_name)
+
+
+def env_geometry(env: int, dim: int):
+    """(state_dim, num_moves, onehot_depth) of an (env id, dim) pair."""
+    if env == ENV_CUBE3:
+        return 54, 12, 6
+    if env == ENV_LIGHTSOUT:
+        return dim * dim, dim * dim, 6
+    return dim * dim, 4, dim * dim
 
 
 # ------------------------------------------------------------------------------ tables (host)
@@ -140,6 +152,9 @@ def next_state(env: int, dim: int, states: torch.Tensor, action: int, prev: bool
     if env == ENV_CUBE3:
         fn = L.dca_cube3_prev_state if prev else L.dca_cube3_next_state
         check(fn(ptr(states), C.c_int64(n), int(action), ptr(out), stream_ptr()), "dca_cube3_next_state")
+    elif env == ENV_LIGHTSOUT:  # every move is its own inverse (lights_out.py:52-53)
+        check(L.dca_lightsout_next_state(ptr(states), C.c_int64(n), dim, int(action), ptr(out), stream_ptr()),
+              "dca_lightsout_next_state")
     else:
         fn = L.dca_npuzzle_prev_state if prev else L.dca_npuzzle_next_state
         check(fn(ptr(states), C.c_int64(n), dim, int(action), ptr(out), stream_ptr()), "dca_npuzzle_next_state")
@@ -153,8 +168,7 @@ def expand_fused(env: int, dim: int, parents: torch.Tensor, *, children: bool = 
     `out` may hold preallocated tensors (keys: children, nnet_in, onehot, solved, hash)."""
     parents = _u8(parents)
     n, D = parents.shape
-    A = 12 if env == ENV_CUBE3 else 4
-    depth = 6 if env == ENV_CUBE3 else D
+    _, A, depth = env_geometry(env, dim)
     dev = parents.device
     out = dict(out) if out else {}
     if children and "children" not in out:
@@ -175,9 +189,9 @@ def expand_fused(env: int, dim: int, parents: torch.Tensor, *, children: bool = 
                                        ptr(oh), ohdt, ptr(out.get("solved")), ptr(out.get("hash")), stream_ptr()),
               "dca_cube3_expand_fused")
     else:
-        check(L.dca_npuzzle_expand_fused(ptr(parents), C.c_int64(n), dim, ptr(out.get("children")), ptr(oh), ohdt,
-                                         ptr(out.get("solved")), ptr(out.get("hash")), stream_ptr()),
-              "dca_npuzzle_expand_fused")
+        fn = L.dca_lightsout_expand_fused if env == ENV_LIGHTSOUT else L.dca_npuzzle_expand_fused
+        check(fn(ptr(parents), C.c_int64(n), dim, ptr(out.get("children")), ptr(oh), ohdt,
+                 ptr(out.get("solved")), ptr(out.get("hash")), stream_ptr()), "dca_npuzzle/lightsout_expand_fused")
         if nnet_in and out.get("children") is not None:
             out["nnet_in"] = out["children"].view(n * A, D)  # n_puzzle.py:84-89: the tiles themselves
     return out
@@ -227,7 +241,7 @@ def generate_states(env: int, dim: int, n: int, back_lo: int, back_hi: int, seed
                     want_moves: bool = False):
     """Device random reverse walks from the goal -> (states [n,D] u8, num_back [n] i32, moves [n,back_hi] i8|None)."""
     dev = require_gpu()
-    D = 54 if env == ENV_CUBE3 else dim * dim
+    D = env_geometry(env, dim)[0]
     states = torch.empty((n, D), dtype=torch.uint8, device=dev)
     nb = torch.empty((n,), dtype=torch.int32, device=dev)
     mv = torch.full((n, max(back_hi, 1)), -1, dtype=torch.int8, device=dev) if want_moves else None

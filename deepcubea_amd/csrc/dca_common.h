@@ -53,6 +53,20 @@ __host__ __device__ inline int npuzzle_swap(int dim, int z, int a) {
     }
 }
 
+// LightsOut: does pressing cell `a` flip cell `i`?  (move matrix lights_out.py:33-44 / environments.cpp:133-154:
+// the cell itself, a + dim if its x = a / dim < dim - 1, a - dim if x > 0, a + 1 if its y = a % dim < dim - 1, a - 1 if y > 0)
+__host__ __device__ inline uint32_t lightsout_flip(int dim, int a, int i) {
+    const int x = a / dim, y = a - x * dim;
+    return (uint32_t)((i == a) | (x < dim - 1 && i == a + dim) | (x > 0 && i == a - dim) | (y < dim - 1 && i == a + 1) |
+                      (y > 0 && i == a - 1));
+}
+
+// byte i of the goal state: cube3 arange(54) (cube3.py:62-69), puzzles 1..n^2-1,0 (n_puzzle.py:69-76), lightsout zeros
+// (lights_out.py:55-63)
+__host__ __device__ inline uint32_t goal_byte(int env, int D, int i) {
+    return env == DCA_ENV_CUBE3 ? (uint32_t)i : env == DCA_ENV_NPUZZLE ? (uint32_t)((i + 1) % D) : 0u;
+}
+
 // ------------------------------------------------------------------------------------------
 // library state hash (include/dca.h)
 // ------------------------------------------------------------------------------------------

@@ -473,7 +473,7 @@ __global__ void k_reset(Eng E) {
         uint64_t w = 0;
         for (int j = 0; j < 8 && k + j < E.D; j++) {
             uint32_t b = s[k + j];
-            uint32_t goal = E.env == DCA_ENV_CUBE3 ? (uint32_t)(k + j) : (uint32_t)((k + j + 1) % E.D);
+            uint32_t goal = goal_byte(E.env, E.D, k + j);
             ok &= (b == goal);
             w |= (uint64_t)b << (8 * j);
             E.root_nnet[k + j] = (uint8_t)(E.env == DCA_ENV_CUBE3 ? (b * 57u) >> 9 : b);
@@ -2439,7 +2439,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
             for (int j = 0; j < 8; j++) {
                 if (k + j < EV::D) {
                     uint32_t b = t.child_byte(r, a, k + j);
-                    uint32_t goal = ENV == DCA_ENV_CUBE3 ? (uint32_t)(k + j) : (uint32_t)((k + j + 1) % EV::D);
+                    uint32_t goal = goal_byte(ENV, EV::D, k + j);
                     ok &= (b == goal);
                     w |= (uint64_t)b << (8 * j);
                     sum += (uint64_t)b * (uint64_t)(7 * (k + j) + 3);
@@ -2832,6 +2832,7 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
     Stamp stamp(E, P_COMMIT);
     __shared__ uint32_t sh[3 * 16 + 3];
     __shared__ uint32_t lh[NBIN];  // this workgroup's pushes into FRONT per selection bin (FRONT's histogram is incremental)
+    __shared__ uint64_t red[4][16];
     const IterState& S1 = st_next(c);
     const uint32_t m = S1.m, base = S1.base;
     const uint32_t fb = c->cur_f, bb = c->cur_b;
@@ -2927,9 +2928,38 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
             c->failed = 1;
         }
     }
-    fold_range(c, fb, tof ? key : ~0ull, tof ? key : 0ull);
-    fold_range(c, bb, tob ? key : ~0ull, tob ? key : 0ull);
-    __syncthreads();  // (block_reserveK's barriers already ordered the LDS counts; this one covers the early-out threads)
+    // running key ranges of the two tiers: ONE atomic per workgroup and bound (a wave-level fold sent thousands of atomics
+    // to the same line while OPEN's top cost still rises with every iteration — the first few dozen iterations of a search,
+    // exactly the window a short search or a 20-step bench episode lives in: k_commit 21 us there vs 15 us later)
+    {
+        uint64_t fmn = tof ? key : ~0ull, fmx = tof ? key : 0ull, bmn = tob ? key : ~0ull, bmx = tob ? key : 0ull;
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint64_t a = __shfl_xor(fmn, o), z = __shfl_xor(fmx, o), x = __shfl_xor(bmn, o), y = __shfl_xor(bmx, o);
+            fmn = a < fmn ? a : fmn;
+            fmx = z > fmx ? z : fmx;
+            bmn = x < bmn ? x : bmn;
+            bmx = y > bmx ? y : bmx;
+        }
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 0) {
+            red[0][wv] = fmn;
+            red[1][wv] = fmx;
+            red[2][wv] = bmn;
+            red[3][wv] = bmx;
+        }
+        __syncthreads();  // (also: block_reserveK's barriers already ordered the LDS counts; this one covers the early-out threads)
+        if (threadIdx.x < 4) {
+            const int q = threadIdx.x;
+            uint64_t v = red[q][0];
+            for (int w = 1; w < 16; w++) v = (q & 1) ? (red[q][w] > v ? red[q][w] : v) : (red[q][w] < v ? red[q][w] : v);
+            const uint32_t buf = q < 2 ? fb : bb;
+            if (q & 1) {
+                if (v > c->rng[buf].kmax) atomicMax((unsigned long long*)&c->rng[buf].kmax, (unsigned long long)v);
+            } else {
+                if (v < c->rng[buf].kmin) atomicMin((unsigned long long*)&c->rng[buf].kmin, (unsigned long long)v);
+            }
+        }
+    }
     if (kBinsPerThread * threadIdx.x < hbin)
         for (int k = 0; k < kBinsPerThread; k++) {
             const uint32_t v = lh[kBinsPerThread * threadIdx.x + k];
@@ -3059,6 +3089,7 @@ int launch_expand_env(const dca_engine* e, int heur_id, bool want_oh, hipStream_
 int launch_expand(const dca_engine* e, int heur_id, bool want_oh, hipStream_t s) {
     const Eng& E = e->E[0];
     if (E.env == DCA_ENV_CUBE3) return launch_expand_env<DCA_ENV_CUBE3, 0>(e, heur_id, want_oh, s);
+    if (E.env == DCA_ENV_LIGHTSOUT) return launch_expand_env<DCA_ENV_LIGHTSOUT, 7>(e, heur_id, want_oh, s);
     switch (E.dim) {
         case 4: return launch_expand_env<DCA_ENV_NPUZZLE, 4>(e, heur_id, want_oh, s);
         case 5: return launch_expand_env<DCA_ENV_NPUZZLE, 5>(e, heur_id, want_oh, s);
@@ -3084,6 +3115,7 @@ int launch_pack_env(const dca_engine* e, hipStream_t s) {
 int launch_pack(const dca_engine* e, hipStream_t s) {
     const Eng& E = e->E[0];
     if (E.env == DCA_ENV_CUBE3) return launch_pack_env<DCA_ENV_CUBE3, 0>(e, s);
+    if (E.env == DCA_ENV_LIGHTSOUT) return launch_pack_env<DCA_ENV_LIGHTSOUT, 7>(e, s);
     switch (E.dim) {
         case 4: return launch_pack_env<DCA_ENV_NPUZZLE, 4>(e, s);
         case 5: return launch_pack_env<DCA_ENV_NPUZZLE, 5>(e, s);
@@ -3190,15 +3222,15 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
                             int semantics, int onehot_dtype, int num_instances) {
     DCA_ARG(out != nullptr);
     *out = nullptr;
-    DCA_ARG(env == DCA_ENV_CUBE3 || (env == DCA_ENV_NPUZZLE && dim >= 4 && dim <= 7));
+    DCA_ARG(env == DCA_ENV_CUBE3 || (env == DCA_ENV_NPUZZLE && dim >= 4 && dim <= 7) || (env == DCA_ENV_LIGHTSOUT && dim == 7));
     DCA_ARG(batch_size >= 1 && batch_size <= (1 << 22));
     DCA_ARG(semantics == DCA_SEM_PY || semantics == DCA_SEM_CPP);
     DCA_ARG(onehot_dtype >= -1 && onehot_dtype <= DCA_DT_BF16);
     DCA_ARG(weight >= 0.0);
     DCA_ARG(num_instances >= 1 && num_instances <= kMaxInstances);
-    const int A = env == DCA_ENV_CUBE3 ? 12 : 4;
     const int D = env == DCA_ENV_CUBE3 ? 54 : dim * dim;
-    const int depth = env == DCA_ENV_CUBE3 ? 6 : D;
+    const int A = env == DCA_ENV_CUBE3 ? 12 : env == DCA_ENV_LIGHTSOUT ? D : 4;
+    const int depth = env == DCA_ENV_NPUZZLE ? D : 6;
     const int64_t Mll = (int64_t)batch_size * A;
     DCA_ARG(max_nodes >= Mll + 16 && max_nodes <= 0x7FFFFF00ll);
     uint64_t cap = 1024;
@@ -3360,7 +3392,7 @@ int dca_engine_reset_instance(dca_engine* e, int inst, const uint8_t* root, void
     DCA_ARG(root != nullptr);
     hipStream_t s = (hipStream_t)stream;
     Eng& E = e->E[inst];
-    for (int i = 0; i < E.D; i++) DCA_ARG(root[i] < (E.env == DCA_ENV_CUBE3 ? 54 : E.D));
+    for (int i = 0; i < E.D; i++) DCA_ARG(root[i] < (E.env == DCA_ENV_CUBE3 ? 54 : E.env == DCA_ENV_LIGHTSOUT ? 2 : E.D));
     // the staging block is reused: make sure an earlier reset's copy has left it
     DCA_HIP(hipStreamSynchronize(s));
     memcpy(e->h_stage, root, (size_t)E.D);

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kThreads) void expand_fused_kernel(
                 for (int j = 0; j < 8; j++) {
                     if (k + j < E::D) {
                         uint32_t b = t.child_byte(r, a, k + j);
-                        uint32_t goal = ENV == DCA_ENV_CUBE3 ? (uint32_t)(k + j) : (uint32_t)((k + j + 1) % E::D);
+                        uint32_t goal = goal_byte(ENV, E::D, k + j);
                         ok &= (b == goal);
                         w |= (uint64_t)b << (8 * j);
                     }
@@ -241,7 +241,7 @@ __global__ void state_scan_kernel(int env, const uint8_t* __restrict__ st, int64
         uint64_t w = 0;
         for (int j = 0; j < 8 && k + j < D; j++) {
             uint32_t b = s[k + j];
-            uint32_t goal = env == DCA_ENV_CUBE3 ? (uint32_t)(k + j) : (uint32_t)((k + j + 1) % D);
+            uint32_t goal = goal_byte(env, D, k + j);
             ok &= (b == goal);
             w |= (uint64_t)b << (8 * j);
             sum += (uint64_t)b * (uint64_t)(7 * (k + j) + 3);
@@ -326,6 +326,11 @@ int expand_dispatch(int env, int dim, const uint8_t* parents, int64_t n, uint8_t
                     void* onehot, int onehot_dtype, uint8_t* solved, uint64_t* hash, hipStream_t s) {
     if (env == DCA_ENV_CUBE3)
         return launch_expand<DCA_ENV_CUBE3, 0>(parents, n, children, nnet_in, onehot, onehot_dtype, solved, hash, s);
+    if (env == DCA_ENV_LIGHTSOUT) {
+        if (dim == 7) return launch_expand<DCA_ENV_LIGHTSOUT, 7>(parents, n, children, nnet_in, onehot, onehot_dtype, solved, hash, s);
+        set_error("unsupported lightsout dim %d (7)", dim);
+        return DCA_E_BADARG;
+    }
     switch (dim) {
         case 4: return launch_expand<DCA_ENV_NPUZZLE, 4>(parents, n, children, nnet_in, onehot, onehot_dtype, solved, hash, s);
         case 5: return launch_expand<DCA_ENV_NPUZZLE, 5>(parents, n, children, nnet_in, onehot, onehot_dtype, solved, hash, s);
@@ -380,6 +385,19 @@ int dca_npuzzle_prev_state(const uint8_t* in, int64_t n, int dim, int action, ui
     return dca_npuzzle_next_state(in, n, dim, action ^ 1, out, stream);
 }
 
+int dca_lightsout_next_state(const uint8_t* in, int64_t n, int dim, int action, uint8_t* out, void* stream) {
+    DCA_ARG(dim == 7 && n >= 0 && action >= 0 && action < dim * dim && (n == 0 || (in && out)));
+    return launch_next<DCA_ENV_LIGHTSOUT, 7>(in, n, action, out, (hipStream_t)stream);
+}
+
+int dca_lightsout_expand_fused(const uint8_t* parents, int64_t n, int dim, uint8_t* children, void* onehot, int onehot_dtype,
+                               uint8_t* is_solved, uint64_t* hash, void* stream) {
+    DCA_ARG(n >= 0 && (n == 0 || parents));
+    DCA_ARG(onehot == nullptr || (onehot_dtype >= DCA_DT_F32 && onehot_dtype <= DCA_DT_BF16));
+    return expand_dispatch(DCA_ENV_LIGHTSOUT, dim, parents, n, children, nullptr, onehot, onehot_dtype, is_solved, hash,
+                           (hipStream_t)stream);
+}
+
 int dca_cube3_expand_fused(const uint8_t* parents, int64_t n, uint8_t* children, uint8_t* color_idx, void* onehot,
                            int onehot_dtype, uint8_t* is_solved, uint64_t* hash, void* stream) {
     DCA_ARG(n >= 0 && (n == 0 || parents));
@@ -400,7 +418,7 @@ static int state_dim_of(int env, int dim, int* D) {
         *D = 54;
         return 0;
     }
-    if (env == DCA_ENV_NPUZZLE && dim >= 4 && dim <= 7) {
+    if ((env == DCA_ENV_NPUZZLE && dim >= 4 && dim <= 7) || (env == DCA_ENV_LIGHTSOUT && dim == 7)) {
         *D = dim * dim;
         return 0;
     }

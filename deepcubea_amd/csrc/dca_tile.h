@@ -19,12 +19,17 @@ struct EnvT<DCA_ENV_NPUZZLE, DIM> {
     static constexpr int D = DIM * DIM, A = 4, DEPTH = DIM * DIM;
 };
 
+template <int DIM>
+struct EnvT<DCA_ENV_LIGHTSOUT, DIM> {
+    static constexpr int D = DIM * DIM, A = DIM * DIM, DEPTH = 6;  // (ResnetModel(num_tiles, 6, ...), lights_out.py:80)
+};
+
 // LDS view of one parent tile + its move tables
 template <int ENV, int DIM, int TP = kTileParents>
 struct Tile {
     using E = EnvT<ENV, DIM>;
     static constexpr int PAR_BYTES = ((TP * E::D + 15) / 16) * 16;
-    static constexpr int TAB_BYTES = ENV == DCA_ENV_CUBE3 ? ((12 * 54 + 15) / 16) * 16 : TP * 8;
+    static constexpr int TAB_BYTES = ENV == DCA_ENV_CUBE3 ? ((12 * 54 + 15) / 16) * 16 : ENV == DCA_ENV_NPUZZLE ? TP * 8 : 16;
     static constexpr int LDS_BYTES = PAR_BYTES + TAB_BYTES + 16 + 256;  // slack: the last one-hot lane may peek one row past the tile
 
     const uint8_t* par;  // [64][D]
@@ -34,6 +39,10 @@ struct Tile {
     __device__ __forceinline__ uint32_t child_byte(uint32_t r, uint32_t a, uint32_t i) const {
         if constexpr (ENV == DCA_ENV_CUBE3) {
             return par[r * E::D + tab[a * E::D + i]];
+        } else if constexpr (ENV == DCA_ENV_LIGHTSOUT) {
+            // (state + 1) % 2 on the pressed cell and its neighbours (lights_out.py:161 / environments.cpp:172-174)
+            const uint32_t v = par[r * E::D + i];
+            return lightsout_flip(DIM, (int)a, (int)i) ? ((v + 1u) & 1u) : v;
         } else {
             uint32_t z = tab[r * 8];
             uint32_t s = tab[r * 8 + 1 + a];
@@ -70,6 +79,8 @@ __device__ __forceinline__ void stage_tables(uint8_t* tab, const uint8_t* par, u
     using E = EnvT<ENV, DIM>;
     if constexpr (ENV == DCA_ENV_CUBE3) {
         for (uint32_t i = threadIdx.x; i < 12 * 54; i += kThreads) tab[i] = d_cube3_perm.p[i / 54][i % 54];
+    } else if constexpr (ENV == DCA_ENV_LIGHTSOUT) {
+        // (no table: the flip mask is arithmetic)
     } else {
         // one lane per parent: locate the blank (n_puzzle.py:51-53) and its 4 swap targets
         for (uint32_t r = threadIdx.x; r < np; r += kThreads) {

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64) void scramble_kernel(int64_t n, int lo, int hi,
     if (i >= n) return;
     uint8_t* cur = rows[0][lane];
     uint8_t* nxt = rows[1][lane];
-    for (int j = 0; j < E::D; j++) cur[j] = (uint8_t)(ENV == DCA_ENV_CUBE3 ? j : (j + 1) % E::D);  // goal
+    for (int j = 0; j < E::D; j++) cur[j] = (uint8_t)goal_byte(ENV, E::D, j);  // goal
     int z = E::D - 1;                                                                           // puzzle blank
     const uint64_t key = splitmix64(seed ^ splitmix64((uint64_t)(index0 + i)));
     const uint32_t range = (uint32_t)(hi - lo + 1);
@@ -50,6 +50,11 @@ __global__ __launch_bounds__(64) void scramble_kernel(int64_t n, int lo, int hi,
             uint8_t* tmp = cur;
             cur = nxt;
             nxt = tmp;
+        } else if constexpr (ENV == DCA_ENV_LIGHTSOUT) {
+            // every move is its own inverse (lights_out.py:52-53): the walk presses cell a
+            for (int j = 0; j < E::D; j++)
+                if (lightsout_flip(DIM, a, j)) cur[j] = (uint8_t)((cur[j] + 1) & 1);
+            (void)ra;
         } else {
             const int s = npuzzle_swap(DIM, z, ra);
             cur[z] = cur[s];
@@ -108,6 +113,9 @@ int dca_generate_states(int env, int dim, int64_t n, int back_lo, int back_hi, u
     if (env == DCA_ENV_CUBE3)
         return launch_scramble<DCA_ENV_CUBE3, 0>(n, back_lo, back_hi, seed, index0, out_states, out_num_back, out_moves,
                                                  moves_stride, s);
+    if (env == DCA_ENV_LIGHTSOUT && dim == 7)
+        return launch_scramble<DCA_ENV_LIGHTSOUT, 7>(n, back_lo, back_hi, seed, index0, out_states, out_num_back, out_moves,
+                                                     moves_stride, s);
     switch (env == DCA_ENV_NPUZZLE ? dim : -1) {
         case 4: return launch_scramble<DCA_ENV_NPUZZLE, 4>(n, back_lo, back_hi, seed, index0, out_states, out_num_back, out_moves, moves_stride, s);
         case 5: return launch_scramble<DCA_ENV_NPUZZLE, 5>(n, back_lo, back_hi, seed, index0, out_states, out_num_back, out_moves, moves_stride, s);
@@ -120,7 +128,7 @@ int dca_generate_states(int env, int dim, int64_t n, int back_lo, int back_hi, u
 
 int dca_bellman_backup(const float* h_children, const uint8_t* solved_parent, int64_t n, int num_moves, int clip_zero,
                        float* ctg_backup, int32_t* argmin, void* stream) {
-    DCA_ARG(n >= 0 && num_moves > 0 && num_moves <= 64 && (n == 0 || h_children != nullptr));
+    DCA_ARG(n >= 0 && num_moves > 0 && num_moves <= 256 && (n == 0 || h_children != nullptr));
     if (n == 0) return 0;
     hipLaunchKernelGGL(bellman_backup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        h_children, solved_parent, n, num_moves, clip_zero, ctg_backup, argmin);

@@ -1,5 +1,5 @@
 """I/O glue of the path: stdout tee (`utils/data_utils.py:12-23`) and a loader for the reference's
-state pickles, whose class paths are `environments.cube3.Cube3State` / `environments.n_puzzle.NPuzzleState`."""
+state pickles, whose class paths are `environments.cube3.Cube3State` / `environments.n_puzzle.NPuzzleState` / `environments.lights_out.LOState`."""
 import io
 import pickle
 import sys
@@ -23,6 +23,7 @@ class _RefUnpickler(pickle.Unpickler):
     _MAP = {
         ("environments.cube3", "Cube3State"): ("deepcubea_amd.environments.cube3", "Cube3State"),
         ("environments.n_puzzle", "NPuzzleState"): ("deepcubea_amd.environments.n_puzzle", "NPuzzleState"),
+        ("environments.lights_out", "LOState"): ("deepcubea_amd.environments.lights_out", "LOState"),
     }
 
     def find_class(self, module, name):

@@ -46,6 +46,7 @@ extern "C" {
 /* environments (utils/env_utils.py:6-28 registry names) */
 #define DCA_ENV_CUBE3 0   /* "cube3": 54 stickers, 12 moves */
 #define DCA_ENV_NPUZZLE 1 /* "puzzle15/24/35/48": dim 4..7, 4 moves U D L R */
+#define DCA_ENV_LIGHTSOUT 2 /* "lightsout7": dim 7, 49 cells in {0,1}, 49 moves (press cell a: it and its 4-neighbours flip) */
 
 /* one-hot element types for the fused encoder (utils/pytorch_models.py:49-52 emits f32) */
 #define DCA_DT_F32 0
@@ -81,6 +82,12 @@ int dca_cube3_prev_state(const uint8_t* in, int64_t n, int action, uint8_t* out,
 int dca_npuzzle_next_state(const uint8_t* in /*[n,dim*dim]*/, int64_t n, int dim, int action, uint8_t* out, void* stream);
 int dca_npuzzle_prev_state(const uint8_t* in, int64_t n, int dim, int action, uint8_t* out, void* stream);
 
+/* LightsOut._move_np (lights_out.py:155-166) / LightsOut::getNextState (environments.cpp:168-180): pressing cell `action`
+ * flips it and its in-board 4-neighbours (move matrix lights_out.py:33-44 / environments.cpp:133-154).  Every move is
+ * its own inverse: prev_state == next_state (lights_out.py:52-53).  dim 7 ("lightsout7", the only size the reference's
+ * C++ core and train.sh use). */
+int dca_lightsout_next_state(const uint8_t* in /*[n,dim*dim]*/, int64_t n, int dim, int action, uint8_t* out, void* stream);
+
 /* ---- a3-a6,a9: fused expansion -----------------------------------------------------------
  * One launch: all children of every parent (Cube3.expand cube3.py:129-161), plus — each
  * optional, pass NULL to skip — the network input colour index (state_to_nnet_input
@@ -99,6 +106,13 @@ int dca_npuzzle_expand_fused(const uint8_t* parents /*[n,D]*/, int64_t n, int di
                              void* onehot /*[n*4,D*D] or NULL*/, int onehot_dtype,
                              uint8_t* is_solved /*[n*4] or NULL*/,
                              uint64_t* hash /*[n*4] or NULL*/, void* stream);
+
+/* lightsout: nnet input = the cells themselves (lights_out.py:70-75); one-hot depth 6 (get_nnet_model, lights_out.py:80) */
+int dca_lightsout_expand_fused(const uint8_t* parents /*[n,D]*/, int64_t n, int dim,
+                               uint8_t* children /*[n,D,D] or NULL*/,
+                               void* onehot /*[n*D,D*6] or NULL*/, int onehot_dtype,
+                               uint8_t* is_solved /*[n*D] or NULL*/,
+                               uint64_t* hash /*[n*D] or NULL*/, void* stream);
 
 /* ---- stand-alone pieces of the same path (used by the Environment mirror) --------------- */
 int dca_is_solved(int env, int dim, const uint8_t* states, int64_t n, uint8_t* out /*[n]*/, void* stream);

@@ -16,7 +16,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "liboracle.so")
 _REF = os.path.join(_HERE, "_ref", "libref_env.so")
 
-ENV_IDS = {"cube3": (0, 0), "puzzle15": (1, 4), "puzzle24": (1, 5), "puzzle35": (1, 6), "puzzle48": (1, 7)}
+ENV_IDS = {"cube3": (0, 0), "puzzle15": (1, 4), "puzzle24": (1, 5), "puzzle35": (1, 6), "puzzle48": (1, 7),
+           "lightsout7": (2, 7)}
+
+
+def num_moves(env: str) -> int:
+    e, d = ENV_IDS[env]
+    return 12 if e == 0 else d * d if e == 2 else 4
 SEM_PY, SEM_CPP = 0, 1
 
 
@@ -89,7 +95,7 @@ def expand(env: str, states: np.ndarray, threads: int = 0):
     e, d = ENV_IDS[env]
     s = np.ascontiguousarray(states, np.uint8)
     n, D = s.shape
-    A = 12 if e == 0 else 4
+    A = num_moves(env)
     ch = np.empty((n, A, D), np.uint8)
     sv = np.empty(n * A, np.uint8)
     hs = np.empty(n * A, np.uint64)
@@ -171,7 +177,7 @@ def ref_expand(env: str, states: np.ndarray, threads: int = 0):
     e, d = ENV_IDS[env]
     s = np.ascontiguousarray(states, np.uint8)
     n, D = s.shape
-    A = 12 if e == 0 else 4
+    A = num_moves(env)
     ch = np.empty((n, A, D), np.uint8)
     sv = np.empty(n * A, np.uint8)
     r.ref_expand(e, d, _p8(s), C.c_int64(n), _p8(ch), _p8(sv), threads)

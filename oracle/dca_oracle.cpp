@@ -86,7 +86,7 @@ struct Tables {
 };
 const Tables T;
 
-enum { ENV_CUBE3 = 0, ENV_NPUZZLE = 1 };
+enum { ENV_CUBE3 = 0, ENV_NPUZZLE = 1, ENV_LIGHTSOUT = 2 };
 enum { SEM_PY = 0, SEM_CPP = 1 };
 
 struct Env {
@@ -97,7 +97,7 @@ inline Env make_env(int id, int dim) {
     e.id = id;
     e.dim = dim;
     e.D = id == ENV_CUBE3 ? 54 : dim * dim;
-    e.A = id == ENV_CUBE3 ? 12 : 4;
+    e.A = id == ENV_CUBE3 ? 12 : id == ENV_LIGHTSOUT ? dim * dim : 4;
     return e;
 }
 
@@ -120,9 +120,22 @@ inline void npuzzle_move(const uint8_t* s, int dim, int a, uint8_t* out) {
     out[z] = s[sw];
     out[sw] = 0;
 }
+// LightsOut::getNextState (environments.cpp:168-180) / LightsOut._move_np (lights_out.py:155-166): the five entries of the
+// move matrix row (environments.cpp:133-154 / lights_out.py:33-44: the cell, right, left, up, down — an off-board
+// neighbour repeats the cell itself) are each set to (old value + 1) % 2, always READ from the old state, so a repeated
+// index is flipped once
+inline void lightsout_move(const uint8_t* s, int dim, int a, uint8_t* out) {
+    const int D = dim * dim;
+    memcpy(out, s, (size_t)D);
+    const int x = a / dim, y = a % dim;
+    const int idx[5] = {a, x < dim - 1 ? a + dim : a, x > 0 ? a - dim : a, y < dim - 1 ? a + 1 : a, y > 0 ? a - 1 : a};
+    for (int i = 0; i < 5; i++) out[idx[i]] = (uint8_t)((s[idx[i]] + 1) % 2);
+}
 inline void env_move(const Env& e, const uint8_t* s, int a, uint8_t* out) {
     if (e.id == ENV_CUBE3)
         cube3_move(s, a, out);
+    else if (e.id == ENV_LIGHTSOUT)
+        lightsout_move(s, e.dim, a, out);
     else
         npuzzle_move(s, e.dim, a, out);
 }
@@ -131,6 +144,8 @@ inline bool env_solved(const Env& e, const uint8_t* s) {
     bool ok = true;
     if (e.id == ENV_CUBE3) {
         for (int i = 0; i < 54; i++) ok &= (s[i] == i);
+    } else if (e.id == ENV_LIGHTSOUT) {  // LightsOut::isSolved (environments.cpp:196-204) / lights_out.py:65-68
+        for (int i = 0; i < e.D; i++) ok &= (s[i] == 0);
     } else {
         for (int i = 0; i < e.D; i++) ok &= (s[i] == (uint8_t)((i + 1) % e.D));
     }

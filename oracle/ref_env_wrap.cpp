@@ -10,6 +10,7 @@
  *   cpp/environments.cpp:222-243  Cube3::getNextState / getNextStates
  *   cpp/environments.cpp:92-113   PuzzleN::getNextState / getNextStates
  *   cpp/environments.cpp:119-126,249-256  isSolved
+ *   cpp/environments.cpp:133-208  LightsOut (move matrix, getNextState, getNextStates, isSolved)
  * driven the way the reference's hot loop drives them
  * (cpp/parallel_weighted_astar.cpp:217-230: `#pragma omp parallel for` over popped nodes,
  *  one heap-allocated Environment per child).
@@ -30,15 +31,18 @@
 static Environment* make_env(int env, int dim, const uint8_t* s, int D) {
     std::vector<uint8_t> v(s, s + D);
     if (env == 0) return new Cube3(v);
+    if (env == 2) return new LightsOut(v, (uint8_t)dim);  // cpp/environments.cpp:156-208 (dim 7: moveMat7)
     return new PuzzleN(v, (uint8_t)dim);
 }
+static inline int env_D(int env, int dim) { return env == 0 ? 54 : dim * dim; }
+static inline int env_A(int env, int dim) { return env == 0 ? 12 : env == 2 ? dim * dim : 4; }
 
 extern "C" {
 
 // children [n, A, D]; solved [n*A] (optional)
 void ref_expand(int env, int dim, const uint8_t* in, int64_t n, uint8_t* children, uint8_t* solved, int threads) {
-    const int D = env == 0 ? 54 : dim * dim;
-    const int A = env == 0 ? 12 : 4;
+    const int D = env_D(env, dim);
+    const int A = env_A(env, dim);
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
 #endif
@@ -57,7 +61,7 @@ void ref_expand(int env, int dim, const uint8_t* in, int64_t n, uint8_t* childre
 }
 
 void ref_next_state(int env, int dim, const uint8_t* in, int64_t n, int action, uint8_t* out) {
-    const int D = env == 0 ? 54 : dim * dim;
+    const int D = env_D(env, dim);
     for (int64_t i = 0; i < n; i++) {
         Environment* e = make_env(env, dim, in + i * D, D);
         Environment* c = e->getNextState(action);
@@ -69,7 +73,7 @@ void ref_next_state(int env, int dim, const uint8_t* in, int64_t n, int action, 
 }
 
 void ref_is_solved(int env, int dim, const uint8_t* in, int64_t n, uint8_t* out) {
-    const int D = env == 0 ? 54 : dim * dim;
+    const int D = env_D(env, dim);
     for (int64_t i = 0; i < n; i++) {
         Environment* e = make_env(env, dim, in + i * D, D);
         out[i] = e->isSolved();
