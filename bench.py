@@ -295,6 +295,11 @@ def run_astar(args, world, rank):
                       "(dca_engine_profile_builtin; max end - min start, averaged over the %d iterations of one "
                       "more episode of the timed shape: same warm-up, same K iterations, rebase iterations included); HIP "
                       "events bracket the K-step regions (device_ms_per_step)" % leg["profile_iters"],
+            # every launch of the iteration against the same roofline (algorithmic bytes / its own span): the table the
+            # single `kernel` above is the longest row of
+            "launch_rooflines": {"k_" + k: {"bytes_per_launch": alg_k[k], "kernel_ms": round(span[k], 5),
+                                            "achieved_GBs": round(alg_k[k] / (span[k] * 1e-3) / 1e9, 1),
+                                            "frac": round(alg_k[k] / (span[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for k in cand},
             "launch_span_ms": {k: round(v, 5) for k, v in span.items()},
             "launch_gap_ms": {k: round(v, 5) for k, v in gap.items()},
             "sum_span_ms": sum(v for k, v in span.items() if not k.startswith("rank_")),
