@@ -48,6 +48,7 @@ class BwasEngine:
                    "dca_engine_create_multi")
         self._zero_h = torch.zeros(1, dtype=torch.float32, device="cuda")
         self.rows_evaluated = 0  # network rows handed to heuristic closures by step()
+        self.last_rows = -1      # packed stepping: rows of the last iteration (0 = nothing left to expand: every instance done)
         self.onehot_stride = self.state_dim * self.depth
         if packed:
             if onehot_stride is not None:
@@ -141,6 +142,7 @@ class BwasEngine:
         if self.packed:
             nn, oh, _, rows = self.pop_expand_packed()
             self.rows_evaluated += rows
+            self.last_rows = rows
             if rows == 0:
                 self.commit_packed(self._zero_h)
                 return
@@ -230,8 +232,13 @@ class BwasEngine:
         self.reset(root)
         if self.semantics == _lib.SEM_PY:
             self.root_commit(heuristic_fn_dev(self.root_nnet_in()).to(torch.float32))
-        for _ in range(max_iters):
+        for it in range(max_iters):
             self.step(heuristic_fn_dev)
+            # The packed row count already comes back from the device every iteration; a finished search packs no rows
+            # (its launches are no-ops), so the status block is only fetched then — and every 16th iteration as a guard —
+            # instead of a second host sync per iteration.
+            if self.packed and self.last_rows != 0 and it % 16 != 15:
+                continue
             if self.status()["done"]:
                 break
         return self._result()
