@@ -133,15 +133,6 @@ struct Ctl {
     uint32_t giant;   // this pop's threshold bin is refined across the grid by k_sel_collect (set by k_sel_scan)
     uint32_t tseg;    // the segment holding the batch's last entry (= bstar unless giant)
     uint32_t pre_b, cn_star;  // entries below the threshold bin / in it (k_rank's histogram writeback)
-    // Fine binning of the plain iterations.  A rebase iteration bins FRONT's whole key range [kmin, T] into 4096 bins — what
-    // the tier decisions need — but between two rebases only the bins below the histogram horizon can ever hold a batch:
-    // k_sel_scan therefore also proposes a binning of [kmin, K_h] alone (K_h = top key of the horizon), 8-100x finer, under
-    // which the threshold bins of the next seven pops hold a few dozen entries instead of several hundred (k_rank then runs
-    // on its thread-per-entry path).  The rebase iteration itself still pops under the coarse binning; E.hist2 is counted
-    // under the fine one on the side (k_sel_collect's second pass, k_rank's hand-backs, k_expand's cpp put-backs) and
-    // k_probe's workgroup 0 installs it (E.hist := E.hist2, sel_kmin / shift / hbin := fine) before k_commit pushes.
-    uint64_t f_kmin, f_khor;
-    uint32_t f_shift, f_hbin, fine_on;
     uint64_t sel_kmin;
     // goals
     uint32_t goal_id;
@@ -210,7 +201,6 @@ struct Eng {
     uint32_t f_keep, f_max;  // FRONT hysteresis: refill/spill down to ~f_keep, spill when above f_max
     uint32_t *hist, *pre, *fill;  // selection histogram, its exclusive prefix [NBIN+1], per-bin fill of the scratch array
     uint32_t* rhist;              // histogram of BACK (refill), separate: `hist` is maintained across iterations
-    uint32_t* hist2;              // the selection histogram under the fine binning while a rebase iteration builds it (Ctl::fine_on)
     uint32_t* subhist;            // [kMaxLevels][kSub] sub-bin counts of a giant threshold bin, one array per refinement level
     int coop;                     // k_sel_collect's grid is fully resident (single-instance engine): grid barriers allowed
     uint64_t* part;  // [2][kCollectBlocks] per-block key ranges (min, max) of the entries k_front_rebase kept
@@ -998,21 +988,6 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
             c->rng[cb].kmax = fmx;
             c->hbin = s_hbin;
         }
-        c->fine_on = 0;
-        if (rebased && g_tune[8] == 0 && s_hbin < (uint32_t)NBIN && !giant && want != 0) {  // (knob 8: fine binning off)
-            const uint64_t khor = new_kmin + ((uint64_t)s_hbin << new_shift) - 1;  // top key of the horizon's last bin
-            if (khor > new_kmin) {
-                uint32_t fs = select_shift(new_kmin, khor);
-                while (((khor - new_kmin) >> fs) >= (uint64_t)(NBIN - 1)) fs++;  // keys above K_h share bin NBIN - 1, alone
-                if (fs < new_shift) {
-                    c->f_kmin = new_kmin;
-                    c->f_khor = khor;
-                    c->f_shift = fs;
-                    c->f_hbin = (uint32_t)((khor - new_kmin) >> fs) + 1u;
-                    c->fine_on = 1;
-                }
-            }
-        }
         if (refill) {
             if (compact) {  // the compacted copy becomes BACK
                 c->cur_b ^= 1;
@@ -1672,36 +1647,6 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
     }
     __syncthreads();
     flush();
-    if constexpr (!FUSED) {
-        // Rebase iteration with a fine binning proposed (Ctl::fine_on): count what STAYS in FRONT at or below the horizon
-        // key under that binning.  The entries this launch just took are tombstones now and skip themselves; the overshoot
-        // of the threshold bin is counted by k_rank when it hands it back.  LDS counters (lcnt is idle after the flush),
-        // one global atomic per touched bin and workgroup — cost ties land on one bin.
-        if (c->fine_on) {
-            const uint64_t fk = c->f_kmin;
-            const uint32_t fs = c->f_shift, fhb = c->f_hbin;  // (counted: fine bins below f_hbin — the rule k_commit applies too)
-            for (int i = t; i < NBIN; i += 256) L.lcnt[i] = 0;
-            __syncthreads();
-            for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-                uint64_t k[ITEMS];
-#pragma unroll
-                for (uint32_t i = 0; i < ITEMS; i++) {
-                    const uint32_t idx = tile * TILE + i * 256 + t, ic = idx < n ? idx : n - 1;
-                    k[i] = keys[ic];
-                    if (idx >= n) k[i] = DEAD;
-                }
-#pragma unroll
-                for (uint32_t i = 0; i < ITEMS; i++)
-                    if (k[i] != DEAD) {
-                        const uint32_t f = bin_of(k[i], fk, fs);
-                        if (f < fhb) atomicAdd(&L.lcnt[f], 1u);
-                    }
-            }
-            __syncthreads();
-            for (int i = t; i < NBIN; i += 256)
-                if (L.lcnt[i]) atomicAdd(&E.hist2[i], L.lcnt[i]);
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1744,14 +1689,8 @@ struct RankShared {
     uint32_t imin, ispan;  // and the same for its (masked) ids
     uint32_t bits, tsub, sp, fail;
     uint32_t ret_base, ret_cnt;            // one reservation of return numbers per work item for the entries it hands back
-    uint32_t fine_on, f_shift;             // rebase iteration with a fine binning proposed: hand-backs are counted into E.hist2
-    uint64_t f_kmin;
     RankItem stack[kRankStack];
 };
-// (the entries k_rank hands back are the threshold bin's overshoot: below the horizon key by construction)
-__device__ __forceinline__ void count_back(const Eng& E, const RankShared& S, bool pred, uint64_t key) {
-    if (S.fine_on && pred) atomicAdd(&E.hist2[bin_of(key, S.f_kmin, S.f_shift)], 1u);
-}
 
 // one entry of the batch at its pop rank
 __device__ __forceinline__ void emit_pop(const Eng& E, Ctl* c, uint32_t rank, uint64_t key, uint32_t id) {
@@ -1769,11 +1708,10 @@ __device__ __forceinline__ void emit_pop(const Eng& E, Ctl* c, uint32_t rank, ui
 // (E.tmp_idx[r]; any one-to-one assignment will do).  FRONT's physical size and key range do not change.
 // One ranked entry: into the batch (pop order) or back to FRONT.  Wave-collective (one returning global atomic per
 // wave) — fine once per thread (the small-bin pass), NOT inside a loop: the large-bin path uses ret_put.
-__device__ __forceinline__ void emit_ranked(const Eng& E, Ctl* c, const RankShared& S, uint32_t nf, bool live, uint32_t rank,
-                                            uint32_t want, uint64_t key, uint32_t id) {
+__device__ __forceinline__ void emit_ranked(const Eng& E, Ctl* c, uint32_t nf, bool live, uint32_t rank, uint32_t want,
+                                            uint64_t key, uint32_t id) {
     if (live && rank < want) emit_pop(E, c, rank, key, id);
     const bool back = live && rank >= want;
-    count_back(E, S, back, key);
     const unsigned long long mask = __ballot(back);
     if (mask == 0) return;
     const int lane = threadIdx.x & 63;
@@ -1803,7 +1741,6 @@ struct RetAcc {};  // (nothing to accumulate: an entry that goes back was inside
 // atomic per wave and call.  (Per-entry atomics on the shared counter — all on one LDS address — cost 30-60 us.)
 __device__ __forceinline__ void ret_put(const Eng& E, Ctl* c, RankShared& S, uint32_t nf, bool pred, uint64_t key,
                                         uint32_t id, RetAcc& acc) {
-    count_back(E, S, pred, key);
     const unsigned long long mask = __ballot(pred);
     if (mask == 0) return;
     const int lane = threadIdx.x & 63;
@@ -1848,7 +1785,6 @@ __device__ __forceinline__ void ret_put_many(const Eng& E, RankShared& S, uint32
         if ((preds >> j) & 1u) {
             E.open_key[nf][slot[j]] = key[j];
             E.open_id[nf][slot[j]] = id[j];
-            count_back(E, S, true, key[j]);
         }
 }
 
@@ -1892,7 +1828,7 @@ __device__ __forceinline__ void rank_small_entries(const Eng& E, Ctl* c, RankSha
             for (uint32_t j = o; j < e; j++) rank += pair_less(E.tmp_key[j], E.tmp_id[j], k, id) ? 1u : 0u;
         }
     }
-    emit_ranked(E, c, S, nf, live, rank, want, k, id);
+    emit_ranked(E, c, nf, live, rank, want, k, id);
     __syncthreads();
 }
 
@@ -2317,12 +2253,6 @@ __global__ __launch_bounds__(RT) void k_rank(const Eng* __restrict__ engs) {
     const uint32_t nf = c->cur_f;  // what the batch does not take goes back where it came from
     const uint32_t tseg = c->tseg, want = c->want;  // (tseg: the segment holding the batch's last entry — the threshold bin)
     const uint32_t n_big = c->n_big, n_ord = c->n_ord;
-    if (t == 0) {
-        S.fine_on = c->fine_on;
-        S.f_shift = c->f_shift;
-        S.f_kmin = c->f_kmin;
-    }
-    __syncthreads();
     if (blockIdx.x == gridDim.x - 1) {
         // housekeeping for the launches that read these arrays while every workgroup is looking (k_sel_collect): FRONT's
         // histogram minus what this pop takes — the bins below the threshold bin leave entirely, the threshold bin keeps
@@ -2457,12 +2387,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
         uint32_t r = r0 + threadIdx.x;
         bool back = threadIdx.x < kTileParents && r >= npop && r < want;
         open_append(E, c, cur_new, back, back ? E.pop_key[r] : 0, back ? E.pop_id[r] : 0);
-        if (back) {  // FRONT's histogram is incremental (a rebase iteration that switches to the fine binning counts there)
-            if (c->fine_on)
-                atomicAdd(&E.hist2[bin_of(E.pop_key[r], c->f_kmin, c->f_shift)], 1u);
-            else
-                atomicAdd(&E.hist[bin_of(E.pop_key[r], c->sel_kmin, c->shift)], 1u);
-        }
+        if (back) atomicAdd(&E.hist[bin_of(E.pop_key[r], c->sel_kmin, c->shift)], 1u);  // FRONT's histogram is incremental
     }
     if (r0 >= npop) return;
     const uint32_t np = min((uint32_t)kTileParents, npop - r0);
@@ -2642,22 +2567,6 @@ __global__ __launch_bounds__(256) void k_probe(const Eng* __restrict__ engs) {
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
     const IterState& S1 = st_next(c);
     const uint32_t m = S1.m, base = S1.base;
-    if (blockIdx.x == 0 && c->fine_on) {
-        // A rebase iteration proposed a fine binning and everything that stays in FRONT below the horizon is counted under it
-        // (k_sel_collect, k_rank, k_expand — all complete): install it before k_commit bins this iteration's children.
-        // Nothing in this launch reads these words.
-        for (int i = threadIdx.x; i < NBIN; i += 256) {
-            E.hist[i] = E.hist2[i];
-            E.hist2[i] = 0;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            c->sel_kmin = c->f_kmin;
-            c->shift = c->f_shift;
-            c->hbin = c->f_hbin;
-            c->fine_on = 0;
-        }
-    }
     if (j >= m) return;
     constexpr int NW = (D + 3) / 4;
     const uint32_t id = base + j;
@@ -3391,7 +3300,6 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
         }
         ALLOC(hist, NBIN);
         ALLOC(rhist, NBIN);
-        ALLOC(hist2, NBIN);
         ALLOC(pre, kSegs + 16);
         ALLOC(fill, kSegs + 8);
         ALLOC(subhist, (size_t)kMaxLevels * kSub);
@@ -3419,7 +3327,6 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
         if (!rc) {
             (void)hipMemset(E.hist, 0, NBIN * sizeof(uint32_t));
             (void)hipMemset(E.rhist, 0, NBIN * sizeof(uint32_t));
-            (void)hipMemset(E.hist2, 0, NBIN * sizeof(uint32_t));
             (void)hipMemset(E.fill, 0, (kSegs + 8) * sizeof(uint32_t));
             (void)hipMemset(E.subhist, 0, (size_t)kMaxLevels * kSub * sizeof(uint32_t));
             (void)hipMemset(E.child_multi, 0, M);
@@ -3743,7 +3650,7 @@ int dca_debug_tune(int knob, int value) {
     if (knob >= 0 && knob < 16) h_tune[knob] = value;  // (host-side knobs: 4 = workgroups of k_sel_collect; set before the first step)
     // diagnostics: 0 extra log2 of sub-bins per large bin, 1 sub-bin size above which a sub-bin is refined on its own,
     // 2 BACK squeeze mark in 1/1024ths of max_nodes, 3 threshold-bin size above which the grid refines the bin (giant
-    // iterations), 5 (host, before create) giant-bin path off, 6 (host) k_sel_scan launched in every iteration, 7 (host) single-iteration graphs only, 8 fine binning of the plain iterations off, 9 largest bin ranked a thread per entry
+    // iterations), 5 (host, before create) giant-bin path off, 6 (host) k_sel_scan launched in every iteration, 7 (host) single-iteration graphs only, 9 largest bin ranked a thread per entry
     DCA_ARG(knob >= 0 && knob < 16);
     DCA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tune), &value, sizeof(int), (size_t)knob * sizeof(int), hipMemcpyHostToDevice));
     return 0;

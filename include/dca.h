@@ -251,7 +251,7 @@ int dca_engine_debug(dca_engine* e, double* out /*host [16]*/, void* stream);
  * knob 0: extra log2 of sub-bins per large bin in k_rank; 1: sub-bin size above which a sub-bin is refined on its own;
  * 2: BACK squeeze mark (1/1024ths of max_nodes); 3: threshold-bin size above which the grid refines the bin; 4: workgroups of
  * k_sel_collect, 5: grid-wide refinement off, 6: k_sel_scan in every iteration, 7: single-iteration graphs only (4-7 host side,
- * set before the engine is created / first stepped); 8: fine binning of the plain iterations off; 0-15 accepted.        */
+ * set before the engine is created / first stepped); 9: largest bin k_rank orders a thread per entry; 0-15 accepted.      */
 int dca_debug_tune(int knob, int value);
 /* child rows of the last pop_expand straight from the node pool (device [m_live, D]); synchronises */
 int dca_engine_last_children(dca_engine* e, const uint8_t** states, int64_t* m_live, void* stream);

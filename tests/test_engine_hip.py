@@ -372,3 +372,26 @@ def test_packed_multi_instance_with_closure(L, co):
         assert r["moves"] == ref["moves"] and r["nodes_generated"] == ref["nodes_generated"]
     assert all(c % 1024 == 0 or c == 1 for c in calls)  # batches are rounded up to 1024 rows (1 = root evaluation)
     eng.close()
+
+
+def test_back_squeeze_without_a_refill_keeps_exactness(L, co):
+    """BACK is append-only with tombstones; spills keep appending to it.  When its buffer nears its physical end while no
+    refill is due, a compaction-only pass squeezes the tombstones out — forced here by lowering the mark to
+    max_nodes / 1024 entries (dca_debug_tune knob 2) under tiny tiers, and followed by the oracle iteration by iteration."""
+    from deepcubea_amd.search_methods.engine import BwasEngine
+    L.check(L.lib().dca_debug_tune(2, 1), "dca_debug_tune")
+    try:
+        for env, scr, w, B, hid, sem in [("cube3", [3, 8, 1, 10, 6, 4], 0.6, 100, 1, 0), ("cube3", [11, 2, 6, 9, 0], 0.8, 50, 1, 1)]:
+            root = scramble(co, env, scr)
+            ref = co.astar(env, root, w, B, sem, heur_builtin_id=hid, trace_cap=200000)
+            eng = BwasEngine(env, w, B, max_nodes=max(1 << 16, 2 * ref["nodes_generated"] + 4 * B * 12 + 64), semantics=sem)
+            eng.set_tiers(40, 100)
+            res = run_traced(L, eng, root, hid)
+            assert not res["failed"], (res, eng.debug())
+            assert res["moves"] == ref["moves"] and res["nodes_generated"] == ref["nodes_generated"]
+            assert res["iterations"] == ref["iterations"] and np.array_equal(res["trace"][:, 2], ref["trace"][:, 2])
+            if sem == 0:
+                assert np.array_equal(res["trace"], ref["trace"])
+            eng.close()
+    finally:
+        L.check(L.lib().dca_debug_tune(2, 0), "dca_debug_tune")
