@@ -2513,12 +2513,18 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
         const uint32_t one16 = E.oh_dtype == DCA_DT_F16 ? 0x3C00u : 0x3F80u;
         uint8_t* goh = E.onehot + (size_t)j0 * ROW * OH;
         const uint32_t nch = (te + EPC - 1) / EPC;
+        // (the child rows are already staged in LDS: one read per position instead of the two-step gather through the move
+        // table; a lane that runs one row past the tile reads the slack behind it — its chunk is never stored)
+        auto staged_nnet = [&](uint32_t i) -> uint32_t {
+            const uint32_t b = lst[i];
+            return ENV == DCA_ENV_CUBE3 ? (b * 57u) >> 9 : b;
+        };
         for (uint32_t q = threadIdx.x; q < nch; q += kThreads) {
             uint32_t e0 = q * EPC;
             uint32_t cch = e0 / ROW, e = e0 - cch * ROW;
             uint32_t pos = e / EV::DEPTH, col = e - pos * EV::DEPTH;
             uint32_t r = cch / EV::A, a = cch - r * EV::A;
-            uint32_t nb = t.nnet_byte(r, a, pos);
+            uint32_t nb = staged_nnet(cch * EV::D + pos);
             uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
             for (uint32_t k = 0; k < EPC; k++) {
@@ -2536,7 +2542,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
                             ++r;
                         }
                     }
-                    nb = t.nnet_byte(r, a, pos);
+                    nb = staged_nnet((r * EV::A + a) * EV::D + pos);
                 }
             }
             uint8_t* dst = goh + (size_t)e0 * OH;
@@ -3078,7 +3084,7 @@ int launch_expand_env(const dca_engine* e, int heur_id, bool want_oh, hipStream_
     const Eng& E = e->E[0];
     dim3 g = gxy((E.B + kEngTile - 1) / kEngTile, e), b(kThreads);
     // tile + tables, then the staged child rows (16 parents x A children x D bytes)
-    const size_t lds = TL::LDS_BYTES + ((kEngTile * EnvT<ENV, DIM>::A * EnvT<ENV, DIM>::D + 15) / 16) * 16;
+    const size_t lds = TL::LDS_BYTES + ((kEngTile * EnvT<ENV, DIM>::A * EnvT<ENV, DIM>::D + 15) / 16) * 16 + 64;  // (+ slack: the one-hot loop peeks one byte past the tile)
     if (E.onehot == nullptr || !want_oh)
         hipLaunchKernelGGL((k_expand<ENV, DIM, 0>), g, b, lds, s, e->d_engs, heur_id);
     else if (E.oh_dtype == DCA_DT_F32)
