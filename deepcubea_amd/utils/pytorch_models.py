@@ -255,12 +255,15 @@ class FastResnet(nn.Module):
             for w, b in raw:
                 sc = _pow2_scale(w)
                 wh, wl = _split_f16(w, sc)
-                self.split_w.append(nn.Parameter(torch.stack([wh, wh, wl], dim=2).reshape(w.shape[0], -1).contiguous(),
-                                                 requires_grad=False))  # W3[:, 3k..3k+2] = (wh, wh, wl)
+                # only the operand layout the selected mode reads is kept (each is a full fp16 copy or three of the weights)
+                if gemm == "library":
+                    self.split_w.append(nn.Parameter(torch.stack([wh, wh, wl], dim=2).reshape(w.shape[0], -1).contiguous(),
+                                                     requires_grad=False))  # W3[:, 3k..3k+2] = (wh, wh, wl)
+                else:
+                    self.split_wh.append(nn.Parameter(wh.contiguous(), requires_grad=False))  # planes for dca_f16x3_gemm
+                    self.split_wl.append(nn.Parameter(wl.contiguous(), requires_grad=False))
                 self.split_b.append(nn.Parameter(b.clone(), requires_grad=False))
                 self.split_alpha.append(nn.Parameter(1.0 / sc, requires_grad=False))
-                self.split_wh.append(nn.Parameter(wh.contiguous(), requires_grad=False))  # planes for dca_f16x3_gemm
-                self.split_wl.append(nn.Parameter(wl.contiguous(), requires_grad=False))
         # layer 1 straight from the uint8 rows (csrc/dca_mlp.hip) where the geometry is instantiated: fp32 weights as
         # three bf16 planes (exact), fp16 as two, bf16 as one
         self.l1_planes = {torch.float32: 3, torch.float16: 2, torch.bfloat16: 1}[dtype]

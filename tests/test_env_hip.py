@@ -229,4 +229,4 @@ def test_environment_api_mirror(L, golden):
     zero = [s for s, k in zip(st, ks) if k == 0]
     assert all(env.is_solved(zero)) if zero else True
     with pytest.raises(ValueError):
-        env_utils.get_environment("lightsout7")
+        env_utils.get_environment("sokoban")
