@@ -16,21 +16,25 @@
 //   OPEN        (cost key u64 = order-preserving bits of the f64 cost, node id u32 | is_solved flag) arrays in two tiers:
 //               FRONT (entries with key <= T, edited IN PLACE: pops tombstone what they take, pushes append) and BACK
 //               (the rest, append-only with tombstones).  pop = exact top-B of FRONT by (cost, id): an incrementally
-//               maintained 4096-bin histogram gives the threshold bin (k_sel_scan); every entry at or below it is
-//               moved, grouped by bin, into a scratch array (k_sel_collect); k_rank orders each bin exactly — small
-//               bins a thread per entry, large ones bucketed in LDS on 64-bit key / id offsets and shared between
-//               workgroups, giant ones (massive cost ties) streamed on the 96-bit (key,id) composite — and puts the
-//               overshoot of the threshold bin back into the slots it came from.  Every 8th ("rebase") iteration one
-//               pass compacts FRONT into its second buffer, evicts what a spill left above T, recounts the histogram
-//               under a fresh binning; refills from BACK and spills to it are decided there, with hysteresis, so an
-//               iteration costs O(|FRONT| + children), independent of |OPEN|.
+//               maintained 4096-bin histogram gives the threshold bin — every workgroup of k_sel_collect scans it for
+//               itself (k_sel_scan only runs in rebase iterations); every entry at or below the threshold bin is moved,
+//               grouped by bin, into a scratch array; k_rank orders each bin exactly — bins of up to 512 entries a thread
+//               per entry, larger ones bucketed in LDS on 64-bit key / id offsets and shared between workgroups — and
+//               puts the overshoot of the threshold bin back into the slots it came from.  A threshold bin too large for
+//               that (massive cost ties: an integer-valued heuristic makes every f-level one tie group of up to millions
+//               of entries) is first cut down IN PLACE by k_sel_collect's whole grid: radix selection on the 96-bit
+//               (key, id) composite, counter grid barriers between its passes (collect_giant).  Every 8th ("rebase")
+//               iteration one pass compacts FRONT into its second buffer, evicts what a spill left above T, recounts the
+//               histogram under a fresh binning; refills from BACK and spills to it are decided there, with hysteresis,
+//               so an iteration costs O(|FRONT| + children), independent of |OPEN|.
 //
-// One BWAS iteration = pop -> expand -> heuristic -> dedup -> push in SIX launches (scan, collect, rank, expand, probe,
-// commit; four more in a rebase iteration), all stream-ordered, no host round trip: counts live in a device control
-// block (hot counters on their own cache lines) and every kernel sizes itself from it.  The per-iteration batch
-// geometry is double buffered by iteration parity (IterState), so the expansion launch itself closes the pop (no
-// single-thread kernel in between).  One engine steps K independent instances at once: every kernel takes the device
-// array of instance descriptors and picks its instance with blockIdx.y.
+// One BWAS iteration = pop -> expand -> heuristic -> dedup -> push in FIVE launches (collect, rank, expand, probe, commit;
+// five more in a rebase iteration), all stream-ordered, no host round trip: counts live in a device control block (hot
+// counters on their own cache lines) and every kernel sizes itself from it; the last workgroup of k_commit closes the
+// iteration and leaves the size of the next batch.  The per-iteration batch geometry is double buffered by iteration parity
+// (IterState), so the expansion launch itself closes the pop (no single-thread kernel in between).  A steady search replays
+// whole rebase periods (8 iterations) as one hipGraph.  One engine steps K independent instances at once: every kernel
+// takes the device array of instance descriptors and picks its instance with blockIdx.y.
 //
 // Sequential-order dedup, done in parallel: children of one batch that hit the same
 // CLOSED slot are chained through the slot's `head`; child j is kept iff g_j < v0 (the slot's value
