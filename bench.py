@@ -14,12 +14,15 @@ Workloads:
                      expand 240 000 children (+is_solved, hash, node fields) -> heuristic -> cost -> CLOSED dedup ->
                      push.  `value` is measured with the built-in hash-derived heuristic 10+5*u01(hash) (SURVEY §8d
                      "engine-only") over episodes of W untimed + K timed iterations on fresh test-set scrambles, repeated
-                     until >= 0.25 s were timed.  The same JSON line carries: `roofline` (dominant launch, timed by
-                     device-side stamps inside the replayed hipGraph), `roofline_iteration` (SURVEY §8(d) bytes x batch /
-                     ms_per_step), `engine_onehot_f32` (the same iteration with the fp32 one-hot rows fused into the
-                     expansion launch), `end_to_end_nnet` (the 14.7M-parameter ResNet heuristic in the loop; synthetic
-                     weights — the reference's checkpoints are not in the mount), `concurrent_instances`, `sharded_queue`
-                     (configs[3] in miniature: scrambles drawn from the shared work queue) and `cpu_baseline`.
+                     until >= 0.25 s were timed.  The same JSON line carries: `roofline` (dominant launch + every launch
+                     against the same roofline, timed by device-side stamps inside the replayed hipGraph over one more
+                     episode of the timed shape), `roofline_iteration` (SURVEY §8(d) bytes x batch / ms_per_step),
+                     `engine_onehot_f32` (the same iteration with the fp32 one-hot rows fused into the expansion launch),
+                     `end_to_end_nnet` (the 14.7M-parameter ResNet heuristic in the loop: fp32 parity mode, bf16 on the
+                     library / on the hand-written layer kernel, reference order; synthetic weights — the reference's
+                     checkpoints are not in the mount), `concurrent_instances`, `sharded_queue` (configs[3]'s path: 32
+                     shipped puzzle15 scrambles per rank drawn from the shared work queue and searched to completion) and
+                     `cpu_baseline` (the C++/OpenMP port + the reference's own compiled environments.cpp on the expansion).
   expand             BASELINE.json configs[1]: fused next_state + one-hot(f32) + is_solved + hash kernel on
                      1M synthetic cube3 states (one step = one launch over the 1M parents).
   avi / train        SURVEY §8(f) rows: AVI update step (configs[4]) and the training step.
