@@ -14,6 +14,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def _free_port() -> str:
+    """A port nobody listens on right now (fixed ports collide when an earlier rendezvous still lingers)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 def _ref_pickle(path, arrays):
     """A states pickle with the REFERENCE's class path (environments.cube3.Cube3State, int64 colors)."""
     pkg, mod = types.ModuleType("environments"), types.ModuleType("environments.cube3")
@@ -202,11 +210,11 @@ def test_cli_two_ranks_sharded(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29541", "-m", "deepcubea_amd.search_methods.astar", "--states", spath,
+           "127.0.0.1", "--master-port", _free_port(), "-m", "deepcubea_amd.search_methods.astar", "--states", spath,
            "--model_dir", "synthetic:11", "--env", "cube3", "--weight", "0.8", "--batch_size", "60", "--results_dir", rdir,
            "--nnet_batch_size", "1000", "--max_nodes", str(1 << 20)]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.returncode == 0, out.stderr[-12000:]  # (the ranks' own tracebacks come before the launcher's summary)
     res = data_utils.load_pickle(os.path.join(rdir, "results.pkl"))
     assert len(res["solutions"]) == 5 and len(res["times"]) == 5 and len(res["num_nodes_generated"]) == 5
     for i, r0 in enumerate(roots):

@@ -8,6 +8,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+def _free_port() -> str:
+    """A port nobody listens on right now (fixed ports collide when an earlier rendezvous still lingers)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 
 def _json_line(out: str) -> dict:
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
@@ -35,7 +43,7 @@ def test_gpus_flag_spawns_one_rank_per_gpu():
 
 def test_driver_style_launch_and_rank_count_check():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29647", os.path.join(ROOT, "bench.py"), "--workload", "selftest",
+           "127.0.0.1", "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--workload", "selftest",
            "--dist-backend", "gloo"]
     r = subprocess.run(cmd + ["--gpus", "2"], capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]

@@ -13,6 +13,14 @@ import torch
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+def _free_port() -> str:
+    """A port nobody listens on right now (fixed ports collide when an earlier rendezvous still lingers)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 
 @pytest.mark.parametrize("tag,bn", [("bn", True), ("nobn", False)])
 def test_train_nnet_on_device_matches_reference_run(tag, bn):
@@ -129,7 +137,7 @@ def test_avi_two_ranks_ddp(tmp_path):
     save = str(tmp_path / "saved_models")
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), DCA_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29547", "-m", "deepcubea_amd.ctg_approx.avi", "--env", "puzzle15",
+           "127.0.0.1", "--master-port", _free_port(), "-m", "deepcubea_amd.ctg_approx.avi", "--env", "puzzle15",
            "--states_per_update", "4000", "--batch_size", "1000", "--nnet_name", "p", "--max_itrs", "4", "--loss_thresh",
            "1e9", "--back_max", "6", "--num_test", "60", "--save_dir", save, "--update_nnet_batch_size", "2000"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
@@ -151,7 +159,7 @@ def test_avi_two_ranks_ddp_uneven_shards(tmp_path):
     save = str(tmp_path / "saved_models")
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), DCA_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29548", "-m", "deepcubea_amd.ctg_approx.avi", "--env", "puzzle15",
+           "127.0.0.1", "--master-port", _free_port(), "-m", "deepcubea_amd.ctg_approx.avi", "--env", "puzzle15",
            "--states_per_update", "4001", "--batch_size", "1000", "--nnet_name", "q", "--max_itrs", "6", "--loss_thresh",
            "1e9", "--back_max", "6", "--num_test", "60", "--save_dir", save, "--update_nnet_batch_size", "2000",
            "--max_update_steps", "3", "--update_num", "2"]
