@@ -237,6 +237,7 @@ def run_astar_leg(args, world, rank, onehot_dtype, min_timed_s, profile_iters):
         if total_t >= min_timed_s or episodes >= 400:
             break
     res = {"value": total_exp / total_t, "ms_per_step": total_t / (episodes * args.steps) * 1e3, "episodes": episodes,
+           "warmup_effective": warm,
            "timed_s": total_t, "device_ms_per_step": dev_ms / (episodes * args.steps), "local_value": local_exp / total_t,
            "open_size_end": st1["open_size"], "closed_size_end": st1["closed_size"],
            "nodes_generated_timed_rank0": total_gen}
@@ -276,6 +277,7 @@ def run_astar(args, world, rank):
                    "env": args.env, "batch_size": B, "weight": w, "children_per_step": B * A, "semantics": args.semantics,
                    "hipgraph": not args.no_graph, "parallelism": "one search instance per GPU x%d" % world,
                    "episodes": leg["episodes"], "timed_s": leg["timed_s"],
+                   "untimed_iterations_per_episode": leg["warmup_effective"],  # max(--warmup, 8): until every pop is a full batch
                    "open_size_end": leg["open_size_end"], "closed_size_end": leg["closed_size_end"],
                    "device_ms_per_step": leg["device_ms_per_step"]},
     }
