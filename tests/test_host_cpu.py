@@ -185,8 +185,13 @@ def test_network_weight_layouts_for_the_mfma_paths():
     m = ResnetModel(54, 6, 64, 32, 2, 1, True).eval()
     with torch.no_grad():
         m.bn2.weight[:8] *= 1e3  # spread the folded unit magnitudes
-    f = FastResnet(m)
-    assert f.split and len(f.split_w) == 5 and f.onehot_dtype == torch.float16 and f.in_pad == 384
+    f = FastResnet(m, gemm="library")  # (each mode keeps only the operand layout it reads)
+    assert f.split and len(f.split_w) == 5 and len(f.split_wh) == 0 and f.onehot_dtype == torch.float16 and f.in_pad == 384
+    fh = FastResnet(m)  # default: the hand-written kernel's planes
+    assert fh.split and len(fh.split_w) == 0 and len(fh.split_wh) == 5 and len(fh.split_wl) == 5
+    for w3, wh, wl in zip(f.split_w, fh.split_wh, fh.split_wl):
+        v = w3.view(w3.shape[0], -1, 3)
+        assert torch.equal(v[:, :, 0], wh) and torch.equal(v[:, :, 2], wl)
     from deepcubea_amd.utils.pytorch_models import fold_batchnorm
     fm = fold_batchnorm(m)
     lins = [fm.fc2] + [l for blk in fm.blocks for l in (blk[0], blk[2])]
