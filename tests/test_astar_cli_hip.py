@@ -214,6 +214,13 @@ def test_cli_two_ranks_sharded(tmp_path):
            "--model_dir", "synthetic:11", "--env", "cube3", "--weight", "0.8", "--batch_size", "60", "--results_dir", rdir,
            "--nnet_batch_size", "1000", "--max_nodes", str(1 << 20)]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    if out.returncode != 0:
+        # Two fresh processes bringing up HIP contexts and a gloo rendezvous next to this one on the same GPU: one failure in
+        # ~10 suite runs was seen on the pool with nothing of the ranks' own in the launcher's summary.  Show it, then try
+        # ONCE more on another port — a second failure is a failure.
+        print("first attempt failed (rc %d):\n%s" % (out.returncode, out.stderr[-12000:]))
+        cmd[cmd.index("--master-port") + 1] = _free_port()
+        out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-12000:]  # (the ranks' own tracebacks come before the launcher's summary)
     res = data_utils.load_pickle(os.path.join(rdir, "results.pkl"))
     assert len(res["solutions"]) == 5 and len(res["times"]) == 5 and len(res["num_nodes_generated"]) == 5
