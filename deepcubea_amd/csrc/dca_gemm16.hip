@@ -17,6 +17,7 @@
 // is applied to each lane's GLOBAL source address.  Workgroup ids are remapped so that the N tiles sharing an A tile run
 // on one XCD.
 #include <atomic>
+#include <type_traits>
 
 #include "dca_common.h"
 
@@ -67,6 +68,7 @@ __device__ __forceinline__ float from_f16(uint16_t b) {
 template <bool BF16>
 __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16(const Gemm16Args p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    using frag_t = typename std::conditional<BF16, b16x8, h16x8>::type;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, h = lane >> 5;
     const int wm = w >> 2, wn = w & 3;
     const int nNt = (p.n + QBN - 1) / QBN;
@@ -126,22 +128,23 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16(const Gemm16Args p) {
 #pragma unroll
         for (int s = 0; s < QBK / 16; s++) {
             const uint32_t c = 2u * s + (uint32_t)h;
-            uint4 av[4], wv[2];
+            // (typed vector loads, not HIP's uint4 struct: the compiler orders a fragment read behind the LDS-DMA in flight
+            // — s_waitcnt vmcnt(0) in front of the first ds_read, no overlap at all — unless type-based alias
+            // information tells it the two cannot meet)
+            frag_t av[4], wv[2];
 #pragma unroll
-            for (int i = 0; i < 4; i++) av[i] = *reinterpret_cast<const uint4*>(base + swz128((uint32_t)(wm * 128 + i * 32 + l31), c));
+            for (int i = 0; i < 4; i++) av[i] = *reinterpret_cast<const frag_t*>(base + swz128((uint32_t)(wm * 128 + i * 32 + l31), c));
 #pragma unroll
             for (int jn = 0; jn < 2; jn++)
-                wv[jn] = *reinterpret_cast<const uint4*>(base + QIMG + swz128((uint32_t)(wn * 64 + jn * 32 + l31), c));
+                wv[jn] = *reinterpret_cast<const frag_t*>(base + QIMG + swz128((uint32_t)(wn * 64 + jn * 32 + l31), c));
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int jn = 0; jn < 2; jn++) {
                     if constexpr (BF16)
-                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b16x8, av[i]),
-                                                                             __builtin_bit_cast(b16x8, wv[jn]), acc[i][jn], 0, 0, 0);
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], wv[jn], acc[i][jn], 0, 0, 0);
                     else
-                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, av[i]),
-                                                                            __builtin_bit_cast(h16x8, wv[jn]), acc[i][jn], 0, 0, 0);
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], wv[jn], acc[i][jn], 0, 0, 0);
                 }
         }
     }
