@@ -38,6 +38,7 @@ struct Gemm16Args {
     const float* bias;   // [n] or null
     const uint16_t* skip;  // [m, ldo] or null (same element type)
     uint16_t* out;       // [m, ldo]
+    unsigned long long* prof;  // diagnostic build only (k_gemm16p<.., true>): phase time stamps of workgroup 0, else null
     int relu;
     int64_t m;
     int n, k;
@@ -63,6 +64,76 @@ __device__ __forceinline__ float from_f16(uint16_t b) {
     _Float16 h;
     __builtin_memcpy(&h, &b, 2);
     return (float)h;
+}
+
+// Layer tail, shared by both schedules.  Accumulator layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+template <bool BF16>
+__device__ __forceinline__ void gemm16_epilogue(const Gemm16Args& p, uint8_t* lds, f32x16 (&acc)[4][2], int64_t m0, int n0, int w,
+                                                int wm, int wn, int lane, int l31, int h) {
+    // Each wave transposes its tile through its own 16 KB of the (now idle) LDS, 32 rows at a time, and leaves with 8-byte accesses:
+    // a lane owns 4 consecutive columns of a row (one 8-byte skip load, one 8-byte store; 16 lanes = 128 contiguous bytes).
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the operand stages
+    float* sl = reinterpret_cast<float*>(lds + w * 16384);
+    float bv[2];
+#pragma unroll
+    for (int jn = 0; jn < 2; jn++) {
+        const int col = n0 + wn * 64 + jn * 32 + l31;
+        bv[jn] = (col < p.n && p.bias) ? p.bias[col] : 0.f;
+    }
+    const int c4 = (lane & 15) * 4;  // this lane's 4 columns inside the wave's 64
+    const int colg = n0 + wn * 64 + c4;
+    const bool full4 = colg + 3 < p.n;
+    auto cvt_in = [](uint16_t b) { return BF16 ? from_bf16(b) : from_f16(b); };
+    auto cvt_out = [](float f) { return BF16 ? to_bf16(f) : to_f16(f); };
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int jn = 0; jn < 2; jn++)
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++)
+                sl[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 64 + jn * 32 + l31] = acc[i][jn][reg] + bv[jn];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private slice: no barrier, just the wave's own writes
+        const int64_t rbase = m0 + wm * 128 + i * 32;
+        uint2 sk[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int64_t r = rbase + q * 4 + (lane >> 4);
+            sk[q] = make_uint2(0u, 0u);
+            if (p.skip && r < p.m && full4) sk[q] = *reinterpret_cast<const uint2*>(p.skip + r * p.ldo + colg);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int rl = q * 4 + (lane >> 4);
+            const int64_t r = rbase + rl;
+            const float4 v = *reinterpret_cast<const float4*>(sl + rl * 64 + c4);
+            if (r >= p.m) continue;
+            float u[4] = {v.x, v.y, v.z, v.w};
+            const int64_t o = r * p.ldo + colg;
+            if (full4) {
+                if (p.skip) {
+                    u[0] += cvt_in((uint16_t)(sk[q].x & 0xFFFFu));
+                    u[1] += cvt_in((uint16_t)(sk[q].x >> 16));
+                    u[2] += cvt_in((uint16_t)(sk[q].y & 0xFFFFu));
+                    u[3] += cvt_in((uint16_t)(sk[q].y >> 16));
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) u[e] = fmaxf(u[e], 0.f);
+                }
+                uint2 ov;
+                ov.x = (uint32_t)cvt_out(u[0]) | ((uint32_t)cvt_out(u[1]) << 16);
+                ov.y = (uint32_t)cvt_out(u[2]) | ((uint32_t)cvt_out(u[3]) << 16);
+                *reinterpret_cast<uint2*>(p.out + o) = ov;
+            } else {  // ragged right edge: element-wise
+                for (int e = 0; e < 4 && colg + e < p.n; e++) {
+                    float ue = u[e] + (p.skip ? cvt_in(p.skip[o + e]) : 0.f);
+                    if (p.relu) ue = fmaxf(ue, 0.f);
+                    p.out[o + e] = cvt_out(ue);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slice is rewritten by the next 32 rows
+    }
 }
 
 template <bool BF16>
@@ -149,78 +220,267 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16(const Gemm16Args p) {
         }
     }
 
-    // epilogue.  Accumulator layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  Each wave
-    // transposes its tile through its own 16 KB of the (now idle) LDS, 32 rows at a time, and leaves with 8-byte accesses:
-    // a lane owns 4 consecutive columns of a row (one 8-byte skip load, one 8-byte store; 16 lanes = 128 contiguous bytes).
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the operand stages
-    float* sl = reinterpret_cast<float*>(lds + w * 16384);
-    float bv[2];
+    gemm16_epilogue<BF16>(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Variant 2: the same tile on an 8-phase "ping-pong" schedule (the CDNA4 guide's 256 x 256 template, re-derived for
+// 32x32x16 MFMAs and this kernel's DMA map).  What the two-stage loop above leaves on the table: its single
+// vmcnt(0) + barrier per K-step drains the LDS-DMA queue (the prefetch distance is one K-step, the tail of the queue is
+// always young), and all eight waves read fragments and then issue MFMAs in step, so a SIMD's matrix pipe idles while
+// both of its waves wait on LDS.  Here
+//   * the two wave rows (waves 0-3 = tile rows 0-127, waves 4-7 = rows 128-255; one wave of each on every SIMD) run
+//     ONE BARRIER APART: while one group issues its 8 MFMAs of a phase (s_setprio 1) the other reads its fragments for
+//     the next and issues DMA — every SIMD always has a wave in the matrix section;
+//   * a K-tile (64 KB) is staged as four 16 KB HALF-TILES, one DMA issue per phase, chosen so that each is read in ONE phase:
+//        A01 = rows {0-63, 128-191} (each wave row's first two 32-row blocks), A23 = the other rows,
+//        B0  = columns wn*64 + [0,32) of every wave column, B1 = columns wn*64 + [32,64);
+//     phase 1 reads B0 + A01 and multiplies them, phase 2 B1 (x A01), phase 3 A23 (x B1), phase 4 reads nothing
+//     (A23 x B0, whose fragments stayed in registers);
+//   * the DMA queue is never drained and every half-tile gets FIVE phases to land: a phase restages a slot that was last
+//     read one or two phases earlier (P1: A23 of tile t+1, P2: A01 of t+2, P3: B0 of t+2, P4: B1 of t+2) and three phases
+//     carry a counted wait for the half-tile the NEXT phase reads — s_waitcnt vmcnt(10): all but the five youngest
+//     half-tiles have landed.  (First cut, measured: one wait per K-tile, vmcnt(6) in phase 4, B0 re-read in phase 4 — the
+//     youngest half-tile of a tile then has three phases to land, and at 1.5 us of DMA latency under load that set the
+//     K-tile time: 1.0 PF at K = 5120, no better than the two-stage loop.)
+// Ordering rules (guide §5, "read a staged buffer one phase AFTER the wait that retires it"):
+//   RAW  every wave waits (vmcnt) BEFORE the first barrier of phase p; the half-tile is first read in phase p+1, which
+//        either group enters only behind a barrier the other group reached after its own wait.
+//   WAR  a wave's fragment reads have RETURNED (lgkmcnt(0)) before the first barrier of the phase that issues them; a slot
+//        is restaged at least one phase later, i.e. behind a barrier that both groups' readers of that slot reached after
+//        that wait.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int PSLOT = 128 * 128;  // one half-tile: 128 rows x 128 B
+constexpr int PBUF = 4 * PSLOT;   // one K-tile: A01 | A23 | B0 | B1
+constexpr int PS_A01 = 0, PS_A23 = 1, PS_B0 = 2, PS_B1 = 3;
+
+#define DCA_BAR() asm volatile("s_barrier" ::: "memory")
+#define DCA_RD_DONE_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <bool BF16, bool PROF = false>
+__global__ __launch_bounds__(QTHREADS, 2) void k_gemm16p(const Gemm16Args p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    using frag_t = typename std::conditional<BF16, b16x8, h16x8>::type;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, h = lane >> 5;
+    const int wm = w >> 2, wn = w & 3;
+    const int nNt = (p.n + QBN - 1) / QBN;
+    const int64_t nMt = (p.m + QBM - 1) / QBM;
+    const int64_t bid = blockIdx.x;
+    const int64_t slot = bid >> 3;
+    const int64_t mt = (slot / nNt) * 8 + (bid & 7);
+    const int nt = (int)(slot % nNt);
+    if (mt >= nMt) return;
+    const int64_t m0 = mt * QBM;
+    const int n0 = nt * QBN;
+
+    // DMA map: instruction q (0, 1) of wave w fills local rows [(q*8 + w)*8, +8) of a half-tile slot; lane i lands on local
+    // row r = that + (i >> 3), physical chunk i & 7, and fetches logical chunk (i & 7) ^ ((r >> 1) & 7) of the matrix row
+    // the slot's local row r stands for.
+    const uint16_t* src[4][2];
 #pragma unroll
-    for (int jn = 0; jn < 2; jn++) {
-        const int col = n0 + wn * 64 + jn * 32 + l31;
-        bv[jn] = (col < p.n && p.bias) ? p.bias[col] : 0.f;
-    }
-    const int c4 = (lane & 15) * 4;  // this lane's 4 columns inside the wave's 64
-    const int colg = n0 + wn * 64 + c4;
-    const bool full4 = colg + 3 < p.n;
-    auto cvt_in = [](uint16_t b) { return BF16 ? from_bf16(b) : from_f16(b); };
-    auto cvt_out = [](float f) { return BF16 ? to_bf16(f) : to_f16(f); };
+    for (int u = 0; u < 4; u++)
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+        for (int q = 0; q < 2; q++) {
+            const uint32_t r = (uint32_t)((q * 8 + w) * 8 + (lane >> 3));
+            const uint32_t c = (uint32_t)(lane & 7) ^ ((r >> 1) & 7u);
+            if (u < 2) {
+                int64_t gr = m0 + (r >> 6) * 128 + (u == PS_A23 ? 64 : 0) + (r & 63);
+                gr = gr < p.m ? gr : p.m - 1;
+                src[u][q] = p.a + gr * p.lda + c * 8;
+            } else {
+                int gn = n0 + (int)((r >> 5) * 64 + (u == PS_B1 ? 32 : 0) + (r & 31));
+                gn = gn < p.n ? gn : p.n - 1;
+                src[u][q] = p.w + (int64_t)gn * p.ldw + c * 8;
+            }
+        }
+    auto issue = [&](int u, int buf, int k0) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            uint8_t* dst = lds + buf * PBUF + u * PSLOT + (q * 8 + w) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[u][q] + k0),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int jn = 0; jn < 2; jn++)
 #pragma unroll
-            for (int reg = 0; reg < 16; reg++)
-                sl[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 64 + jn * 32 + l31] = acc[i][jn][reg] + bv[jn];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private slice: no barrier, just the wave's own writes
-        const int64_t rbase = m0 + wm * 128 + i * 32;
-        uint2 sk[8];
+            for (int e = 0; e < 16; e++) acc[i][jn][e] = 0.f;
+
+    // fragment addresses inside a slot: local row = (wave's block) * 32 + l31, logical chunk 2 s + h
+    uint32_t foff[4];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int64_t r = rbase + q * 4 + (lane >> 4);
-            sk[q] = make_uint2(0u, 0u);
-            if (p.skip && r < p.m && full4) sk[q] = *reinterpret_cast<const uint2*>(p.skip + r * p.ldo + colg);
-        }
+    for (int s = 0; s < 4; s++) foff[s] = swz128((uint32_t)l31, 2u * s + (uint32_t)h);
+    const uint32_t a_row0 = (uint32_t)wm * 64u * 128u;  // A slots: this wave row's 64 local rows
+    const uint32_t b_row0 = (uint32_t)wn * 32u * 128u;  // B slots: this wave column's 32 local rows
+
+    frag_t av[2][4], wv0[4], wv1[4];
+    auto read_a = [&](const uint8_t* base, int u) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int rl = q * 4 + (lane >> 4);
-            const int64_t r = rbase + rl;
-            const float4 v = *reinterpret_cast<const float4*>(sl + rl * 64 + c4);
-            if (r >= p.m) continue;
-            float u[4] = {v.x, v.y, v.z, v.w};
-            const int64_t o = r * p.ldo + colg;
-            if (full4) {
-                if (p.skip) {
-                    u[0] += cvt_in((uint16_t)(sk[q].x & 0xFFFFu));
-                    u[1] += cvt_in((uint16_t)(sk[q].x >> 16));
-                    u[2] += cvt_in((uint16_t)(sk[q].y & 0xFFFFu));
-                    u[3] += cvt_in((uint16_t)(sk[q].y >> 16));
-                }
-                if (p.relu) {
+        for (int ii = 0; ii < 2; ii++)
 #pragma unroll
-                    for (int e = 0; e < 4; e++) u[e] = fmaxf(u[e], 0.f);
-                }
-                uint2 ov;
-                ov.x = (uint32_t)cvt_out(u[0]) | ((uint32_t)cvt_out(u[1]) << 16);
-                ov.y = (uint32_t)cvt_out(u[2]) | ((uint32_t)cvt_out(u[3]) << 16);
-                *reinterpret_cast<uint2*>(p.out + o) = ov;
-            } else {  // ragged right edge: element-wise
-                for (int e = 0; e < 4 && colg + e < p.n; e++) {
-                    float ue = u[e] + (p.skip ? cvt_in(p.skip[o + e]) : 0.f);
-                    if (p.relu) ue = fmaxf(ue, 0.f);
-                    p.out[o + e] = cvt_out(ue);
-                }
+            for (int s = 0; s < 4; s++)
+                av[ii][s] = *reinterpret_cast<const frag_t*>(base + u * PSLOT + a_row0 + ii * 4096 + foff[s]);
+    };
+    auto read_b = [&](const uint8_t* base, int u, frag_t (&wv)[4]) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) wv[s] = *reinterpret_cast<const frag_t*>(base + u * PSLOT + b_row0 + foff[s]);
+    };
+#define DCA_MMA8(I0, JN, WV)                                                                                          \
+    do {                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        __builtin_amdgcn_s_setprio(1);                                                                                \
+        _Pragma("unroll") for (int s = 0; s < 4; s++) _Pragma("unroll") for (int ii = 0; ii < 2; ii++) {              \
+            if constexpr (BF16)                                                                                       \
+                acc[(I0) + ii][JN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ii][s], WV[s], acc[(I0) + ii][JN], 0, 0, 0); \
+            else                                                                                                      \
+                acc[(I0) + ii][JN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[ii][s], WV[s], acc[(I0) + ii][JN], 0, 0, 0);  \
+        }                                                                                                             \
+        __builtin_amdgcn_s_setprio(0);                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+    } while (0)
+#define DCA_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
+    const int nk = p.k / QBK;
+    // one K-tile; N1 / N2: tiles kt+1 / kt+2 exist (compile-time, so the steady-state body is branch-free).  On entry:
+    // issued = all of tile kt and A01, B0, B1 of kt+1; landed and visible = A01, B0 of kt.  The vmcnt numbers count the
+    // DMA instructions (2 per half-tile) issued AFTER the half-tile being waited for.
+    // diagnostic build: lane 0 of waves 0 and 4 of workgroup 0 leaves s_memtime stamps of K-tiles [kProfT0, +4) in the LDS
+    // above the operand buffers — 4 per phase: phase entry, reads + DMA issue + vmcnt wait done, first barrier passed,
+    // MFMAs issued
+    constexpr int kProfT0 = 6;
+    auto stamp = [&](int kt, int ph, int pt) {
+        if constexpr (PROF) {
+            if (blockIdx.x == 0 && (w & 3) == 0 && lane == 0 && kt >= kProfT0 && kt < kProfT0 + 4) {
+                volatile unsigned long long* pl = reinterpret_cast<volatile unsigned long long*>(lds + 2 * PBUF);
+                pl[(wm * 4 + (kt - kProfT0)) * 16 + ph * 4 + pt] = __builtin_readcyclecounter();
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slice is rewritten by the next 32 rows
+    };
+    auto tile = [&](int kt, auto n1c, auto n2c) {
+        constexpr bool N1 = decltype(n1c)::value, N2 = decltype(n2c)::value;
+        const int b = kt & 1;
+        const uint8_t* base = lds + b * PBUF;
+        // phase 1: (A01, B0); restage A23 of kt+1 (last read: phase 3 of kt-1); retire B1 of kt
+        stamp(kt, 0, 0);
+        read_b(base, PS_B0, wv0);
+        read_a(base, PS_A01);
+        if constexpr (N1) {
+            issue(PS_A23, b ^ 1, (kt + 1) * QBK);
+            DCA_VMCNT(10);  // behind B1(kt): A23(kt), A01 B0 B1 A23 (kt+1)
+        } else {
+            DCA_VMCNT(2);   // behind B1(kt): A23(kt)
+        }
+        stamp(kt, 0, 1);
+        DCA_RD_DONE_BAR();
+        stamp(kt, 0, 2);
+        DCA_MMA8(0, 0, wv0);
+        stamp(kt, 0, 3);
+        DCA_BAR();
+        // phase 2: (A01, B1); restage A01 of kt+2 (last read: phase 1); retire A23 of kt
+        stamp(kt, 1, 0);
+        read_b(base, PS_B1, wv1);
+        if constexpr (N2) {
+            issue(PS_A01, b, (kt + 2) * QBK);
+            DCA_VMCNT(10);  // behind A23(kt): A01 B0 B1 A23 (kt+1), A01(kt+2)
+        } else if constexpr (N1) {
+            DCA_VMCNT(8);
+        } else {
+            DCA_VMCNT(0);
+        }
+        stamp(kt, 1, 1);
+        DCA_RD_DONE_BAR();
+        stamp(kt, 1, 2);
+        DCA_MMA8(0, 1, wv1);
+        stamp(kt, 1, 3);
+        DCA_BAR();
+        // phase 3: (A23, B1); restage B0 of kt+2 (read once, in phase 1: its fragments stay in registers for phase 4)
+        stamp(kt, 2, 0);
+        read_a(base, PS_A23);
+        if constexpr (N2) issue(PS_B0, b, (kt + 2) * QBK);
+        stamp(kt, 2, 1);
+        DCA_RD_DONE_BAR();
+        stamp(kt, 2, 2);
+        DCA_MMA8(2, 1, wv1);
+        stamp(kt, 2, 3);
+        DCA_BAR();
+        // phase 4: (A23, B0) from registers; restage B1 of kt+2 (last read: phase 2); retire A01, B0 of kt+1
+        stamp(kt, 3, 0);
+        if constexpr (N2) {
+            issue(PS_B1, b, (kt + 2) * QBK);
+            DCA_VMCNT(10);  // behind B0(kt+1): B1 A23 (kt+1), A01 B0 B1 (kt+2)
+        } else if constexpr (N1) {
+            DCA_VMCNT(4);   // behind B0(kt+1): B1 A23 (kt+1)
+        }
+        stamp(kt, 3, 1);
+        DCA_RD_DONE_BAR();
+        stamp(kt, 3, 2);
+        DCA_MMA8(2, 0, wv0);
+        stamp(kt, 3, 3);
+        DCA_BAR();
+    };
+
+    issue(PS_A01, 0, 0);
+    issue(PS_B0, 0, 0);
+    issue(PS_B1, 0, 0);
+    issue(PS_A23, 0, 0);
+    if (nk > 1) {
+        issue(PS_A01, 1, QBK);
+        issue(PS_B0, 1, QBK);
+        issue(PS_B1, 1, QBK);
+        DCA_VMCNT(10);  // A01, B0 of tile 0 have landed
+    } else {
+        DCA_VMCNT(4);
     }
+    DCA_BAR();
+    if (wm == 1) DCA_BAR();  // the second wave row runs one barrier behind the first from here on
+    {
+        int kt = 0;
+        for (; kt + 2 < nk; kt++) tile(kt, std::true_type{}, std::true_type{});
+        if (kt + 1 < nk) {
+            tile(kt, std::true_type{}, std::false_type{});
+            kt++;
+        }
+        tile(kt, std::false_type{}, std::false_type{});
+    }
+    if (wm == 0) DCA_BAR();  // ... and the first waits for it here
+#undef DCA_VMCNT
+    if constexpr (PROF) {
+        __syncthreads();
+        if (blockIdx.x == 0 && t < 128 && p.prof)
+            p.prof[t] = reinterpret_cast<const volatile unsigned long long*>(lds + 2 * PBUF)[t];
+    }
+#undef DCA_MMA8
+
+    gemm16_epilogue<BF16>(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h);
 }
 
 }  // namespace dca
 
 using namespace dca;
 
+static int g_gemm16_variant = 2;
+static unsigned long long* g_gemm16_prof = nullptr;  // device buffer of 128 stamps: the next bf16 launches run the diagnostic build
+
 extern "C" {
+
+/* tuning / test hook: 1 = two K-step stages, one drain + barrier per K-step; 2 (default) = the 8-phase ping-pong schedule */
+int dca_gemm16_variant(int v) {
+    DCA_ARG(v == 1 || v == 2);
+    g_gemm16_variant = v;
+    return 0;
+}
+
+/* diagnostic hook (tools/gemm16_phase_probe.py): with a device buffer of 128 u64, bf16 launches of variant 2 run a build that
+ * stamps s_memtime at four points of every phase of K-tiles 6..9 in workgroup 0 (waves 0 and 4); NULL switches it off. */
+int dca_debug_gemm16_profile(unsigned long long* stamps) {
+    g_gemm16_prof = stamps;
+    return 0;
+}
 
 int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int n, int64_t ldw, int dtype, const float* bias,
                const void* skip, int relu, void* out, int64_t ldo, void* stream) {
@@ -237,6 +497,10 @@ int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int 
         if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
+            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16p<true>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
+            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16p<false>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
+            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16p<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        QLDS + 1024));
             attr_devs.fetch_or(bit, std::memory_order_release);
         }
     }
@@ -247,6 +511,7 @@ int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int 
     p.skip = reinterpret_cast<const uint16_t*>(skip);
     p.out = reinterpret_cast<uint16_t*>(out);
     p.relu = relu;
+    p.prof = g_gemm16_prof;
     p.m = m;
     p.n = n;
     p.k = k;
@@ -260,10 +525,20 @@ int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int 
         set_error("dca_gemm16: too many tiles");
         return DCA_E_BADARG;
     }
-    if (dtype == DCA_DT_BF16)
-        hipLaunchKernelGGL(k_gemm16<true>, dim3((unsigned)blocks), dim3(QTHREADS), QLDS, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL(k_gemm16<false>, dim3((unsigned)blocks), dim3(QTHREADS), QLDS, (hipStream_t)stream, p);
+    const dim3 grid((unsigned)blocks), block(QTHREADS);
+    if (g_gemm16_variant == 2) {
+        if (dtype == DCA_DT_BF16 && g_gemm16_prof)
+            hipLaunchKernelGGL((k_gemm16p<true, true>), grid, block, QLDS + 1024, (hipStream_t)stream, p);
+        else if (dtype == DCA_DT_BF16)
+            hipLaunchKernelGGL(k_gemm16p<true>, grid, block, QLDS, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL(k_gemm16p<false>, grid, block, QLDS, (hipStream_t)stream, p);
+    } else {
+        if (dtype == DCA_DT_BF16)
+            hipLaunchKernelGGL(k_gemm16<true>, grid, block, QLDS, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL(k_gemm16<false>, grid, block, QLDS, (hipStream_t)stream, p);
+    }
     return launch_check("k_gemm16");
 }
 

@@ -120,8 +120,16 @@ def test_hand_written_layers_equal_the_library_arrangement(golden):
 # ---------------------------------------------------------------------------------------------------------------------
 # dca_gemm16 (csrc/dca_gemm16.hip): the same layer in the non-parity 16-bit modes, tail in the epilogue
 # ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(params=[1, 2], ids=["two_stage", "eight_phase"])
+def variant16(request):
+    from deepcubea_amd import _lib
+    _lib.gemm16_variant(request.param)
+    yield request.param
+    _lib.gemm16_variant(2)
+
+
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
-def test_gemm16_identity_catches_transposition(dt):
+def test_gemm16_identity_catches_transposition(dt, variant16):
     from deepcubea_amd import _lib
     _lib.require_gpu()
     k = n = 256
@@ -137,7 +145,7 @@ def test_gemm16_identity_catches_transposition(dt):
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("m,n,k", [(1, 4, 64), (300, 200, 128), (257, 1024, 1024), (1000, 1024, 5120), (513, 260, 192)])
-def test_gemm16_layer_tail_against_float64(dt, m, n, k):
+def test_gemm16_layer_tail_against_float64(dt, m, n, k, variant16):
     """relu(a.w^T + bias + skip) rounded to the 16-bit type: the kernel accumulates in fp32, the yardstick in float64 — they
     may land on opposite sides of a rounding boundary, so one unit in the last place of the output type is allowed (and
     nothing more); ragged m / n, the in-place residual form (out == skip), no-bias / no-skip / no-ReLU forms."""
@@ -165,6 +173,31 @@ def test_gemm16_layer_tail_against_float64(dt, m, n, k):
         assert bool((err <= tol).all()), (use_b, use_s, relu, float((err / tol).max()))
         if relu:
             assert float(y.float().min()) >= 0.0
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_gemm16_schedules_agree_bit_for_bit_under_load(dt):
+    """Race screen for the 8-phase schedule: both schedules add the same products in the same order, so their outputs are
+    bit-identical — unless a fragment read ever meets a half-tile that has not landed (or has been restaged).  Full-chip
+    problems (every CU busy, DMA latency at its worst), K-tile counts 1..5, 16, 17 and 80, repeated launches."""
+    from deepcubea_amd import _lib
+    _lib.require_gpu()
+    g = torch.Generator().manual_seed(99)
+    for m, n, k, reps in ((70000, 1024, 1024, 6), (70000, 1024, 1088, 3), (33000, 1024, 5120, 3), (66000, 768, 64, 2),
+                          (66000, 512, 128, 2), (66000, 512, 192, 2), (66000, 512, 256, 2), (66000, 260, 320, 2)):
+        a = (torch.randn(m, k, generator=g) * 0.5).to(dt).cuda()
+        w = (torch.randn(n, k, generator=g) / k ** 0.5).to(dt).cuda()
+        bias = torch.randn(n, generator=g).cuda()
+        _lib.gemm16_variant(1)
+        want = _lib.gemm16(a, w, bias, None, True)
+        _lib.gemm16_variant(2)
+        try:
+            for _ in range(reps):
+                got = _lib.gemm16(a, w, bias, None, True)
+                assert torch.equal(got, want), (m, n, k, int((got != want).sum()))
+        finally:
+            _lib.gemm16_variant(2)
+        del a, w, want, got
 
 
 @torch.no_grad()

@@ -77,11 +77,13 @@ for dt, nm in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")):
         skip = torch.randn(m, n, generator=g).to(dt).cuda()
         flops = 2.0 * m * n * k
         row = {"dtype": nm, "m": m, "n": n, "k": k}
-        ms = timed(lambda: _lib.gemm16(x, w, b32, None, True))
-        row["hip_bias_relu_ms"], row["hip_bias_relu_tflops"] = round(ms, 4), round(flops / ms / 1e9, 1)
         out = skip.clone()
-        ms = timed(lambda: _lib.gemm16(x, w, None, out, True, out=out))
-        row["hip_skip_relu_ms"], row["hip_skip_relu_tflops"] = round(ms, 4), round(flops / ms / 1e9, 1)
+        for v, tag in ((1, "hip_two_stage"), (2, "hip")):
+            _lib.gemm16_variant(v)
+            ms = timed(lambda: _lib.gemm16(x, w, b32, None, True))
+            row[tag + "_bias_relu_ms"], row[tag + "_bias_relu_tflops"] = round(ms, 4), round(flops / ms / 1e9, 1)
+            ms = timed(lambda: _lib.gemm16(x, w, None, out, True, out=out))
+            row[tag + "_skip_relu_ms"], row[tag + "_skip_relu_tflops"] = round(ms, 4), round(flops / ms / 1e9, 1)
         ms = timed(lambda: torch._addmm_activation(bdt, x, w.t()))
         row["library_bias_relu_ms"], row["library_bias_relu_tflops"] = round(ms, 4), round(flops / ms / 1e9, 1)
         out2 = skip.clone()
