@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "dca_engine_profile_builtin", "dca_engine_set_tiers", "dca_engine_debug", "dca_debug_tune", "dca_engine_status", "dca_engine_last_children", "dca_engine_solution",
     "dca_bn_workspace_bytes", "dca_bn_train_forward", "dca_bn_train_backward",
     "dca_l1_supported", "dca_l1_kpad", "dca_l1_onehot_gemm", "dca_act_split", "dca_f16x3_gemm", "dca_split_planes", "dca_f16x3_gemm_variant",
-    "dca_gemm16", "dca_gemm16_variant", "dca_debug_gemm16_profile", "dca_lightsout_next_state", "dca_lightsout_expand_fused",
+    "dca_gemm16", "dca_gemm16_variant", "dca_lightsout_next_state", "dca_lightsout_expand_fused",
 ]
 
 
@@ -417,12 +417,6 @@ def gemm16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], skip:
 def gemm16_variant(v: int) -> None:
     """Tuning / test hook: 2 (default) = 8-phase ping-pong schedule, 1 = two-stage loop (one drain + barrier per K-step)."""
     check(lib().dca_gemm16_variant(int(v)), "dca_gemm16_variant")
-
-
-def gemm16_phase_stamps(stamps: Optional[torch.Tensor]) -> None:
-    """Diagnostic: int64 device tensor of 128 entries -> bf16 launches of the 8-phase kernel stamp their phases there; None = off."""
-    assert stamps is None or (stamps.dtype == torch.int64 and stamps.numel() >= 128 and stamps.is_cuda)
-    check(lib().dca_debug_gemm16_profile(ptr(stamps) if stamps is not None else C.c_void_p(0)), "dca_debug_gemm16_profile")
 
 
 def f16x3_gemm_variant(v: int) -> None:

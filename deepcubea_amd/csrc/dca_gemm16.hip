@@ -38,7 +38,6 @@ struct Gemm16Args {
     const float* bias;   // [n] or null
     const uint16_t* skip;  // [m, ldo] or null (same element type)
     uint16_t* out;       // [m, ldo]
-    unsigned long long* prof;  // diagnostic build only (k_gemm16p<.., true>): phase time stamps of workgroup 0, else null
     int relu;
     int64_t m;
     int n, k;
@@ -243,7 +242,10 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16(const Gemm16Args p) {
 //     carry a counted wait for the half-tile the NEXT phase reads — s_waitcnt vmcnt(10): all but the five youngest
 //     half-tiles have landed.  (First cut, measured: one wait per K-tile, vmcnt(6) in phase 4, B0 re-read in phase 4 — the
 //     youngest half-tile of a tile then has three phases to land, and at 1.5 us of DMA latency under load that set the
-//     K-tile time: 1.0 PF at K = 5120, no better than the two-stage loop.)
+//     K-tile time: 1.0 PF at K = 5120, no better than the two-stage loop.  Also measured: one phase per 32-deep K-tile
+//     over a RING of five 32 KB buffers (all 160 KB of LDS; 12 fragment reads + 16 MFMAs per phase, half the barriers,
+//     every tile three whole phases = 1.5 K-steps to land): 1.06 PF at K = 5120, 0.78 at K = 1024 — the coarser phases
+//     lose what the longer lead gains; this finer interleave stays.)
 // Ordering rules (guide §5, "read a staged buffer one phase AFTER the wait that retires it"):
 //   RAW  every wave waits (vmcnt) BEFORE the first barrier of phase p; the half-tile is first read in phase p+1, which
 //        either group enters only behind a barrier the other group reached after its own wait.
@@ -258,7 +260,7 @@ constexpr int PS_A01 = 0, PS_A23 = 1, PS_B0 = 2, PS_B1 = 3;
 #define DCA_BAR() asm volatile("s_barrier" ::: "memory")
 #define DCA_RD_DONE_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-template <bool BF16, bool PROF = false>
+template <bool BF16>
 __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16p(const Gemm16Args p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     using frag_t = typename std::conditional<BF16, b16x8, h16x8>::type;
@@ -349,24 +351,11 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16p(const Gemm16Args p) {
     // one K-tile; N1 / N2: tiles kt+1 / kt+2 exist (compile-time, so the steady-state body is branch-free).  On entry:
     // issued = all of tile kt and A01, B0, B1 of kt+1; landed and visible = A01, B0 of kt.  The vmcnt numbers count the
     // DMA instructions (2 per half-tile) issued AFTER the half-tile being waited for.
-    // diagnostic build: lane 0 of waves 0 and 4 of workgroup 0 leaves s_memtime stamps of K-tiles [kProfT0, +4) in the LDS
-    // above the operand buffers — 4 per phase: phase entry, reads + DMA issue + vmcnt wait done, first barrier passed,
-    // MFMAs issued
-    constexpr int kProfT0 = 6;
-    auto stamp = [&](int kt, int ph, int pt) {
-        if constexpr (PROF) {
-            if (blockIdx.x == 0 && (w & 3) == 0 && lane == 0 && kt >= kProfT0 && kt < kProfT0 + 4) {
-                volatile unsigned long long* pl = reinterpret_cast<volatile unsigned long long*>(lds + 2 * PBUF);
-                pl[(wm * 4 + (kt - kProfT0)) * 16 + ph * 4 + pt] = __builtin_readcyclecounter();
-            }
-        }
-    };
     auto tile = [&](int kt, auto n1c, auto n2c) {
         constexpr bool N1 = decltype(n1c)::value, N2 = decltype(n2c)::value;
         const int b = kt & 1;
         const uint8_t* base = lds + b * PBUF;
         // phase 1: (A01, B0); restage A23 of kt+1 (last read: phase 3 of kt-1); retire B1 of kt
-        stamp(kt, 0, 0);
         read_b(base, PS_B0, wv0);
         read_a(base, PS_A01);
         if constexpr (N1) {
@@ -375,14 +364,10 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16p(const Gemm16Args p) {
         } else {
             DCA_VMCNT(2);   // behind B1(kt): A23(kt)
         }
-        stamp(kt, 0, 1);
         DCA_RD_DONE_BAR();
-        stamp(kt, 0, 2);
         DCA_MMA8(0, 0, wv0);
-        stamp(kt, 0, 3);
         DCA_BAR();
         // phase 2: (A01, B1); restage A01 of kt+2 (last read: phase 1); retire A23 of kt
-        stamp(kt, 1, 0);
         read_b(base, PS_B1, wv1);
         if constexpr (N2) {
             issue(PS_A01, b, (kt + 2) * QBK);
@@ -392,35 +377,24 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16p(const Gemm16Args p) {
         } else {
             DCA_VMCNT(0);
         }
-        stamp(kt, 1, 1);
         DCA_RD_DONE_BAR();
-        stamp(kt, 1, 2);
         DCA_MMA8(0, 1, wv1);
-        stamp(kt, 1, 3);
         DCA_BAR();
         // phase 3: (A23, B1); restage B0 of kt+2 (read once, in phase 1: its fragments stay in registers for phase 4)
-        stamp(kt, 2, 0);
         read_a(base, PS_A23);
         if constexpr (N2) issue(PS_B0, b, (kt + 2) * QBK);
-        stamp(kt, 2, 1);
         DCA_RD_DONE_BAR();
-        stamp(kt, 2, 2);
         DCA_MMA8(2, 1, wv1);
-        stamp(kt, 2, 3);
         DCA_BAR();
         // phase 4: (A23, B0) from registers; restage B1 of kt+2 (last read: phase 2); retire A01, B0 of kt+1
-        stamp(kt, 3, 0);
         if constexpr (N2) {
             issue(PS_B1, b, (kt + 2) * QBK);
             DCA_VMCNT(10);  // behind B0(kt+1): B1 A23 (kt+1), A01 B0 B1 (kt+2)
         } else if constexpr (N1) {
             DCA_VMCNT(4);   // behind B0(kt+1): B1 A23 (kt+1)
         }
-        stamp(kt, 3, 1);
         DCA_RD_DONE_BAR();
-        stamp(kt, 3, 2);
         DCA_MMA8(2, 0, wv0);
-        stamp(kt, 3, 3);
         DCA_BAR();
     };
 
@@ -449,11 +423,6 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16p(const Gemm16Args p) {
     }
     if (wm == 0) DCA_BAR();  // ... and the first waits for it here
 #undef DCA_VMCNT
-    if constexpr (PROF) {
-        __syncthreads();
-        if (blockIdx.x == 0 && t < 128 && p.prof)
-            p.prof[t] = reinterpret_cast<const volatile unsigned long long*>(lds + 2 * PBUF)[t];
-    }
 #undef DCA_MMA8
 
     gemm16_epilogue<BF16>(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h);
@@ -464,7 +433,6 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16p(const Gemm16Args p) {
 using namespace dca;
 
 static int g_gemm16_variant = 2;
-static unsigned long long* g_gemm16_prof = nullptr;  // device buffer of 128 stamps: the next bf16 launches run the diagnostic build
 
 extern "C" {
 
@@ -472,13 +440,6 @@ extern "C" {
 int dca_gemm16_variant(int v) {
     DCA_ARG(v == 1 || v == 2);
     g_gemm16_variant = v;
-    return 0;
-}
-
-/* diagnostic hook (tools/gemm16_phase_probe.py): with a device buffer of 128 u64, bf16 launches of variant 2 run a build that
- * stamps s_memtime at four points of every phase of K-tiles 6..9 in workgroup 0 (waves 0 and 4); NULL switches it off. */
-int dca_debug_gemm16_profile(unsigned long long* stamps) {
-    g_gemm16_prof = stamps;
     return 0;
 }
 
@@ -499,8 +460,6 @@ int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int 
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16p<true>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16p<false>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
-            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16p<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        QLDS + 1024));
             attr_devs.fetch_or(bit, std::memory_order_release);
         }
     }
@@ -511,7 +470,6 @@ int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int 
     p.skip = reinterpret_cast<const uint16_t*>(skip);
     p.out = reinterpret_cast<uint16_t*>(out);
     p.relu = relu;
-    p.prof = g_gemm16_prof;
     p.m = m;
     p.n = n;
     p.k = k;
@@ -527,9 +485,7 @@ int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int 
     }
     const dim3 grid((unsigned)blocks), block(QTHREADS);
     if (g_gemm16_variant == 2) {
-        if (dtype == DCA_DT_BF16 && g_gemm16_prof)
-            hipLaunchKernelGGL((k_gemm16p<true, true>), grid, block, QLDS + 1024, (hipStream_t)stream, p);
-        else if (dtype == DCA_DT_BF16)
+        if (dtype == DCA_DT_BF16)
             hipLaunchKernelGGL(k_gemm16p<true>, grid, block, QLDS, (hipStream_t)stream, p);
         else
             hipLaunchKernelGGL(k_gemm16p<false>, grid, block, QLDS, (hipStream_t)stream, p);

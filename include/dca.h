@@ -340,10 +340,6 @@ int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int 
  * queue never drained); 1 = two whole K-step stages with one drain + barrier per K-step (the A/B reference).  Bit-identical
  * results (same accumulation order). */
 int dca_gemm16_variant(int variant);
-/* diagnostic hook (tools/gemm16_phase_probe.py): with a device buffer of 128 u64, the next bf16 launches of variant 2 run a
- * build that leaves s_memtime stamps of K-tiles 6..9 of workgroup 0 there ([wave row 0|1][tile 0..3][phase 0..3][entry, reads
- * issued + vmcnt wait done, first barrier passed, MFMAs issued]); NULL switches it off.  Never on in production. */
-int dca_debug_gemm16_profile(unsigned long long* stamps);
 /* fp32 [m, n] (row stride ld) -> its fp16 planes (row stride ldo); n % 4 == 0 */
 int dca_split_planes(const float* x, int64_t m, int64_t n, int64_t ld, void* out_h, void* out_l, int64_t ldo,
                      int* overflow /*or NULL*/, void* stream);
