@@ -21,6 +21,7 @@
 // (2 x 64 KB LDS, <= 256 VGPRs) overlap one group's staging with the other's MFMAs.  Workgroup ids are remapped so that
 // the N tiles sharing an A tile run on ONE XCD (its L2 then reads the A tile from HBM once).
 #include <atomic>
+#include <type_traits>
 
 #include "dca_common.h"
 
@@ -196,6 +197,86 @@ constexpr int HLDS = 2 * HSTAGE;      // two stages: 128 KB
 
 __device__ __forceinline__ uint32_t swz64(uint32_t row, uint32_t chunk) { return row * 64u + ((chunk ^ ((row >> 2) & 3u)) << 4); }
 
+// Layer tail of the 256 x 256 kernels (shared by the two-stage and the ping-pong schedule).
+__device__ __forceinline__ void f16x3_epilogue(const GemmArgs& p, uint8_t* lds, f32x16 (&acc)[4][2], int64_t m0, int n0, int w, int wm,
+                                               int wn, int lane, int l31, int h) {
+    // epilogue.  The accumulator layout (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) would make
+    // every store a 4-byte (fp32) or 2-byte (planes) column access — measured 1.8 ms per layer, more than the K loop.  So
+    // each wave transposes its tile through its own 16 KB of the (now idle) LDS, 32 rows at a time, and leaves with
+    // 16-byte accesses: a lane owns 4 consecutive columns of a row — one float4 skip load, one float4 store, two 8-byte
+    // plane stores; 16 lanes cover a row's 256 contiguous bytes.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the operand stages
+    float* sl = reinterpret_cast<float*>(lds + w * 16384);
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    float cs[2], bv[2];
+#pragma unroll
+    for (int jn = 0; jn < 2; jn++) {
+        const int col = n0 + wn * 64 + jn * 32 + l31;
+        const bool cv = col < p.n;
+        cs[jn] = cv ? (p.col_scale ? p.alpha * p.col_scale[col] : p.alpha) : 0.f;
+        bv[jn] = (cv && p.bias) ? p.bias[col] : 0.f;
+    }
+    const int c4 = (lane & 15) * 4;              // this lane's 4 columns inside the wave's 64
+    const int colg = n0 + wn * 64 + c4;
+    const bool full4 = colg + 3 < p.n;
+    bool ovf = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int jn = 0; jn < 2; jn++)
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++)
+                sl[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 64 + jn * 32 + l31] = acc[i][jn][reg] * cs[jn] + bv[jn];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private slice: no barrier, just the wave's own writes
+        const int64_t rbase = m0 + wm * 128 + i * 32;
+        float4 sk[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int64_t r = rbase + q * 4 + (lane >> 4);
+            sk[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.skip && r < p.m && full4) sk[q] = *reinterpret_cast<const float4*>(p.skip + r * p.ldo + colg);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int rl = q * 4 + (lane >> 4);
+            const int64_t r = rbase + rl;
+            const float4 v = *reinterpret_cast<const float4*>(sl + rl * 64 + c4);
+            if (r >= p.m) continue;
+            float u[4] = {v.x + sk[q].x, v.y + sk[q].y, v.z + sk[q].z, v.w + sk[q].w};
+            const int64_t o = r * p.ldo + colg;
+            if (full4) {
+                h4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (p.relu) u[e] = fmaxf(u[e], 0.f);
+                    ovf |= !(fabsf(u[e]) <= 60000.0f);
+                    hi[e] = (_Float16)u[e];
+                    lo[e] = (_Float16)(u[e] - (float)hi[e]);
+                }
+                if (p.x_out) *reinterpret_cast<float4*>(p.x_out + o) = make_float4(u[0], u[1], u[2], u[3]);
+                if (p.oh) {
+                    *reinterpret_cast<h4*>(p.oh + o) = hi;
+                    *reinterpret_cast<h4*>(p.ol + o) = lo;
+                }
+            } else {  // ragged right edge (n not a multiple of 4 columns here): element-wise
+                for (int e = 0; e < 4 && colg + e < p.n; e++) {
+                    float ue = u[e] + (p.skip ? p.skip[o + e] : 0.f);
+                    if (p.relu) ue = fmaxf(ue, 0.f);
+                    ovf |= !(fabsf(ue) <= 60000.0f);
+                    if (p.x_out) p.x_out[o + e] = ue;
+                    if (p.oh) {
+                        const _Float16 hh = (_Float16)ue;
+                        p.oh[o + e] = hh;
+                        p.ol[o + e] = (_Float16)(ue - (float)hh);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slice is rewritten by the next 32 rows
+    }
+    if (ovf && p.oh && p.overflow) *p.overflow = 1;
+}
+
 __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v2(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, h = lane >> 5;
@@ -283,81 +364,202 @@ __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v2(const GemmArgs p)
         }
     }
 
-    // epilogue.  The accumulator layout (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) would make
-    // every store a 4-byte (fp32) or 2-byte (planes) column access — measured 1.8 ms per layer, more than the K loop.  So
-    // each wave transposes its tile through its own 16 KB of the (now idle) LDS, 32 rows at a time, and leaves with
-    // 16-byte accesses: a lane owns 4 consecutive columns of a row — one float4 skip load, one float4 store, two 8-byte
-    // plane stores; 16 lanes cover a row's 256 contiguous bytes.
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the operand stages
-    float* sl = reinterpret_cast<float*>(lds + w * 16384);
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    float cs[2], bv[2];
+    f16x3_epilogue(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// v3 (default): the same tile and the same per-accumulator order of products as v2 (bit-identical results) on the
+// ping-pong schedule of csrc/dca_gemm16.hip (variant 2; the derivation and the RAW / WAR argument are written out there):
+// the two wave rows run one barrier apart — one issues the 12 MFMAs of its phase while the other reads the fragments of
+// the next and issues DMA — a K-step (64 KB) is staged as four 16 KB half-tiles (A01 / A23 = each wave row's first / last
+// two 32-row blocks, B0 / B1 = each wave column's first / last 32 columns; both fp16 planes of those rows, 64 B per row
+// per plane), one restaged per phase, every half-tile given five phases to land, counted s_waitcnt vmcnt(10) — the DMA
+// queue is never drained.  Phases: (A01,B0) (A01,B1) (A23,B1) (A23,B0); B0's fragments stay in registers for the fourth.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int PSLOT3 = 2 * 128 * 64;  // one half-tile: two planes of 128 rows x 64 B
+constexpr int PBUF3 = 4 * PSLOT3;     // one K-step: A01 | A23 | B0 | B1
+constexpr int PS_A01 = 0, PS_A23 = 1, PS_B0 = 2, PS_B1 = 3;
+
+#define DCA_BAR() asm volatile("s_barrier" ::: "memory")
+#define DCA_RD_DONE_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define DCA_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
+__global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v3(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, h = lane >> 5;
+    const int wm = w >> 2, wn = w & 3;
+    const int nNt = (p.n + HBN_T - 1) / HBN_T;
+    const int64_t nMt = (p.m + HBM_T - 1) / HBM_T;
+    const int64_t bid = blockIdx.x;
+    const int64_t slot = bid >> 3;
+    const int64_t mt = (slot / nNt) * 8 + (bid & 7);  // the N tiles of one M tile sit on one XCD
+    const int nt = (int)(slot % nNt);
+    if (mt >= nMt) return;
+    const int64_t m0 = mt * HBM_T;
+    const int n0 = nt * HBN_T;
+
+    // DMA map: instruction q (0 = high plane, 1 = low plane) of wave w fills local rows [w*16, +16) of that plane of a
+    // half-tile slot; lane i lands on local row r = w*16 + (i >> 2), physical chunk i & 3, and fetches logical chunk
+    // (i & 3) ^ ((r >> 2) & 3) of the matrix row the slot's local row r stands for.
+    const _Float16* src[4][2];
+    {
+        const uint32_t r = (uint32_t)(w * 16 + (lane >> 2));
+        const uint32_t c = (uint32_t)(lane & 3) ^ ((r >> 2) & 3u);
 #pragma unroll
-    for (int jn = 0; jn < 2; jn++) {
-        const int col = n0 + wn * 64 + jn * 32 + l31;
-        const bool cv = col < p.n;
-        cs[jn] = cv ? (p.col_scale ? p.alpha * p.col_scale[col] : p.alpha) : 0.f;
-        bv[jn] = (cv && p.bias) ? p.bias[col] : 0.f;
+        for (int u = 0; u < 4; u++) {
+            if (u < 2) {
+                int64_t gr = m0 + (r >> 6) * 128 + (u == PS_A23 ? 64 : 0) + (r & 63);
+                gr = gr < p.m ? gr : p.m - 1;
+                src[u][0] = p.ah + gr * p.lda + c * 8;
+                src[u][1] = p.al + gr * p.lda + c * 8;
+            } else {
+                int gn = n0 + (int)((r >> 5) * 64 + (u == PS_B1 ? 32 : 0) + (r & 31));
+                gn = gn < p.n ? gn : p.n - 1;
+                src[u][0] = p.wh + (int64_t)gn * p.ldw + c * 8;
+                src[u][1] = p.wl + (int64_t)gn * p.ldw + c * 8;
+            }
+        }
     }
-    const int c4 = (lane & 15) * 4;              // this lane's 4 columns inside the wave's 64
-    const int colg = n0 + wn * 64 + c4;
-    const bool full4 = colg + 3 < p.n;
-    bool ovf = false;
+    auto issue = [&](int u, int buf, int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+        for (int q = 0; q < 2; q++) {
+            uint8_t* dst = lds + buf * PBUF3 + u * PSLOT3 + q * 8192 + w * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[u][q] + k0),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int jn = 0; jn < 2; jn++)
 #pragma unroll
-            for (int reg = 0; reg < 16; reg++)
-                sl[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 64 + jn * 32 + l31] = acc[i][jn][reg] * cs[jn] + bv[jn];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private slice: no barrier, just the wave's own writes
-        const int64_t rbase = m0 + wm * 128 + i * 32;
-        float4 sk[8];
+            for (int e = 0; e < 16; e++) acc[i][jn][e] = 0.f;
+
+    // fragment addresses inside a plane of a slot: local row = (wave's block) * 32 + l31, logical chunk 2 s + h
+    uint32_t foff[2];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int64_t r = rbase + q * 4 + (lane >> 4);
-            sk[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.skip && r < p.m && full4) sk[q] = *reinterpret_cast<const float4*>(p.skip + r * p.ldo + colg);
-        }
+    for (int s = 0; s < 2; s++) foff[s] = swz64((uint32_t)l31, 2u * s + (uint32_t)h);
+    const uint32_t a_row0 = (uint32_t)wm * 64u * 64u;  // A slots: this wave row's 64 local rows
+    const uint32_t b_row0 = (uint32_t)wn * 32u * 64u;  // B slots: this wave column's 32 local rows
+
+    f16x8 avh[2][2], avl[2][2], wh0[2], wl0[2], wh1[2], wl1[2];
+    auto read_a = [&](const uint8_t* base, int u) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int rl = q * 4 + (lane >> 4);
-            const int64_t r = rbase + rl;
-            const float4 v = *reinterpret_cast<const float4*>(sl + rl * 64 + c4);
-            if (r >= p.m) continue;
-            float u[4] = {v.x + sk[q].x, v.y + sk[q].y, v.z + sk[q].z, v.w + sk[q].w};
-            const int64_t o = r * p.ldo + colg;
-            if (full4) {
-                h4 hi, lo;
+        for (int ii = 0; ii < 2; ii++)
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    if (p.relu) u[e] = fmaxf(u[e], 0.f);
-                    ovf |= !(fabsf(u[e]) <= 60000.0f);
-                    hi[e] = (_Float16)u[e];
-                    lo[e] = (_Float16)(u[e] - (float)hi[e]);
-                }
-                if (p.x_out) *reinterpret_cast<float4*>(p.x_out + o) = make_float4(u[0], u[1], u[2], u[3]);
-                if (p.oh) {
-                    *reinterpret_cast<h4*>(p.oh + o) = hi;
-                    *reinterpret_cast<h4*>(p.ol + o) = lo;
-                }
-            } else {  // ragged right edge (n not a multiple of 4 columns here): element-wise
-                for (int e = 0; e < 4 && colg + e < p.n; e++) {
-                    float ue = u[e] + (p.skip ? p.skip[o + e] : 0.f);
-                    if (p.relu) ue = fmaxf(ue, 0.f);
-                    ovf |= !(fabsf(ue) <= 60000.0f);
-                    if (p.x_out) p.x_out[o + e] = ue;
-                    if (p.oh) {
-                        const _Float16 hh = (_Float16)ue;
-                        p.oh[o + e] = hh;
-                        p.ol[o + e] = (_Float16)(ue - (float)hh);
-                    }
-                }
+            for (int s = 0; s < 2; s++) {
+                avh[ii][s] = *reinterpret_cast<const f16x8*>(base + u * PSLOT3 + a_row0 + ii * 2048 + foff[s]);
+                avl[ii][s] = *reinterpret_cast<const f16x8*>(base + u * PSLOT3 + 8192 + a_row0 + ii * 2048 + foff[s]);
             }
+    };
+    auto read_b = [&](const uint8_t* base, int u, f16x8 (&wh)[2], f16x8 (&wl)[2]) {
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            wh[s] = *reinterpret_cast<const f16x8*>(base + u * PSLOT3 + b_row0 + foff[s]);
+            wl[s] = *reinterpret_cast<const f16x8*>(base + u * PSLOT3 + 8192 + b_row0 + foff[s]);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slice is rewritten by the next 32 rows
+    };
+    // 12 MFMAs: per accumulator the order of v2 (low x high, high x low, high x high, K ascending), the two accumulators
+    // of the phase interleaved so that no MFMA waits on the one before it
+#define DCA_MMA12(I0, JN, WH, WL)                                                                                       \
+    do {                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        __builtin_amdgcn_s_setprio(1);                                                                                  \
+        _Pragma("unroll") for (int s = 0; s < 2; s++) {                                                                 \
+            _Pragma("unroll") for (int ii = 0; ii < 2; ii++)                                                            \
+                acc[(I0) + ii][JN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl[ii][s], WH[s], acc[(I0) + ii][JN], 0, 0, 0); \
+            _Pragma("unroll") for (int ii = 0; ii < 2; ii++)                                                            \
+                acc[(I0) + ii][JN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[ii][s], WL[s], acc[(I0) + ii][JN], 0, 0, 0); \
+            _Pragma("unroll") for (int ii = 0; ii < 2; ii++)                                                            \
+                acc[(I0) + ii][JN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[ii][s], WH[s], acc[(I0) + ii][JN], 0, 0, 0); \
+        }                                                                                                               \
+        __builtin_amdgcn_s_setprio(0);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    } while (0)
+
+    const int nk = p.k / HBK;
+    // one K-step; N1 / N2: steps kt+1 / kt+2 exist (compile-time: the steady-state body is branch-free).  On entry:
+    // issued = all of step kt and A01, B0, B1 of kt+1; landed and visible = A01, B0 of kt.  The vmcnt numbers count the
+    // DMA instructions (2 per half-tile) issued AFTER the half-tile being waited for.
+    auto step = [&](int kt, auto n1c, auto n2c) {
+        constexpr bool N1 = decltype(n1c)::value, N2 = decltype(n2c)::value;
+        const int b = kt & 1;
+        const uint8_t* base = lds + b * PBUF3;
+        // phase 1: (A01, B0); restage A23 of kt+1; retire B1 of kt
+        read_b(base, PS_B0, wh0, wl0);
+        read_a(base, PS_A01);
+        if constexpr (N1) {
+            issue(PS_A23, b ^ 1, (kt + 1) * HBK);
+            DCA_VMCNT(10);  // behind B1(kt): A23(kt), A01 B0 B1 A23 (kt+1)
+        } else {
+            DCA_VMCNT(2);   // behind B1(kt): A23(kt)
+        }
+        DCA_RD_DONE_BAR();
+        DCA_MMA12(0, 0, wh0, wl0);
+        DCA_BAR();
+        // phase 2: (A01, B1); restage A01 of kt+2; retire A23 of kt
+        read_b(base, PS_B1, wh1, wl1);
+        if constexpr (N2) {
+            issue(PS_A01, b, (kt + 2) * HBK);
+            DCA_VMCNT(10);  // behind A23(kt): A01 B0 B1 A23 (kt+1), A01(kt+2)
+        } else if constexpr (N1) {
+            DCA_VMCNT(8);
+        } else {
+            DCA_VMCNT(0);
+        }
+        DCA_RD_DONE_BAR();
+        DCA_MMA12(0, 1, wh1, wl1);
+        DCA_BAR();
+        // phase 3: (A23, B1); restage B0 of kt+2
+        read_a(base, PS_A23);
+        if constexpr (N2) issue(PS_B0, b, (kt + 2) * HBK);
+        DCA_RD_DONE_BAR();
+        DCA_MMA12(2, 1, wh1, wl1);
+        DCA_BAR();
+        // phase 4: (A23, B0) from registers; restage B1 of kt+2; retire A01, B0 of kt+1
+        if constexpr (N2) {
+            issue(PS_B1, b, (kt + 2) * HBK);
+            DCA_VMCNT(10);  // behind B0(kt+1): B1 A23 (kt+1), A01 B0 B1 (kt+2)
+        } else if constexpr (N1) {
+            DCA_VMCNT(4);   // behind B0(kt+1): B1 A23 (kt+1)
+        }
+        DCA_RD_DONE_BAR();
+        DCA_MMA12(2, 0, wh0, wl0);
+        DCA_BAR();
+    };
+
+    issue(PS_A01, 0, 0);
+    issue(PS_B0, 0, 0);
+    issue(PS_B1, 0, 0);
+    issue(PS_A23, 0, 0);
+    if (nk > 1) {
+        issue(PS_A01, 1, HBK);
+        issue(PS_B0, 1, HBK);
+        issue(PS_B1, 1, HBK);
+        DCA_VMCNT(10);  // A01, B0 of step 0 have landed
+    } else {
+        DCA_VMCNT(4);
     }
-    if (ovf && p.oh && p.overflow) *p.overflow = 1;
+    DCA_BAR();
+    if (wm == 1) DCA_BAR();  // the second wave row runs one barrier behind the first from here on
+    {
+        int kt = 0;
+        for (; kt + 2 < nk; kt++) step(kt, std::true_type{}, std::true_type{});
+        if (kt + 1 < nk) {
+            step(kt, std::true_type{}, std::false_type{});
+            kt++;
+        }
+        step(kt, std::false_type{}, std::false_type{});
+    }
+    if (wm == 0) DCA_BAR();  // ... and the first waits for it here
+#undef DCA_MMA12
+#undef DCA_VMCNT
+#undef DCA_RD_DONE_BAR
+#undef DCA_BAR
+
+    f16x3_epilogue(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h);
 }
 
 // fp32 [m, n] (row stride ld) -> its two fp16 planes (and the overflow flag): the entry into an f16x3 layer for
@@ -388,13 +590,15 @@ __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ 
 
 using namespace dca;
 
-static int g_gemm_variant = 2;
+static int g_gemm_variant = 0;
 
 extern "C" {
 
-/* tuning / test hook: 1 = the register-staged 128 x 128 kernel, 2 (default) = the LDS-DMA 256 x 256 kernel */
+/* tuning / test hook: 1 = the register-staged 128 x 128 kernel, 2 = the LDS-DMA 256 x 256 kernel with two whole-K-step stages,
+ * 3 = the same tile on the ping-pong / half-tile schedule (bit-identical to 2), 0 (default) = 3 for k >= 2048, else 2 (measured
+ * at 204 800 x 1024: k = 5120 5.71 vs 5.96 ms, k = 1024 1.56 vs 1.47 ms) */
 int dca_f16x3_gemm_variant(int v) {
-    DCA_ARG(v == 1 || v == 2);
+    DCA_ARG(v >= 0 && v <= 3);
     g_gemm_variant = v;
     return 0;
 }
@@ -415,6 +619,7 @@ int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t l
         if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f16x3_gemm_v1), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS));
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f16x3_gemm_v2), hipFuncAttributeMaxDynamicSharedMemorySize, HLDS));
+            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f16x3_gemm_v3), hipFuncAttributeMaxDynamicSharedMemorySize, HLDS));
             attr_devs.fetch_or(bit, std::memory_order_release);
         }
     }
@@ -442,7 +647,8 @@ int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t l
     // has them); anything else takes the register-staged kernel
     const bool wide_ok = ldo % 4 == 0 && ((uintptr_t)out_h | (uintptr_t)out_l) % 8 == 0 &&
                          ((uintptr_t)x_out | (uintptr_t)skip) % 16 == 0;
-    const int variant = (g_gemm_variant == 2 && wide_ok) ? 2 : 1;
+    const int want = g_gemm_variant == 0 ? (k >= 2048 ? 3 : 2) : g_gemm_variant;
+    const int variant = (want >= 2 && wide_ok) ? want : 1;
     const int bm = variant == 1 ? GBM : HBM_T, bn = variant == 1 ? GBN : HBN_T;
     const int64_t nMt = (m + bm - 1) / bm;
     const int64_t nNt = (n + bn - 1) / bn;
@@ -453,8 +659,10 @@ int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t l
     }
     if (variant == 1)
         hipLaunchKernelGGL(k_f16x3_gemm_v1, dim3((unsigned)blocks), dim3(GTHREADS), GLDS, (hipStream_t)stream, p);
-    else
+    else if (variant == 2)
         hipLaunchKernelGGL(k_f16x3_gemm_v2, dim3((unsigned)blocks), dim3(HTHREADS), HLDS, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(k_f16x3_gemm_v3, dim3((unsigned)blocks), dim3(HTHREADS), HLDS, (hipStream_t)stream, p);
     return launch_check("k_f16x3_gemm");
 }
 

@@ -44,12 +44,12 @@ for n, k in ((1024, 1024), (1024, 5120)):
     a3, _ = _lib.act_split(x, None, None, 1.0, False, False)
     flops = 2.0 * m * n * k * 3
     row = {"m": m, "n": n, "k": k}
-    for v in (2, 1):
+    for v in (3, 2, 1):
         _lib.f16x3_gemm_variant(v)
         ms = timed(lambda: _lib.f16x3_gemm(planes, whc, wlc, inv, 1.0, b, skip, True, True, True))
         row["hip_v%d_ms" % v] = round(ms, 4)
         row["hip_v%d_mfma_tflops" % v] = round(flops / ms / 1e9, 1)
-    _lib.f16x3_gemm_variant(2)
+    _lib.f16x3_gemm_variant(0)
 
     def lib_layer():
         y = torch.mm(a3, w3.t(), out_dtype=torch.float32)
