@@ -423,7 +423,7 @@ def run_astar_concurrent(args, world, rank, sem, hid):
             "how": "one engine, every kernel launched once for all instances (grid.y = instance)"}
 
 
-def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool = False, gemm16: str = "auto"):
+def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool = False, gemm16: str = "library"):
     """Same loop, heuristic = ResNet(54*6 -> 5000 -> 1000 -> 4 res blocks -> 1) on PyTorch-ROCm, synthetic weights
     (numpy PCG64 seed 2024).  Default = the CLI's default path: dedup-first engine stepping (only the children that
     survive the CLOSED check are evaluated — same search, astar.py:272-282) + the padded / epilogue-fused network
@@ -495,10 +495,8 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
             "layer1": "library GEMM on one-hot rows" if eval_all_children or not fast.uses_l1_kernel
             else "dca_l1_onehot_gemm (hand-written MFMA, %d bf16 plane(s))" % fast.l1_planes,
             "dense_layers": ("library fp32 GEMMs" if eval_all_children else "dca_f16x3_gemm (hand-written MFMA, epilogue-fused)")
-            if dtype_name == "fp32" else {"hip": "dca_gemm16 (hand-written MFMA, epilogue-fused) for every layer",
-                                          "library": "library (hipBLASLt) GEMMs + clamp pass",
-                                          "auto": "dca_gemm16 (hand-written MFMA: residual add + ReLU + rounding in the epilogue) for the "
-                                                  "layers closing a residual block, library (hipBLASLt) bias+ReLU GEMMs for the others"}[gemm16],
+            if dtype_name == "fp32" else ("dca_gemm16 (hand-written MFMA, epilogue-fused)" if gemm16 == "hip"
+                                          else "library (hipBLASLt) GEMMs + clamp pass"),
             "network_rows_per_step": rows, "children_per_step": B * A,
             "heuristic_tflops_per_gpu": flops / (wall / steps) / 1e12,
             # fp32 default path = f16x3 split layers: 3 f16 MFMA flops per useful flop -> ceiling 2500/3 "fp32-equivalent"
@@ -762,7 +760,6 @@ def main():
         line["end_to_end_nnet"] = {"fp32": run_astar_nnet(args, world, rank, "fp32"),
                                    "bf16": run_astar_nnet(args, world, rank, "bf16"),
                                    "bf16_hand_written_gemm": run_astar_nnet(args, world, rank, "bf16", gemm16="hip"),
-                                   "bf16_library_gemm": run_astar_nnet(args, world, rank, "bf16", gemm16="library"),
                                    "fp32_eval_all_children": run_astar_nnet(args, world, rank, "fp32", True)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("astar", "expand"):
         if args.workload == "expand":

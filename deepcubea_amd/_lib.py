@@ -420,6 +420,6 @@ def gemm16_variant(v: int) -> None:
 
 
 def f16x3_gemm_variant(v: int) -> None:
-    """Tuning / test hook: 3 = LDS-DMA 256x256 kernel on the ping-pong schedule, 2 = the same tile with two whole-K-step stages
-    (bit-identical), 0 (default) = 3 for k >= 2048 else 2, 1 = register-staged 128x128 kernel."""
+    """Tuning / test hook: 3 (default) = LDS-DMA 256x256 kernel on the ping-pong schedule, 2 = the same tile with two whole-K-step
+    stages (bit-identical), 1 = register-staged 128x128 kernel."""
     check(lib().dca_f16x3_gemm_variant(int(v)), "dca_f16x3_gemm_variant")

@@ -590,15 +590,15 @@ __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ 
 
 using namespace dca;
 
-static int g_gemm_variant = 0;
+static int g_gemm_variant = 3;
 
 extern "C" {
 
 /* tuning / test hook: 1 = the register-staged 128 x 128 kernel, 2 = the LDS-DMA 256 x 256 kernel with two whole-K-step stages,
- * 3 = the same tile on the ping-pong / half-tile schedule (bit-identical to 2), 0 (default) = 3 for k >= 2048, else 2 (measured
- * at 204 800 x 1024: k = 5120 5.71 vs 5.96 ms, k = 1024 1.56 vs 1.47 ms) */
+ * 3 (default) = the same tile on the ping-pong / half-tile schedule (bit-identical to 2; measured at 204 800 x 1024, candidates
+ * taking turns: k = 1024 1.42 vs 1.47 ms, k = 5120 5.67 vs 6.07 ms) */
 int dca_f16x3_gemm_variant(int v) {
-    DCA_ARG(v >= 0 && v <= 3);
+    DCA_ARG(v >= 1 && v <= 3);
     g_gemm_variant = v;
     return 0;
 }
@@ -647,8 +647,7 @@ int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t l
     // has them); anything else takes the register-staged kernel
     const bool wide_ok = ldo % 4 == 0 && ((uintptr_t)out_h | (uintptr_t)out_l) % 8 == 0 &&
                          ((uintptr_t)x_out | (uintptr_t)skip) % 16 == 0;
-    const int want = g_gemm_variant == 0 ? (k >= 2048 ? 3 : 2) : g_gemm_variant;
-    const int variant = (want >= 2 && wide_ok) ? want : 1;
+    const int variant = (g_gemm_variant >= 2 && wide_ok) ? g_gemm_variant : 1;
     const int bm = variant == 1 ? GBM : HBM_T, bn = variant == 1 ? GBN : HBN_T;
     const int64_t nMt = (m + bm - 1) / bm;
     const int64_t nNt = (n + bn - 1) / bn;

@@ -180,7 +180,7 @@ class FastResnet(nn.Module):
     written by the engine's pack kernel through `forward_onehot`.  fp32 is the 1e-5 parity mode."""
 
     def __init__(self, model: ResnetModel, dtype: torch.dtype = torch.float32, split: bool = True, gemm: str = "hip",
-                 gemm16: str = "auto"):
+                 gemm16: str = "library"):
         super().__init__()
         m = fold_batchnorm(model)
         self.state_dim, self.one_hot_depth = m.state_dim, m.one_hot_depth
@@ -229,14 +229,13 @@ class FastResnet(nn.Module):
         # f16 GEMM over the 3x-wide interleaved operand plus the dca_act_split glue kernel per layer (kept for comparison)
         self.gemm = gemm
         assert gemm in ("hip", "library")
-        # bf16 / fp16 (non-parity) modes.  "library" = hipBLASLt GEMMs with fused bias+ReLU; a residual block's closing layer
-        # costs it an extra pass (GEMM into the skip, then a separate ReLU).  "hip" = one dca_gemm16 launch per layer, whole
-        # tail (bias, residual add, ReLU, rounding) in the epilogue (csrc/dca_gemm16.hip).  Measured per layer at 204 800 rows
-        # (profiles/r03_gemm_bench.txt, ms, hip / library): 5120->1024 bias+ReLU 1.93 / 1.67, 1024->1024 bias+ReLU 0.54 / 0.46,
-        # 1024->1024 residual+ReLU 0.57 / 0.67.  "auto" (default) takes each layer where it is faster: the hand-written kernel
-        # for the layers that close a residual block, the library for the plain ones.
+        # bf16 / fp16 (non-parity) modes.  "library" (default) = hipBLASLt GEMMs with fused bias+ReLU, plus one ReLU pass per
+        # residual block; "hip" = one dca_gemm16 launch per layer, whole tail (bias, residual add, ReLU, rounding) in the
+        # epilogue (csrc/dca_gemm16.hip).  Measured per layer at 204 800 rows, candidates taking turns
+        # (profiles/r03_gemm_bench.txt, ms, hip / library): 5120->1024 bias+ReLU 1.98 / 1.67, 1024->1024 bias+ReLU 0.54 / 0.41,
+        # 1024->1024 residual+ReLU 0.57 / 0.56 — the library's hand-scheduled assembly kernels still lead, so they stay the default.
         self.gemm16 = gemm16
-        assert gemm16 in ("auto", "hip", "library")
+        assert gemm16 in ("hip", "library")
         # set by the split kernels when a value does not fit fp16 (|v| > 60000): that batch is redone with fp32 GEMMs
         self.register_buffer("_overflow", torch.zeros(1, dtype=torch.int32), persistent=False)
         self.split_fallbacks = 0
@@ -319,16 +318,12 @@ class FastResnet(nn.Module):
         and the rounding to 16 bits in its epilogue (csrc/dca_gemm16.hip).  Otherwise (the default for the 16-bit modes, fp32
         without the split, the host): library GEMMs with fused epilogues."""
         W, B = self.weights, self.biases
-        if x.is_cuda and self.gemm16 != "library" and self.dtype in (torch.bfloat16, torch.float16) and x.dtype == self.dtype:
+        if x.is_cuda and self.gemm16 == "hip" and self.dtype in (torch.bfloat16, torch.float16) and x.dtype == self.dtype:
             from .. import _lib
             Bf = self.biases_f32
-            if self.gemm16 == "hip":
-                plain = lambda a, k: _lib.gemm16(a, W[k], Bf[k], None, True)
-            else:
-                plain = lambda a, k: torch._addmm_activation(B[k], a, W[k].t())
-            x = plain(x.contiguous(), 1)
+            x = _lib.gemm16(x.contiguous(), W[1], Bf[1], None, True)
             for k in range(2, len(W), 2):
-                h = plain(x, k)
+                h = _lib.gemm16(x, W[k], Bf[k], None, True)
                 x = _lib.gemm16(h, W[k + 1], None, x, True, out=x)  # (the block's second bias rides in W through h's constant-one unit)
             return (x @ self.w_out.t()).float() + self.b_out
         x = torch._addmm_activation(B[1], x, W[1].t())

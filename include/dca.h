@@ -323,10 +323,10 @@ int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t l
                    int64_t ldw, const float* col_scale /*[n] or NULL*/, double alpha, const float* bias /*[n] or NULL*/,
                    const float* skip /*[m, ldo] fp32 or NULL*/, int relu, void* out_h, void* out_l, float* x_out, int64_t ldo,
                    int* overflow, void* stream);
-/* tuning / test hook: 3 = 256 x 256 tiles filled by LDS-DMA on the ping-pong / half-tile schedule (two wave groups one barrier
- * apart, the DMA queue never drained); 2 = the same tile with two whole-K-step stages and one drain + barrier per K-step
- * (bit-identical to 3: same products in the same order); 0 (default) = 3 for k >= 2048, else 2 (where each measured faster);
- * 1 = 128 x 128 tiles staged through registers (the A/B reference; same results to fp32 rounding). */
+/* tuning / test hook: 3 (default) = 256 x 256 tiles filled by LDS-DMA on the ping-pong / half-tile schedule (two wave groups one
+ * barrier apart, the DMA queue never drained); 2 = the same tile with two whole-K-step stages and one drain + barrier per K-step
+ * (bit-identical to 3: same products in the same order); 1 = 128 x 128 tiles staged through registers (the A/B reference; same
+ * results to fp32 rounding). */
 int dca_f16x3_gemm_variant(int variant);
 
 /* The same layer in the NON-parity 16-bit modes (`--nnet_dtype bf16 | fp16`; replaces the library GEMM + separate clamp pass of

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """MFMA-pipe throughput of the hand-written f16x3 dense-layer kernel (both variants) next to round 1's arrangement (one
 library f16 GEMM over the interleaved 3x operand + the dca_act_split glue kernel) on the cube3 network's layer shapes.
-TFLOP/s are ISSUED f16 MFMA flops (3 products per useful one); `useful` = /3.   python tools/gemm_bench.py [rows]"""
+TFLOP/s are ISSUED f16 MFMA flops (3 products per useful one); `useful` = /3.  Candidates take turns over four rounds (the first
+is a warm-up), medians reported.   python tools/gemm_bench.py [rows]"""
 import json
 import os
 import sys
@@ -29,6 +30,19 @@ def timed(fn, iters=10):
     return e0.elapsed_time(e1) / iters
 
 
+def interleaved(cands, rounds=4):
+    """Median ms of each candidate over `rounds` rounds in which the candidates take turns (whatever is measured first in a
+    process runs up to 5 % slower — clocks still ramping — so one pass in a fixed order mis-ranks kernels 3-6 % apart;
+    round 0 is the warm-up and is dropped)."""
+    ms = {name: [] for name, _ in cands}
+    for r in range(rounds):
+        for name, fn in cands:
+            t = timed(fn)
+            if r > 0:
+                ms[name].append(t)
+    return {name: sorted(v)[len(v) // 2] for name, v in ms.items()}
+
+
 for n, k in ((1024, 1024), (1024, 5120)):
     g = torch.Generator().manual_seed(n + k)
     x = torch.randn(m, k, generator=g).cuda()
@@ -44,23 +58,23 @@ for n, k in ((1024, 1024), (1024, 5120)):
     a3, _ = _lib.act_split(x, None, None, 1.0, False, False)
     flops = 2.0 * m * n * k * 3
     row = {"m": m, "n": n, "k": k}
-    for v in (3, 2, 1):
-        _lib.f16x3_gemm_variant(v)
-        ms = timed(lambda: _lib.f16x3_gemm(planes, whc, wlc, inv, 1.0, b, skip, True, True, True))
-        row["hip_v%d_ms" % v] = round(ms, 4)
-        row["hip_v%d_mfma_tflops" % v] = round(flops / ms / 1e9, 1)
-    _lib.f16x3_gemm_variant(0)
+    def hip_layer(v):
+        def run():
+            _lib.f16x3_gemm_variant(v)
+            return _lib.f16x3_gemm(planes, whc, wlc, inv, 1.0, b, skip, True, True, True)
+        return run
 
     def lib_layer():
         y = torch.mm(a3, w3.t(), out_dtype=torch.float32)
         return _lib.act_split(y, b, skip, inv, True, True)
 
-    ms = timed(lib_layer)
-    row["library_gemm_plus_glue_ms"] = round(ms, 4)
-    row["library_mfma_tflops_incl_glue"] = round(flops / ms / 1e9, 1)
-    ms = timed(lambda: torch.mm(a3, w3.t(), out_dtype=torch.float32))
-    row["library_gemm_only_ms"] = round(ms, 4)
-    row["library_gemm_only_mfma_tflops"] = round(flops / ms / 1e9, 1)
+    res = interleaved([("hip_v3", hip_layer(3)), ("hip_v2", hip_layer(2)), ("hip_v1", hip_layer(1)),
+                       ("library_gemm_plus_glue", lib_layer),
+                       ("library_gemm_only", lambda: torch.mm(a3, w3.t(), out_dtype=torch.float32))])
+    _lib.f16x3_gemm_variant(3)
+    for name, ms in res.items():
+        row[name + "_ms"] = round(ms, 4)
+        row[name + "_mfma_tflops"] = round(flops / ms / 1e9, 1)
     print(json.dumps(row))
     del x, planes, a3, skip
     torch.cuda.empty_cache()
@@ -77,18 +91,21 @@ for dt, nm in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")):
         skip = torch.randn(m, n, generator=g).to(dt).cuda()
         flops = 2.0 * m * n * k
         row = {"dtype": nm, "m": m, "n": n, "k": k}
-        out = skip.clone()
-        for v, tag in ((1, "hip_two_stage"), (2, "hip")):
-            _lib.gemm16_variant(v)
-            ms = timed(lambda: _lib.gemm16(x, w, b32, None, True))
-            row[tag + "_bias_relu_ms"], row[tag + "_bias_relu_tflops"] = round(ms, 4), round(flops / ms / 1e9, 1)
-            ms = timed(lambda: _lib.gemm16(x, w, None, out, True, out=out))
-            row[tag + "_skip_relu_ms"], row[tag + "_skip_relu_tflops"] = round(ms, 4), round(flops / ms / 1e9, 1)
-        ms = timed(lambda: torch._addmm_activation(bdt, x, w.t()))
-        row["library_bias_relu_ms"], row["library_bias_relu_tflops"] = round(ms, 4), round(flops / ms / 1e9, 1)
-        out2 = skip.clone()
-        ms = timed(lambda: out2.addmm_(x, w.t()).relu_())
-        row["library_skip_relu_ms"], row["library_skip_relu_tflops"] = round(ms, 4), round(flops / ms / 1e9, 1)
+        out, out2 = skip.clone(), skip.clone()
+
+        def hip16(v, with_skip):
+            def run():
+                _lib.gemm16_variant(v)
+                return _lib.gemm16(x, w, None, out, True, out=out) if with_skip else _lib.gemm16(x, w, b32, None, True)
+            return run
+
+        res = interleaved([("hip_bias_relu", hip16(2, False)), ("hip_skip_relu", hip16(2, True)),
+                           ("hip_two_stage_bias_relu", hip16(1, False)), ("hip_two_stage_skip_relu", hip16(1, True)),
+                           ("library_bias_relu", lambda: torch._addmm_activation(bdt, x, w.t())),
+                           ("library_skip_relu", lambda: out2.addmm_(x, w.t()).relu_())])
+        _lib.gemm16_variant(2)
+        for name, ms in res.items():
+            row[name + "_ms"], row[name + "_tflops"] = round(ms, 4), round(flops / ms / 1e9, 1)
         print(json.dumps(row))
         del x, skip, out, out2
         torch.cuda.empty_cache()
