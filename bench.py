@@ -431,7 +431,7 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
     from deepcubea_amd import _lib
     from deepcubea_amd.search_methods.engine import BwasEngine
     from deepcubea_amd.utils import nnet_utils
-    from deepcubea_amd.utils.pytorch_models import FastResnet, ResnetModel, fold_batchnorm
+    from deepcubea_amd.utils.pytorch_models import FastResnet, Fp8Resnet, ResnetModel, fold_batchnorm
     from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
     from deepcubea_amd.utils import env_utils
     B, w = args.batch_size, args.weight
@@ -441,7 +441,7 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
     model = env.get_nnet_model()  # cube3: ResnetModel(54, 6, 5000, 1000, 4, 1, True)
     load_synthetic_weights(model, 2024)
     macs = sum(m.in_features * m.out_features for m in model.modules() if isinstance(m, torch.nn.Linear))
-    dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[dtype_name]
+    dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16, "fp8": torch.bfloat16}[dtype_name]
     max_rounds = 64
     cap = max(1 << 20, (steps * max_rounds + warm + 12) * B * A + 64 * B * A // 2)
     if eval_all_children:
@@ -450,7 +450,7 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
                                               autocast_dtype=None if dt == torch.float32 else dt)
         eng = BwasEngine(args.env, w, B, max_nodes=cap, onehot_dtype=dt)
     else:
-        fast = FastResnet(model, dt, gemm16=gemm16).cuda()
+        fast = (Fp8Resnet(model) if dtype_name == "fp8" else FastResnet(model, dt, gemm16=gemm16)).cuda()
         hfn = nnet_utils.get_heuristic_fn_dev(fast, clip_zero=False, batch_size=args.nnet_batch_size)
         if fast.uses_l1_kernel:  # layer 1 = the library's one-hot MFMA kernel on the packed uint8 rows
             eng = BwasEngine(args.env, w, B, max_nodes=cap, packed=True)
@@ -493,14 +493,17 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
             "steps": steps, "timed_s": wall, "heuristic_dtype": dtype_name, "weights": "synthetic (numpy PCG64 seed 2024, BN folded)",
             "order": "eval_all_children (reference order)" if eval_all_children else "dedup_first (CLI default)",
             "layer1": "library GEMM on one-hot rows" if eval_all_children or not fast.uses_l1_kernel
-            else "dca_l1_onehot_gemm (hand-written MFMA, %d bf16 plane(s))" % fast.l1_planes,
+            else "dca_l1_onehot_gemm (hand-written MFMA, %d bf16 plane(s)%s)" % ((1, ", e4m3 output") if dtype_name == "fp8"
+                                                                                else (fast.l1_planes, "")),
             "dense_layers": ("library fp32 GEMMs" if eval_all_children else "dca_f16x3_gemm (hand-written MFMA, epilogue-fused)")
-            if dtype_name == "fp32" else ("dca_gemm16 (hand-written MFMA, epilogue-fused)" if gemm16 == "hip"
-                                          else "library (hipBLASLt) GEMMs + clamp pass"),
+            if dtype_name == "fp32" else ("dca_gemm8 (hand-written e4m3 MFMA, dequantise + tail + requantise in the epilogue)"
+                                          if dtype_name == "fp8" else "dca_gemm16 (hand-written MFMA, epilogue-fused)"
+                                          if gemm16 == "hip" else "library (hipBLASLt) GEMMs + clamp pass"),
             "network_rows_per_step": rows, "children_per_step": B * A,
             "heuristic_tflops_per_gpu": flops / (wall / steps) / 1e12,
             # fp32 default path = f16x3 split layers: 3 f16 MFMA flops per useful flop -> ceiling 2500/3 "fp32-equivalent"
-            "mfma_peak_tflops": (157.3 if eval_all_children else 2500.0 / 3) if dtype_name == "fp32" else 2500.0,
+            "mfma_peak_tflops": (157.3 if eval_all_children else 2500.0 / 3) if dtype_name == "fp32"
+            else (5000.0 if dtype_name == "fp8" else 2500.0),
             "mfma_pipe": ("f32-input MFMA" if eval_all_children else "f16/bf16 MFMA, fp32-accurate via operand splitting "
                           "(useful flops = 1/3 of the issued ones)") if dtype_name == "fp32" else "f16/bf16 MFMA"}
 
@@ -760,6 +763,7 @@ def main():
         line["end_to_end_nnet"] = {"fp32": run_astar_nnet(args, world, rank, "fp32"),
                                    "bf16": run_astar_nnet(args, world, rank, "bf16"),
                                    "bf16_hand_written_gemm": run_astar_nnet(args, world, rank, "bf16", gemm16="hip"),
+                                   "fp8_hand_written_gemm": run_astar_nnet(args, world, rank, "fp8"),
                                    "fp32_eval_all_children": run_astar_nnet(args, world, rank, "fp32", True)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("astar", "expand"):
         if args.workload == "expand":

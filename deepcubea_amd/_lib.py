@@ -17,7 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdca_hip.so")
 
 ENV_CUBE3, ENV_NPUZZLE, ENV_LIGHTSOUT = 0, 1, 2
-DT_F32, DT_F16, DT_BF16, DT_F16X3, DT_F16_PLANES = 0, 1, 2, 3, 4
+DT_F32, DT_F16, DT_BF16, DT_F16X3, DT_F16_PLANES, DT_E4M3 = 0, 1, 2, 3, 4, 5
+E4M3 = torch.float8_e4m3fn  # OCP e4m3: the fp8 format of gfx950's matrix pipes
 SEM_PY, SEM_CPP = 0, 1
 HEUR_MOD97, HEUR_KNUTH3, HEUR_HASHU01, HEUR_ZERO, HEUR_MANHATTAN = 0, 1, 2, 3, 4
 
@@ -37,7 +38,7 @@ ABI_SYMBOLS = [
     "dca_engine_profile_builtin", "dca_engine_set_tiers", "dca_engine_debug", "dca_debug_tune", "dca_engine_status", "dca_engine_last_children", "dca_engine_solution",
     "dca_bn_workspace_bytes", "dca_bn_train_forward", "dca_bn_train_backward",
     "dca_l1_supported", "dca_l1_kpad", "dca_l1_onehot_gemm", "dca_act_split", "dca_f16x3_gemm", "dca_split_planes", "dca_f16x3_gemm_variant",
-    "dca_gemm16", "dca_gemm16_variant", "dca_lightsout_next_state", "dca_lightsout_expand_fused",
+    "dca_gemm16", "dca_gemm16_variant", "dca_gemm8", "dca_quant_e4m3", "dca_lightsout_next_state", "dca_lightsout_expand_fused",
 ]
 
 
@@ -339,6 +340,9 @@ def l1_onehot_gemm(states_nnet: torch.Tensor, depth: int, w_tiles: torch.Tensor,
     elif split:
         out = torch.empty((m, 3 * n_pad), dtype=torch.float16, device=x.device)
         code = DT_F16X3
+    elif out_dtype == E4M3:  # (planes == 1; the caller has folded the activation scale into the weights and bias)
+        out = torch.empty((m, n_pad), dtype=E4M3, device=x.device)
+        code = DT_E4M3
     else:
         out = torch.empty((m, n_pad), dtype=out_dtype, device=x.device)
         code = _TORCH_DT[out_dtype]
@@ -411,6 +415,36 @@ def gemm16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], skip:
     assert out.dtype == a.dtype and out.shape == (m, n) and out.is_contiguous() and out.data_ptr() != a.data_ptr()
     check(lib().dca_gemm16(ptr(a), C.c_int64(m), int(k), C.c_int64(k), ptr(w), int(n), C.c_int64(k), _TORCH_DT[a.dtype],
                            ptr(bias), ptr(skip), int(relu), ptr(out), C.c_int64(n), stream_ptr()), "dca_gemm16")
+    return out
+
+
+def gemm8(a: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, bias: Optional[torch.Tensor], skip: Optional[torch.Tensor],
+          relu: bool, want16: bool, out8_scale: Optional[float], out16: Optional[torch.Tensor] = None):
+    """One dense layer in the fp8 mode (dca_gemm8): v = relu?((a . w^T) * scale + bias (+ skip)), a [m, k] / w [n, k] e4m3, scale /
+    bias [n] fp32, skip [m, n] bf16.  Returns (bf16 v or None, e4m3(sat(v * out8_scale)) or None); `out16` may be `skip`."""
+    assert a.dtype == E4M3 and w.dtype == E4M3 and a.is_contiguous() and w.is_contiguous()
+    m, k = a.shape
+    n = w.shape[0]
+    assert w.shape[1] == k and scale.dtype == torch.float32 and scale.numel() == n
+    assert bias is None or (bias.dtype == torch.float32 and bias.numel() == n)
+    assert skip is None or (skip.dtype == torch.bfloat16 and skip.shape == (m, n) and skip.is_contiguous())
+    if want16 and out16 is None:
+        out16 = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
+    assert out16 is None or (out16.dtype == torch.bfloat16 and out16.shape == (m, n) and out16.is_contiguous())
+    out8 = torch.empty((m, n), dtype=E4M3, device=a.device) if out8_scale is not None else None
+    check(lib().dca_gemm8(ptr(a), C.c_int64(m), int(k), C.c_int64(k), ptr(w), int(n), C.c_int64(k), ptr(scale), ptr(bias), ptr(skip),
+                          int(relu), ptr(out16), C.c_int64(n), ptr(out8), C.c_int64(n),
+                          C.c_double(out8_scale if out8_scale is not None else 1.0), stream_ptr()), "dca_gemm8")
+    return out16, out8
+
+
+def quant_e4m3(x: torch.Tensor, scale: float) -> torch.Tensor:
+    """fp32 / bf16 [m, n] -> e4m3(sat(x * scale)) (dca_quant_e4m3)."""
+    assert x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous() and x.dim() == 2 and x.shape[1] % 4 == 0
+    m, n = x.shape
+    out = torch.empty((m, n), dtype=E4M3, device=x.device)
+    check(lib().dca_quant_e4m3(ptr(x), _TORCH_DT[x.dtype], C.c_int64(m), C.c_int64(n), C.c_int64(n), C.c_double(scale), ptr(out),
+                               C.c_int64(n), stream_ptr()), "dca_quant_e4m3")
     return out
 
 

@@ -1,0 +1,406 @@
+// dca_gemm8.hip — the dense layers of the cost-to-go network in the NON-parity fp8 mode (`--nnet_dtype fp8`; SURVEY §8(f)-2,
+// "a hand-written bf16 (then fp8) GEMM with the bias/skip/ReLU epilogue"): OCP e4m3 operands, fp32
+// accumulation on v_mfma_f32_32x32x64_f8f6f4 (the non-scaled form of gfx950's block-scaled MFMA: twice the bf16 rate),
+// ONE launch per layer with the whole tail — dequantisation, bias, residual add, ReLU, and the QUANTISATION of the result for
+// the next layer — in the epilogue.
+//
+// Reference arithmetic (utils/pytorch_models.py:57-86, BatchNorm folded):  v = relu?(x . W^T + b (+ skip)), here with
+//   x ~ s_x * x8 (one scale per activation tensor, calibrated by the caller), W[n,:] ~ s_w[n] * w8[n,:] (one scale per output
+//   unit), so v = (x8 . w8^T)[m,n] * scale[n] + b[n] (+ skip), scale[n] = s_x * s_w[n] handed in by the caller.
+// The residual stream stays bf16 (out16 / skip); the next layer's operand leaves as e4m3(sat(v * out8_scale)).
+//
+// Tile and schedule are those of csrc/dca_gemm16.hip variant 2 (the derivation and the RAW / WAR argument are written out
+// there): 256 x 256 outputs per workgroup, 8 waves as 2 (M) x 4 (N), the two wave rows one barrier apart (one multiplies while
+// the other reads fragments and issues DMA), a K-tile of 128 BYTES per row — the same 128-byte LDS rows, the same XOR swizzle
+// on the DMA source address, the same four 16 KB half-tile slots per K-tile and the same counted s_waitcnt vmcnt(10) — only a
+// K-tile is now 128 deep: per phase a wave issues 4 MFMAs of 32x32x64 (16 passes each) where the bf16 kernel issues 8 of
+// 32x32x16 (8 passes), i.e. the same matrix-pipe time for twice the products.  A lane's 32-byte MFMA operand is two 16-byte
+// chunks of its row (lane half h of K-step t takes chunks 4t + 2h and 4t + 2h + 1); A and B use the same chunk -> byte
+// order, which is all the instruction needs (it pairs byte b of the A lane with byte b of the B lane of the same half).
+#include <atomic>
+#include <type_traits>
+
+#include "dca_common.h"
+
+namespace dca {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int EBM = 256, EBN = 256, EBK = 128, ETHREADS = 512;
+constexpr int ESLOT = 128 * 128;  // one half-tile: 128 rows x 128 B
+constexpr int EBUF = 4 * ESLOT;   // one K-tile: A01 | A23 | B0 | B1
+constexpr int ELDS = 2 * EBUF;    // 128 KB
+constexpr int ES_A01 = 0, ES_A23 = 1, ES_B0 = 2, ES_B1 = 3;
+
+struct Gemm8Args {
+    const uint8_t* a;    // [m, lda] e4m3
+    const uint8_t* w;    // [n, ldw] e4m3 (row = output unit)
+    const float* scale;  // [n]: activation scale x weight scale of the unit
+    const float* bias;   // [n] or null
+    const uint16_t* skip;  // [m, ldo16] bf16 or null
+    uint16_t* out16;     // [m, ldo16] bf16 or null
+    uint8_t* out8;       // [m, ldo8] e4m3 or null
+    float out8_scale;    // out8 = e4m3(sat(v * out8_scale))
+    int relu;
+    int64_t m;
+    int n, k;
+    int64_t lda, ldw, ldo16, ldo8;
+};
+
+__device__ __forceinline__ uint32_t swz128b(uint32_t row, uint32_t chunk) { return row * 128u + ((chunk ^ ((row >> 1) & 7u)) << 4); }
+
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {  // round to nearest even; NaN stays NaN
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+// four floats -> four e4m3 bytes (round to nearest even, saturating at +-448: e4m3fn has no infinity)
+__device__ __forceinline__ uint32_t pack_e4m3(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -448.f), 448.f);
+    b = fminf(fmaxf(b, -448.f), 448.f);
+    c = fminf(fmaxf(c, -448.f), 448.f);
+    d = fminf(fmaxf(d, -448.f), 448.f);
+    uint32_t r = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    r = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, (int)r, true);
+    return r;
+}
+
+#define DCA_BAR() asm volatile("s_barrier" ::: "memory")
+#define DCA_RD_DONE_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define DCA_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
+__global__ __launch_bounds__(ETHREADS, 2) void k_gemm8(const Gemm8Args p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, h = lane >> 5;
+    const int wm = w >> 2, wn = w & 3;
+    const int nNt = (p.n + EBN - 1) / EBN;
+    const int64_t nMt = (p.m + EBM - 1) / EBM;
+    const int64_t bid = blockIdx.x;
+    const int64_t slot = bid >> 3;
+    const int64_t mt = (slot / nNt) * 8 + (bid & 7);  // the N tiles of one M tile sit on one XCD (workgroup b runs on XCD b % 8)
+    const int nt = (int)(slot % nNt);
+    if (mt >= nMt) return;
+    const int64_t m0 = mt * EBM;
+    const int n0 = nt * EBN;
+
+    // DMA map: instruction q (0, 1) of wave w fills local rows [(q*8 + w)*8, +8) of a half-tile slot; lane i lands on local
+    // row r = that + (i >> 3), physical chunk i & 7, and fetches logical chunk (i & 7) ^ ((r >> 1) & 7) of the matrix row
+    // the slot's local row r stands for.  Rows past the matrix edge are clamped: their products are never stored.
+    const uint8_t* src[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t r = (uint32_t)((q * 8 + w) * 8 + (lane >> 3));
+            const uint32_t c = (uint32_t)(lane & 7) ^ ((r >> 1) & 7u);
+            if (u < 2) {
+                int64_t gr = m0 + (r >> 6) * 128 + (u == ES_A23 ? 64 : 0) + (r & 63);
+                gr = gr < p.m ? gr : p.m - 1;
+                src[u][q] = p.a + gr * p.lda + c * 16;
+            } else {
+                int gn = n0 + (int)((r >> 5) * 64 + (u == ES_B1 ? 32 : 0) + (r & 31));
+                gn = gn < p.n ? gn : p.n - 1;
+                src[u][q] = p.w + (int64_t)gn * p.ldw + c * 16;
+            }
+        }
+    auto issue = [&](int u, int buf, int k0) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            uint8_t* dst = lds + buf * EBUF + u * ESLOT + (q * 8 + w) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[u][q] + k0),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int jn = 0; jn < 2; jn++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][jn][e] = 0.f;
+
+    // fragment addresses inside a slot: local row = (wave's block) * 32 + l31; K-step ks of the tile, half j of the operand
+    uint32_t foff[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) foff[ks][j] = swz128b((uint32_t)l31, 4u * ks + 2u * (uint32_t)h + j);
+    const uint32_t a_row0 = (uint32_t)wm * 64u * 128u;  // A slots: this wave row's 64 local rows
+    const uint32_t b_row0 = (uint32_t)wn * 32u * 128u;  // B slots: this wave column's 32 local rows
+
+    // (typed vector loads: see dca_gemm16.hip — a struct-typed load would be ordered behind the LDS-DMA in flight)
+    auto frag = [&](const uint8_t* q, int ks) {
+        const i32x4 lo = *reinterpret_cast<const i32x4*>(q + foff[ks][0]);
+        const i32x4 hi = *reinterpret_cast<const i32x4*>(q + foff[ks][1]);
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    i32x8 av[2][2], wv0[2], wv1[2];
+    auto read_a = [&](const uint8_t* base, int u) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ii++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) av[ii][ks] = frag(base + u * ESLOT + a_row0 + ii * 4096, ks);
+    };
+    auto read_b = [&](const uint8_t* base, int u, i32x8 (&wv)[2]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) wv[ks] = frag(base + u * ESLOT + b_row0, ks);
+    };
+#define DCA_MMA4(I0, JN, WV)                                                                                             \
+    do {                                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        __builtin_amdgcn_s_setprio(1);                                                                                   \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ks++) _Pragma("unroll") for (int ii = 0; ii < 2; ii++)                \
+            acc[(I0) + ii][JN] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av[ii][ks], WV[ks], acc[(I0) + ii][JN], \
+                                                                                 0, 0, 0, 0, 0, 0);                      \
+        __builtin_amdgcn_s_setprio(0);                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+    } while (0)
+
+    const int nk = p.k / EBK;
+    // one K-tile; N1 / N2: tiles kt+1 / kt+2 exist (compile-time: the steady-state body is branch-free).  On entry: issued =
+    // all of tile kt and A01, B0, B1 of kt+1; landed and visible = A01, B0 of kt.  The vmcnt numbers count the DMA
+    // instructions (2 per half-tile) issued AFTER the half-tile being waited for.
+    auto tile = [&](int kt, auto n1c, auto n2c) {
+        constexpr bool N1 = decltype(n1c)::value, N2 = decltype(n2c)::value;
+        const int b = kt & 1;
+        const uint8_t* base = lds + b * EBUF;
+        // phase 1: (A01, B0); restage A23 of kt+1; retire B1 of kt
+        read_b(base, ES_B0, wv0);
+        read_a(base, ES_A01);
+        if constexpr (N1) {
+            issue(ES_A23, b ^ 1, (kt + 1) * EBK);
+            DCA_VMCNT(10);
+        } else {
+            DCA_VMCNT(2);
+        }
+        DCA_RD_DONE_BAR();
+        DCA_MMA4(0, 0, wv0);
+        DCA_BAR();
+        // phase 2: (A01, B1); restage A01 of kt+2; retire A23 of kt
+        read_b(base, ES_B1, wv1);
+        if constexpr (N2) {
+            issue(ES_A01, b, (kt + 2) * EBK);
+            DCA_VMCNT(10);
+        } else if constexpr (N1) {
+            DCA_VMCNT(8);
+        } else {
+            DCA_VMCNT(0);
+        }
+        DCA_RD_DONE_BAR();
+        DCA_MMA4(0, 1, wv1);
+        DCA_BAR();
+        // phase 3: (A23, B1); restage B0 of kt+2
+        read_a(base, ES_A23);
+        if constexpr (N2) issue(ES_B0, b, (kt + 2) * EBK);
+        DCA_RD_DONE_BAR();
+        DCA_MMA4(2, 1, wv1);
+        DCA_BAR();
+        // phase 4: (A23, B0) from registers; restage B1 of kt+2; retire A01, B0 of kt+1
+        if constexpr (N2) {
+            issue(ES_B1, b, (kt + 2) * EBK);
+            DCA_VMCNT(10);
+        } else if constexpr (N1) {
+            DCA_VMCNT(4);
+        }
+        DCA_RD_DONE_BAR();
+        DCA_MMA4(2, 0, wv0);
+        DCA_BAR();
+    };
+
+    issue(ES_A01, 0, 0);
+    issue(ES_B0, 0, 0);
+    issue(ES_B1, 0, 0);
+    issue(ES_A23, 0, 0);
+    if (nk > 1) {
+        issue(ES_A01, 1, EBK);
+        issue(ES_B0, 1, EBK);
+        issue(ES_B1, 1, EBK);
+        DCA_VMCNT(10);  // A01, B0 of tile 0 have landed
+    } else {
+        DCA_VMCNT(4);
+    }
+    DCA_BAR();
+    if (wm == 1) DCA_BAR();  // the second wave row runs one barrier behind the first from here on
+    {
+        int kt = 0;
+        for (; kt + 2 < nk; kt++) tile(kt, std::true_type{}, std::true_type{});
+        if (kt + 1 < nk) {
+            tile(kt, std::true_type{}, std::false_type{});
+            kt++;
+        }
+        tile(kt, std::false_type{}, std::false_type{});
+    }
+    if (wm == 0) DCA_BAR();  // ... and the first waits for it here
+#undef DCA_MMA4
+
+    // epilogue.  Accumulator layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  Each wave
+    // transposes its tile through its own 16 KB of the (now idle) LDS, 32 rows at a time: a lane then owns 4 consecutive
+    // columns of a row — one 8-byte skip load, one 8-byte bf16 store, one 4-byte e4m3 store.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the operand slots
+    float* sl = reinterpret_cast<float*>(lds + w * 16384);
+    float sc[2], bv[2];
+#pragma unroll
+    for (int jn = 0; jn < 2; jn++) {
+        const int col = n0 + wn * 64 + jn * 32 + l31;
+        sc[jn] = col < p.n ? p.scale[col] : 0.f;
+        bv[jn] = (col < p.n && p.bias) ? p.bias[col] : 0.f;
+    }
+    const int c4 = (lane & 15) * 4;  // this lane's 4 columns inside the wave's 64
+    const int colg = n0 + wn * 64 + c4;
+    const bool full4 = colg + 3 < p.n;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int jn = 0; jn < 2; jn++)
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++)
+                sl[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 64 + jn * 32 + l31] = acc[i][jn][reg] * sc[jn] + bv[jn];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private slice: no barrier, just the wave's own writes
+        const int64_t rbase = m0 + wm * 128 + i * 32;
+        uint2 sk[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int64_t r = rbase + q * 4 + (lane >> 4);
+            sk[q] = make_uint2(0u, 0u);
+            if (p.skip && r < p.m && full4) sk[q] = *reinterpret_cast<const uint2*>(p.skip + r * p.ldo16 + colg);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int rl = q * 4 + (lane >> 4);
+            const int64_t r = rbase + rl;
+            const float4 v = *reinterpret_cast<const float4*>(sl + rl * 64 + c4);
+            if (r >= p.m) continue;
+            float u[4] = {v.x, v.y, v.z, v.w};
+            if (full4) {
+                if (p.skip) {
+                    u[0] += bf16_to_f32((uint16_t)(sk[q].x & 0xFFFFu));
+                    u[1] += bf16_to_f32((uint16_t)(sk[q].x >> 16));
+                    u[2] += bf16_to_f32((uint16_t)(sk[q].y & 0xFFFFu));
+                    u[3] += bf16_to_f32((uint16_t)(sk[q].y >> 16));
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) u[e] = fmaxf(u[e], 0.f);
+                }
+                if (p.out16) {
+                    uint2 ov;
+                    ov.x = (uint32_t)f32_to_bf16(u[0]) | ((uint32_t)f32_to_bf16(u[1]) << 16);
+                    ov.y = (uint32_t)f32_to_bf16(u[2]) | ((uint32_t)f32_to_bf16(u[3]) << 16);
+                    *reinterpret_cast<uint2*>(p.out16 + r * p.ldo16 + colg) = ov;
+                }
+                if (p.out8) {
+                    const float s = p.out8_scale;
+                    *reinterpret_cast<uint32_t*>(p.out8 + r * p.ldo8 + colg) = pack_e4m3(u[0] * s, u[1] * s, u[2] * s, u[3] * s);
+                }
+            } else {  // ragged right edge: element-wise
+                for (int e = 0; e < 4 && colg + e < p.n; e++) {
+                    float ue = u[e] + (p.skip ? bf16_to_f32(p.skip[r * p.ldo16 + colg + e]) : 0.f);
+                    if (p.relu) ue = fmaxf(ue, 0.f);
+                    if (p.out16) p.out16[r * p.ldo16 + colg + e] = f32_to_bf16(ue);
+                    if (p.out8) p.out8[r * p.ldo8 + colg + e] = (uint8_t)(pack_e4m3(ue * p.out8_scale, 0.f, 0.f, 0.f) & 0xFFu);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slice is rewritten by the next 32 rows
+    }
+}
+#undef DCA_VMCNT
+#undef DCA_RD_DONE_BAR
+#undef DCA_BAR
+
+// bf16 / fp32 [m, n] -> e4m3(sat(x * scale)): the entry into an fp8 layer for activations that did not come out of an fp8 epilogue
+template <typename T>
+__global__ __launch_bounds__(256) void k_quant_e4m3(const T* __restrict__ x, int64_t m, int64_t n, int64_t ld, float scale,
+                                                    uint8_t* __restrict__ out, int64_t ldo) {
+    const int64_t n4 = n / 4;
+    const int64_t total = m * n4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / n4, c = (i - r * n4) * 4;
+        float u[4];
+        if constexpr (std::is_same<T, float>::value) {
+            const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
+            u[0] = v.x, u[1] = v.y, u[2] = v.z, u[3] = v.w;
+        } else {
+            const uint2 v = *reinterpret_cast<const uint2*>(x + r * ld + c);
+            u[0] = bf16_to_f32((uint16_t)(v.x & 0xFFFFu)), u[1] = bf16_to_f32((uint16_t)(v.x >> 16));
+            u[2] = bf16_to_f32((uint16_t)(v.y & 0xFFFFu)), u[3] = bf16_to_f32((uint16_t)(v.y >> 16));
+        }
+        *reinterpret_cast<uint32_t*>(out + r * ldo + c) = pack_e4m3(u[0] * scale, u[1] * scale, u[2] * scale, u[3] * scale);
+    }
+}
+
+}  // namespace dca
+
+using namespace dca;
+
+extern "C" {
+
+int dca_gemm8(const void* a, int64_t m, int k, int64_t lda, const void* w, int n, int64_t ldw, const float* scale, const float* bias,
+              const void* skip, int relu, void* out16, int64_t ldo16, void* out8, int64_t ldo8, double out8_scale, void* stream) {
+    DCA_ARG(a && w && scale && (out16 || out8) && m >= 0 && n >= 1 && k >= EBK && k % EBK == 0);
+    DCA_ARG(lda >= k && ldw >= k && lda % 16 == 0 && ldw % 16 == 0);
+    DCA_ARG(((uintptr_t)a | (uintptr_t)w) % 16 == 0);
+    DCA_ARG((!out16 && !skip) || (ldo16 >= n && ldo16 % 4 == 0 && ((uintptr_t)out16 | (uintptr_t)skip) % 8 == 0));
+    DCA_ARG(!out8 || (ldo8 >= n && ldo8 % 4 == 0 && (uintptr_t)out8 % 4 == 0 && out8_scale > 0.0));
+    if (m == 0) return 0;
+    {   // the dynamic-LDS limit is a per-device function attribute: set it once for every device this process uses
+        static std::atomic<uint64_t> attr_devs{0};
+        int dev = 0;
+        DCA_HIP(hipGetDevice(&dev));
+        const uint64_t bit = 1ull << (dev & 63);
+        if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
+            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm8), hipFuncAttributeMaxDynamicSharedMemorySize, ELDS));
+            attr_devs.fetch_or(bit, std::memory_order_release);
+        }
+    }
+    Gemm8Args p;
+    p.a = reinterpret_cast<const uint8_t*>(a);
+    p.w = reinterpret_cast<const uint8_t*>(w);
+    p.scale = scale;
+    p.bias = bias;
+    p.skip = reinterpret_cast<const uint16_t*>(skip);
+    p.out16 = reinterpret_cast<uint16_t*>(out16);
+    p.out8 = reinterpret_cast<uint8_t*>(out8);
+    p.out8_scale = (float)out8_scale;
+    p.relu = relu;
+    p.m = m;
+    p.n = n;
+    p.k = k;
+    p.lda = lda;
+    p.ldw = ldw;
+    p.ldo16 = ldo16;
+    p.ldo8 = ldo8;
+    const int64_t nMt = (m + EBM - 1) / EBM;
+    const int64_t nNt = (n + EBN - 1) / EBN;
+    const int64_t blocks = ((nMt + 7) / 8) * 8 * nNt;
+    if (blocks > 0x7FFFFFFFll) {
+        set_error("dca_gemm8: too many tiles");
+        return DCA_E_BADARG;
+    }
+    hipLaunchKernelGGL(k_gemm8, dim3((unsigned)blocks), dim3(ETHREADS), ELDS, (hipStream_t)stream, p);
+    return launch_check("k_gemm8");
+}
+
+int dca_quant_e4m3(const void* x, int dtype, int64_t m, int64_t n, int64_t ld, double scale, void* out, int64_t ldo, void* stream) {
+    DCA_ARG(x && out && m >= 0 && n >= 4 && n % 4 == 0 && ld >= n && ld % 4 == 0 && ldo >= n && ldo % 4 == 0 && scale > 0.0);
+    DCA_ARG(dtype == DCA_DT_F32 || dtype == DCA_DT_BF16);
+    DCA_ARG((uintptr_t)x % (dtype == DCA_DT_F32 ? 16 : 8) == 0 && (uintptr_t)out % 4 == 0);
+    if (m == 0) return 0;
+    int64_t blocks = (m * (n / 4) + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (dtype == DCA_DT_F32)
+        hipLaunchKernelGGL(k_quant_e4m3<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const float*>(x), m, n, ld, (float)scale, reinterpret_cast<uint8_t*>(out), ldo);
+    else
+        hipLaunchKernelGGL(k_quant_e4m3<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const uint16_t*>(x), m, n, ld, (float)scale, reinterpret_cast<uint8_t*>(out), ldo);
+    return launch_check("k_quant_e4m3");
+}
+
+}  // extern "C"

@@ -49,7 +49,8 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
 }
 
 template <int D, int DEPTH, int P,
-          int OUT /*0 f32, 1 f16, 2 bf16, 3 f16x3 split (vh, vl, vh) interleaved, 4 two fp16 planes (high, then low at +m*ldo)*/>
+          int OUT /*0 f32, 1 f16, 2 bf16, 3 f16x3 split (vh, vl, vh) interleaved, 4 two fp16 planes (high, then low at +m*ldo),
+                    5 e4m3 bytes (saturating)*/>
 __global__ __launch_bounds__(kL1Threads) void k_l1_onehot_gemm(const uint8_t* __restrict__ nn, int64_t m,
                                                         const uint8_t* __restrict__ wt /*[ntile][P][KC][64][8] bf16*/,
                                                         const float* __restrict__ bias, int relu, void* __restrict__ out,
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(kL1Threads) void k_l1_onehot_gemm(const uint8_t* __
             }
         }
         // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-        if constexpr (OUT == 1 || OUT == 2 || OUT == 4) {
+        if constexpr (OUT == 1 || OUT == 2 || OUT == 4 || OUT == 5) {
             // 16-bit outputs: straight from the accumulator layout every store instruction would write 2 bytes per lane,
             // 64 contiguous bytes per row (3.1 ms for the 204 800 x 5120 planes, the fp32 output of the same tile 2.3 ms).
             // Each wave transposes 16 rows x 64 columns at a time through 4 KB of its own LDS — one word per element:
@@ -177,6 +178,8 @@ __global__ __launch_bounds__(kL1Threads) void k_l1_onehot_gemm(const uint8_t* __
                             uint32_t w;
                             if constexpr (OUT == 2) {
                                 w = f32_to_bf16_rne(v);
+                            } else if constexpr (OUT == 5) {  // e4m3fn has no infinity: saturate at +-448
+                                w = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v, -448.f), 448.f), 0.f, 0, false) & 0xFFu;
                             } else {
                                 const _Float16 hh = (_Float16)v;
                                 uint16_t hb, lb = 0;
@@ -196,7 +199,11 @@ __global__ __launch_bounds__(kL1Threads) void k_l1_onehot_gemm(const uint8_t* __
                         const int rl = q * 4 + (lane >> 4), c4 = (lane & 15) * 4;
                         const uint4 pk = *reinterpret_cast<const uint4*>(sl + rl * 64 + c4);
                         const int64_t r = rw + 32 * i + 16 * half + rl;
-                        if (r < m) {
+                        if constexpr (OUT == 5) {  // one byte per element: 4-byte stores, 16 lanes cover 64 contiguous bytes of a row
+                            if (r < m)
+                                *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(out) + r * ldo + n0 + c4) =
+                                    (pk.x & 0xFFu) | ((pk.y & 0xFFu) << 8) | ((pk.z & 0xFFu) << 16) | (pk.w << 24);
+                        } else if (r < m) {
                             const u16x4 hi = {(uint16_t)pk.x, (uint16_t)pk.y, (uint16_t)pk.z, (uint16_t)pk.w};
                             uint16_t* q0 = reinterpret_cast<uint16_t*>(out) + r * ldo + n0 + c4;
                             *reinterpret_cast<u16x4*>(q0) = hi;
@@ -270,7 +277,14 @@ int launch_l1_out(const uint8_t* nn, int64_t m, const uint8_t* wt, const float* 
         DCA_L1_LAUNCH(2);
     else if (out_dtype == DCA_DT_F16X3)
         DCA_L1_LAUNCH(3);
-    else
+    else if (out_dtype == DCA_DT_E4M3) {
+        if constexpr (P == 1) {  // (the fp8 mode keeps layer 1's weights as ONE bf16 plane: no other combination is built)
+            DCA_L1_LAUNCH(5);
+        } else {
+            set_error("dca_l1_onehot_gemm: e4m3 output takes planes == 1");
+            return DCA_E_BADARG;
+        }
+    } else
         DCA_L1_LAUNCH(4);
 #undef DCA_L1_LAUNCH
     return launch_check("k_l1_onehot_gemm");
@@ -372,7 +386,7 @@ int64_t dca_l1_kpad(int state_dim, int depth) { return (((int64_t)state_dim * de
 int dca_l1_onehot_gemm(const uint8_t* nnet_in, int64_t m, int state_dim, int depth, const void* w_tiles, int planes,
                        int64_t n_pad, const float* bias, int relu, void* out, int out_dtype, int* overflow, void* stream) {
     DCA_ARG(nnet_in && w_tiles && bias && out && m >= 0 && planes >= 1 && planes <= 3 && n_pad >= 64 && n_pad % 64 == 0);
-    DCA_ARG(out_dtype >= DCA_DT_F32 && out_dtype <= DCA_DT_F16_PLANES);
+    DCA_ARG(out_dtype >= DCA_DT_F32 && out_dtype <= DCA_DT_E4M3);
     if (!dca_l1_supported(state_dim, depth)) {
         set_error("dca_l1_onehot_gemm: geometry (%d, %d) not instantiated (weight tile must fit LDS)", state_dim, depth);
         return DCA_E_BADARG;

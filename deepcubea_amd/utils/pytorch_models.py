@@ -8,7 +8,7 @@ the int64 `F.one_hot` intermediate of pytorch_models.py:49-52 never exists on th
 """
 from __future__ import annotations
 
-from typing import Optional
+from typing import List, Optional
 
 import torch
 import torch.nn as nn
@@ -385,3 +385,120 @@ class FastResnet(nn.Module):
             ph, _ = _lib.f16x3_gemm(planes, Wh[ka], Wl[ka], A[ka], 1.0, B[ka], None, True, True, False, ovf)
             planes, x = _lib.f16x3_gemm(ph, Wh[kb], Wl[kb], A[kb], 1.0, B[kb], x, True, blk + 1 < nblk, True, ovf)
         return x @ self.w_out.t() + self.b_out
+
+
+class Fp8Resnet(nn.Module):
+    """The same network (pytorch_models.py:5-86 of the reference, BatchNorm folded, widths padded as in `FastResnet`) evaluated
+    at fp8 operand precision on the device: a NON-parity speed mode (`--nnet_dtype fp8`), twice the matrix rate of bf16.
+
+      * layer 1: the one-hot MFMA kernel (`dca_l1_onehot_gemm`, one bf16 weight plane) writing its output already QUANTISED
+        to OCP e4m3 (the activation scale is folded into the layer's weights and bias);
+      * every other dense layer: ONE `dca_gemm8` launch (csrc/dca_gemm8.hip) — e4m3 operands, fp32 accumulation on
+        `v_mfma_f32_32x32x64_f8f6f4`, and dequantisation + bias + residual add + ReLU + quantisation of the result for the
+        next layer in the epilogue.  The residual stream stays bf16; weights carry one scale per output unit, activations one
+        scale per tensor;
+      * the activation scales are calibrated once, on the first batch of at least 1024 rows this module sees (amax of every
+        intermediate tensor in a bf16 evaluation of at most 4096 of its rows, 25 % headroom, saturating conversion), or
+        explicitly (`calibrate`); thinner batches before that (a search's root) are evaluated in bf16.
+
+    Same call interface as `FastResnet` (uint8 network inputs through `forward`).  Needs the layer-1 kernel's geometry
+    (`dca_l1_supported`) and a GPU; there is no host path and no one-hot-row path."""
+
+    E4M3_MAX = 448.0
+    HEADROOM = 1.25
+    MIN_CALIB_ROWS = 1024
+
+    def __init__(self, model: ResnetModel):
+        super().__init__()
+        from .. import _lib
+        self.base = FastResnet(model, torch.bfloat16, gemm16="library")  # calibration path; also owns the folded bf16 weights
+        if not self.base.uses_l1_kernel:
+            raise ValueError("Fp8Resnet needs the layer-1 one-hot kernel (dca_l1_supported) for this geometry")
+        b = self.base
+        self.state_dim, self.one_hot_depth, self.in_pad, self.in_dim = b.state_dim, b.one_hot_depth, b.in_pad, b.in_dim
+        self.dtype = _lib.E4M3
+        W = [w.detach().float().cpu() for w in b.weights]
+        B = [x.detach().float().cpu() for x in b.biases_f32]
+        r = b.res_dim
+        # undo FastResnet's bias folding (the block's second bias rides through a constant-one hidden unit there; quantised to
+        # e4m3 that unit would carry a 6 % error into every bias): explicit biases, added to the fp32 accumulator
+        for k in range(2, len(W), 2):
+            B[k + 1] = W[k + 1][:, r].clone()
+            W[k + 1][:, r] = 0.0
+            B[k][r] = 0.0
+        self.w8, self.w_scale, self.bias = nn.ParameterList(), nn.ParameterList(), nn.ParameterList()
+        for k in range(1, len(W)):
+            sw = (W[k].abs().amax(dim=1) / self.E4M3_MAX).clamp_min(1e-30)
+            self.w8.append(nn.Parameter((W[k] / sw[:, None]).to(_lib.E4M3), requires_grad=False))
+            self.w_scale.append(nn.Parameter(sw.contiguous(), requires_grad=False))
+            self.bias.append(nn.Parameter(B[k].contiguous(), requires_grad=False))
+        self._w1 = W[0][:, :self.in_dim].contiguous()  # layer 1 is rebuilt with the activation scale folded in (calibrate)
+        self._b1 = B[0].contiguous()
+        self.l1_tiles8 = None
+        self.l1_bias8 = None
+        self.act_scale: List[float] = []  # [h1, x after fc2, then (h, x) per residual block]
+        self.layer_scale = None           # per dense layer: activation scale of its input x w_scale, on the device
+
+    @property
+    def uses_l1_kernel(self) -> bool:
+        return True
+
+    @property
+    def onehot_dtype(self) -> torch.dtype:
+        return torch.bfloat16
+
+    @property
+    def l1_planes(self) -> int:
+        return 1
+
+    def forward_onehot(self, x: torch.Tensor) -> torch.Tensor:
+        raise RuntimeError("Fp8Resnet takes the engine's packed uint8 network-input rows (forward), not one-hot rows")
+
+    @torch.no_grad()
+    def calibrate(self, states_nnet: torch.Tensor) -> None:
+        """Per-tensor activation scales from a bf16 evaluation of (at most 4096 of) these rows."""
+        from .. import _lib
+        b = self.base
+        W, Bb = b.weights, b.biases
+        x = _lib.l1_onehot_gemm(states_nnet[:4096].contiguous(), self.one_hot_depth, b.l1_tiles, b.l1_planes, b.l1_bias, True, b.dtype)
+        amax = [float(x.float().abs().max())]
+        x = torch._addmm_activation(Bb[1], x, W[1].t())
+        amax.append(float(x.float().abs().max()))
+        for k in range(2, len(W), 2):
+            h = torch._addmm_activation(Bb[k], x, W[k].t())
+            amax.append(float(h.float().abs().max()))
+            x = x.addmm_(h, W[k + 1].t()).relu_()
+            amax.append(float(x.float().abs().max()))
+        self.act_scale = [max(a, 1e-6) * self.HEADROOM / self.E4M3_MAX for a in amax]
+        dev = states_nnet.device
+        kpad = _lib.l1_kpad(self.state_dim, self.one_hot_depth)
+        inv1 = 1.0 / self.act_scale[0]
+        w1 = (self._w1 * inv1).to(torch.bfloat16).float()
+        self.l1_tiles8 = l1_weight_tiles(w1, 1, kpad).to(dev)
+        self.l1_bias8 = (self._b1 * inv1).to(dev)
+        # input scale of dense layer j (0 = fc2): h1, then inside block i: x_i for the first Linear, h_i for the second
+        s_in = [self.act_scale[0]]
+        for i in range((len(self.w8) - 1) // 2):
+            s_in += [self.act_scale[1 + 2 * i], self.act_scale[2 + 2 * i]]
+        self.layer_scale = [(self.w_scale[j].to(dev) * s_in[j]).contiguous() for j in range(len(self.w8))]
+
+    @torch.no_grad()
+    def forward(self, states_nnet: torch.Tensor) -> torch.Tensor:
+        """uint8 network inputs [M, state_dim] (device) -> [M, out_dim] float32."""
+        from .. import _lib
+        if not states_nnet.is_cuda:
+            raise RuntimeError("Fp8Resnet runs on the GPU only")
+        if self.layer_scale is None:
+            if states_nnet.shape[0] < self.MIN_CALIB_ROWS:  # a search's root / first thin batches: bf16 until there is a sample
+                return self.base(states_nnet)
+            self.calibrate(states_nnet)
+        s = self.act_scale
+        h8 = _lib.l1_onehot_gemm(states_nnet, self.one_hot_depth, self.l1_tiles8, 1, self.l1_bias8, True, _lib.E4M3)
+        x16, x8 = _lib.gemm8(h8, self.w8[0], self.layer_scale[0], self.bias[0], None, True, True, 1.0 / s[1])
+        nblk = (len(self.w8) - 1) // 2
+        for i in range(nblk):
+            ja, jb = 1 + 2 * i, 2 + 2 * i
+            _, h8 = _lib.gemm8(x8, self.w8[ja], self.layer_scale[ja], self.bias[ja], None, True, False, 1.0 / s[2 + 2 * i])
+            nxt = None if i == nblk - 1 else 1.0 / s[3 + 2 * i]  # the last block's output only feeds the bf16 output layer
+            x16, x8 = _lib.gemm8(h8, self.w8[jb], self.layer_scale[jb], self.bias[jb], x16, True, True, nxt, out16=x16)
+        return (x16 @ self.base.w_out.t()).float() + self.base.b_out

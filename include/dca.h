@@ -54,6 +54,8 @@ extern "C" {
 #define DCA_DT_BF16 2
 #define DCA_DT_F16X3 3 /* dca_l1_onehot_gemm only: the f16x3 split operand (vh, vl, vh) per element, [m, 3*n_pad] fp16 */
 #define DCA_DT_F16_PLANES 4 /* dca_l1_onehot_gemm only: dca_f16x3_gemm's operand — [m, n_pad] fp16 high halves, then [m, n_pad] low halves */
+#define DCA_DT_E4M3 5 /* dca_l1_onehot_gemm only: OCP fp8 e4m3 bytes, saturating (dca_gemm8's operand; the caller folds the activation
+                         scale into the layer's weights and bias) */
 
 /* BWAS semantics: which reference implementation is reproduced */
 #define DCA_SEM_PY 0  /* search_methods/astar.py: f64 cost, FIFO ties, CLOSED starts empty */
@@ -342,6 +344,19 @@ int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int 
  * queue never drained); 1 = two whole K-step stages with one drain + barrier per K-step (the A/B reference).  Bit-identical
  * results (same accumulation order). */
 int dca_gemm16_variant(int variant);
+
+/* The same layer in the NON-parity fp8 mode (`--nnet_dtype fp8`; csrc/dca_gemm8.hip): OCP e4m3 operands a [m, lda] / w [n, ldw]
+ * (bytes; k % 128 == 0, lda / ldw % 16 == 0), fp32 accumulation on v_mfma_f32_32x32x64_f8f6f4, and the whole tail in the epilogue:
+ *   v = relu?( (a . w^T)[m,n] * scale[n] + bias[n] (+ skip[m,n]) )        scale[n] = activation scale x weight scale of unit n
+ * leaving as bf16 (out16 [m, ldo16], the residual stream; may be `skip` itself) and / or quantised for the next layer:
+ * out8 [m, ldo8] = e4m3(sat(v * out8_scale)).  skip is bf16 with out16's row stride.  Replaces utils/pytorch_models.py:57-86
+ * (BatchNorm folded) as PyTorch runs it, at fp8 operand precision: never a parity mode. */
+int dca_gemm8(const void* a, int64_t m, int k, int64_t lda, const void* w, int n, int64_t ldw, const float* scale /*[n]*/,
+              const float* bias /*[n] or NULL*/, const void* skip /*bf16 [m, ldo16] or NULL*/, int relu, void* out16 /*or NULL*/,
+              int64_t ldo16, void* out8 /*or NULL*/, int64_t ldo8, double out8_scale, void* stream);
+/* x [m, n] (row stride ld; DCA_DT_F32 or DCA_DT_BF16) -> e4m3(sat(x * scale)) bytes [m, ldo]: the entry into an fp8 layer for
+ * activations that did not come out of an fp8 epilogue.  n % 4 == 0. */
+int dca_quant_e4m3(const void* x, int dtype, int64_t m, int64_t n, int64_t ld, double scale, void* out, int64_t ldo, void* stream);
 /* fp32 [m, n] (row stride ld) -> its fp16 planes (row stride ldo); n % 4 == 0 */
 int dca_split_planes(const float* x, int64_t m, int64_t n, int64_t ld, void* out_h, void* out_l, int64_t ldo,
                      int* overflow /*or NULL*/, void* stream);

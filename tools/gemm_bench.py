@@ -109,3 +109,30 @@ for dt, nm in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")):
         print(json.dumps(row))
         del x, skip, out, out2
         torch.cuda.empty_cache()
+
+# ---- the fp8 (e4m3) layer: dca_gemm8 (dequantise + tail + requantise in the epilogue) vs the library's scaled fp8 GEMM
+# (torch._scaled_mm -> hipBLASLt, bf16 output, no tail)
+E4M3 = torch.float8_e4m3fn
+for n, k in ((1024, 1024), (1024, 5120)):
+    g = torch.Generator().manual_seed(n + k)
+    x8 = torch.randn(m, k, generator=g).clamp(-448, 448).to(E4M3).cuda()
+    w8 = torch.randn(n, k, generator=g).clamp(-448, 448).to(E4M3).cuda()
+    sc = torch.full((n,), 1.0 / k ** 0.5).cuda()
+    b32 = torch.randn(n, generator=g).cuda()
+    skip = torch.randn(m, n, generator=g).to(torch.bfloat16).cuda()
+    flops = 2.0 * m * n * k
+    row = {"dtype": "e4m3", "m": m, "n": n, "k": k}
+    out = skip.clone()
+    cands = [("hip_bias_relu_to_e4m3", lambda: _lib.gemm8(x8, w8, sc, b32, None, True, False, 8.0)),
+             ("hip_skip_relu_to_bf16_and_e4m3", lambda: _lib.gemm8(x8, w8, sc, b32, out, True, True, 8.0, out16=out))]
+    one = torch.ones((), device="cuda")
+    try:
+        torch._scaled_mm(x8[:256], w8.t(), scale_a=one, scale_b=one, out_dtype=torch.bfloat16)
+        cands.append(("library_scaled_mm_to_bf16", lambda: torch._scaled_mm(x8, w8.t(), scale_a=one, scale_b=one, out_dtype=torch.bfloat16)))
+    except Exception as e:  # noqa: BLE001
+        row["library_scaled_mm"] = "unavailable: %s" % str(e)[:80]
+    for name, ms in interleaved(cands).items():
+        row[name + "_ms"], row[name + "_tflops"] = round(ms, 4), round(flops / ms / 1e9, 1)
+    print(json.dumps(row))
+    del x8, w8, skip, out
+    torch.cuda.empty_cache()
