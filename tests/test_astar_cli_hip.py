@@ -163,6 +163,32 @@ def test_nnet_bf16_mode_still_solves(tmp_path):
     eng.close()
 
 
+def test_nnet_fp8_mode_still_solves(tmp_path):
+    """fp8 heuristic (Fp8Resnet: dca_gemm8 layers, calibrated on the first batch of >= 1024 rows) = explicitly non-parity mode:
+    only validity of the solution is asserted; the mode must actually have switched to the e4m3 kernels on the way."""
+    from deepcubea_amd.search_methods.engine import BwasEngine
+    from deepcubea_amd.utils import nnet_utils
+    from deepcubea_amd.utils.pytorch_models import Fp8Resnet, ResnetModel
+    from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
+    from oracle import c_oracle as co
+    m = ResnetModel(54, 6, 5000, 1000, 4, 1, True)
+    load_synthetic_weights(m, 3)
+    fast = Fp8Resnet(m.eval()).cuda()
+    hfn = nnet_utils.get_heuristic_fn_dev(fast)
+    s = np.arange(54, dtype=np.uint8)[None]
+    for a in [2, 7, 9, 4]:
+        s = co.next_state("cube3", s, a)
+    eng = BwasEngine("cube3", 0.8, 200, max_nodes=1 << 21, packed=True)
+    res = eng.solve(s[0], hfn, max_iters=3000)
+    assert res["solved"]
+    assert fast.layer_scale is not None and len(fast.act_scale) == 10  # calibrated: the later batches ran on dca_gemm8
+    t = s.copy()
+    for a in res["moves"]:
+        t = co.next_state("cube3", t, a)
+    assert co.is_solved("cube3", t)[0]
+    eng.close()
+
+
 def test_cli_instances_per_gpu(tmp_path):
     """--instances_per_gpu K: K scrambles stepped by one engine, one network call per iteration for all of them."""
     from deepcubea_amd.search_methods import astar
