@@ -313,3 +313,38 @@ def test_compare_solutions_refuses_misaligned_sets():
     assert c["num_states"] == 2 and c["pct_equal"] == 100.0
     with pytest.raises(ValueError):
         cs.compare(a, b, offset=3)
+
+
+def test_fp8_network_bookkeeping_on_the_host():
+    """Fp8Resnet's host-side preparation (no GPU, no kernels): FastResnet's bias folding undone into explicit biases, one e4m3
+    weight matrix + one scale per output unit per dense layer.  Evaluated here in float64 WITHOUT activation quantisation, the
+    dequantised layers must reproduce the fp32 network up to the e4m3 rounding of the weights (3 mantissa bits: a few percent
+    after averaging over the fan-in) — an unfolding or scale mix-up would be off by O(1)."""
+    import torch
+    from deepcubea_amd.utils.pytorch_models import FastResnet, Fp8Resnet, ResnetModel
+    from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
+    net = ResnetModel(54, 6, 300, 120, 3, 1, True)
+    load_synthetic_weights(net, 7)
+    net.eval()
+    f8 = Fp8Resnet(net)
+    ref = FastResnet(net, torch.float32, split=False)
+    assert len(f8.w8) == 1 + 2 * 3 and all(w.dtype == torch.float8_e4m3fn for w in f8.w8)
+    assert all(float(w.float().abs().max()) <= 448.0 for w in f8.w8)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randint(0, 6, (64, 54), dtype=torch.uint8, generator=g)
+    oh = torch.nn.functional.one_hot(x.long(), 6).double().view(64, -1)
+    want = ref.forward_onehot(torch.nn.functional.pad(oh.float(), (0, ref.in_pad - oh.shape[1])))[:, 0].double()
+    # float64 evaluation of the prepared layers: layer 1 from the kept bf16-rounded fp32 weights, then (w8 * scale, bias)
+    h = torch.relu(oh @ f8._w1.double().t() + f8._b1.double())
+    W = [w.float().double() * s.double()[:, None] for w, s in zip(f8.w8, f8.w_scale)]
+    B = [b.double() for b in f8.bias]
+    xx = torch.relu(h @ W[0].t() + B[0])
+    for i in range(3):
+        hh = torch.relu(xx @ W[1 + 2 * i].t() + B[1 + 2 * i])
+        xx = torch.relu(xx + hh @ W[2 + 2 * i].t() + B[2 + 2 * i])
+    got = (xx @ f8.base.w_out.double().t() + f8.base.b_out.double())[:, 0]
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) / scale < 0.08
+    assert float(torch.corrcoef(torch.stack([got, want]))[0, 1]) > 0.995
+    with pytest.raises(RuntimeError):
+        f8(x)  # no host path: the fp8 mode runs on the GPU only
