@@ -8,7 +8,9 @@
 // bias, residual add, ReLU and the rounding to the 16-bit output ride in the epilogue: activations cross HBM once in
 // each direction, 2 bytes per element.
 //
-// Tiling (the f16x3 kernel's, dca_gemm.hip v2, with one operand plane instead of two): workgroup = 256 x 256 outputs, 8
+// Two schedules over the same tile (dca_gemm16_variant): variant 1 below — two whole K-step stages — and variant 2, the
+// default, further down: the ping-pong schedule over half-tile slots (its header has the derivation).
+// Tiling (the f16x3 kernel's, dca_gemm.hip, with one operand plane instead of two): workgroup = 256 x 256 outputs, 8
 // waves as 2 (M) x 4 (N), each wave 4 x 2 tiles of v_mfma_f32_32x32x16_{bf16,f16} (128 accumulator VGPRs, 32 MFMAs per
 // K-step of 64).  The two operand images of a K-step (256 rows x 128 B each = 64 KB) are filled by
 // global_load_lds_dwordx4 (LDS-DMA: no staging registers) into one of TWO stages, so the loads of step t+1 fly under the
