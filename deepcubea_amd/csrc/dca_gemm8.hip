@@ -254,6 +254,19 @@ __global__ __launch_bounds__(ETHREADS, 2) void k_gemm8(const Gemm8Args p) {
     const int c4 = (lane & 15) * 4;  // this lane's 4 columns inside the wave's 64
     const int colg = n0 + wn * 64 + c4;
     const bool full4 = colg + 3 < p.n;
+    // residual rows: the loads of round i+1 are issued before round i is worked on (two register sets), so only the first
+    // round waits a full memory latency — the waits between rounds would otherwise add up (4 x ~1.5 us per tile)
+    uint2 sk[2][8];
+    auto load_skip = [&](int i, uint2 (&dst)[8]) {
+        const int64_t rb = m0 + wm * 128 + i * 32;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int64_t r = rb + q * 4 + (lane >> 4);
+            dst[q] = make_uint2(0u, 0u);
+            if (p.skip && r < p.m && full4) dst[q] = *reinterpret_cast<const uint2*>(p.skip + r * p.ldo16 + colg);
+        }
+    };
+    load_skip(0, sk[0]);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
 #pragma unroll
@@ -263,13 +276,7 @@ __global__ __launch_bounds__(ETHREADS, 2) void k_gemm8(const Gemm8Args p) {
                 sl[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 64 + jn * 32 + l31] = acc[i][jn][reg] * sc[jn] + bv[jn];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private slice: no barrier, just the wave's own writes
         const int64_t rbase = m0 + wm * 128 + i * 32;
-        uint2 sk[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int64_t r = rbase + q * 4 + (lane >> 4);
-            sk[q] = make_uint2(0u, 0u);
-            if (p.skip && r < p.m && full4) sk[q] = *reinterpret_cast<const uint2*>(p.skip + r * p.ldo16 + colg);
-        }
+        if (i + 1 < 4) load_skip(i + 1, sk[(i + 1) & 1]);
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int rl = q * 4 + (lane >> 4);
@@ -279,10 +286,11 @@ __global__ __launch_bounds__(ETHREADS, 2) void k_gemm8(const Gemm8Args p) {
             float u[4] = {v.x, v.y, v.z, v.w};
             if (full4) {
                 if (p.skip) {
-                    u[0] += bf16_to_f32((uint16_t)(sk[q].x & 0xFFFFu));
-                    u[1] += bf16_to_f32((uint16_t)(sk[q].x >> 16));
-                    u[2] += bf16_to_f32((uint16_t)(sk[q].y & 0xFFFFu));
-                    u[3] += bf16_to_f32((uint16_t)(sk[q].y >> 16));
+                    const uint2 s2 = sk[i & 1][q];
+                    u[0] += bf16_to_f32((uint16_t)(s2.x & 0xFFFFu));
+                    u[1] += bf16_to_f32((uint16_t)(s2.x >> 16));
+                    u[2] += bf16_to_f32((uint16_t)(s2.y & 0xFFFFu));
+                    u[3] += bf16_to_f32((uint16_t)(s2.y >> 16));
                 }
                 if (p.relu) {
 #pragma unroll

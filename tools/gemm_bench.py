@@ -2,7 +2,7 @@
 """MFMA-pipe throughput of the hand-written f16x3 dense-layer kernel (both variants) next to round 1's arrangement (one
 library f16 GEMM over the interleaved 3x operand + the dca_act_split glue kernel) on the cube3 network's layer shapes.
 TFLOP/s are ISSUED f16 MFMA flops (3 products per useful one); `useful` = /3.  Candidates take turns over four rounds (the first
-is a warm-up), medians reported.   python tools/gemm_bench.py [rows]"""
+is a warm-up), medians reported.   python tools/gemm_bench.py [rows] [f16x3|16|e4m3]"""
 import json
 import os
 import sys
@@ -15,6 +15,7 @@ from deepcubea_amd import _lib  # noqa: E402
 from deepcubea_amd.utils.pytorch_models import _pow2_scale, _split_f16  # noqa: E402
 
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 204800
+only = sys.argv[2] if len(sys.argv) > 2 else ""  # "f16x3" | "16" | "e4m3": that section alone
 
 
 def timed(fn, iters=10):
@@ -43,7 +44,7 @@ def interleaved(cands, rounds=4):
     return {name: sorted(v)[len(v) // 2] for name, v in ms.items()}
 
 
-for n, k in ((1024, 1024), (1024, 5120)):
+for n, k in ((1024, 1024), (1024, 5120)) if only in ("", "f16x3") else ():
     g = torch.Generator().manual_seed(n + k)
     x = torch.randn(m, k, generator=g).cuda()
     w = torch.randn(n, k, generator=g) / k ** 0.5
@@ -81,7 +82,7 @@ for n, k in ((1024, 1024), (1024, 5120)):
 
 # ---- the 16-bit (non-parity) layer: dca_gemm16 with its tail in the epilogue vs the library's addmm_activation (+ the
 # separate ReLU pass a residual layer needs there)
-for dt, nm in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")):
+for dt, nm in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")) if only in ("", "16") else ():
     for n, k in ((1024, 1024), (1024, 5120)):
         g = torch.Generator().manual_seed(n + k)
         x = (torch.randn(m, k, generator=g) * 0.5).to(dt).cuda()
@@ -113,7 +114,7 @@ for dt, nm in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")):
 # ---- the fp8 (e4m3) layer: dca_gemm8 (dequantise + tail + requantise in the epilogue) vs the library's scaled fp8 GEMM
 # (torch._scaled_mm -> hipBLASLt, bf16 output, no tail)
 E4M3 = torch.float8_e4m3fn
-for n, k in ((1024, 1024), (1024, 5120)):
+for n, k in ((1024, 1024), (1024, 5120)) if only in ("", "e4m3") else ():
     g = torch.Generator().manual_seed(n + k)
     x8 = torch.randn(m, k, generator=g).clamp(-448, 448).to(E4M3).cuda()
     w8 = torch.randn(n, k, generator=g).clamp(-448, 448).to(E4M3).cuda()
