@@ -152,4 +152,4 @@ def test_fp8_network_deviation_from_the_fp32_network_is_stated():
     print("network vs fp32 network, deviation / max|h|: fp8 max %.3e rms %.3e (bf16 max %.3e); correlation fp8~fp32 %.5f"
           % (dev8, rms8, dev16, corr))
     assert not bool(torch.isnan(y8).any())
-    assert dev8 < 0.25 and rms8 < 0.05 and corr > 0.98
+    assert dev8 < 0.25 and rms8 < 0.05 and corr > 0.97  # measured: 0.103, 0.026, 0.987
