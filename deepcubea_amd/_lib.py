@@ -39,6 +39,7 @@ ABI_SYMBOLS = [
     "dca_bn_workspace_bytes", "dca_bn_train_forward", "dca_bn_train_backward",
     "dca_l1_supported", "dca_l1_kpad", "dca_l1_onehot_gemm", "dca_act_split", "dca_f16x3_gemm", "dca_split_planes", "dca_f16x3_gemm_variant",
     "dca_gemm16", "dca_gemm16_variant", "dca_gemm8", "dca_quant_e4m3", "dca_lightsout_next_state", "dca_lightsout_expand_fused",
+    "dca_head_gemv", "dca_engine_packed_state", "dca_engine_info",
 ]
 
 
@@ -445,6 +446,19 @@ def quant_e4m3(x: torch.Tensor, scale: float) -> torch.Tensor:
     out = torch.empty((m, n), dtype=E4M3, device=x.device)
     check(lib().dca_quant_e4m3(ptr(x), _TORCH_DT[x.dtype], C.c_int64(m), C.c_int64(n), C.c_int64(n), C.c_double(scale), ptr(out),
                                C.c_int64(n), stream_ptr()), "dca_quant_e4m3")
+    return out
+
+
+def head_gemv(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """Output layer (dca_head_gemv): x [m, k] fp32 / fp16 / bf16 (rows may be strided), w [n_out, k] fp32, bias [n_out] fp32
+    -> [m, n_out] fp32, summed in a fixed order (a row's bits do not depend on m or on the row's position)."""
+    assert x.is_cuda and x.dim() == 2 and x.stride(1) == 1 and x.dtype in _TORCH_DT
+    assert w.dtype == torch.float32 and w.is_contiguous() and w.shape[1] == x.shape[1]
+    assert bias is None or (bias.dtype == torch.float32 and bias.numel() == w.shape[0])
+    m, k = x.shape
+    out = torch.empty((m, w.shape[0]), dtype=torch.float32, device=x.device)
+    check(lib().dca_head_gemv(C.c_void_p(x.data_ptr()), _TORCH_DT[x.dtype], C.c_int64(m), int(k), C.c_int64(x.stride(0)), ptr(w),
+                              ptr(bias), int(w.shape[0]), ptr(out), stream_ptr()), "dca_head_gemv")
     return out
 
 

@@ -72,6 +72,11 @@ constexpr int kSegs = NBIN + 1 + kSub;
 constexpr uint32_t kGiantBinDefault = 8192;   // = kLdsEnt: larger threshold bins are refined by the grid, not by one workgroup
 constexpr int kMaxLevels = 9;                 // 96 composite bits / 11 bits per level
 constexpr unsigned long long kBarrierTimeout = 200000000ull;  // 2 s of the 100 MHz wall clock: a stuck grid barrier fails the search
+// The FIRST barrier of a giant iteration doubles as the residency check: nothing of the search has been modified before it, so
+// a launch whose workgroups are not all resident (another process or stream holds CUs / LDS) gives the path up there — by
+// consensus, see collect_grid_barrier — and takes the single-workgroup streaming path instead, for the rest of the engine's life.
+constexpr unsigned long long kBarrierTimeoutFirst = 25000000ull;  // 0.25 s (a resident grid passes it in well under a millisecond)
+constexpr uint32_t GBAR_BROKEN = 0x80000000u;  // bit 31 of the arrival counter: the barrier was abandoned before it completed
 constexpr uint32_t NIL = 0xFFFFFFFFu;
 // OPEN entries carry "this node is solved" in bit 31 of the id (node ids stay below 2^31): the pop then knows a goal
 // without touching the node pool.  Every compare / index uses the id with the flag masked off.
@@ -135,6 +140,7 @@ struct Ctl {
     // selection
     uint32_t want, bstar, shift, n_big, n_ord;
     uint32_t giant;   // this pop's threshold bin is refined across the grid by k_sel_collect (set by k_sel_scan)
+    uint32_t coop_off;  // a grid barrier found the launch not fully resident: giant bins go to k_rank's streaming path from now on (survives resets)
     uint32_t tseg;    // the segment holding the batch's last entry (= bstar unless giant)
     uint32_t pre_b, cn_star;  // entries below the threshold bin / in it (k_rank's histogram writeback)
     uint64_t sel_kmin;
@@ -200,6 +206,7 @@ struct Eng {
     uint8_t* move;
     uint8_t* solved;
     Slot* tab;
+    uint32_t* closed_slots;  // [max_nodes] the CLOSED slots in use, in insertion order: a reset clears these instead of the whole table
     uint64_t* open_key[4];
     uint32_t* open_id[4];
     uint32_t f_keep, f_max;  // FRONT hysteresis: refill/spill down to ~f_keep, spill when above f_max
@@ -458,7 +465,17 @@ __device__ __forceinline__ void fold_range(Ctl* c, uint32_t buf, uint64_t kmn, u
 // ---------------------------------------------------------------------------------------------
 // reset / root
 // ---------------------------------------------------------------------------------------------
-__global__ void k_init_table(Slot* tab, uint32_t cap) {
+// CLOSED is cleared before a search starts.  The table is sized for max_nodes (`--max_nodes auto`: ~1e9 ids, a 32 GiB table),
+// most searches touch a sliver of it: k_commit records the slot of every state it inserts (E.closed_slots, in insertion
+// order), and a reset clears THOSE — unless the last search used more than 1/8 of the table (a streaming clear is cheaper than
+// random 16-byte stores then), the table has never been cleared, or the last iteration was abandoned between its probe and
+// its commit (`force`: slots were claimed that the list does not hold yet).  Both kernels are enqueued; each one looks at the
+// previous search's count (still in the control block: k_reset runs behind them) and one of them returns at once.
+__device__ __forceinline__ bool clear_by_list(const Ctl* c, uint32_t cap, int force) {
+    return !force && (uint64_t)c->closed_n.v * 8ull < (uint64_t)cap;
+}
+__global__ void k_init_table(Slot* tab, uint32_t cap, const Ctl* c, int force) {
+    if (clear_by_list(c, cap, force)) return;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t stride = gridDim.x * blockDim.x;
     for (; i < cap; i += stride) {
@@ -467,11 +484,25 @@ __global__ void k_init_table(Slot* tab, uint32_t cap) {
         tab[i].head = 0;
     }
 }
+__global__ void k_clear_table_list(Slot* tab, uint32_t cap, const uint32_t* __restrict__ slots, const Ctl* c, int force) {
+    if (!clear_by_list(c, cap, force)) return;
+    const uint32_t n = c->closed_n.v;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t sl = slots[i];
+        if (sl < cap) {
+            tab[sl].entry = EMPTY;
+            tab[sl].g = GINF;
+            tab[sl].head = 0;
+        }
+    }
+}
 
 __global__ void k_reset(Eng E) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Ctl* c = E.ctl;
+    const uint32_t coop_off = c->coop_off;  // a property of how the GPU is shared, not of the search
     memset(c, 0, sizeof(Ctl));
+    c->coop_off = coop_off;
     const uint8_t* s = E.state;  // node 0 = root, already copied in
     uint64_t h = hash_init(E.D);
     bool ok = true;
@@ -506,6 +537,7 @@ __global__ void k_reset(Eng E) {
         uint32_t slot = (uint32_t)h & E.tab_mask;
         E.tab[slot].entry = ((h >> 32) << 32) | 0u;
         E.tab[slot].g = 0;
+        E.closed_slots[0] = slot;
         c->closed_n.v = 1;
         c->gen = 1;
         uint64_t key = key_of_cost(0.0);
@@ -959,7 +991,7 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
     // f-level one tie group of up to millions of entries) is not handed to k_rank whole: k_sel_collect refines it across
     // the grid first ("giant" iteration) and k_rank only sees the few thousand entries around the batch's end.
     const uint32_t giant_limit = g_tune[3] > 0 ? (uint32_t)g_tune[3] : kGiantBinDefault;
-    const bool giant = E.coop && want != 0 && pre[s_bstar + 1] - pre[s_bstar] > giant_limit;
+    const bool giant = E.coop && !c->coop_off && want != 0 && pre[s_bstar + 1] - pre[s_bstar] > giant_limit;
     if (giant)
         for (int i = t; i < kMaxLevels * kSub; i += 1024) E.subhist[i] = 0;
     for (int k = 0; k < kBinsPerThread; k++) {
@@ -1122,36 +1154,67 @@ struct SelParams {
     bool giant;
 };
 
-// all threads of the workgroup; false = the barrier timed out or another workgroup gave up (the search is failed)
-__device__ __forceinline__ bool collect_grid_barrier(Ctl* c, CollectLds& L, uint32_t target) {
+// All threads of the workgroup.  -> BAR_PASS; BAR_FAIL = a later barrier timed out or another workgroup gave up (the search is
+// failed); BAR_BROKEN (first barrier only) = the launch is not fully resident — some workgroup waited kBarrierTimeoutFirst for
+// the others — and the giant path is abandoned BY CONSENSUS: the workgroup that gives up sets bit 31 of the arrival counter with
+// a compare-and-swap that only succeeds while the count is still short of the target, so either every workgroup passes
+// (the count reached the target before anybody gave up: arrivals never clear the bit, nobody can give up afterwards because the
+// swap's expected value is stale) or every workgroup — those polling, and those that only become resident after the early ones
+// left — sees the bit and takes the same fallback.  Nothing of the search has been modified before the first barrier.
+enum { BAR_FAIL = 0, BAR_PASS = 1, BAR_BROKEN = 2 };
+__device__ __forceinline__ int collect_grid_barrier(Ctl* c, CollectLds& L, uint32_t target, bool first) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave's stores / atomics have left
     __syncthreads();
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(&c->gbar.v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bool ok = true;
+        uint32_t v = __hip_atomic_fetch_add(&c->gbar.v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        int res = BAR_PASS;
         const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load(&c->gbar.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(4);
-            if (__hip_atomic_load(&c->failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-                wall_clock64() - t0 > kBarrierTimeout) {
-                ok = false;
+        const unsigned long long limit = first ? kBarrierTimeoutFirst : kBarrierTimeout;
+        for (;;) {
+            if (v & GBAR_BROKEN) {
+                res = first ? BAR_BROKEN : BAR_FAIL;
                 break;
             }
+            if (v >= target) break;
+            __builtin_amdgcn_s_sleep(4);
+            if (__hip_atomic_load(&c->failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                res = BAR_FAIL;
+                break;
+            }
+            if (wall_clock64() - t0 > limit) {
+                if (!first) {
+                    res = BAR_FAIL;
+                    break;
+                }
+                uint32_t expect = v;
+                if (__hip_atomic_compare_exchange_strong(&c->gbar.v, &expect, v | GBAR_BROKEN, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT)) {
+                    res = BAR_BROKEN;
+                    break;
+                }
+                v = expect;  // the count moved on: look again (it may be complete now)
+                continue;
+            }
+            v = __hip_atomic_load(&c->gbar.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (!ok) {  // not every workgroup is resident (or one of them died): refuse to continue with half a selection
+        if (res == BAR_FAIL) {  // a workgroup died or stalled mid-selection: refuse to continue with half a selection
             __hip_atomic_store(&c->failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&c->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (res == BAR_BROKEN) {
+            __hip_atomic_store(&c->coop_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        L.ok = ok ? 1u : 0u;
+        L.ok = (uint32_t)res;
     }
     __syncthreads();
-    return L.ok != 0;
+    return (int)L.ok;
 }
 
-__device__ __noinline__ void collect_giant(const Eng& E, Ctl* c, CollectLds& L, const SelParams P) {
+// -> BAR_PASS: the batch's segments are collected; BAR_FAIL: the search failed; BAR_BROKEN: the launch is not fully resident,
+// nothing was touched — the caller collects the bins the ordinary way (k_rank then streams the giant bin on one workgroup)
+__device__ __noinline__ int collect_giant(const Eng& E, Ctl* c, CollectLds& L, const SelParams P) {
     const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const uint32_t n = P.n;
     const uint64_t bkmin = P.kmin;
@@ -1215,7 +1278,7 @@ __device__ __noinline__ void collect_giant(const Eng& E, Ctl* c, CollectLds& L, 
             }
         }
     }
-    if (!collect_grid_barrier(c, L, ++phase * gridDim.x)) return;
+    if (const int r = collect_grid_barrier(c, L, ++phase * gridDim.x, true); r != BAR_PASS) return r;
     const uint64_t gkmin = __hip_atomic_load(&c->grange.kmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint64_t gkmax = __hip_atomic_load(&c->grange.kmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t gimin = __hip_atomic_load(&c->grange.imin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1254,7 +1317,7 @@ __device__ __noinline__ void collect_giant(const Eng& E, Ctl* c, CollectLds& L, 
         uint32_t* gh = E.subhist + (size_t)lvl * kSub;
         for (uint32_t i = t; i < (uint32_t)kSub; i += 256)
             if (lh[i]) atomicAdd(&gh[i], lh[i]);
-        if (!collect_grid_barrier(c, L, ++phase * gridDim.x)) return;
+        if (collect_grid_barrier(c, L, ++phase * gridDim.x, false) != BAR_PASS) return BAR_FAIL;
         // every workgroup: prefix over the level's counts, the sub-bin holding the need-th entry
         constexpr int PER = kSub / 256;
         uint32_t v[PER], sum = 0;
@@ -1284,7 +1347,7 @@ __device__ __noinline__ void collect_giant(const Eng& E, Ctl* c, CollectLds& L, 
         tsub = L.tsub;
         if (tsub == ~0u) {  // counts and FRONT disagree (cannot happen)
             if (t == 0) c->failed = 1, c->done = 1;
-            return;
+            return BAR_FAIL;
         }
         const uint32_t cn = subpre[tsub + 1] - subpre[tsub];
         if (cn <= giant_limit || shc == 0 || lvl + 1 >= kMaxLevels) break;
@@ -1423,6 +1486,7 @@ __device__ __noinline__ void collect_giant(const Eng& E, Ctl* c, CollectLds& L, 
     }
     __syncthreads();
     flush();
+    return BAR_PASS;
 }
 
 // FUSED: this launch opens the iteration — there is no k_sel_scan in front of it.  Every workgroup derives the pop's
@@ -1497,7 +1561,7 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
         P.pre_b = L.pre[P.bstar];
         P.cn_star = L.pre[P.bstar + 1] - P.pre_b;
         const uint32_t giant_limit = g_tune[3] > 0 ? (uint32_t)g_tune[3] : kGiantBinDefault;
-        P.giant = E.coop && P.cn_star > giant_limit;
+        P.giant = E.coop && !c->coop_off && P.cn_star > giant_limit;
         if (blockIdx.x == 0) {
             // the record k_rank (and the rest of the iteration) reads — what k_sel_scan writes in a rebase iteration
             for (uint32_t i = t; i <= (uint32_t)NBIN; i += 256) E.pre[i] = L.pre[i];
@@ -1547,8 +1611,23 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
         __syncthreads();
     }
     if (P.giant) {
-        collect_giant(E, c, L, P);
-        return;
+        if (collect_giant(E, c, L, P) != BAR_BROKEN) return;
+        // Not every workgroup of this launch is resident (the GPU is shared): every workgroup arrives here — nothing has been
+        // touched yet — and collects the bins the ordinary way; workgroup 0 takes back what was published for k_rank: the
+        // threshold bin is an ordinary (large) bin again, streamed by one workgroup there.
+        if (blockIdx.x == 0 && t == 0) {
+            const uint32_t cn = P.cn_star;
+            uint32_t G = cn <= (uint32_t)kLdsEnt ? (cn + 1023u) / 1024u : 1u;
+            G = G > 8u ? 8u : G;
+            const uint32_t at = c->n_big;
+            if (cn > kTinyBin) {
+                for (uint32_t g = 0; g < G; g++) E.big_list[at + g] = P.bstar | (g << 16) | (G << 20);
+                c->n_big = at + G;
+            }
+            c->giant = 0;
+        }
+        P.giant = false;
+        __syncthreads();
     }
     const uint32_t n = P.n;
     const uint64_t kmin = P.kmin;
@@ -2730,7 +2809,13 @@ __global__ __launch_bounds__(256) void k_pack(const Eng* __restrict__ engs) {
     const Eng& E = engs[blockIdx.y];
     using EV = EnvT<ENV, DIM>;
     Ctl* c = E.ctl;
-    if (c->done) return;
+    if (c->done) {  // the host learns it with the packed row count it reads anyway: pk_n[1] = finished instances, [2] = failed ones
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            atomicAdd(&E.pk_n[1], 1u);
+            if (c->failed) atomicAdd(&E.pk_n[2], 1u);
+        }
+        return;
+    }
     Stamp stamp(E, P_PACK);
     const uint32_t m = st_next(c).m, base = st_next(c).base;
     if (blockIdx.x * 256 >= m) return;
@@ -2861,12 +2946,13 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
     const bool live = j < m;
     const uint32_t id = base + j;
     bool keep = false, is_new = false;
-    uint32_t gj = 0;
+    uint32_t gj = 0, my_slot = 0;
     if (live) {
         const uint8_t fl = E.child_flags[j];
         is_new = (fl & F_NEW) != 0;
         gj = E.pop_g[j / (uint32_t)E.A] + 1u;
         const uint32_t slot = E.child_slot[j];
+        my_slot = slot;
         bool is_min;
         uint32_t first = j;
         bool multi = false;
@@ -2925,6 +3011,7 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
     uint32_t* const ctr[3] = {&c->open_n[fb].v, &c->open_n[bb].v, &c->closed_n.v};
     uint32_t pos[3];
     block_reserveK<1024, 3>(cnt, ctr, pos, sh);
+    if (is_new && pos[2] < E.max_nodes) E.closed_slots[pos[2]] = my_slot;  // what the next reset clears (k_clear_table_list)
     if (tof) {
         if (pos[0] < E.front_cap) {
             E.open_key[fb][pos[0]] = key;
@@ -3041,7 +3128,9 @@ struct dca_engine {
     float* pk_h;
     int64_t pk_rows;       // rows packed by the last dca_engine_pop_expand_packed
     int phase;             // 0 idle, 1 between pop_expand and commit, 2 between pop_expand_packed and commit_packed
+    uint8_t tab_cleared[kMaxInstances];  // the instance's CLOSED table has been cleared in full at least once
     unsigned collect_blocks;  // grid of k_sel_collect: two workgroups per CU, all resident (its giant-bin path barriers across it)
+    long collect_resident;    // workgroups of k_sel_collect the device can hold at once per the occupancy query (-1: query failed)
     hipGraph_t graph[3];   // [0] iteration without / [1] with the refill check, [2] a whole period: rebase iteration + 7 plain ones
     hipGraphExec_t graph_exec[3];
     int graph_heur;
@@ -3303,6 +3392,7 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
         ALLOC(move, N);
         ALLOC(solved, N);
         ALLOC(tab, (size_t)cap);
+        ALLOC(closed_slots, N);
         E.front_cap = (uint32_t)(N + (size_t)(2 * kRefillPeriod) * Bz);
         for (int b = 0; b < 4; b++) {  // FRONT and its compaction target (0/1) + BACK and its compaction target (2/3)
             ALLOC(open_key[b], b < 2 ? (size_t)E.front_cap : N);
@@ -3354,6 +3444,22 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sel_collect<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CollectLds));
         if (err != hipSuccess) rc = hip_fail(err, "hipFuncSetAttribute(k_sel_collect)");
+        // The giant-bin path barriers across k_sel_collect's grid: ask the runtime how many of its workgroups a CU holds and
+        // keep the path only if the whole grid fits (the query is advisory — it cannot see other processes or streams — so
+        // the first barrier of every giant iteration checks residency for real and falls back by itself, collect_grid_barrier).
+        if (err == hipSuccess) {
+            int per_cu_a = 0, per_cu_b = 0, dev = 0, cus = 0;
+            (void)hipGetDevice(&dev);
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            hipError_t oa = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_a, k_sel_collect<false>, 256, sizeof(CollectLds));
+            hipError_t ob = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, k_sel_collect<true>, 256, sizeof(CollectLds));
+            const int per_cu = per_cu_a < per_cu_b ? per_cu_a : per_cu_b;
+            e->collect_resident = (oa == hipSuccess && ob == hipSuccess && cus > 0) ? (long)per_cu * cus : -1;
+            if (e->collect_resident >= 0 && e->collect_resident < (long)e->collect_blocks) {
+                for (size_t i = 0; i < K; i++) e->E[i].coop = 0;
+            }
+            (void)hipGetLastError();
+        }
     }
     if (!rc) {
         // k_rank buckets a bin inside 96 KB of dynamic LDS: beyond the default limit
@@ -3409,7 +3515,13 @@ int dca_engine_reset_instance(dca_engine* e, int inst, const uint8_t* root, void
     DCA_HIP(hipStreamSynchronize(s));
     memcpy(e->h_stage, root, (size_t)E.D);
     DCA_HIP(hipMemcpyAsync(E.state, e->h_stage, (size_t)E.D, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_init_table, dim3(4096), dim3(256), 0, s, E.tab, E.tab_cap);
+    {
+        // (an iteration abandoned between its two halves has claimed slots the list does not hold yet: clear everything)
+        const int force = (e->tab_cleared[inst] == 0 || e->phase != 0) ? 1 : 0;
+        hipLaunchKernelGGL(k_init_table, dim3(4096), dim3(256), 0, s, E.tab, E.tab_cap, E.ctl, force);
+        hipLaunchKernelGGL(k_clear_table_list, dim3(1024), dim3(256), 0, s, E.tab, E.tab_cap, E.closed_slots, E.ctl, force);
+        e->tab_cleared[inst] = 1;
+    }
     hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, s, E);
     e->phase = 0;
     e->host_iter = 0;  // the next iteration is a rebase iteration (full histogram) for every instance
@@ -3516,11 +3628,11 @@ int dca_engine_pop_expand_packed(dca_engine* e, const uint8_t** nnet_in, const v
         return DCA_E_STATE;
     }
     hipStream_t s = (hipStream_t)stream;
-    DCA_HIP(hipMemsetAsync(e->pk_n, 0, sizeof(uint32_t), s));
+    DCA_HIP(hipMemsetAsync(e->pk_n, 0, 4 * sizeof(uint32_t), s));
     if (int rc = enqueue_first_half(e, -1, rebase_due(e->host_iter++), s, false)) return rc;
     if (int rc = enqueue_dedup(e, true, s)) return rc;
     if (int rc = launch_pack(e, s)) return rc;
-    DCA_HIP(hipMemcpyAsync(e->h_pk_n, e->pk_n, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    DCA_HIP(hipMemcpyAsync(e->h_pk_n, e->pk_n, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     DCA_HIP(hipStreamSynchronize(s));
     e->pk_rows = (int64_t)*e->h_pk_n;
     *rows = e->pk_rows;
@@ -3528,6 +3640,17 @@ int dca_engine_pop_expand_packed(dca_engine* e, const uint8_t** nnet_in, const v
     if (onehot) *onehot = e->pk_onehot;
     if (src) *src = e->pk_src;
     e->phase = 2;
+    return 0;
+}
+
+int dca_engine_packed_state(dca_engine* e, int* instances_done, int* instances_failed) {
+    DCA_ARG(e != nullptr);
+    if (e->h_pk_n == nullptr) {
+        set_error("dca_engine_packed_state before dca_engine_enable_packed");
+        return DCA_E_STATE;
+    }
+    if (instances_done) *instances_done = (int)e->h_pk_n[1];
+    if (instances_failed) *instances_failed = (int)e->h_pk_n[2];
     return 0;
 }
 
@@ -3663,6 +3786,15 @@ int dca_debug_tune(int knob, int value) {
     // iterations), 5 (host, before create) giant-bin path off, 6 (host) k_sel_scan launched in every iteration, 7 (host) single-iteration graphs only, 9 largest bin ranked a thread per entry
     DCA_ARG(knob >= 0 && knob < 16);
     DCA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tune), &value, sizeof(int), (size_t)knob * sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int dca_engine_info(dca_engine* e, int64_t* out) {
+    DCA_ARG(e != nullptr && out != nullptr);
+    out[0] = (int64_t)e->collect_blocks;
+    out[1] = (int64_t)e->collect_resident;
+    out[2] = (int64_t)e->E[0].coop;
+    out[3] = (int64_t)e->E[0].tab_cap * (int64_t)sizeof(Slot);
     return 0;
 }
 

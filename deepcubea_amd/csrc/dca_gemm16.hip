@@ -451,6 +451,11 @@ int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int 
     DCA_ARG(dtype == DCA_DT_BF16 || dtype == DCA_DT_F16);
     DCA_ARG(lda >= k && ldw >= k && lda % 8 == 0 && ldw % 8 == 0 && ldo >= n && ldo % 4 == 0);
     DCA_ARG(((uintptr_t)a | (uintptr_t)w) % 16 == 0 && ((uintptr_t)out | (uintptr_t)skip) % 8 == 0);
+    if (m > 0) {  // `out` may alias `skip`, never the operand (its tiles are re-read while other tiles' epilogues write)
+        const uintptr_t a0 = (uintptr_t)a, a1 = a0 + ((size_t)(m - 1) * (size_t)lda + (size_t)k) * 2;
+        const uintptr_t o0 = (uintptr_t)out, o1 = o0 + ((size_t)(m - 1) * (size_t)ldo + (size_t)n) * 2;
+        DCA_ARG(!(o0 < a1 && a0 < o1));
+    }
     if (m == 0) return 0;
     {   // the dynamic-LDS limit is a per-device function attribute: set it once for every device this process uses
         static std::atomic<uint64_t> attr_devs{0};

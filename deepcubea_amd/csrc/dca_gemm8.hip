@@ -356,6 +356,15 @@ int dca_gemm8(const void* a, int64_t m, int k, int64_t lda, const void* w, int n
     DCA_ARG(((uintptr_t)a | (uintptr_t)w) % 16 == 0);
     DCA_ARG((!out16 && !skip) || (ldo16 >= n && ldo16 % 4 == 0 && ((uintptr_t)out16 | (uintptr_t)skip) % 8 == 0));
     DCA_ARG(!out8 || (ldo8 >= n && ldo8 % 4 == 0 && (uintptr_t)out8 % 4 == 0 && out8_scale > 0.0));
+    {   // the A tiles are re-read through LDS-DMA while the epilogues of other tiles write: no output may overlap the operand
+        const uintptr_t a0 = (uintptr_t)a, a1 = a0 + (m > 0 ? (size_t)(m - 1) * (size_t)lda + (size_t)k : 0);
+        auto overlaps = [&](const void* o, int64_t ld, size_t esz) {
+            if (!o || m == 0) return false;
+            const uintptr_t o0 = (uintptr_t)o, o1 = o0 + ((size_t)(m - 1) * (size_t)ld + (size_t)n) * esz;
+            return o0 < a1 && a0 < o1;
+        };
+        DCA_ARG(!overlaps(out8, ldo8, 1) && !overlaps(out16, ldo16, 2));
+    }
     if (m == 0) return 0;
     {   // the dynamic-LDS limit is a per-device function attribute: set it once for every device this process uses
         static std::atomic<uint64_t> attr_devs{0};

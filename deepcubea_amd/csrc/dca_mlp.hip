@@ -371,7 +371,75 @@ __global__ __launch_bounds__(256) void k_act_split(const float* __restrict__ y, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Output layer of the cost-to-go network (utils/pytorch_models.py:83-86: fc_out, 1000 -> out_dim, out_dim = 1 for every
+// environment of the reference): out[r][o] = x[r] . w[o] + b[o].  A [m, 1024] x [1024, 1] product is a streaming pass
+// over x (HBM-bound: 4 KB per row), not a GEMM — and the library GEMV it used to be picks its kernel, and with it the
+// order of the 1024 additions, from m.  Here the order is FIXED: one wave per row, lane l accumulates the 4-element
+// chunks l, l + 64, l + 128 ... left to right (fmaf chain), then a xor-butterfly folds the 64 lane sums — a row's
+// value is the same bits whatever row index, batch size or launch it is evaluated in, which is what lets the
+// dedup-first search (kept children, packed) and the reference-order search (all children) be compared bit for bit.
+// x: fp32, or bf16 / fp16 (the non-parity modes' residual stream), converted on load; accumulation fp32.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename XT>
+__device__ __forceinline__ float4 head_load4(const XT* p);
+template <>
+__device__ __forceinline__ float4 head_load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <>
+__device__ __forceinline__ float4 head_load4<_Float16>(const _Float16* p) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const h4 v = *reinterpret_cast<const h4*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+template <>
+__device__ __forceinline__ float4 head_load4<uint16_t>(const uint16_t* p) {  // bf16 bit patterns
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xFFFF0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xFFFF0000u));
+}
+
+constexpr int kHeadMaxOut = 8;
+template <typename XT>
+__global__ __launch_bounds__(256) void k_head_gemv(const XT* __restrict__ x, int64_t m, int k, int64_t ldx,
+                                                   const float* __restrict__ w /*[n_out, k]*/, const float* __restrict__ b,
+                                                   int n_out, float* __restrict__ out /*[m, n_out]*/) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t head_lds[];
+    float* lw = reinterpret_cast<float*>(head_lds);  // the weights, once per workgroup
+    for (int i = threadIdx.x; i < n_out * k; i += 256) lw[i] = w[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nch = k >> 2;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wv; r < m; r += (int64_t)gridDim.x * 4) {
+        const XT* row = x + r * ldx;
+        float acc[kHeadMaxOut];
+#pragma unroll
+        for (int o = 0; o < kHeadMaxOut; o++) acc[o] = 0.f;
+        for (int c = lane; c < nch; c += 64) {
+            const float4 v = head_load4<XT>(row + 4 * c);
+#pragma unroll
+            for (int o = 0; o < kHeadMaxOut; o++) {
+                if (o < n_out) {
+                    const float4 q = *reinterpret_cast<const float4*>(lw + o * k + 4 * c);
+                    acc[o] = fmaf(v.x, q.x, acc[o]);
+                    acc[o] = fmaf(v.y, q.y, acc[o]);
+                    acc[o] = fmaf(v.z, q.z, acc[o]);
+                    acc[o] = fmaf(v.w, q.w, acc[o]);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < kHeadMaxOut; o++) {
+            if (o < n_out) {
+                float s = acc[o];
+                for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);  // every lane ends with the same bits
+                if (lane == 0) out[r * n_out + o] = s + (b ? b[o] : 0.f);
+            }
+        }
+    }
+}
+
 }  // namespace dca
+
 
 using namespace dca;
 
@@ -415,6 +483,29 @@ int dca_act_split(const float* y, const float* bias, const float* skip, const fl
                        (float)alpha, relu,
                        m, n, x_out, reinterpret_cast<_Float16*>(a3), a3_planes, overflow);
     return launch_check("k_act_split");
+}
+
+int dca_head_gemv(const void* x, int x_dtype, int64_t m, int k, int64_t ldx, const float* w, const float* bias, int n_out,
+                  float* out, void* stream) {
+    DCA_ARG(x && w && out && m >= 0 && k >= 4 && k % 4 == 0 && ldx >= k && n_out >= 1 && n_out <= kHeadMaxOut);
+    DCA_ARG(x_dtype == DCA_DT_F32 || x_dtype == DCA_DT_F16 || x_dtype == DCA_DT_BF16);
+    DCA_ARG((size_t)n_out * (size_t)k * sizeof(float) <= 64 * 1024);
+    DCA_ARG((uintptr_t)x % (x_dtype == DCA_DT_F32 ? 16 : 8) == 0 && ldx % 4 == 0 && (uintptr_t)w % 16 == 0);
+    if (m == 0) return 0;
+    int64_t blocks = (m + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    const size_t lds = (size_t)n_out * (size_t)k * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    if (x_dtype == DCA_DT_F32)
+        hipLaunchKernelGGL(k_head_gemv<float>, dim3((unsigned)blocks), dim3(256), lds, s, reinterpret_cast<const float*>(x), m, k,
+                           ldx, w, bias, n_out, out);
+    else if (x_dtype == DCA_DT_F16)
+        hipLaunchKernelGGL(k_head_gemv<_Float16>, dim3((unsigned)blocks), dim3(256), lds, s,
+                           reinterpret_cast<const _Float16*>(x), m, k, ldx, w, bias, n_out, out);
+    else
+        hipLaunchKernelGGL(k_head_gemv<uint16_t>, dim3((unsigned)blocks), dim3(256), lds, s,
+                           reinterpret_cast<const uint16_t*>(x), m, k, ldx, w, bias, n_out, out);
+    return launch_check("k_head_gemv");
 }
 
 }  // extern "C"

@@ -86,7 +86,7 @@ def _max_nodes(args, instances: int) -> int:
     v = getattr(args, "max_nodes", "auto")
     if str(v).lower() != "auto":
         return int(v)
-    return BwasEngine.auto_max_nodes(args.env, args.batch_size, instances)
+    return BwasEngine.auto_max_nodes(args.env, args.batch_size, instances, sharers=sharding.ranks_on_my_device())
 
 
 _BUILTIN = {"manhattan": _lib.HEUR_MANHATTAN, "zero": _lib.HEUR_ZERO, "hashu01": _lib.HEUR_HASHU01}

@@ -65,15 +65,19 @@ class BwasEngine:
         CLOSED table (16-byte slots, power of two >= 2 ids per id: up to 4 slots), four OPEN buffers of (key, id), the
         pop's scratch arrays (tmp key/id/bin/idx, ord key/id)."""
         D = _lib.env_ids(env_name)[2]
-        return D + 10 + 4 * 16 + 4 * 12 + 18 + 12
+        return D + 10 + 4 * 16 + 4 + 4 * 12 + 18 + 12  # (+4: the list of CLOSED slots in use, what a reset clears)
 
     @staticmethod
-    def auto_max_nodes(env_name: str, batch_size: int, num_instances: int = 1, fraction: float = 0.8) -> int:
-        """Largest node pool that fits `fraction` of the HBM currently free on this device (288 GB on an MI355X), split
-        between the engine's instances; capped by the 31-bit node id."""
+    def auto_max_nodes(env_name: str, batch_size: int, num_instances: int = 1, fraction: float = 0.8,
+                       sharers: int = 1) -> int:
+        """Largest node pool that fits `fraction` of this process's share of the device's HBM (288 GB on an MI355X), split
+        between the engine's instances; capped by the 31-bit node id.  `sharers`: processes that use this device (ranks
+        mapped onto the same GPU, sharding.ranks_on_my_device()): each takes 1/sharers of the TOTAL memory at most — the
+        free amount alone is a race between them — and never more than what is free right now."""
         _lib.require_gpu()
-        free, _total = torch.cuda.mem_get_info()
-        n = int(free * fraction) // (BwasEngine.bytes_per_node(env_name) * max(1, int(num_instances)))
+        free, total = torch.cuda.mem_get_info()
+        budget = min(free, total // max(1, int(sharers)))
+        n = int(budget * fraction) // (BwasEngine.bytes_per_node(env_name) * max(1, int(num_instances)))
         floor = int(batch_size) * _lib.env_ids(env_name)[3] * 4 + 64
         return max(floor, min(n, 0x7FFFFF00 // 2))  # (the CLOSED table's slot index is 32-bit: 2 slots per id)
 
@@ -137,6 +141,17 @@ class BwasEngine:
         assert h.is_cuda and h.dtype == torch.float32 and h.is_contiguous()
         _lib.check(_lib.lib().dca_engine_commit_packed(self._h, _lib.ptr(h), _lib.stream_ptr()), "dca_engine_commit_packed")
 
+    def packed_state(self) -> Tuple[int, int]:
+        """(instances finished, instances failed) as the last pop_expand_packed found them — no extra host sync."""
+        nd, nf = C.c_int(0), C.c_int(0)
+        _lib.check(_lib.lib().dca_engine_packed_state(self._h, C.byref(nd), C.byref(nf)), "dca_engine_packed_state")
+        return int(nd.value), int(nf.value)
+
+    def info(self) -> dict:
+        out = (C.c_int64 * 4)()
+        _lib.check(_lib.lib().dca_engine_info(self._h, out), "dca_engine_info")
+        return dict(zip(["collect_blocks", "collect_resident", "grid_refinement", "closed_table_bytes"], list(out)))
+
     def step(self, heuristic_fn_dev: Callable[[torch.Tensor], torch.Tensor]) -> None:
         """One BWAS iteration (AStar.step, astar.py:256-317) with a device heuristic closure."""
         if self.packed:
@@ -147,6 +162,10 @@ class BwasEngine:
                 self.commit_packed(self._zero_h)
                 return
             n = min((rows + 1023) // 1024 * 1024, self.packed_capacity)  # few distinct GEMM shapes
+            try:  # rows past `rows` are padding (stale or zero): a model that calibrates on its input must not look at them
+                heuristic_fn_dev.valid_rows = rows
+            except AttributeError:
+                pass
             h = heuristic_fn_dev(oh[:n], True) if oh is not None else heuristic_fn_dev(nn[:n])
             assert h.shape[0] >= rows
             self.commit_packed(h.to(torch.float32).contiguous())
@@ -234,10 +253,11 @@ class BwasEngine:
             self.root_commit(heuristic_fn_dev(self.root_nnet_in()).to(torch.float32))
         for it in range(max_iters):
             self.step(heuristic_fn_dev)
-            # The packed row count already comes back from the device every iteration; a finished search packs no rows
-            # (its launches are no-ops), so the status block is only fetched then — and every 16th iteration as a guard —
-            # instead of a second host sync per iteration.
-            if self.packed and self.last_rows != 0 and it % 16 != 15:
+            # Packed stepping: the done / failed flags come back with the packed row count every iteration (one host sync,
+            # which the row count needs anyway), so a search that finishes or fails is noticed at the next iteration's pop.
+            if self.packed:
+                if self.packed_state()[0] >= self.num_instances:
+                    break
                 continue
             if self.status()["done"]:
                 break

@@ -34,7 +34,39 @@ def init_from_env(backend: str = "gloo") -> Tuple[int, int]:
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
         if not dist.is_initialized():
             dist.init_process_group(backend, rank=rank, world_size=world)
+        if ranks_on_my_device() > 1:
+            _share_gpu(rank)
     return world, rank
+
+
+def ranks_on_my_device() -> int:
+    """How many ranks of this node are mapped onto the GPU this rank uses (LOCAL_RANK % device_count).  The deployment
+    model is one rank per GPU (nnet_utils.py:292-301 of the reference); more local ranks than GPUs — a test
+    box, a partitioned node — share devices, and the engine has to know: its node pool may only take its share of the
+    HBM, and the grid-wide refinement of giant tie bins assumes it has the GPU to itself."""
+    if not torch.cuda.is_available():
+        return 1
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    ndev = max(1, torch.cuda.device_count())
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    mine = local_rank % ndev
+    return max(1, sum(1 for r in range(local_world) if r % ndev == mine))
+
+
+_shared_noted = False
+
+
+def _share_gpu(rank: int) -> None:
+    """Several ranks on one GPU: select the engine's single-workgroup path for giant tie bins before any engine exists
+    (`dca_debug_tune(5, 1)`; the grid-wide path needs every workgroup of a launch resident, which two processes on one
+    device cannot promise each other — it would notice by itself at its first barrier and fall back, 0.25 s later)."""
+    global _shared_noted
+    from .. import _lib
+    _lib.check(_lib.lib().dca_debug_tune(5, 1), "dca_debug_tune")
+    if not _shared_noted:
+        _shared_noted = True
+        print("rank %d: %d ranks share this GPU — node pool sized to 1/%d of its memory, grid-wide tie refinement off"
+              % (rank, ranks_on_my_device(), ranks_on_my_device()))
 
 
 def shard_indices(n: int, world: int, rank: int) -> List[int]:

@@ -50,6 +50,7 @@ def get_heuristic_fn_dev(nnet: nn.Module, clip_zero: bool = False, batch_size: O
     explicitly non-parity fast mode."""
     nnet.eval()
     in_pad = getattr(nnet, "in_pad", None)  # FastResnet: one-hot rows carry its padded stride and dtype
+    takes_valid = bool(getattr(nnet, "takes_valid_rows", False))
 
     @torch.no_grad()
     def heuristic_fn_dev(x: torch.Tensor, is_onehot: bool = False) -> torch.Tensor:
@@ -57,15 +58,25 @@ def get_heuristic_fn_dev(nnet: nn.Module, clip_zero: bool = False, batch_size: O
         if is_onehot and in_pad is not None and (x.shape[1] != in_pad or x.dtype != nnet.onehot_dtype):
             x = torch.nn.functional.pad(x.to(nnet.onehot_dtype), (0, in_pad - x.shape[1]))
         step = n if batch_size is None else batch_size
+        # rows past `valid_rows` (set by BwasEngine.step for one call) are padding: only a model that calibrates on its
+        # input cares (Fp8Resnet) — every row is evaluated either way
+        valid = getattr(heuristic_fn_dev, "valid_rows", None)
+        heuristic_fn_dev.valid_rows = None
         outs = []
         for s in range(0, n, max(step, 1)):
             xb = x[s:s + step]
             with torch.autocast("cuda", dtype=autocast_dtype, enabled=autocast_dtype is not None):
-                yb = nnet.forward_onehot(xb) if is_onehot else nnet(xb)
+                if is_onehot:
+                    yb = nnet.forward_onehot(xb)
+                elif takes_valid:
+                    yb = nnet(xb, valid_rows=None if valid is None else max(0, min(valid - s, xb.shape[0])))
+                else:
+                    yb = nnet(xb)
             outs.append(yb[:, 0].float())
         y = torch.cat(outs) if len(outs) != 1 else outs[0]
         return torch.clamp_min(y, 0.0) if clip_zero else y
 
+    heuristic_fn_dev.valid_rows = None
     return heuristic_fn_dev
 
 

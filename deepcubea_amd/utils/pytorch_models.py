@@ -220,6 +220,8 @@ class FastResnet(nn.Module):
         self.biases_f32 = nn.ParameterList([nn.Parameter(b.to(dtype).float(), requires_grad=False) for b in bs])
         self.w_out = nn.Parameter(wo.to(dtype), requires_grad=False)
         self.b_out = nn.Parameter(bo.float(), requires_grad=False)
+        # the output layer runs as dca_head_gemv on the device (fixed summation order): fp32 copy of the weights in `dtype`
+        self.w_out_f32 = nn.Parameter(wo.to(dtype).float().contiguous(), requires_grad=False)
         # fp32 mode on the device: every dense layer after the first as ONE f16 GEMM with fp32 output over the split
         # operands A3[3k..3k+2] = (xh, xl, xh), W3[3k..3k+2] = (wh, wh, wl) (csrc/dca_mlp.hip k_act_split): fp32-accurate, 2.4-2.9x faster
         # than the library's fp32 GEMM.  Weights are pre-scaled by a power of two so their low halves stay normal numbers.
@@ -289,6 +291,14 @@ class FastResnet(nn.Module):
     def uses_l1_kernel(self) -> bool:
         return self.l1_tiles is not None
 
+    def _head(self, x: torch.Tensor) -> torch.Tensor:
+        """fc_out (pytorch_models.py:83-86 of the reference): [M, res_pad] -> [M, out_dim] float32.  On the device: the
+        library's own streaming kernel (dca_head_gemv) — a row's value then has the same bits whatever batch it sits in."""
+        if x.is_cuda and self.w_out_f32.shape[0] <= 8:
+            from .. import _lib
+            return _lib.head_gemv(x, self.w_out_f32, self.b_out)
+        return (x @ self.w_out.t()).float() + self.b_out
+
     @property
     def onehot_dtype(self) -> torch.dtype:
         """Element type of the one-hot rows `forward_onehot` wants on the device (0/1 are exact in every type)."""
@@ -325,12 +335,12 @@ class FastResnet(nn.Module):
             for k in range(2, len(W), 2):
                 h = _lib.gemm16(x, W[k], Bf[k], None, True)
                 x = _lib.gemm16(h, W[k + 1], None, x, True, out=x)  # (the block's second bias rides in W through h's constant-one unit)
-            return (x @ self.w_out.t()).float() + self.b_out
+            return self._head(x)
         x = torch._addmm_activation(B[1], x, W[1].t())
         for k in range(2, len(W), 2):
             h = torch._addmm_activation(B[k], x, W[k].t())
             x = x.addmm_(h, W[k + 1].t()).relu_()  # in place: the skip is the GEMM's C operand, no copy of it
-        return (x @ self.w_out.t()).float() + self.b_out  # fc_out: [M,rp] x [rp,out_dim], fp32 bias add
+        return self._head(x)  # fc_out: [M,rp] x [rp,out_dim], fp32 bias add
 
     @torch.no_grad()
     def encode(self, states_nnet: torch.Tensor) -> torch.Tensor:
@@ -371,7 +381,7 @@ class FastResnet(nn.Module):
             ah, _ = _lib.act_split(y, B[ka], None, A[ka], True, False, overflow=ovf)
             y = torch.mm(ah, W[kb].t(), out_dtype=f32)
             a3, x = _lib.act_split(y, B[kb], x, A[kb], True, True, want_a3=blk + 1 < nblk, overflow=ovf)
-        return x @ self.w_out.t() + self.b_out
+        return self._head(x)
 
     def _after_l1_planes(self, planes: torch.Tensor) -> torch.Tensor:
         """fp16 planes of relu(layer 1) [2, M, h1_pad] -> [M, out_dim]: one dca_f16x3_gemm launch per dense layer (scale,
@@ -384,7 +394,7 @@ class FastResnet(nn.Module):
             ka, kb = 1 + 2 * blk, 2 + 2 * blk
             ph, _ = _lib.f16x3_gemm(planes, Wh[ka], Wl[ka], A[ka], 1.0, B[ka], None, True, True, False, ovf)
             planes, x = _lib.f16x3_gemm(ph, Wh[kb], Wl[kb], A[kb], 1.0, B[kb], x, True, blk + 1 < nblk, True, ovf)
-        return x @ self.w_out.t() + self.b_out
+        return self._head(x)
 
 
 class Fp8Resnet(nn.Module):
@@ -482,16 +492,20 @@ class Fp8Resnet(nn.Module):
             s_in += [self.act_scale[1 + 2 * i], self.act_scale[2 + 2 * i]]
         self.layer_scale = [(self.w_scale[j].to(dev) * s_in[j]).contiguous() for j in range(len(self.w8))]
 
+    takes_valid_rows = True  # get_heuristic_fn_dev passes the engine's live row count (the batch is padded to 1024 rows)
+
     @torch.no_grad()
-    def forward(self, states_nnet: torch.Tensor) -> torch.Tensor:
-        """uint8 network inputs [M, state_dim] (device) -> [M, out_dim] float32."""
+    def forward(self, states_nnet: torch.Tensor, valid_rows: Optional[int] = None) -> torch.Tensor:
+        """uint8 network inputs [M, state_dim] (device) -> [M, out_dim] float32.  valid_rows: the first rows that hold real
+        states (the engine pads its batches to 1024 rows with zero / stale rows): only those may calibrate the scales."""
         from .. import _lib
         if not states_nnet.is_cuda:
             raise RuntimeError("Fp8Resnet runs on the GPU only")
         if self.layer_scale is None:
-            if states_nnet.shape[0] < self.MIN_CALIB_ROWS:  # a search's root / first thin batches: bf16 until there is a sample
+            real = states_nnet.shape[0] if valid_rows is None else min(int(valid_rows), states_nnet.shape[0])
+            if real < self.MIN_CALIB_ROWS:  # a search's root / first thin batches: bf16 until there is a sample of REAL rows
                 return self.base(states_nnet)
-            self.calibrate(states_nnet)
+            self.calibrate(states_nnet[:real])
         s = self.act_scale
         h8 = _lib.l1_onehot_gemm(states_nnet, self.one_hot_depth, self.l1_tiles8, 1, self.l1_bias8, True, _lib.E4M3)
         x16, x8 = _lib.gemm8(h8, self.w8[0], self.layer_scale[0], self.bias[0], None, True, True, 1.0 / s[1])
@@ -501,4 +515,4 @@ class Fp8Resnet(nn.Module):
             _, h8 = _lib.gemm8(x8, self.w8[ja], self.layer_scale[ja], self.bias[ja], None, True, False, 1.0 / s[2 + 2 * i])
             nxt = None if i == nblk - 1 else 1.0 / s[3 + 2 * i]  # the last block's output only feeds the bf16 output layer
             x16, x8 = _lib.gemm8(h8, self.w8[jb], self.layer_scale[jb], self.bias[jb], x16, True, True, nxt, out16=x16)
-        return (x16 @ self.base.w_out.t()).float() + self.base.b_out
+        return self.base._head(x16)

@@ -226,6 +226,10 @@ int dca_engine_enable_packed(dca_engine* e, int onehot_dtype, int64_t onehot_row
 int dca_engine_pop_expand_packed(dca_engine* e, const uint8_t** nnet_in, const void** onehot, const uint32_t** src,
                                  int64_t* rows, void* stream);
 int dca_engine_commit_packed(dca_engine* e, const float* h, void* stream);
+/* what the last pop_expand_packed found besides its row count (no extra sync: read with it): how many of the engine's
+ * instances were already finished when it ran (done: goal popped and accepted, OPEN empty, or failed) and how many of those
+ * failed (node pool exhausted, ...).  A host loop stops stepping when instances_done == K instead of polling the status. */
+int dca_engine_packed_state(dca_engine* e, int* instances_done, int* instances_failed);
 /* both halves with a built-in heuristic (evaluated inside the expansion launch), `iters`
  * iterations enqueued without any host sync (kernels no-op once the search is done).
  * use_graph != 0 replays one captured hipGraph per iteration instead of eager launches.           */
@@ -255,6 +259,10 @@ int dca_engine_debug(dca_engine* e, double* out /*host [16]*/, void* stream);
  * k_sel_collect, 5: grid-wide refinement off, 6: k_sel_scan in every iteration, 7: single-iteration graphs only (4-7 host side,
  * set before the engine is created / first stepped); 9: largest bin k_rank orders a thread per entry; 0-15 accepted.      */
 int dca_debug_tune(int knob, int value);
+/* static facts about an engine (host int64[4]): [0] workgroups of k_sel_collect's grid, [1] how many of them the device holds
+ * at once according to hipOccupancyMaxActiveBlocksPerMultiprocessor (-1: query failed), [2] 1 if the grid-wide refinement of
+ * giant tie bins (grid barriers; needs [1] >= [0]) is enabled, [3] bytes of the CLOSED table */
+int dca_engine_info(dca_engine* e, int64_t* out /*host [4]*/);
 /* child rows of the last pop_expand straight from the node pool (device [m_live, D]); synchronises */
 int dca_engine_last_children(dca_engine* e, const uint8_t** states, int64_t* m_live, void* stream);
 /* root->goal move list (astar.py:213-229 get_path / cpp:336-341).  synchronises.                 */
@@ -360,6 +368,14 @@ int dca_quant_e4m3(const void* x, int dtype, int64_t m, int64_t n, int64_t ld, d
 /* fp32 [m, n] (row stride ld) -> its fp16 planes (row stride ldo); n % 4 == 0 */
 int dca_split_planes(const float* x, int64_t m, int64_t n, int64_t ld, void* out_h, void* out_l, int64_t ldo,
                      int* overflow /*or NULL*/, void* stream);
+
+/* Output layer of the cost-to-go network (utils/pytorch_models.py:83-86, fc_out: res_dim -> out_dim, out_dim = 1 for every
+ * environment of the reference): out[m, n_out] = x[m, k] . w[n_out, k]^T + bias, fp32 accumulation in a FIXED order (one wave
+ * per row, lane-strided fmaf chains, xor-butterfly fold): a row's value does not depend on its position, on m or on the launch
+ * — the library GEMV this replaces chose its kernel (and summation order) from m.  x: DCA_DT_F32 / F16 / BF16 rows (row
+ * stride ldx elements, k % 4 == 0, ldx % 4 == 0); w, bias, out fp32; n_out <= 8. */
+int dca_head_gemv(const void* x, int x_dtype, int64_t m, int k, int64_t ldx, const float* w /*[n_out, k]*/,
+                  const float* bias /*[n_out] or NULL*/, int n_out, float* out /*[m, n_out]*/, void* stream);
 
 #ifdef __cplusplus
 }
