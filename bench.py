@@ -289,6 +289,10 @@ def run_astar(args, world, rank):
         # k_rank reads those and writes the batch in pop order; k_sel_scan walks the 4096-bin histogram.  The rebase pass
         # (slot "sel_hist", every 8th iteration: its span here is averaged over all profiled iterations) is left out.
         alg_k = dict(alg, sel_collect=8.0 * n_front + 36.0 * n_ord, rank=18.0 * n_ord + 16.0 * B, sel_scan=4096 * 16.0)
+        if "probe" not in span:
+            # four launches per iteration: the CLOSED probe runs inside the expansion launch, from the rows the tile holds in
+            # LDS — its own row (D) is no longer re-read and the hash (8 written + 8 read) never leaves the registers
+            alg_k["expand"] = alg["expand"] + alg["probe"] - B * A * (STATE_DIM[args.env] + 16)
         cand = {k: v for k, v in span.items() if k in alg_k and not k.startswith("per_")}
         dom = max(cand, key=cand.get)  # the launch that takes the most time, whatever bounds it
         ach = alg_k[dom] / (span[dom] * 1e-3) / 1e9

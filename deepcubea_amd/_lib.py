@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "dca_bn_workspace_bytes", "dca_bn_train_forward", "dca_bn_train_backward",
     "dca_l1_supported", "dca_l1_kpad", "dca_l1_onehot_gemm", "dca_act_split", "dca_f16x3_gemm", "dca_split_planes", "dca_f16x3_gemm_variant",
     "dca_gemm16", "dca_gemm16_variant", "dca_gemm8", "dca_quant_e4m3", "dca_lightsout_next_state", "dca_lightsout_expand_fused",
-    "dca_head_gemv", "dca_engine_packed_state", "dca_engine_info",
+    "dca_head_gemv", "dca_engine_packed_state", "dca_engine_info", "dca_gemm2_skew",
 ]
 
 
@@ -457,17 +457,26 @@ def head_gemv(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) ->
     assert bias is None or (bias.dtype == torch.float32 and bias.numel() == w.shape[0])
     m, k = x.shape
     out = torch.empty((m, w.shape[0]), dtype=torch.float32, device=x.device)
+    if m == 0:
+        return out
     check(lib().dca_head_gemv(C.c_void_p(x.data_ptr()), _TORCH_DT[x.dtype], C.c_int64(m), int(k), C.c_int64(x.stride(0)), ptr(w),
                               ptr(bias), int(w.shape[0]), ptr(out), stream_ptr()), "dca_head_gemv")
     return out
 
 
+def gemm2_skew(sixteenths: int) -> None:
+    """Tuning hook of the two-workgroups-per-CU kernels (csrc/dca_gemm2.hip): start-up skew of every CU's second workgroup in
+    1/16ths of a tile's K-loop time (default 8; 0 = none)."""
+    check(lib().dca_gemm2_skew(int(sixteenths)), "dca_gemm2_skew")
+
+
 def gemm16_variant(v: int) -> None:
-    """Tuning / test hook: 2 (default) = 8-phase ping-pong schedule, 1 = two-stage loop (one drain + barrier per K-step)."""
+    """Tuning / test hook: 3 = 128 x 256 tiles, two workgroups per CU (csrc/dca_gemm2.hip); 2 = 8-phase ping-pong schedule on
+    256 x 256 tiles, 1 = two-stage loop (one drain + barrier per K-step).  Bit-identical results."""
     check(lib().dca_gemm16_variant(int(v)), "dca_gemm16_variant")
 
 
 def f16x3_gemm_variant(v: int) -> None:
-    """Tuning / test hook: 3 (default) = LDS-DMA 256x256 kernel on the ping-pong schedule, 2 = the same tile with two whole-K-step
-    stages (bit-identical), 1 = register-staged 128x128 kernel."""
+    """Tuning / test hook: 4 = 128 x 256 tiles, two workgroups per CU (csrc/dca_gemm2.hip), 3 = LDS-DMA 256x256 kernel on the
+    ping-pong schedule, 2 = the same tile with two whole-K-step stages (2, 3, 4 bit-identical), 1 = register-staged 128x128 kernel."""
     check(lib().dca_f16x3_gemm_variant(int(v)), "dca_f16x3_gemm_variant")

@@ -1171,7 +1171,8 @@ __device__ __forceinline__ int collect_grid_barrier(Ctl* c, CollectLds& L, uint3
         uint32_t v = __hip_atomic_fetch_add(&c->gbar.v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
         int res = BAR_PASS;
         const unsigned long long t0 = wall_clock64();
-        const unsigned long long limit = first ? kBarrierTimeoutFirst : kBarrierTimeout;
+        // (knob 10: the first barrier gives up at once — what a launch that is not fully resident does after 0.25 s; tests)
+        const unsigned long long limit = first ? (g_tune[10] ? 0ull : kBarrierTimeoutFirst) : kBarrierTimeout;
         for (;;) {
             if (v & GBAR_BROKEN) {
                 res = first ? BAR_BROKEN : BAR_FAIL;
@@ -2433,8 +2434,64 @@ __device__ __forceinline__ void close_pop(const Eng& E, Ctl* c, const IterState&
     c->expanded += npop;
 }
 
+constexpr uint8_t F_KEEP = 1, F_MIN = 2, F_NEW = 4;
+
+// Word `w` (bytes 4w .. 4w+3) of the child that move `a` makes of a parent whose row is spread over the 16 lanes of this
+// lane's group, one 4-byte word per lane (`pw`; bytes past the row are 0).  On-chip only: the gather runs over lane
+// shuffles.  All 64 lanes must call it together (shuffles read from lanes of the caller's own 16-lane group).
+template <int ENV, int DIM>
+__device__ __forceinline__ uint32_t child_word_from_parent(uint32_t pw, uint32_t w, uint32_t a, const uint8_t* ltab) {
+    using EV = EnvT<ENV, DIM>;
+    const int gbase = (int)(threadIdx.x & 63u) & ~15;
+    uint32_t out = 0;
+    if constexpr (ENV == DCA_ENV_CUBE3) {
+#pragma unroll
+        for (uint32_t b = 0; b < 4; b++) {
+            const uint32_t i = 4 * w + b;
+            const uint32_t p = i < (uint32_t)EV::D ? ltab[a * EV::D + i] : 0u;
+            const uint32_t v = (uint32_t)__shfl((int)pw, gbase + (int)(p >> 2));
+            if (i < (uint32_t)EV::D) out |= ((v >> (8 * (p & 3))) & 0xFFu) << (8 * b);
+        }
+    } else if constexpr (ENV == DCA_ENV_LIGHTSOUT) {
+#pragma unroll
+        for (uint32_t b = 0; b < 4; b++) {
+            const uint32_t i = 4 * w + b;
+            if (i < (uint32_t)EV::D) {
+                const uint32_t v = (pw >> (8 * b)) & 0xFFu;
+                out |= (lightsout_flip(DIM, (int)a, (int)i) ? ((v + 1u) & 1u) : v) << (8 * b);
+            }
+        }
+    } else {
+        // the blank: first zero byte of the row (n_puzzle.py:51-53), found group-wide
+        uint32_t z = 0xFFFFu;
+#pragma unroll
+        for (int b = 3; b >= 0; b--)
+            if (4 * w + b < (uint32_t)EV::D && ((pw >> (8 * b)) & 0xFFu) == 0u) z = 4 * w + b;
+        for (int o = 8; o > 0; o >>= 1) {
+            const uint32_t y = (uint32_t)__shfl_xor((int)z, o);
+            z = y < z ? y : z;
+        }
+        z = z < (uint32_t)EV::D ? z : 0u;
+        const uint32_t sw = (uint32_t)npuzzle_swap(DIM, (int)z, (int)a);
+#pragma unroll
+        for (uint32_t b = 0; b < 4; b++) {
+            const uint32_t i = 4 * w + b;
+            const uint32_t src = i < (uint32_t)EV::D ? ((i == z) ? sw : i) : 0u;  // next[z] = cur[s]; next[s] = 0
+            const uint32_t v = (uint32_t)__shfl((int)pw, gbase + (int)(src >> 2));
+            if (i < (uint32_t)EV::D) out |= ((i == sw) ? 0u : ((v >> (8 * (src & 3))) & 0xFFu)) << (8 * b);
+        }
+    }
+    return out;
+}
+
 constexpr int kEngTile = 16;  // parents per workgroup: a 20 000-parent batch then fills the chip (1250 workgroups)
-template <int ENV, int DIM, int OH>
+// PROBE: the CLOSED probe of the batch's children (what k_probe does in a launch of its own) runs here, from the rows the
+// tile holds in LDS — one launch, one boundary and one 13 MB re-read of the child rows less per iteration.  The one thing
+// k_probe could rely on and this kernel cannot: a representative inserted by ANOTHER workgroup of the same launch has no
+// row in HBM yet.  It needs none: its id says which popped parent and which move made it (id = base + rank * A + move),
+// and the parent's row was written an iteration ago — the tile rebuilds the representative from it (16 lanes per pending
+// comparison) and compares exactly.
+template <int ENV, int DIM, int OH, bool PROBE>
 __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ engs, int heur_id) {
     const Eng& E = engs[blockIdx.y];
     using EV = EnvT<ENV, DIM>;
@@ -2448,6 +2505,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
     uint8_t* ltab = smem + TL::PAR_BYTES;
     uint8_t* lst = smem + TL::LDS_BYTES;  // child rows of the tile, laid out exactly like their HBM destination
     __shared__ uint32_t l_pid[kEngTile], l_g[kEngTile];
+    __shared__ uint32_t l_qn, l_qcc[PROBE ? kThreads : 1], l_qrep[PROBE ? kThreads : 1], l_qres[PROBE ? kThreads : 1];
     static_assert((EV::D + 3) / 4 < 16, "no spare lane per row for the parent's path cost");
     // batch geometry: every workgroup derives it from the state the previous iteration left (S[iters & 1]) and the
     // pop that k_rank just finished; workgroup 0 also records it for the rest of the iteration (close_pop)
@@ -2511,10 +2569,18 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
     const uint32_t nchild = np * EV::A;
     const uint32_t j0 = r0 * EV::A;  // first child index of the tile within the batch
 
-    // per child: hash, is_solved, node fields, built-in heuristic
-    for (uint32_t cc = threadIdx.x; cc < nchild; cc += kThreads) {
+    // per child: hash, is_solved, node fields, built-in heuristic (rounds of 256 children; uniform: the probe below
+    // synchronises the workgroup inside a round)
+    if (PROBE && threadIdx.x == 0) l_qn = 0;
+    for (uint32_t cc0 = 0; cc0 < nchild; cc0 += kThreads) {
+        const uint32_t cc = cc0 + threadIdx.x;
+        const bool cvalid = cc < nchild;
+        uint64_t h = 0;
+        uint64_t roww[(EV::D + 7) / 8];  // the child's row, 8 bytes a word (PROBE: compared against representatives' rows)
+        if (cvalid) {
         uint32_t r = cc / EV::A, a = cc - r * EV::A;
-        uint64_t h = hash_init(EV::D), sum = 0;
+        uint64_t sum = 0;
+        h = hash_init(EV::D);
         uint32_t manh = 0;
         bool ok = true;
 #pragma unroll
@@ -2532,6 +2598,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
                 }
             }
             h = hash_word(h, w);
+            roww[k >> 3] = w;
             // stage the gathered bytes (rows start on even offsets when D is even: 2-byte stores; else bytes)
             uint8_t* dst = lst + cc * EV::D + k;
 #pragma unroll
@@ -2548,13 +2615,142 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
         const uint32_t j = j0 + cc, id = base + j, pid = l_pid[r];
         const uint32_t gp = l_g[r];
         if (a == 0) E.pop_g[r0 + r] = gp;  // the parents' path costs in pop order: what the dedup / push kernels read
-        E.child_hash[j] = h;
+        if constexpr (!PROBE) {
+            E.child_hash[j] = h;
+            E.child_multi[j] = 0;  // (PROBE: the marks are cleared by k_commit after it has read them — another workgroup of this
+                                   // launch may set this child's mark before or after this point)
+        }
         E.g[id] = (int32_t)(gp + 1u);  // path cost + unit transition cost (astar.py:125-126 / cpp:219)
-        E.child_multi[j] = 0;
         E.parent[id] = pid;
         E.move[id] = (uint8_t)a;
         E.solved[id] = ok ? 1 : 0;
         if (heur_id >= 0) E.child_h[j] = heur_from(heur_id, sum, h, manh);
+        }
+        if constexpr (PROBE) {
+            // ---- find-or-insert the CLOSED slot of this round's children (k_probe's loop, rows taken from LDS)
+            constexpr int NWD = (EV::D + 3) / 4;
+            const uint32_t j = j0 + cc, id = base + j;
+            const uint64_t tag = h >> 32;
+            bool active = cvalid, inserted = false, paused = false;
+            uint32_t slot = (uint32_t)h & E.tab_mask, v0 = GINF, rep_id = 0, probes = 0, qi = 0;
+            __syncthreads();  // the round's rows are staged (lst) — and l_qn is zero
+            for (;;) {
+                if (active && !paused) {
+                    for (;;) {
+                        // look first, claim second; one 16-byte load fetches the entry with its value (see k_probe)
+                        const uint4 sl = *reinterpret_cast<const uint4*>(&E.tab[slot]);
+                        uint64_t e = ((uint64_t)sl.y << 32) | sl.x;
+                        v0 = sl.z;
+                        if (e == EMPTY) {
+                            const uint64_t old = atomicCAS((unsigned long long*)&E.tab[slot].entry, (unsigned long long)EMPTY,
+                                                           (unsigned long long)((tag << 32) | id));
+                            if (old == EMPTY) {
+                                inserted = true;
+                                active = false;
+                                break;
+                            }
+                            e = old;  // claimed meanwhile by another child of this batch: its value is still GINF, as loaded
+                        }
+                        if ((e >> 32) == tag) {
+                            const uint32_t rep = (uint32_t)e;
+                            if (rep >= base) {
+                                // a representative of THIS batch: no row in HBM yet — the workgroup rebuilds it from its parent
+                                qi = atomicAdd(&l_qn, 1u);
+                                l_qcc[qi] = cc;
+                                l_qrep[qi] = rep;
+                                paused = true;
+                                break;
+                            }
+                            // exact key equality against the representative's state bytes (State.__eq__, cube3.py:23-24)
+                            const uint8_t* rrow = E.state + (size_t)rep * EV::D;
+                            uint32_t diff = 0;
+#pragma unroll
+                            for (int k = 0; k < NWD; k++) {
+                                uint32_t v = 0;
+                                if (4 * k + 4 <= EV::D) {
+                                    __builtin_memcpy(&v, rrow + 4 * k, 4);
+                                } else {
+                                    for (int b = 0; 4 * k + b < EV::D; b++) v |= (uint32_t)rrow[4 * k + b] << (8 * b);
+                                }
+                                diff |= v ^ (uint32_t)(roww[k >> 1] >> (32 * (k & 1)));  // (bytes past the row are 0 in both)
+                            }
+                            if (diff == 0) {
+                                rep_id = rep;
+                                active = false;
+                                break;
+                            }
+                        }
+                        slot = (slot + 1) & E.tab_mask;
+                        if (++probes > E.tab_mask) {  // table full (cannot happen while pool <= cap/2)
+                            c->failed = 1;
+                            active = false;
+                            break;
+                        }
+                    }
+                }
+                __syncthreads();
+                const uint32_t nq = l_qn;
+                if (nq == 0) break;
+                // pending comparisons, 16 at a time: lane group g rebuilds the representative of item q0 + g from its parent
+                for (uint32_t q0 = 0; q0 < nq; q0 += kThreads / 16) {
+                    const uint32_t item = q0 + (threadIdx.x >> 4), w = threadIdx.x & 15u;
+                    const bool iv = item < nq;
+                    const uint32_t itc = iv ? item : 0u;
+                    const uint32_t rrel = l_qrep[itc] - base;
+                    const uint32_t rk = rrel / (uint32_t)EV::A, a2 = rrel - rk * (uint32_t)EV::A;
+                    const uint32_t ppid = E.pop_id[rk] & ID_MASK;
+                    const uint8_t* prow = E.state + (size_t)ppid * EV::D;
+                    uint32_t pw = 0;
+                    if (w < (uint32_t)NWD) {
+                        if (4 * w + 4 <= (uint32_t)EV::D) {
+                            __builtin_memcpy(&pw, prow + 4 * w, 4);
+                        } else {
+                            for (uint32_t b = 0; 4 * w + b < (uint32_t)EV::D; b++) pw |= (uint32_t)prow[4 * w + b] << (8 * b);
+                        }
+                    }
+                    const uint32_t cw = child_word_from_parent<ENV, DIM>(pw, w, a2, ltab);
+                    const uint8_t* mrow = lst + l_qcc[itc] * EV::D;
+                    uint32_t mv = 0;
+                    for (uint32_t b = 0; b < 4 && 4 * w + b < (uint32_t)EV::D; b++) mv |= (uint32_t)mrow[4 * w + b] << (8 * b);
+                    uint32_t diff = w < (uint32_t)NWD ? (cw ^ mv) : 0u;
+                    for (int o = 8; o > 0; o >>= 1) diff |= (uint32_t)__shfl_xor((int)diff, o);
+                    if (iv && w == 0) l_qres[item] = diff == 0 ? 1u : 0u;
+                }
+                __syncthreads();
+                if (paused) {
+                    paused = false;
+                    if (l_qres[qi]) {
+                        rep_id = l_qrep[qi];
+                        active = false;
+                    } else {  // same tag, another state: keep probing
+                        slot = (slot + 1) & E.tab_mask;
+                        probes++;
+                    }
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) l_qn = 0;
+                __syncthreads();
+            }
+            // chain hook (see k_probe): the child that claimed an empty slot needs none
+            if (cvalid) {
+                uint32_t prev = NIL;
+                if (!inserted) {
+                    const uint32_t old_head = atomicExch(&E.tab[slot].head, id);
+                    if (old_head >= base)
+                        prev = old_head - base;
+                    else if (rep_id >= base)
+                        prev = rep_id - base;
+                }
+                E.child_next[j] = prev;
+                E.child_slot[j] = slot;
+                E.child_v0[j] = v0;
+                E.child_flags[j] = inserted ? F_NEW : 0;
+                if (prev != NIL) {
+                    E.child_multi[j] = 1;
+                    E.child_multi[prev] = 1;
+                }
+            }
+        }
     }
 
     // child rows -> node pool (final place), network-input rows -> batch buffer: straight 16-byte copies of the
@@ -2646,7 +2842,6 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
 // ---------------------------------------------------------------------------------------------
 // dedup A: find-or-insert the CLOSED slot of every child, chain the child to it
 // ---------------------------------------------------------------------------------------------
-constexpr uint8_t F_KEEP = 1, F_MIN = 2, F_NEW = 4;
 template <int D>
 __global__ __launch_bounds__(256) void k_probe(const Eng* __restrict__ engs) {
     const Eng& E = engs[blockIdx.y];
@@ -2982,6 +3177,10 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
             }
         }
         if (FUSED && multi && j == first) fix_representative(E, base, slot, id);
+        // the chain marks of this batch have served (k_decide read them in the dedup-first stepping): cleared here, the
+        // last launch of the iteration, because the fused expansion cannot clear them itself — another workgroup of that
+        // launch may be setting this child's mark at any moment
+        E.child_multi[j] = 0;
     }
     uint64_t key = 0;
     uint32_t pid_flag = 0;
@@ -3170,6 +3369,9 @@ static inline bool rebase_due(long host_iter) { return host_iter < kRampIters ||
 static int h_tune[16];  // host copy of the diagnostic knobs (dca_debug_tune)
 
 inline dim3 gxy(unsigned x, const dca_engine* e) { return dim3(x, (unsigned)e->K); }
+// the CLOSED probe runs inside the expansion launch (four launches per iteration); knob 11 restores the separate k_probe
+// launch (round-3 behaviour, the A/B reference)
+inline bool fuse_probe() { return h_tune[11] == 0; }
 
 template <int ENV, int DIM>
 int launch_expand_env(const dca_engine* e, int heur_id, bool want_oh, hipStream_t s) {
@@ -3178,12 +3380,23 @@ int launch_expand_env(const dca_engine* e, int heur_id, bool want_oh, hipStream_
     dim3 g = gxy((E.B + kEngTile - 1) / kEngTile, e), b(kThreads);
     // tile + tables, then the staged child rows (16 parents x A children x D bytes)
     const size_t lds = TL::LDS_BYTES + ((kEngTile * EnvT<ENV, DIM>::A * EnvT<ENV, DIM>::D + 15) / 16) * 16 + 64;  // (+ slack: the one-hot loop peeks one byte past the tile)
-    if (E.onehot == nullptr || !want_oh)
-        hipLaunchKernelGGL((k_expand<ENV, DIM, 0>), g, b, lds, s, e->d_engs, heur_id);
-    else if (E.oh_dtype == DCA_DT_F32)
-        hipLaunchKernelGGL((k_expand<ENV, DIM, 4>), g, b, lds, s, e->d_engs, heur_id);
-    else
-        hipLaunchKernelGGL((k_expand<ENV, DIM, 2>), g, b, lds, s, e->d_engs, heur_id);
+    const bool fuse = fuse_probe();
+    if (E.onehot == nullptr || !want_oh) {
+        if (fuse)
+            hipLaunchKernelGGL((k_expand<ENV, DIM, 0, true>), g, b, lds, s, e->d_engs, heur_id);
+        else
+            hipLaunchKernelGGL((k_expand<ENV, DIM, 0, false>), g, b, lds, s, e->d_engs, heur_id);
+    } else if (E.oh_dtype == DCA_DT_F32) {
+        if (fuse)
+            hipLaunchKernelGGL((k_expand<ENV, DIM, 4, true>), g, b, lds, s, e->d_engs, heur_id);
+        else
+            hipLaunchKernelGGL((k_expand<ENV, DIM, 4, false>), g, b, lds, s, e->d_engs, heur_id);
+    } else {
+        if (fuse)
+            hipLaunchKernelGGL((k_expand<ENV, DIM, 2, true>), g, b, lds, s, e->d_engs, heur_id);
+        else
+            hipLaunchKernelGGL((k_expand<ENV, DIM, 2, false>), g, b, lds, s, e->d_engs, heur_id);
+    }
     return launch_check("k_expand");
 }
 
@@ -3266,7 +3479,7 @@ int enqueue_first_half(dca_engine* e, int heur_id, bool with_refill, hipStream_t
 // (k_pack needs the flags before the heuristic runs); otherwise k_commit<true> decides while it pushes.
 int enqueue_dedup(dca_engine* e, bool with_decide, hipStream_t s) {
     const Eng& E = e->E[0];
-    launch_probe(e, s);
+    if (!fuse_probe()) launch_probe(e, s);
     if (with_decide) hipLaunchKernelGGL(k_decide, gxy((E.M + 255) / 256, e), dim3(256), 0, s, e->d_engs);
     return launch_check("dedup kernels");
 }
@@ -3523,6 +3736,7 @@ int dca_engine_reset_instance(dca_engine* e, int inst, const uint8_t* root, void
         e->tab_cleared[inst] = 1;
     }
     hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, s, E);
+    DCA_HIP(hipMemsetAsync(E.child_multi, 0, (size_t)E.M, s));  // chain marks of an abandoned iteration (k_commit clears its own)
     e->phase = 0;
     e->host_iter = 0;  // the next iteration is a rebase iteration (full histogram) for every instance
     return launch_check("k_reset");
@@ -3789,12 +4003,15 @@ int dca_debug_tune(int knob, int value) {
     return 0;
 }
 
-int dca_engine_info(dca_engine* e, int64_t* out) {
+int dca_engine_info(dca_engine* e, int64_t* out, void* stream) {
     DCA_ARG(e != nullptr && out != nullptr);
+    if (int rc = fetch_ctl(e, 0, (hipStream_t)stream)) return rc;
     out[0] = (int64_t)e->collect_blocks;
     out[1] = (int64_t)e->collect_resident;
     out[2] = (int64_t)e->E[0].coop;
     out[3] = (int64_t)e->E[0].tab_cap * (int64_t)sizeof(Slot);
+    out[4] = (int64_t)e->h_ctl->coop_off;
+    out[5] = out[6] = out[7] = 0;
     return 0;
 }
 

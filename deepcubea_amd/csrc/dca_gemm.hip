@@ -592,13 +592,34 @@ using namespace dca;
 
 static int g_gemm_variant = 3;
 
+namespace dca {
+// csrc/dca_gemm2.hip: the two-workgroups-per-CU kernels (variant 4 here, variant 3 of dca_gemm16)
+struct Gemm2Args {
+    const uint16_t *a, *a2, *w, *w2;
+    int64_t m;
+    int n, k;
+    int64_t lda, ldw, ldo;
+    const float* col_scale;
+    const float* bias;
+    const void* skip;
+    float alpha;
+    int relu;
+    uint16_t *oh, *ol;
+    float* x_out;
+    int* overflow;
+    int skew_ticks;
+    int cus;
+};
+int gemm2_launch(int mode, const Gemm2Args& p, hipStream_t s);
+}  // namespace dca
+
 extern "C" {
 
 /* tuning / test hook: 1 = the register-staged 128 x 128 kernel, 2 = the LDS-DMA 256 x 256 kernel with two whole-K-step stages,
  * 3 (default) = the same tile on the ping-pong / half-tile schedule (bit-identical to 2; measured at 204 800 x 1024, candidates
  * taking turns: k = 1024 1.42 vs 1.47 ms, k = 5120 5.67 vs 6.07 ms) */
 int dca_f16x3_gemm_variant(int v) {
-    DCA_ARG(v >= 1 && v <= 3);
+    DCA_ARG(v >= 1 && v <= 4);
     g_gemm_variant = v;
     return 0;
 }
@@ -648,6 +669,31 @@ int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t l
     const bool wide_ok = ldo % 4 == 0 && ((uintptr_t)out_h | (uintptr_t)out_l) % 8 == 0 &&
                          ((uintptr_t)x_out | (uintptr_t)skip) % 16 == 0;
     const int variant = (g_gemm_variant >= 2 && wide_ok) ? g_gemm_variant : 1;
+    if (variant == 4) {  // 128 x 256 tiles, 4 waves, two workgroups per CU (csrc/dca_gemm2.hip); bit-identical to 2 and 3
+        Gemm2Args q;
+        q.a = reinterpret_cast<const uint16_t*>(a_h);
+        q.a2 = reinterpret_cast<const uint16_t*>(a_l);
+        q.w = reinterpret_cast<const uint16_t*>(w_h);
+        q.w2 = reinterpret_cast<const uint16_t*>(w_l);
+        q.m = m;
+        q.n = n;
+        q.k = k;
+        q.lda = lda;
+        q.ldw = ldw;
+        q.ldo = ldo;
+        q.col_scale = col_scale;
+        q.bias = bias;
+        q.skip = skip;
+        q.alpha = (float)alpha;
+        q.relu = relu;
+        q.oh = reinterpret_cast<uint16_t*>(out_h);
+        q.ol = reinterpret_cast<uint16_t*>(out_l);
+        q.x_out = x_out;
+        q.overflow = overflow;
+        q.skew_ticks = 0;
+        q.cus = 0;
+        return gemm2_launch(0, q, (hipStream_t)stream);
+    }
     const int bm = variant == 1 ? GBM : HBM_T, bn = variant == 1 ? GBN : HBN_T;
     const int64_t nMt = (m + bm - 1) / bm;
     const int64_t nNt = (n + bn - 1) / bn;

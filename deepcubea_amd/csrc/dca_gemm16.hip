@@ -436,11 +436,32 @@ using namespace dca;
 
 static int g_gemm16_variant = 2;
 
+namespace dca {
+// csrc/dca_gemm2.hip: the two-workgroups-per-CU kernels (variant 3 here, variant 4 of dca_f16x3_gemm)
+struct Gemm2Args {
+    const uint16_t *a, *a2, *w, *w2;
+    int64_t m;
+    int n, k;
+    int64_t lda, ldw, ldo;
+    const float* col_scale;
+    const float* bias;
+    const void* skip;
+    float alpha;
+    int relu;
+    uint16_t *oh, *ol;
+    float* x_out;
+    int* overflow;
+    int skew_ticks;
+    int cus;
+};
+int gemm2_launch(int mode, const Gemm2Args& p, hipStream_t s);
+}  // namespace dca
+
 extern "C" {
 
 /* tuning / test hook: 1 = two K-step stages, one drain + barrier per K-step; 2 (default) = the 8-phase ping-pong schedule */
 int dca_gemm16_variant(int v) {
-    DCA_ARG(v == 1 || v == 2);
+    DCA_ARG(v >= 1 && v <= 3);
     g_gemm16_variant = v;
     return 0;
 }
@@ -457,6 +478,31 @@ int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int 
         DCA_ARG(!(o0 < a1 && a0 < o1));
     }
     if (m == 0) return 0;
+    if (g_gemm16_variant == 3) {  // 128 x 256 tiles, 4 waves, two workgroups per CU (csrc/dca_gemm2.hip); bit-identical to 1 and 2
+        Gemm2Args q;
+        q.a = reinterpret_cast<const uint16_t*>(a);
+        q.a2 = nullptr;
+        q.w = reinterpret_cast<const uint16_t*>(w);
+        q.w2 = nullptr;
+        q.m = m;
+        q.n = n;
+        q.k = k;
+        q.lda = lda;
+        q.ldw = ldw;
+        q.ldo = ldo;
+        q.col_scale = nullptr;
+        q.bias = bias;
+        q.skip = skip;
+        q.alpha = 1.f;
+        q.relu = relu;
+        q.oh = reinterpret_cast<uint16_t*>(out);
+        q.ol = nullptr;
+        q.x_out = nullptr;
+        q.overflow = nullptr;
+        q.skew_ticks = 0;
+        q.cus = 0;
+        return gemm2_launch(dtype == DCA_DT_BF16 ? 1 : 2, q, (hipStream_t)stream);
+    }
     {   // the dynamic-LDS limit is a per-device function attribute: set it once for every device this process uses
         static std::atomic<uint64_t> attr_devs{0};
         int dev = 0;

@@ -376,10 +376,13 @@ __global__ __launch_bounds__(256) void k_act_split(const float* __restrict__ y, 
 // environment of the reference): out[r][o] = x[r] . w[o] + b[o].  A [m, 1024] x [1024, 1] product is a streaming pass
 // over x (HBM-bound: 4 KB per row), not a GEMM — and the library GEMV it used to be picks its kernel, and with it the
 // order of the 1024 additions, from m.  Here the order is FIXED: one wave per row, lane l accumulates the 4-element
-// chunks l, l + 64, l + 128 ... left to right (fmaf chain), then a xor-butterfly folds the 64 lane sums — a row's
-// value is the same bits whatever row index, batch size or launch it is evaluated in, which is what lets the
-// dedup-first search (kept children, packed) and the reference-order search (all children) be compared bit for bit.
-// x: fp32, or bf16 / fp16 (the non-parity modes' residual stream), converted on load; accumulation fp32.
+// chunks l, l + 64, l + 128 ... left to right, then a xor-butterfly folds the 64 lane sums — a row's value is the same
+// bits whatever row index, batch size or launch it is evaluated in, which is what lets the dedup-first search (kept
+// children, packed) and the reference-order search (all children) be compared bit for bit.  The sums run in FLOAT64
+// (products of two fp32 values are exact there; the kernel is HBM-bound, the fp64 FMAs are free) and are rounded to fp32
+// once: at trained magnitudes (|h| ~ 25, one fp32 ulp = 1.9e-6) an fp32 summation alone spends a third of the north
+// star's 1e-5 budget (measured: 1.08e-5 end to end with an fp32 chain, test_heuristic_tolerance_at_trained_network_magnitudes).
+// x: fp32, or bf16 / fp16 (the non-parity modes' residual stream), converted on load.
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename XT>
 __device__ __forceinline__ float4 head_load4(const XT* p);
@@ -411,28 +414,28 @@ __global__ __launch_bounds__(256) void k_head_gemv(const XT* __restrict__ x, int
     const int nch = k >> 2;
     for (int64_t r = (int64_t)blockIdx.x * 4 + wv; r < m; r += (int64_t)gridDim.x * 4) {
         const XT* row = x + r * ldx;
-        float acc[kHeadMaxOut];
+        double acc[kHeadMaxOut];
 #pragma unroll
-        for (int o = 0; o < kHeadMaxOut; o++) acc[o] = 0.f;
+        for (int o = 0; o < kHeadMaxOut; o++) acc[o] = 0.0;
         for (int c = lane; c < nch; c += 64) {
             const float4 v = head_load4<XT>(row + 4 * c);
 #pragma unroll
             for (int o = 0; o < kHeadMaxOut; o++) {
                 if (o < n_out) {
                     const float4 q = *reinterpret_cast<const float4*>(lw + o * k + 4 * c);
-                    acc[o] = fmaf(v.x, q.x, acc[o]);
-                    acc[o] = fmaf(v.y, q.y, acc[o]);
-                    acc[o] = fmaf(v.z, q.z, acc[o]);
-                    acc[o] = fmaf(v.w, q.w, acc[o]);
+                    acc[o] = fma((double)v.x, (double)q.x, acc[o]);
+                    acc[o] = fma((double)v.y, (double)q.y, acc[o]);
+                    acc[o] = fma((double)v.z, (double)q.z, acc[o]);
+                    acc[o] = fma((double)v.w, (double)q.w, acc[o]);
                 }
             }
         }
 #pragma unroll
         for (int o = 0; o < kHeadMaxOut; o++) {
             if (o < n_out) {
-                float s = acc[o];
+                double s = acc[o];
                 for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);  // every lane ends with the same bits
-                if (lane == 0) out[r * n_out + o] = s + (b ? b[o] : 0.f);
+                if (lane == 0) out[r * n_out + o] = (float)(s + (b ? (double)b[o] : 0.0));
             }
         }
     }

@@ -148,9 +148,9 @@ class BwasEngine:
         return int(nd.value), int(nf.value)
 
     def info(self) -> dict:
-        out = (C.c_int64 * 4)()
-        _lib.check(_lib.lib().dca_engine_info(self._h, out), "dca_engine_info")
-        return dict(zip(["collect_blocks", "collect_resident", "grid_refinement", "closed_table_bytes"], list(out)))
+        out = (C.c_int64 * 8)()
+        _lib.check(_lib.lib().dca_engine_info(self._h, out, _lib.stream_ptr()), "dca_engine_info")
+        return dict(zip(["collect_blocks", "collect_resident", "grid_refinement", "closed_table_bytes", "coop_off"], list(out)))
 
     def step(self, heuristic_fn_dev: Callable[[torch.Tensor], torch.Tensor]) -> None:
         """One BWAS iteration (AStar.step, astar.py:256-317) with a device heuristic closure."""

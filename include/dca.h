@@ -259,10 +259,13 @@ int dca_engine_debug(dca_engine* e, double* out /*host [16]*/, void* stream);
  * k_sel_collect, 5: grid-wide refinement off, 6: k_sel_scan in every iteration, 7: single-iteration graphs only (4-7 host side,
  * set before the engine is created / first stepped); 9: largest bin k_rank orders a thread per entry; 0-15 accepted.      */
 int dca_debug_tune(int knob, int value);
-/* static facts about an engine (host int64[4]): [0] workgroups of k_sel_collect's grid, [1] how many of them the device holds
- * at once according to hipOccupancyMaxActiveBlocksPerMultiprocessor (-1: query failed), [2] 1 if the grid-wide refinement of
- * giant tie bins (grid barriers; needs [1] >= [0]) is enabled, [3] bytes of the CLOSED table */
-int dca_engine_info(dca_engine* e, int64_t* out /*host [4]*/);
+/* facts about an engine (host int64[8]): [0] workgroups of k_sel_collect's grid, [1] how many of them the device holds at once
+ * according to hipOccupancyMaxActiveBlocksPerMultiprocessor (-1: query failed), [2] 1 if the grid-wide refinement of giant tie
+ * bins (grid barriers; needs [1] >= [0]) was enabled at creation, [3] bytes of the CLOSED table, [4] 1 once a grid barrier
+ * found the launch not fully resident (the GPU is shared) and the engine fell back to the single-workgroup path for good;
+ * [5..7] reserved.  Synchronises.  (knob 10 of dca_debug_tune makes the first barrier of every giant iteration give up at
+ * once: the test hook for that fallback.) */
+int dca_engine_info(dca_engine* e, int64_t* out /*host [8]*/, void* stream);
 /* child rows of the last pop_expand straight from the node pool (device [m_live, D]); synchronises */
 int dca_engine_last_children(dca_engine* e, const uint8_t** states, int64_t* m_live, void* stream);
 /* root->goal move list (astar.py:213-229 get_path / cpp:336-341).  synchronises.                 */
@@ -338,6 +341,11 @@ int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t l
  * (bit-identical to 3: same products in the same order); 1 = 128 x 128 tiles staged through registers (the A/B reference; same
  * results to fp32 rounding). */
 int dca_f16x3_gemm_variant(int variant);
+/* variant 4 of dca_f16x3_gemm / variant 3 of dca_gemm16 (csrc/dca_gemm2.hip): 128 x 256 tiles on 4-wave workgroups, TWO of
+ * them per CU, so that one workgroup's layer tail (output + residual traffic, matrix pipes idle) runs under the other's MFMAs;
+ * three-stage LDS-DMA ring, one counted wait + one barrier per stage; results bit-identical to the 256 x 256 variants.
+ * dca_gemm2_skew: start-up skew of every CU's second workgroup in 1/16ths of a tile's K-loop time (default 8; 0 = none). */
+int dca_gemm2_skew(int sixteenths);
 
 /* The same layer in the NON-parity 16-bit modes (`--nnet_dtype bf16 | fp16`; replaces the library GEMM + separate clamp pass of
  * utils/pytorch_models.py:57-86 as PyTorch runs it): out = relu?( a . w^T + bias (+ skip) ), operands and result in `dtype`
@@ -370,8 +378,8 @@ int dca_split_planes(const float* x, int64_t m, int64_t n, int64_t ld, void* out
                      int* overflow /*or NULL*/, void* stream);
 
 /* Output layer of the cost-to-go network (utils/pytorch_models.py:83-86, fc_out: res_dim -> out_dim, out_dim = 1 for every
- * environment of the reference): out[m, n_out] = x[m, k] . w[n_out, k]^T + bias, fp32 accumulation in a FIXED order (one wave
- * per row, lane-strided fmaf chains, xor-butterfly fold): a row's value does not depend on its position, on m or on the launch
+ * environment of the reference): out[m, n_out] = x[m, k] . w[n_out, k]^T + bias, float64 accumulation in a FIXED order (one wave
+ * per row, lane-strided FMA chains, xor-butterfly fold, one rounding to fp32): a row's value does not depend on its position, on m or on the launch
  * — the library GEMV this replaces chose its kernel (and summation order) from m.  x: DCA_DT_F32 / F16 / BF16 rows (row
  * stride ldx elements, k % 4 == 0, ldx % 4 == 0); w, bias, out fp32; n_out <= 8. */
 int dca_head_gemv(const void* x, int x_dtype, int64_t m, int k, int64_t ldx, const float* w /*[n_out, k]*/,

@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[3, 2, 1], ids=["ping_pong_256", "two_stage_256", "regstage_128"])
+@pytest.fixture(params=[4, 3, 2, 1], ids=["two_wg_per_cu_128x256", "ping_pong_256", "two_stage_256", "regstage_128"])
 def variant(request):
     from deepcubea_amd import _lib
     _lib.f16x3_gemm_variant(request.param)
@@ -134,12 +134,21 @@ def test_f16x3_schedules_agree_bit_for_bit_under_load():
         planes = _lib.split_planes(x)
         _lib.f16x3_gemm_variant(2)
         (ph, pl), y = _lib.f16x3_gemm(planes, wh, wl, inv, 1.0, b, None, True, True, True)
-        _lib.f16x3_gemm_variant(3)
         try:
-            for _ in range(reps):
-                (qh, ql), z = _lib.f16x3_gemm(planes, wh, wl, inv, 1.0, b, None, True, True, True)
-                assert torch.equal(z, y), (m, n, k, int((z != y).sum()))
-                assert torch.equal(qh, ph) and torch.equal(ql, pl)
+            for v in (3, 4):  # 4: 128 x 256 tiles, two workgroups per CU, three-stage ring (csrc/dca_gemm2.hip)
+                _lib.f16x3_gemm_variant(v)
+                for _ in range(reps):
+                    (qh, ql), z = _lib.f16x3_gemm(planes, wh, wl, inv, 1.0, b, None, True, True, True)
+                    assert torch.equal(z, y), (v, m, n, k, int((z != y).sum()))
+                    assert torch.equal(qh, ph) and torch.equal(ql, pl)
+            # the residual form (fp32 skip rows through the tail), ragged m inside the last tile
+            skip = torch.randn(m, n, generator=g).cuda()
+            _lib.f16x3_gemm_variant(2)
+            (ph, pl), y = _lib.f16x3_gemm(planes, wh, wl, inv, 1.0, b, skip, True, True, True)
+            _lib.f16x3_gemm_variant(4)
+            (qh, ql), z = _lib.f16x3_gemm(planes, wh, wl, inv, 1.0, b, skip, True, True, True)
+            assert torch.equal(z, y) and torch.equal(qh, ph) and torch.equal(ql, pl)
+            del skip
         finally:
             _lib.f16x3_gemm_variant(3)
         del x, planes, y, z, ph, pl, qh, ql
@@ -148,7 +157,7 @@ def test_f16x3_schedules_agree_bit_for_bit_under_load():
 # ---------------------------------------------------------------------------------------------------------------------
 # dca_gemm16 (csrc/dca_gemm16.hip): the same layer in the non-parity 16-bit modes, tail in the epilogue
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[1, 2], ids=["two_stage", "eight_phase"])
+@pytest.fixture(params=[1, 2, 3], ids=["two_stage", "eight_phase", "two_wg_per_cu_128x256"])
 def variant16(request):
     from deepcubea_amd import _lib
     _lib.gemm16_variant(request.param)
@@ -218,11 +227,21 @@ def test_gemm16_schedules_agree_bit_for_bit_under_load(dt):
         bias = torch.randn(n, generator=g).cuda()
         _lib.gemm16_variant(1)
         want = _lib.gemm16(a, w, bias, None, True)
-        _lib.gemm16_variant(2)
         try:
-            for _ in range(reps):
-                got = _lib.gemm16(a, w, bias, None, True)
-                assert torch.equal(got, want), (m, n, k, int((got != want).sum()))
+            for v in (2, 3):  # 3: 128 x 256 tiles, two workgroups per CU, three-stage ring (csrc/dca_gemm2.hip)
+                _lib.gemm16_variant(v)
+                for _ in range(reps):
+                    got = _lib.gemm16(a, w, bias, None, True)
+                    assert torch.equal(got, want), (v, m, n, k, int((got != want).sum()))
+            skip = torch.randn(m, n, generator=g).to(dt).cuda()
+            _lib.gemm16_variant(1)
+            want = _lib.gemm16(a, w, None, skip, True)
+            _lib.gemm16_variant(3)
+            got = _lib.gemm16(a, w, None, skip, True)
+            assert torch.equal(got, want)
+            got = _lib.gemm16(a, w, None, skip, True, out=skip)  # in place: the residual stream
+            assert torch.equal(got, want)
+            del skip
         finally:
             _lib.gemm16_variant(2)
         del a, w, want, got
