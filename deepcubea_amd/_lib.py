@@ -39,7 +39,8 @@ ABI_SYMBOLS = [
     "dca_bn_workspace_bytes", "dca_bn_train_forward", "dca_bn_train_backward",
     "dca_l1_supported", "dca_l1_kpad", "dca_l1_onehot_gemm", "dca_act_split", "dca_f16x3_gemm", "dca_split_planes", "dca_f16x3_gemm_variant",
     "dca_gemm16", "dca_gemm16_variant", "dca_gemm8", "dca_quant_e4m3", "dca_lightsout_next_state", "dca_lightsout_expand_fused",
-    "dca_head_gemv", "dca_engine_packed_state", "dca_engine_info", "dca_gemm2_skew",
+    "dca_head_gemv", "dca_engine_packed_state", "dca_engine_info", "dca_gemm2_skew", "dca_f16x3_gemm_timeline",
+    "dca_engine_set_weight_instance", "dca_engine_set_weights", "dca_engine_park_instance", "dca_engine_last_popped",
 ]
 
 

@@ -3266,6 +3266,29 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
     commit_ticket(E, c);
 }
 
+// The parents of the last pop (between pop_expand and commit): their state rows, and per parent 1 = popped, 2 = popped and
+// solved, 0 = slot unused (short batch, instance finished).  What an ASTAR update backs up (updater.py:44-50: every popped
+// node of every instance gets a training target).
+__global__ __launch_bounds__(256) void k_gather_popped(const Eng* __restrict__ engs, uint8_t* __restrict__ out_states,
+                                                       uint8_t* __restrict__ out_flags) {
+    const Eng& E = engs[blockIdx.y];
+    const Ctl* c = E.ctl;
+    const uint32_t B = (uint32_t)E.B, D = (uint32_t)E.D;
+    const uint32_t npop = c->done ? 0u : st_next(c).npop;
+    for (uint32_t r = blockIdx.x; r < B; r += gridDim.x) {
+        uint8_t* dst = out_states + ((size_t)blockIdx.y * B + r) * D;
+        if (r < npop) {
+            const uint32_t idf = E.pop_id[r];
+            const uint8_t* src = E.state + (size_t)(idf & ID_MASK) * D;
+            for (uint32_t b = threadIdx.x; b < D; b += blockDim.x) dst[b] = src[b];
+            if (threadIdx.x == 0) out_flags[(size_t)blockIdx.y * B + r] = (idf & ID_SOLVED) ? 2 : 1;
+        } else {
+            for (uint32_t b = threadIdx.x; b < D; b += blockDim.x) dst[b] = 0;
+            if (threadIdx.x == 0) out_flags[(size_t)blockIdx.y * B + r] = 0;
+        }
+    }
+}
+
 __global__ void k_solution(Eng E, int32_t* out /*[0]=len, [1..]=moves root->goal*/, double* path_cost) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Ctl* c = E.ctl;
@@ -3565,6 +3588,11 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         e->collect_blocks = (unsigned)(2 * cus < kCollectBlocks ? 2 * cus : kCollectBlocks);
         if (h_tune[4] > 0 && h_tune[4] < (int)e->collect_blocks) e->collect_blocks = (unsigned)h_tune[4];
+        // K instances share every launch (grid.y): keep the launch at about two workgroups per CU in total
+        if (num_instances > 1) {
+            const unsigned per = e->collect_blocks / (unsigned)num_instances;
+            e->collect_blocks = per < 8u ? 8u : per;
+        }
     }
     const size_t K = (size_t)num_instances;
     const size_t N = (size_t)max_nodes, M = (size_t)Mll, Bz = (size_t)batch_size + 64;
@@ -4001,6 +4029,54 @@ int dca_debug_tune(int knob, int value) {
     DCA_ARG(knob >= 0 && knob < 16);
     DCA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tune), &value, sizeof(int), (size_t)knob * sizeof(int), hipMemcpyHostToDevice));
     return 0;
+}
+
+int dca_engine_set_weight_instance(dca_engine* e, int inst, double weight) {
+    DCA_INST(e, inst);
+    DCA_ARG(weight >= 0.0);
+    if (e->phase != 0) {
+        set_error("dca_engine_set_weight_instance between pop_expand and commit");
+        return DCA_E_STATE;
+    }
+    e->E[inst].w = weight;
+    e->E[inst].wf = (float)weight;
+    DCA_HIP(hipDeviceSynchronize());  // (no launch may still be reading the instance array)
+    return upload_engs(e);
+}
+
+int dca_engine_set_weights(dca_engine* e, const double* weights, int n) {
+    DCA_ARG(e != nullptr && weights != nullptr && n >= 1 && n <= e->K);
+    if (e->phase != 0) {
+        set_error("dca_engine_set_weights between pop_expand and commit");
+        return DCA_E_STATE;
+    }
+    for (int i = 0; i < n; i++) {
+        DCA_ARG(weights[i] >= 0.0);
+        e->E[i].w = weights[i];
+        e->E[i].wf = (float)weights[i];
+    }
+    DCA_HIP(hipDeviceSynchronize());  // (no launch may still be reading the instance array)
+    return upload_engs(e);
+}
+
+int dca_engine_park_instance(dca_engine* e, int inst, void* stream) {
+    DCA_INST(e, inst);
+    const int32_t one = 1;
+    DCA_HIP(hipStreamSynchronize((hipStream_t)stream));
+    DCA_HIP(hipMemcpy(&e->E[inst].ctl->done, &one, sizeof(one), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int dca_engine_last_popped(dca_engine* e, uint8_t* states, uint8_t* flags, void* stream) {
+    DCA_ARG(e != nullptr && states != nullptr && flags != nullptr);
+    if (e->phase == 0) {
+        set_error("dca_engine_last_popped outside an iteration (call it between pop_expand and commit)");
+        return DCA_E_STATE;
+    }
+    const Eng& E = e->E[0];
+    const unsigned gx = (unsigned)(E.B < 1024 ? E.B : 1024);
+    hipLaunchKernelGGL(k_gather_popped, gxy(gx, e), dim3(64), 0, (hipStream_t)stream, e->d_engs, states, flags);
+    return launch_check("k_gather_popped");
 }
 
 int dca_engine_info(dca_engine* e, int64_t* out, void* stream) {

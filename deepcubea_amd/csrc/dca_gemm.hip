@@ -384,9 +384,14 @@ constexpr int PS_A01 = 0, PS_A23 = 1, PS_B0 = 2, PS_B1 = 3;
 #define DCA_RD_DONE_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define DCA_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
-__global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v3(const GemmArgs p) {
+// PROF: four wall-clock stamps per workgroup (entry, first operands landed, K loop done, tail done) into p.overflow's
+// neighbour array — tools/gemm_timeline.py; never launched by the library's own paths
+template <bool PROF>
+__global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v3(const GemmArgs p, unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, h = lane >> 5;
+    unsigned long long ts0 = 0;
+    if constexpr (PROF) ts0 = wall_clock64();
     const int wm = w >> 2, wn = w & 3;
     const int nNt = (p.n + HBN_T - 1) / HBN_T;
     const int64_t nMt = (p.m + HBM_T - 1) / HBM_T;
@@ -543,6 +548,8 @@ __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v3(const GemmArgs p)
         DCA_VMCNT(4);
     }
     DCA_BAR();
+    unsigned long long ts1 = 0, ts2 = 0;
+    if constexpr (PROF) ts1 = wall_clock64();
     if (wm == 1) DCA_BAR();  // the second wave row runs one barrier behind the first from here on
     {
         int kt = 0;
@@ -554,12 +561,30 @@ __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v3(const GemmArgs p)
         step(kt, std::false_type{}, std::false_type{});
     }
     if (wm == 0) DCA_BAR();  // ... and the first waits for it here
+    if constexpr (PROF) ts2 = wall_clock64();
 #undef DCA_MMA12
 #undef DCA_VMCNT
 #undef DCA_RD_DONE_BAR
 #undef DCA_BAR
 
     f16x3_epilogue(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h);
+    if constexpr (PROF) {
+        const unsigned long long ts3 = wall_clock64();       // this wave has issued its last store
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and they have been acknowledged
+        if (t == 0) {
+            unsigned long long* q = stamps + (size_t)blockIdx.x * 6;
+            q[0] = ts0;
+            q[1] = ts1;
+            q[2] = ts2;
+            q[5] = ts3;
+            q[3] = wall_clock64();
+            uint32_t xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            uint32_t hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            q[4] = ((unsigned long long)xcc << 32) | hwid;
+        }
+    }
 }
 
 // fp32 [m, n] (row stride ld) -> its two fp16 planes (and the overflow flag): the entry into an f16x3 layer for
@@ -591,6 +616,7 @@ __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ 
 using namespace dca;
 
 static int g_gemm_variant = 3;
+static unsigned long long* g_gemm_stamps = nullptr;  // diagnostics: device [blocks][5] u64 (dca_f16x3_gemm_timeline)
 
 namespace dca {
 // csrc/dca_gemm2.hip: the two-workgroups-per-CU kernels (variant 4 here, variant 3 of dca_gemm16)
@@ -624,6 +650,14 @@ int dca_f16x3_gemm_variant(int v) {
     return 0;
 }
 
+/* diagnostics (tools/gemm_timeline.py): the next variant-3 launches write six u64 per workgroup into `stamps` (device):
+ * wall clock (100 MHz) at entry, when the first operands have landed, at the end of the K loop, when the tile's stores have
+ * been acknowledged, and (XCC id << 32 | HW_ID).  NULL switches it off. */
+int dca_f16x3_gemm_timeline(void* stamps) {
+    g_gemm_stamps = reinterpret_cast<unsigned long long*>(stamps);
+    return 0;
+}
+
 int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t lda, const void* w_h, const void* w_l, int n,
                    int64_t ldw, const float* col_scale, double alpha, const float* bias, const float* skip, int relu,
                    void* out_h, void* out_l, float* x_out, int64_t ldo, int* overflow, void* stream) {
@@ -640,7 +674,8 @@ int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t l
         if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f16x3_gemm_v1), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS));
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f16x3_gemm_v2), hipFuncAttributeMaxDynamicSharedMemorySize, HLDS));
-            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f16x3_gemm_v3), hipFuncAttributeMaxDynamicSharedMemorySize, HLDS));
+            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f16x3_gemm_v3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, HLDS));
+            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f16x3_gemm_v3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, HLDS));
             attr_devs.fetch_or(bit, std::memory_order_release);
         }
     }
@@ -706,8 +741,11 @@ int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t l
         hipLaunchKernelGGL(k_f16x3_gemm_v1, dim3((unsigned)blocks), dim3(GTHREADS), GLDS, (hipStream_t)stream, p);
     else if (variant == 2)
         hipLaunchKernelGGL(k_f16x3_gemm_v2, dim3((unsigned)blocks), dim3(HTHREADS), HLDS, (hipStream_t)stream, p);
+    else if (g_gemm_stamps != nullptr)
+        hipLaunchKernelGGL(k_f16x3_gemm_v3<true>, dim3((unsigned)blocks), dim3(HTHREADS), HLDS, (hipStream_t)stream, p, g_gemm_stamps);
     else
-        hipLaunchKernelGGL(k_f16x3_gemm_v3, dim3((unsigned)blocks), dim3(HTHREADS), HLDS, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(k_f16x3_gemm_v3<false>, dim3((unsigned)blocks), dim3(HTHREADS), HLDS, (hipStream_t)stream, p,
+                           (unsigned long long*)nullptr);
     return launch_check("k_f16x3_gemm");
 }
 

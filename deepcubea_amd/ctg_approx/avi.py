@@ -52,7 +52,7 @@ _OPTIONS = (
     ("num_update_procs", int, 1, "ignored: the update runs on the GPU"),
     ("update_nnet_batch_size", int, 10000, "states per heuristic call during the update (memory only)"),
     ("max_update_steps", int, 1, "GBFS steps used to add states to the training set (grows by one per update)"),
-    ("update_method", str, "GBFS", "GBFS (ASTAR updates are not provided)"),
+    ("update_method", str, "GBFS", "GBFS or ASTAR. If max_update_steps is 1 then either one is the same."),
     ("eps_max", float, 0, "per-instance GBFS eps is uniform in [0, eps_max]"),
     ("num_test", int, 10000, "Number of test states."),
     ("back_max", int, REQUIRED, "Maximum number of backwards steps from goal"),

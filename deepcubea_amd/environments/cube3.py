@@ -42,6 +42,7 @@ class Cube3(Environment):
     _env_id = _lib.ENV_CUBE3
     _dim = 0
     state_dim = 54
+    env_name = "cube3"  # the registry name (utils/env_utils.py), what the engine is created with
     _state_cls = Cube3State
 
     def __init__(self):

@@ -46,6 +46,7 @@ class LightsOut(Environment):
         self.dtype = np.uint8  # lights_out.py:29
         self.dim: int = dim
         self._dim = dim
+        self.env_name = "lightsout%d" % dim  # the registry name (utils/env_utils.py)
         self.num_tiles: int = dim ** 2
         self.state_dim = self.num_tiles
         # lights_out.py:33-44 — kept for callers that read it; the device kernels compute the same mask arithmetically

@@ -47,6 +47,7 @@ class NPuzzle(Environment):
         self.dim: int = dim
         self._dim = dim
         self.state_dim = dim * dim
+        self.env_name = "puzzle%d" % (dim * dim - 1)  # the registry name (utils/env_utils.py)
         self.dtype = np.uint8  # reference: uint8 for dim<=15 (n_puzzle.py:35-38); tiles < 49 always fit
         self.goal_tiles: np.ndarray = np.concatenate((np.arange(1, dim * dim), [0])).astype(np.uint8)
 

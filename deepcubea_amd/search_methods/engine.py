@@ -141,6 +141,30 @@ class BwasEngine:
         assert h.is_cuda and h.dtype == torch.float32 and h.is_contiguous()
         _lib.check(_lib.lib().dca_engine_commit_packed(self._h, _lib.ptr(h), _lib.stream_ptr()), "dca_engine_commit_packed")
 
+    def set_weight(self, weight: float, instance: int = 0) -> None:
+        """Weight of path cost of ONE instance (astar.py:196 `weights`: AStar takes a list, one per instance)."""
+        _lib.check(_lib.lib().dca_engine_set_weight_instance(self._h, int(instance), C.c_double(float(weight))),
+                   "dca_engine_set_weight_instance")
+
+    def set_weights(self, weights) -> None:
+        """Weights of path cost of instances 0 .. len(weights)-1 at once (between iterations)."""
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        _lib.check(_lib.lib().dca_engine_set_weights(self._h, w.ctypes.data_as(C.c_void_p), int(w.size)), "dca_engine_set_weights")
+
+    def park(self, instance: int) -> None:
+        """Mark an instance finished (its launches are no-ops) until it is reset again."""
+        _lib.check(_lib.lib().dca_engine_park_instance(self._h, int(instance), _lib.stream_ptr()), "dca_engine_park_instance")
+
+    def last_popped(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Between pop_expand and commit: (states u8 [K*batch, D], flags u8 [K*batch]) of the parents just popped,
+        instance-major; flags 0 = none, 1 = popped, 2 = popped and solved."""
+        n = self.num_instances * self.batch_size
+        st = torch.empty((n, self.state_dim), dtype=torch.uint8, device="cuda")
+        fl = torch.empty((n,), dtype=torch.uint8, device="cuda")
+        _lib.check(_lib.lib().dca_engine_last_popped(self._h, _lib.ptr(st), _lib.ptr(fl), _lib.stream_ptr()),
+                   "dca_engine_last_popped")
+        return st, fl
+
     def packed_state(self) -> Tuple[int, int]:
         """(instances finished, instances failed) as the last pop_expand_packed found them — no extra host sync."""
         nd, nf = C.c_int(0), C.c_int(0)

@@ -9,7 +9,8 @@ one replica per GPU: states are generated, expanded, evaluated and backed up wit
     states_nnet, ctg, is_solved = updater.update()      # same triple as updater.py:116-123
 
 The training step that consumes these targets is `utils/nnet_utils.train_nnet`; `ctg_approx/avi.py` ties both into
-the reference's loop.  ASTAR updates (updater.py:36-54) are not provided.
+the reference's loop.  ASTAR updates (updater.py:36-54; `--update_method astar`, what the reference's lightsout7 training
+line uses, train.sh:65) run on the multi-instance BWAS engine: `astar_update_dev`.
 """
 from __future__ import annotations
 
@@ -107,6 +108,90 @@ def gbfs_update_dev(states: torch.Tensor, env, num_steps: int, heuristic_fn_dev:
     return su[order], cg[order], solved
 
 
+def astar_update_dev(states: torch.Tensor, env, num_steps: int, heuristic_fn_dev: Callable,
+                     weights: Optional[np.ndarray] = None, generator: Optional[np.random.Generator] = None,
+                     instances_per_launch: int = 64, engine=None, onehot_dtype=None):
+    """updater.py:36-54 astar_update on the device: one batch-1 weighted A* per training state (`AStar(states, env,
+    heuristic_fn, weights)` with weights ~ U[0, 1), one per instance), `num_steps` steps (`astar.step(heuristic_fn, 1)`:
+    every unsolved instance pops its cheapest node, expands it, the network scores ALL children, the CLOSED check drops
+    duplicates, the rest is pushed), then `Node.compute_bellman` on every popped node: 0 for a solved node, else
+    min over its children of (transition cost 1 + the child's heuristic, clipped at 0 like the update's heuristic servers,
+    avi.py:213).  The searches are the engine's (libdca_hip.so, PY semantics: float64 cost = w * g + h, (cost, push count)
+    order, sequential CLOSED rule), up to `instances_per_launch` of them sharing every launch (grid.y = instance) and ONE
+    network call per step.  Each group of `instances_per_launch` states is one `astar_update` call of the reference (its
+    `update_runner` cuts the states into `update_batch_size` pieces the same way, updater.py:62-71), including how that call
+    pairs weights with instances: `AStar.step` zips `self.weights` with the instances that have not found a goal yet
+    (astar.py:262-263, 279-281), so once an instance has finished, the j-th REMAINING instance searches with weights[j]
+    — reproduced here step by step (the fixtures recorded from the reference depend on it).
+    -> (states_update u8 [T, D], cost_to_go f32 [T], is_solved bool [n]) in the reference's order: instance-major, each
+    instance's popped nodes in pop order (misc_utils.flatten(astar.get_popped_nodes())).
+    onehot_dtype: the closure wants one-hot rows (a network whose first layer has no uint8 kernel, e.g. lightsout7's): the
+    expansion launch writes them (pytorch_models.py:49-52) and they are handed over with is_onehot=True."""
+    from ..search_methods.engine import BwasEngine
+    n, D = states.shape
+    A = env.get_num_moves()
+    dev = states.device
+    if weights is None:
+        weights = (generator or np.random.default_rng()).random(n)  # updater.py:37 np.random.rand(len(states))
+    weights = np.asarray(weights, np.float64)
+    assert weights.shape == (n,)
+    K = max(1, min(int(instances_per_launch), 64, n))
+    own = engine is None
+    if own:
+        # ids: the root, then <= A + 15 per step (a batch's ids start on a multiple of 16)
+        engine = BwasEngine(env.env_name, 0.0, 1, max_nodes=64 + num_steps * (A + 16) + A + 16, num_instances=K,
+                            onehot_dtype=onehot_dtype)
+    eng = engine
+    assert eng.batch_size == 1 and eng.num_instances >= K
+    Kc = eng.num_instances
+    roots_np = states.cpu().numpy()
+    out_states: List[torch.Tensor] = []
+    out_ctg: List[torch.Tensor] = []
+    out_inst: List[torch.Tensor] = []
+    found = torch.zeros(n, dtype=torch.bool, device=dev)
+    for g0 in range(0, n, Kc):
+        k = min(Kc, n - g0)
+        for i in range(k):
+            eng.reset(roots_np[g0 + i], i)
+        for i in range(k, Kc):
+            eng.park(i)
+        # root nodes: heuristic of all roots in one call (astar.py:246-249 add_heuristic_and_cost(root_nodes, ...))
+        root_nn = _lib.nnet_input(env._env_id, env._dim, states[g0:g0 + k].contiguous())
+        h_root = heuristic_fn_dev(root_nn).to(torch.float32)
+        for i in range(k):
+            eng.root_commit(h_root[i:i + 1], i)
+        inst_ids = torch.arange(g0, g0 + Kc, device=dev)
+        done_host = np.zeros(k, bool)  # instances that have popped a goal: no longer stepped (astar.py:262-263)
+        for _ in range(num_steps):
+            w_step = np.zeros(Kc, np.float64)
+            alive = np.flatnonzero(~done_host)
+            if alive.size == 0:
+                break
+            w_step[alive] = weights[g0:g0 + alive.size]  # zip(self.weights, remaining instances): positional (astar.py:279-281)
+            eng.set_weights(w_step)
+            nn, oh = eng.pop_expand()
+            h = (heuristic_fn_dev(oh, True) if oh is not None else heuristic_fn_dev(nn)).to(torch.float32).contiguous()
+            popped, flags = eng.last_popped()  # [Kc, D], [Kc]
+            live = flags[:k] != 0
+            if bool(live.any()):
+                hk = torch.clamp_min(h.view(Kc, A)[:k], 0.0)
+                backup = 1.0 + hk.min(dim=1).values           # tc + node_c.heuristic, min over the children (astar.py:43-44)
+                backup = torch.where(flags[:k] == 2, torch.zeros_like(backup), backup)  # a solved node backs up to 0
+                out_states.append(popped[:k][live])
+                out_ctg.append(backup[live])
+                out_inst.append(inst_ids[:k][live])
+                found[g0:g0 + k] |= flags[:k] == 2
+            eng.commit(h)
+            done_host |= (flags[:k] == 2).cpu().numpy()
+    if own:
+        eng.close()
+    if not out_states:
+        return (torch.zeros((0, D), dtype=torch.uint8, device=dev), torch.zeros(0, dtype=torch.float32, device=dev), found)
+    su, cg, inst = torch.cat(out_states), torch.cat(out_ctg), torch.cat(out_inst)
+    order = torch.sort(inst, stable=True).indices  # instance-major, pops in step order
+    return su[order], cg[order], found
+
+
 class Updater:
     """Drop-in for updaters/updater.py:84-165: same constructor meaning and `update()` triple, but
     `heur_fn_i_q / heur_fn_o_qs` become a device heuristic closure and the worker processes become ranks:
@@ -115,8 +200,9 @@ class Updater:
     def __init__(self, env, num_states: int, back_max: int, heuristic_fn_dev: Callable, num_steps: int,
                  update_method: str = "GBFS", update_batch_size: int = 1_000_000, eps_max: float = 0.0, seed: int = 0,
                  onehot_dtype=None):
-        if update_method.upper() != "GBFS":
-            raise ValueError("Unknown update method %s" % update_method)  # updater.py:73 (ASTAR not provided)
+        if update_method.upper() not in ("GBFS", "ASTAR"):
+            raise ValueError("Unknown update method %s" % update_method)  # updater.py:73
+        self.method = update_method.upper()
         self.env, self.num_states, self.back_max = env, int(num_states), int(back_max)
         self.hfn, self.num_steps, self.eps_max = heuristic_fn_dev, int(num_steps), float(eps_max)
         self.batch, self.seed, self.onehot_dtype = int(update_batch_size), int(seed), onehot_dtype
@@ -136,8 +222,12 @@ class Updater:
             m = min(self.batch, self.local_n - start)
             states, _, _ = _lib.generate_states(env._env_id, env._dim, m, 0, self.back_max, self.seed,
                                                 self.index0 + start)  # updater.py:66 env.generate_states(n,(0,back_max))
-            su, ctg, solved = gbfs_update_dev(states, env, self.num_steps, self.hfn, self.eps_max, gen,
-                                              self.onehot_dtype)
+            if self.method == "ASTAR":
+                wts = np.random.default_rng([self.seed, self.rank, start]).random(m)  # updater.py:37 np.random.rand
+                su, ctg, solved = astar_update_dev(states, env, self.num_steps, self.hfn, wts, onehot_dtype=self.onehot_dtype)
+            else:
+                su, ctg, solved = gbfs_update_dev(states, env, self.num_steps, self.hfn, self.eps_max, gen,
+                                                  self.onehot_dtype)
             sn.append(_lib.nnet_input(env._env_id, env._dim, su))  # updater.py:75 state_to_nnet_input
             cg.append(ctg)
             sv.append(solved)

@@ -259,6 +259,18 @@ int dca_engine_debug(dca_engine* e, double* out /*host [16]*/, void* stream);
  * k_sel_collect, 5: grid-wide refinement off, 6: k_sel_scan in every iteration, 7: single-iteration graphs only (4-7 host side,
  * set before the engine is created / first stepped); 9: largest bin k_rank orders a thread per entry; 0-15 accepted.      */
 int dca_debug_tune(int knob, int value);
+/* ASTAR updates (updaters/updater.py:36-54 of the reference: one batch-1 search per training state, each with its own random
+ * weight, stepped together; every popped node becomes a training target).
+ *   set_weight_instance  weight of path cost of one instance (astar.py:196 `weights`), between iterations; set_weights: of the
+ *                        first n instances at once (one synchronisation);
+ *   park_instance        marks an instance finished (its launches become no-ops) until its next reset;
+ *   last_popped          between pop_expand and commit: the parents of this pop, instance-major — states device u8
+ *                        [K*batch, D], flags device u8 [K*batch]: 0 = nothing popped in that slot, 1 = popped, 2 = popped and
+ *                        solved (Node.is_solved: its backup is 0, astar.py:38-40). */
+int dca_engine_set_weight_instance(dca_engine* e, int inst, double weight);
+int dca_engine_set_weights(dca_engine* e, const double* weights /*host [n], instances 0..n-1*/, int n);
+int dca_engine_park_instance(dca_engine* e, int inst, void* stream);
+int dca_engine_last_popped(dca_engine* e, uint8_t* states, uint8_t* flags, void* stream);
 /* facts about an engine (host int64[8]): [0] workgroups of k_sel_collect's grid, [1] how many of them the device holds at once
  * according to hipOccupancyMaxActiveBlocksPerMultiprocessor (-1: query failed), [2] 1 if the grid-wide refinement of giant tie
  * bins (grid barriers; needs [1] >= [0]) was enabled at creation, [3] bytes of the CLOSED table, [4] 1 once a grid barrier
@@ -346,6 +358,11 @@ int dca_f16x3_gemm_variant(int variant);
  * three-stage LDS-DMA ring, one counted wait + one barrier per stage; results bit-identical to the 256 x 256 variants.
  * dca_gemm2_skew: start-up skew of every CU's second workgroup in 1/16ths of a tile's K-loop time (default 8; 0 = none). */
 int dca_gemm2_skew(int sixteenths);
+/* diagnostics (tools/gemm_timeline.py): while `stamps` (device u64 [workgroups][6]) is set, variant-3 launches of
+ * dca_f16x3_gemm record per workgroup the 100 MHz wall clock [0] at entry, [1] when the first operands have landed, [2] at the
+ * end of the K loop, [5] when wave 0 has issued its last store, [3] when its stores have been acknowledged, and
+ * [4] (XCC id << 32 | HW_ID).  NULL switches it off. */
+int dca_f16x3_gemm_timeline(void* stamps);
 
 /* The same layer in the NON-parity 16-bit modes (`--nnet_dtype bf16 | fp16`; replaces the library GEMM + separate clamp pass of
  * utils/pytorch_models.py:57-86 as PyTorch runs it): out = relu?( a . w^T + bias (+ skip) ), operands and result in `dtype`

@@ -258,8 +258,9 @@ def test_updater_shards_states_like_split_evenly(monkeypatch):
             seen.append(u.local_n)
         assert tot == n
     assert seen[1:4] == [4, 3, 3]
+    assert Updater(_Env(), 10, 30, None, 1, update_method="astar").method == "ASTAR"  # updater.py:70-71
     with pytest.raises(ValueError):
-        Updater(_Env(), 10, 30, None, 1, update_method="astar")
+        Updater(_Env(), 10, 30, None, 1, update_method="bfs")  # updater.py:72-73 "Unknown update method"
 
 
 def test_results_pickle_names_the_reference_classes(tmp_path):
