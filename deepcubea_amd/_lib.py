@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdca_hip.so")
 
-ENV_CUBE3, ENV_NPUZZLE, ENV_LIGHTSOUT = 0, 1, 2
+ENV_CUBE3, ENV_NPUZZLE, ENV_LIGHTSOUT, ENV_CUBE4 = 0, 1, 2, 3
 DT_F32, DT_F16, DT_BF16, DT_F16X3, DT_F16_PLANES, DT_E4M3 = 0, 1, 2, 3, 4, 5
 E4M3 = torch.float8_e4m3fn  # OCP e4m3: the fp8 format of gfx950's matrix pipes
 SEM_PY, SEM_CPP = 0, 1
@@ -40,6 +40,7 @@ ABI_SYMBOLS = [
     "dca_l1_supported", "dca_l1_kpad", "dca_l1_onehot_gemm", "dca_act_split", "dca_f16x3_gemm", "dca_split_planes", "dca_f16x3_gemm_variant",
     "dca_gemm16", "dca_gemm16_variant", "dca_gemm8", "dca_quant_e4m3", "dca_lightsout_next_state", "dca_lightsout_expand_fused",
     "dca_head_gemv", "dca_engine_packed_state", "dca_engine_info", "dca_gemm2_skew", "dca_f16x3_gemm_timeline",
+    "dca_cube4_perm_table", "dca_cube4_next_state", "dca_cube4_prev_state", "dca_cube4_expand_fused",
     "dca_engine_set_weight_instance", "dca_engine_set_weights", "dca_engine_park_instance", "dca_engine_last_popped",
 ]
 
@@ -67,9 +68,10 @@ def lib() -> C.CDLL:
         _lib = C.CDLL(LIB_PATH)
         _lib.dca_last_error.restype = C.c_char_p
         _lib.dca_cube3_perm_table.restype = C.POINTER(C.c_uint8)
+        _lib.dca_cube4_perm_table.restype = C.POINTER(C.c_uint8)
         for name in ABI_SYMBOLS:
             fn = getattr(_lib, name)  # AttributeError here = stale build of libdca_hip.so
-            if name not in ("dca_last_error", "dca_cube3_perm_table", "dca_engine_destroy", "dca_bn_workspace_bytes",
+            if name not in ("dca_last_error", "dca_cube3_perm_table", "dca_cube4_perm_table", "dca_engine_destroy", "dca_bn_workspace_bytes",
                             "dca_l1_kpad"):
                 fn.restype = C.c_int
         _lib.dca_l1_kpad.restype = C.c_int64
@@ -110,6 +112,8 @@ def env_ids(env_name: str):
     name = env_name.lower()
     if name == "cube3":
         return ENV_CUBE3, 0, 54, 12, 6
+    if name == "cube4":  # environment kernels only (no network / search driver: the reference's harness has none either)
+        return ENV_CUBE4, 0, 96, 24, 6
     m = re.search(r"puzzle(\d+)", name)
     if m:
         dim = int(math.sqrt(int(m.group(1)) + 1))
@@ -125,6 +129,8 @@ def env_geometry(env: int, dim: int):
     """(state_dim, num_moves, onehot_depth) of an (env id, dim) pair."""
     if env == ENV_CUBE3:
         return 54, 12, 6
+    if env == ENV_CUBE4:
+        return 96, 24, 6
     if env == ENV_LIGHTSOUT:
         return dim * dim, dim * dim, 6
     return dim * dim, 4, dim * dim
@@ -133,6 +139,10 @@ def env_geometry(env: int, dim: int):
 # ------------------------------------------------------------------------------ tables (host)
 def cube3_perm_table() -> np.ndarray:
     return np.ctypeslib.as_array(lib().dca_cube3_perm_table(), (12, 54)).copy()
+
+
+def cube4_perm_table() -> np.ndarray:
+    return np.ctypeslib.as_array(lib().dca_cube4_perm_table(), (24, 96)).copy()
 
 
 def npuzzle_swap_table(dim: int) -> np.ndarray:
@@ -155,6 +165,9 @@ def next_state(env: int, dim: int, states: torch.Tensor, action: int, prev: bool
     if env == ENV_CUBE3:
         fn = L.dca_cube3_prev_state if prev else L.dca_cube3_next_state
         check(fn(ptr(states), C.c_int64(n), int(action), ptr(out), stream_ptr()), "dca_cube3_next_state")
+    elif env == ENV_CUBE4:
+        fn = L.dca_cube4_prev_state if prev else L.dca_cube4_next_state
+        check(fn(ptr(states), C.c_int64(n), int(action), ptr(out), stream_ptr()), "dca_cube4_next_state")
     elif env == ENV_LIGHTSOUT:  # every move is its own inverse (lights_out.py:52-53)
         check(L.dca_lightsout_next_state(ptr(states), C.c_int64(n), dim, int(action), ptr(out), stream_ptr()),
               "dca_lightsout_next_state")
@@ -187,7 +200,11 @@ def expand_fused(env: int, dim: int, parents: torch.Tensor, *, children: bool = 
     oh = out.get("onehot")
     ohdt = _TORCH_DT[oh.dtype] if oh is not None else DT_F32
     L = lib()
-    if env == ENV_CUBE3:
+    if env == ENV_CUBE4:
+        assert oh is None and not nnet_in, "cube4 has no network input in the reference (environment kernels only)"
+        check(L.dca_cube4_expand_fused(ptr(parents), C.c_int64(n), ptr(out.get("children")), ptr(out.get("solved")),
+                                       ptr(out.get("hash")), stream_ptr()), "dca_cube4_expand_fused")
+    elif env == ENV_CUBE3:
         check(L.dca_cube3_expand_fused(ptr(parents), C.c_int64(n), ptr(out.get("children")), ptr(out.get("nnet_in")),
                                        ptr(oh), ohdt, ptr(out.get("solved")), ptr(out.get("hash")), stream_ptr()),
               "dca_cube3_expand_fused")

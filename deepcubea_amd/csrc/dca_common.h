@@ -41,6 +41,56 @@ constexpr Cube3Perm make_cube3_perm() {
 }
 inline constexpr Cube3Perm kCube3Perm = make_cube3_perm();
 
+// ------------------------------------------------------------------------------------------
+// cube4 (the 4x4x4 cube of the reference's C++ core, cpp/environments.cpp:263-370; 96 stickers = face*16 + row*4 + col, faces
+// U D L R B F; 24 moves: a = 2 f + d turns the OUTER layer of face f, a = 12 + 2 f + d the INNER slice next to it; d = 0 is
+// the reference's "_n1" direction, d = 1 its inverse).  next[i] = cur[p[a][i]], like cube3.  Built at compile time from the
+// geometry: a "_n1" turn rotates the face's own 4x4 grid — new(r, c) = old(c, 3 - r), outer moves only — and carries four
+// strips of four stickers around the face in 4-cycles (c0 c1 c2 c3): next[c0] = cur[c1], next[c1] = cur[c2], ...; strip k of
+// a layer is {start + k * step}, the inner slice's strips are the outer ones shifted by `inner`.  Pinned against the
+// reference's own compiled class (oracle/_ref) on every move: sha256 7eb3d1a8... of the 24 x 96 table (tests).
+// ------------------------------------------------------------------------------------------
+struct Cube4Perm {
+    uint8_t p[24][96];
+};
+
+constexpr Cube4Perm make_cube4_perm() {
+    // per face: first strip's four stickers (one per neighbouring face), the step from strip to strip, the shift to the inner slice
+    constexpr int side[6][3][4] = {
+        {{35, 67, 51, 83}, {4, 4, 4, 4}, {-1, -1, -1, -1}},   // U
+        {{32, 80, 48, 64}, {4, 4, 4, 4}, {1, 1, 1, 1}},       // D
+        {{0, 80, 16, 79}, {1, 1, 1, -1}, {4, 4, 4, -4}},      // L
+        {{12, 67, 28, 92}, {1, -1, 1, 1}, {-4, 4, -4, -4}},   // R
+        {{3, 32, 28, 63}, {4, 1, -4, -1}, {-1, 4, 1, -4}},    // B
+        {{0, 51, 31, 44}, {4, -1, -4, 1}, {1, 4, -1, -4}},    // F
+    };
+    Cube4Perm t{};
+    for (int a = 0; a < 24; a++)
+        for (int i = 0; i < 96; i++) t.p[a][i] = (uint8_t)i;
+    for (int f = 0; f < 6; f++)
+        for (int layer = 0; layer < 2; layer++) {
+            const int a = layer * 12 + 2 * f;
+            if (layer == 0)
+                for (int r = 0; r < 4; r++)
+                    for (int c = 0; c < 4; c++) {
+                        const int dst = f * 16 + r * 4 + c, src = f * 16 + c * 4 + (3 - r);
+                        t.p[a][dst] = (uint8_t)src;
+                        t.p[a + 1][src] = (uint8_t)dst;
+                    }
+            for (int k = 0; k < 4; k++) {
+                int cyc[4] = {0, 0, 0, 0};
+                for (int j = 0; j < 4; j++) cyc[j] = side[f][0][j] + k * side[f][1][j] + layer * side[f][2][j];
+                for (int j = 0; j < 4; j++) {
+                    const int x = cyc[j], y = cyc[(j + 1) % 4];
+                    t.p[a][x] = (uint8_t)y;
+                    t.p[a + 1][y] = (uint8_t)x;
+                }
+            }
+        }
+    return t;
+}
+inline constexpr Cube4Perm kCube4Perm = make_cube4_perm();
+
 // blank-swap target for the sliding puzzles (n_puzzle.py:174-214 / environments.cpp:4-46):
 // moves U,D,L,R; ineligible moves are no-ops (return z).
 __host__ __device__ inline int npuzzle_swap(int dim, int z, int a) {
@@ -64,7 +114,18 @@ __host__ __device__ inline uint32_t lightsout_flip(int dim, int a, int i) {
 // byte i of the goal state: cube3 arange(54) (cube3.py:62-69), puzzles 1..n^2-1,0 (n_puzzle.py:69-76), lightsout zeros
 // (lights_out.py:55-63)
 __host__ __device__ inline uint32_t goal_byte(int env, int D, int i) {
-    return env == DCA_ENV_CUBE3 ? (uint32_t)i : env == DCA_ENV_NPUZZLE ? (uint32_t)((i + 1) % D) : 0u;
+    return (env == DCA_ENV_CUBE3 || env == DCA_ENV_CUBE4) ? (uint32_t)i : env == DCA_ENV_NPUZZLE ? (uint32_t)((i + 1) % D) : 0u;
+}
+// is_solved, one byte at a time: `ok` after byte i (value b) of a state given `ok` before it.  cube3 / puzzles / lightsout:
+// equality with the goal byte (cube3.py:71-75, cpp:119-126,249-256).  cube4: every face shows ONE colour (sticker / 16 equal
+// to the face's first sticker / 16 — cpp/environments.cpp:355-365: any arrangement of same-coloured stickers counts);
+// `first` carries the current face's first colour between calls.
+__host__ __device__ inline bool solved_step(int env, int D, int i, uint32_t b, bool ok, uint32_t& first) {
+    if (env == DCA_ENV_CUBE4) {
+        if ((i & 15) == 0) first = b >> 4;
+        return ok && (b >> 4) == first;
+    }
+    return ok && b == goal_byte(env, D, i);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -57,9 +57,10 @@ __global__ __launch_bounds__(kThreads) void expand_fused_kernel(
     const int64_t p0 = (int64_t)blockIdx.x * kTileParents;
     const uint32_t np = (uint32_t)min((int64_t)kTileParents, n - p0);
     stage_tile(lpar, parents + p0 * E::D, np * E::D, (align_mask & 1) != 0);
-    if constexpr (ENV == DCA_ENV_CUBE3) stage_tables<ENV, DIM>(ltab, lpar, np);
+    constexpr bool kStaticTable = ENV == DCA_ENV_CUBE3 || ENV == DCA_ENV_CUBE4;  // the move table does not depend on the parents
+    if constexpr (kStaticTable) stage_tables<ENV, DIM>(ltab, lpar, np);
     __syncthreads();
-    if constexpr (ENV != DCA_ENV_CUBE3) {
+    if constexpr (!kStaticTable) {
         stage_tables<ENV, DIM>(ltab, lpar, np);
         __syncthreads();
     }
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(kThreads) void expand_fused_kernel(
             uint32_t r = c / E::A, a = c - r * E::A;
             uint64_t h = hash_init(E::D);
             bool ok = true;
+            uint32_t first = 0;
 #pragma unroll
             for (int k = 0; k < E::D; k += 8) {
                 uint64_t w = 0;
@@ -80,8 +82,7 @@ __global__ __launch_bounds__(kThreads) void expand_fused_kernel(
                 for (int j = 0; j < 8; j++) {
                     if (k + j < E::D) {
                         uint32_t b = t.child_byte(r, a, k + j);
-                        uint32_t goal = goal_byte(ENV, E::D, k + j);
-                        ok &= (b == goal);
+                        ok = solved_step(ENV, E::D, k + j, b, ok, first);
                         w |= (uint64_t)b << (8 * j);
                     }
                 }
@@ -194,9 +195,10 @@ __global__ __launch_bounds__(kThreads) void next_state_kernel(const uint8_t* __r
     const int64_t p0 = (int64_t)blockIdx.x * kTileParents;
     const uint32_t np = (uint32_t)min((int64_t)kTileParents, n - p0);
     stage_tile(lpar, in + p0 * E::D, np * E::D, (align_mask & 1) != 0);
-    if constexpr (ENV == DCA_ENV_CUBE3) stage_tables<ENV, DIM>(ltab, lpar, np);
+    constexpr bool kStaticTable = ENV == DCA_ENV_CUBE3 || ENV == DCA_ENV_CUBE4;
+    if constexpr (kStaticTable) stage_tables<ENV, DIM>(ltab, lpar, np);
     __syncthreads();
-    if constexpr (ENV != DCA_ENV_CUBE3) {
+    if constexpr (!kStaticTable) {
         stage_tables<ENV, DIM>(ltab, lpar, np);
         __syncthreads();
     }
@@ -237,12 +239,12 @@ __global__ void state_scan_kernel(int env, const uint8_t* __restrict__ st, int64
     uint32_t manh = 0;
     const int pdim = D == 16 ? 4 : D == 25 ? 5 : D == 36 ? 6 : D == 49 ? 7 : 0;  // sliding-puzzle side (0: cube3)
     bool ok = true;
+    uint32_t first = 0;
     for (int k = 0; k < D; k += 8) {
         uint64_t w = 0;
         for (int j = 0; j < 8 && k + j < D; j++) {
             uint32_t b = s[k + j];
-            uint32_t goal = goal_byte(env, D, k + j);
-            ok &= (b == goal);
+            ok = solved_step(env, D, k + j, b, ok, first);
             w |= (uint64_t)b << (8 * j);
             sum += (uint64_t)b * (uint64_t)(7 * (k + j) + 3);
             if (pdim) manh += manhattan_term(pdim, (uint32_t)(k + j), b);
@@ -326,6 +328,7 @@ int expand_dispatch(int env, int dim, const uint8_t* parents, int64_t n, uint8_t
                     void* onehot, int onehot_dtype, uint8_t* solved, uint64_t* hash, hipStream_t s) {
     if (env == DCA_ENV_CUBE3)
         return launch_expand<DCA_ENV_CUBE3, 0>(parents, n, children, nnet_in, onehot, onehot_dtype, solved, hash, s);
+    if (env == DCA_ENV_CUBE4) return launch_expand<DCA_ENV_CUBE4, 0>(parents, n, children, nullptr, nullptr, 0, solved, hash, s);
     if (env == DCA_ENV_LIGHTSOUT) {
         if (dim == 7) return launch_expand<DCA_ENV_LIGHTSOUT, 7>(parents, n, children, nnet_in, onehot, onehot_dtype, solved, hash, s);
         set_error("unsupported lightsout dim %d (7)", dim);
@@ -385,6 +388,21 @@ int dca_npuzzle_prev_state(const uint8_t* in, int64_t n, int dim, int action, ui
     return dca_npuzzle_next_state(in, n, dim, action ^ 1, out, stream);
 }
 
+const uint8_t* dca_cube4_perm_table(void) { return &kCube4Perm.p[0][0]; }
+
+int dca_cube4_next_state(const uint8_t* in, int64_t n, int action, uint8_t* out, void* stream) {
+    DCA_ARG(n >= 0 && action >= 0 && action < 24 && (n == 0 || (in && out)));
+    return launch_next<DCA_ENV_CUBE4, 0>(in, n, action, out, (hipStream_t)stream);
+}
+int dca_cube4_prev_state(const uint8_t* in, int64_t n, int action, uint8_t* out, void* stream) {
+    DCA_ARG(action >= 0 && action < 24);  // the "_1" table of a move is the inverse of its "_n1" table (cpp:264-320)
+    return dca_cube4_next_state(in, n, action ^ 1, out, stream);
+}
+int dca_cube4_expand_fused(const uint8_t* parents, int64_t n, uint8_t* children, uint8_t* is_solved, uint64_t* hash, void* stream) {
+    DCA_ARG(n >= 0 && (n == 0 || parents));
+    return expand_dispatch(DCA_ENV_CUBE4, 0, parents, n, children, nullptr, nullptr, 0, is_solved, hash, (hipStream_t)stream);
+}
+
 int dca_lightsout_next_state(const uint8_t* in, int64_t n, int dim, int action, uint8_t* out, void* stream) {
     DCA_ARG(dim == 7 && n >= 0 && action >= 0 && action < dim * dim && (n == 0 || (in && out)));
     return launch_next<DCA_ENV_LIGHTSOUT, 7>(in, n, action, out, (hipStream_t)stream);
@@ -418,6 +436,10 @@ static int state_dim_of(int env, int dim, int* D) {
         *D = 54;
         return 0;
     }
+    if (env == DCA_ENV_CUBE4) {
+        *D = 96;
+        return 0;
+    }
     if ((env == DCA_ENV_NPUZZLE && dim >= 4 && dim <= 7) || (env == DCA_ENV_LIGHTSOUT && dim == 7)) {
         *D = dim * dim;
         return 0;
@@ -436,7 +458,7 @@ int dca_is_solved(int env, int dim, const uint8_t* states, int64_t n, uint8_t* o
     return launch_check("state_scan_kernel");
 }
 int dca_hash64(const uint8_t* states, int64_t n, int state_dim, uint64_t* out, void* stream) {
-    DCA_ARG(n >= 0 && state_dim > 0 && state_dim <= 64 && (n == 0 || (states && out)));
+    DCA_ARG(n >= 0 && state_dim > 0 && state_dim <= 96 && (n == 0 || (states && out)));
     if (n == 0) return 0;
     hipLaunchKernelGGL(state_scan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        DCA_ENV_CUBE3, states, n, state_dim, nullptr, out, nullptr, 0);

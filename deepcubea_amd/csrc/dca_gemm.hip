@@ -548,8 +548,11 @@ __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v3(const GemmArgs p,
         DCA_VMCNT(4);
     }
     DCA_BAR();
-    unsigned long long ts1 = 0, ts2 = 0;
-    if constexpr (PROF) ts1 = wall_clock64();
+    unsigned long long ts1 = 0, ts2 = 0, cy1 = 0, cy2 = 0;
+    if constexpr (PROF) {
+        ts1 = wall_clock64();
+        cy1 = clock64();  // shader-clock cycles: with the wall clock, the clock the K loop actually ran at
+    }
     if (wm == 1) DCA_BAR();  // the second wave row runs one barrier behind the first from here on
     {
         int kt = 0;
@@ -561,7 +564,10 @@ __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v3(const GemmArgs p,
         step(kt, std::false_type{}, std::false_type{});
     }
     if (wm == 0) DCA_BAR();  // ... and the first waits for it here
-    if constexpr (PROF) ts2 = wall_clock64();
+    if constexpr (PROF) {
+        ts2 = wall_clock64();
+        cy2 = clock64();
+    }
 #undef DCA_MMA12
 #undef DCA_VMCNT
 #undef DCA_RD_DONE_BAR
@@ -572,7 +578,9 @@ __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v3(const GemmArgs p,
         const unsigned long long ts3 = wall_clock64();       // this wave has issued its last store
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and they have been acknowledged
         if (t == 0) {
-            unsigned long long* q = stamps + (size_t)blockIdx.x * 6;
+            unsigned long long* q = stamps + (size_t)blockIdx.x * 8;
+            q[6] = cy2 - cy1;
+            q[7] = 0;
             q[0] = ts0;
             q[1] = ts1;
             q[2] = ts2;

@@ -19,6 +19,11 @@ struct EnvT<DCA_ENV_NPUZZLE, DIM> {
     static constexpr int D = DIM * DIM, A = 4, DEPTH = DIM * DIM;
 };
 
+template <>
+struct EnvT<DCA_ENV_CUBE4, 0> {
+    static constexpr int D = 96, A = 24, DEPTH = 6;  // (no network for cube4 in the reference: DEPTH only sizes unused code)
+};
+
 template <int DIM>
 struct EnvT<DCA_ENV_LIGHTSOUT, DIM> {
     static constexpr int D = DIM * DIM, A = DIM * DIM, DEPTH = 6;  // (ResnetModel(num_tiles, 6, ...), lights_out.py:80)
@@ -29,7 +34,8 @@ template <int ENV, int DIM, int TP = kTileParents>
 struct Tile {
     using E = EnvT<ENV, DIM>;
     static constexpr int PAR_BYTES = ((TP * E::D + 15) / 16) * 16;
-    static constexpr int TAB_BYTES = ENV == DCA_ENV_CUBE3 ? ((12 * 54 + 15) / 16) * 16 : ENV == DCA_ENV_NPUZZLE ? TP * 8 : 16;
+    static constexpr int TAB_BYTES = ENV == DCA_ENV_CUBE3 ? ((12 * 54 + 15) / 16) * 16
+                                     : ENV == DCA_ENV_CUBE4 ? 24 * 96 : ENV == DCA_ENV_NPUZZLE ? TP * 8 : 16;
     static constexpr int LDS_BYTES = PAR_BYTES + TAB_BYTES + 16 + 256;  // slack: the last one-hot lane may peek one row past the tile
 
     const uint8_t* par;  // [64][D]
@@ -37,7 +43,7 @@ struct Tile {
 
     // byte i of child (parent r, move a)
     __device__ __forceinline__ uint32_t child_byte(uint32_t r, uint32_t a, uint32_t i) const {
-        if constexpr (ENV == DCA_ENV_CUBE3) {
+        if constexpr (ENV == DCA_ENV_CUBE3 || ENV == DCA_ENV_CUBE4) {
             return par[r * E::D + tab[a * E::D + i]];
         } else if constexpr (ENV == DCA_ENV_LIGHTSOUT) {
             // (state + 1) % 2 on the pressed cell and its neighbours (lights_out.py:161 / environments.cpp:172-174)
@@ -62,6 +68,7 @@ struct Tile {
 
 // device copy of the gather map (constant-initialised from the same constexpr builder)
 static __constant__ Cube3Perm d_cube3_perm = make_cube3_perm();
+static __constant__ Cube4Perm d_cube4_perm = make_cube4_perm();
 
 __device__ __forceinline__ void stage_tile(uint8_t* lds, const uint8_t* __restrict__ g, uint32_t nbytes, bool aligned) {
     if (aligned) {
@@ -79,6 +86,8 @@ __device__ __forceinline__ void stage_tables(uint8_t* tab, const uint8_t* par, u
     using E = EnvT<ENV, DIM>;
     if constexpr (ENV == DCA_ENV_CUBE3) {
         for (uint32_t i = threadIdx.x; i < 12 * 54; i += kThreads) tab[i] = d_cube3_perm.p[i / 54][i % 54];
+    } else if constexpr (ENV == DCA_ENV_CUBE4) {
+        for (uint32_t i = threadIdx.x; i < 24 * 96; i += kThreads) tab[i] = d_cube4_perm.p[i / 96][i % 96];
     } else if constexpr (ENV == DCA_ENV_LIGHTSOUT) {
         // (no table: the flip mask is arithmetic)
     } else {

@@ -47,6 +47,10 @@ extern "C" {
 #define DCA_ENV_CUBE3 0   /* "cube3": 54 stickers, 12 moves */
 #define DCA_ENV_NPUZZLE 1 /* "puzzle15/24/35/48": dim 4..7, 4 moves U D L R */
 #define DCA_ENV_LIGHTSOUT 2 /* "lightsout7": dim 7, 49 cells in {0,1}, 49 moves (press cell a: it and its 4-neighbours flip) */
+#define DCA_ENV_CUBE4 3   /* the 4x4x4 cube of the reference's C++ core (cpp/environments.cpp:263-370): 96 stickers, 24 moves
+                           * (12 outer-layer turns, then 12 inner-slice turns; move a^1 is the inverse of move a); solved =
+                           * every face shows one colour (sticker / 16).  Environment kernels only: the reference's Python
+                           * harness has no Cube4 (astar.py:473-486), so there is no network input / search driver for it. */
 
 /* one-hot element types for the fused encoder (utils/pytorch_models.py:49-52 emits f32) */
 #define DCA_DT_F32 0
@@ -115,6 +119,17 @@ int dca_lightsout_expand_fused(const uint8_t* parents /*[n,D]*/, int64_t n, int 
                                void* onehot /*[n*D,D*6] or NULL*/, int onehot_dtype,
                                uint8_t* is_solved /*[n*D] or NULL*/,
                                uint64_t* hash /*[n*D] or NULL*/, void* stream);
+
+/* cube4 — the remaining environment of the reference's C++ core (cpp/environments.cpp:263-370, tables environments.h:125-145):
+ * 96 stickers (face * 16 + row * 4 + col), 24 moves; getNextState = a permutation gather (perm_table: next[i] =
+ * cur[perm[a][i]], [24][96]), prev_state(a) = next_state(a ^ 1), isSolved = every face shows one colour (sticker / 16).
+ * The reference's Python harness cannot drive Cube4 (astar.py:473-486 has no state_dim for it): no network input, no one-hot,
+ * no engine instantiation here either — the environment kernels (the DCA_ENV_CUBE4 instantiation of the same tile code). */
+const uint8_t* dca_cube4_perm_table(void);
+int dca_cube4_next_state(const uint8_t* states /*[n,96]*/, int64_t n, int action, uint8_t* out, void* stream);
+int dca_cube4_prev_state(const uint8_t* states, int64_t n, int action, uint8_t* out, void* stream);
+int dca_cube4_expand_fused(const uint8_t* parents /*[n,96]*/, int64_t n, uint8_t* children /*[n,24,96] or NULL*/,
+                           uint8_t* is_solved /*[n*24] or NULL*/, uint64_t* hash /*[n*24] or NULL*/, void* stream);
 
 /* ---- stand-alone pieces of the same path (used by the Environment mirror) --------------- */
 int dca_is_solved(int env, int dim, const uint8_t* states, int64_t n, uint8_t* out /*[n]*/, void* stream);
@@ -358,10 +373,10 @@ int dca_f16x3_gemm_variant(int variant);
  * three-stage LDS-DMA ring, one counted wait + one barrier per stage; results bit-identical to the 256 x 256 variants.
  * dca_gemm2_skew: start-up skew of every CU's second workgroup in 1/16ths of a tile's K-loop time (default 8; 0 = none). */
 int dca_gemm2_skew(int sixteenths);
-/* diagnostics (tools/gemm_timeline.py): while `stamps` (device u64 [workgroups][6]) is set, variant-3 launches of
+/* diagnostics (tools/gemm_timeline.py): while `stamps` (device u64 [workgroups][8]) is set, variant-3 launches of
  * dca_f16x3_gemm record per workgroup the 100 MHz wall clock [0] at entry, [1] when the first operands have landed, [2] at the
  * end of the K loop, [5] when wave 0 has issued its last store, [3] when its stores have been acknowledged, and
- * [4] (XCC id << 32 | HW_ID).  NULL switches it off. */
+ * [4] (XCC id << 32 | HW_ID), [6] shader-clock cycles of the K loop ([2] - [1] in core cycles: the clock it ran at).  NULL: off. */
 int dca_f16x3_gemm_timeline(void* stamps);
 
 /* The same layer in the NON-parity 16-bit modes (`--nnet_dtype bf16 | fp16`; replaces the library GEMM + separate clamp pass of

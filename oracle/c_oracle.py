@@ -17,12 +17,12 @@ _LIB = os.path.join(_HERE, "liboracle.so")
 _REF = os.path.join(_HERE, "_ref", "libref_env.so")
 
 ENV_IDS = {"cube3": (0, 0), "puzzle15": (1, 4), "puzzle24": (1, 5), "puzzle35": (1, 6), "puzzle48": (1, 7),
-           "lightsout7": (2, 7)}
+           "lightsout7": (2, 7), "cube4": (3, 0)}
 
 
 def num_moves(env: str) -> int:
     e, d = ENV_IDS[env]
-    return 12 if e == 0 else d * d if e == 2 else 4
+    return 12 if e == 0 else 24 if e == 3 else d * d if e == 2 else 4
 SEM_PY, SEM_CPP = 0, 1
 
 

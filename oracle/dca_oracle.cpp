@@ -50,6 +50,29 @@ const int kCycles[6][5][4] = {
     {{0, 29, 17, 24}, {3, 28, 14, 25}, {6, 27, 11, 26}, {45, 47, 53, 51}, {46, 50, 52, 48}},
 };
 
+// ------------------------------------------------------------------------------------------
+// cube4 (cpp/environments.cpp:263-370): the 4-cycles of the twelve "_n1" moves — six outer-layer turns (8 cycles: four inside
+// the face's own 4x4 grid, four strips around it), then six inner-slice turns (4 cycles; unused rows are zero) — in the
+// order of the reference's table list (U0 D0 L0 R0 B0 F0 U1 D1 L1 R1 B1 F1; action = 2 * index, + 1 for the "_1" inverse).
+// (a b c d): next[a] = cur[b], next[b] = cur[c], next[c] = cur[d], next[d] = cur[a] — the same permutations as the reference's
+// rotateIdxs_old / rotateIdxs_new pair lists (which repeat corner stickers; the repeats write the same value twice).
+// Checked move by move against the reference's compiled class (oracle/_ref) in tests/test_cube4_cpu.py.
+// ------------------------------------------------------------------------------------------
+const int kCube4Cycles[12][8][4] = {
+    {{0, 3, 15, 12}, {1, 7, 14, 8}, {2, 11, 13, 4}, {5, 6, 10, 9}, {35, 67, 51, 83}, {39, 71, 55, 87}, {43, 75, 59, 91}, {47, 79, 63, 95}},
+    {{16, 19, 31, 28}, {17, 23, 30, 24}, {18, 27, 29, 20}, {21, 22, 26, 25}, {32, 80, 48, 64}, {36, 84, 52, 68}, {40, 88, 56, 72}, {44, 92, 60, 76}},
+    {{0, 80, 16, 79}, {1, 81, 17, 78}, {2, 82, 18, 77}, {3, 83, 19, 76}, {32, 35, 47, 44}, {33, 39, 46, 40}, {34, 43, 45, 36}, {37, 38, 42, 41}},
+    {{12, 67, 28, 92}, {13, 66, 29, 93}, {14, 65, 30, 94}, {15, 64, 31, 95}, {48, 51, 63, 60}, {49, 55, 62, 56}, {50, 59, 61, 52}, {53, 54, 58, 57}},
+    {{3, 32, 28, 63}, {7, 33, 24, 62}, {11, 34, 20, 61}, {15, 35, 16, 60}, {64, 67, 79, 76}, {65, 71, 78, 72}, {66, 75, 77, 68}, {69, 70, 74, 73}},
+    {{0, 51, 31, 44}, {4, 50, 27, 45}, {8, 49, 23, 46}, {12, 48, 19, 47}, {80, 83, 95, 92}, {81, 87, 94, 88}, {82, 91, 93, 84}, {85, 86, 90, 89}},
+    {{34, 66, 50, 82}, {38, 70, 54, 86}, {42, 74, 58, 90}, {46, 78, 62, 94}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}},
+    {{33, 81, 49, 65}, {37, 85, 53, 69}, {41, 89, 57, 73}, {45, 93, 61, 77}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}},
+    {{4, 84, 20, 75}, {5, 85, 21, 74}, {6, 86, 22, 73}, {7, 87, 23, 72}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}},
+    {{8, 71, 24, 88}, {9, 70, 25, 89}, {10, 69, 26, 90}, {11, 68, 27, 91}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}},
+    {{2, 36, 29, 59}, {6, 37, 25, 58}, {10, 38, 21, 57}, {14, 39, 17, 56}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}},
+    {{1, 55, 30, 40}, {5, 54, 26, 41}, {9, 53, 22, 42}, {13, 52, 18, 43}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}},
+};
+
 struct Tables {
     // scatter form used by the reference: newState[new_idx[a][i]] = state[old_idx[a][i]]
     // (cube3.py:167, environments.cpp:225-229); 20 distinct pairs per move.
@@ -86,7 +109,7 @@ struct Tables {
 };
 const Tables T;
 
-enum { ENV_CUBE3 = 0, ENV_NPUZZLE = 1, ENV_LIGHTSOUT = 2 };
+enum { ENV_CUBE3 = 0, ENV_NPUZZLE = 1, ENV_LIGHTSOUT = 2, ENV_CUBE4 = 3 };
 enum { SEM_PY = 0, SEM_CPP = 1 };
 
 struct Env {
@@ -96,8 +119,8 @@ inline Env make_env(int id, int dim) {
     Env e;
     e.id = id;
     e.dim = dim;
-    e.D = id == ENV_CUBE3 ? 54 : dim * dim;
-    e.A = id == ENV_CUBE3 ? 12 : id == ENV_LIGHTSOUT ? dim * dim : 4;
+    e.D = id == ENV_CUBE3 ? 54 : id == ENV_CUBE4 ? 96 : dim * dim;
+    e.A = id == ENV_CUBE3 ? 12 : id == ENV_CUBE4 ? 24 : id == ENV_LIGHTSOUT ? dim * dim : 4;
     return e;
 }
 
@@ -131,8 +154,27 @@ inline void lightsout_move(const uint8_t* s, int dim, int a, uint8_t* out) {
     const int idx[5] = {a, x < dim - 1 ? a + dim : a, x > 0 ? a - dim : a, y < dim - 1 ? a + 1 : a, y > 0 ? a - 1 : a};
     for (int i = 0; i < 5; i++) out[idx[i]] = (uint8_t)((s[idx[i]] + 1) % 2);
 }
+// Cube4::getNextState (environments.cpp:329-343): newState[newIdx] = state[oldIdx] over the move's pair list — every source is
+// read from the OLD state; here the pairs are the move's 4-cycles (action 2 m: next[c_j] = cur[c_{j+1}]; 2 m + 1: the inverse)
+inline void cube4_move(const uint8_t* s, int a, uint8_t* out) {
+    memcpy(out, s, 96);
+    const int m = a >> 1;
+    for (int c = 0; c < 8; c++) {
+        const int* cy = kCube4Cycles[m][c];
+        if (cy[0] == cy[1]) continue;  // unused row of an inner-slice move
+        for (int j = 0; j < 4; j++) {
+            const int x = cy[j], y = cy[(j + 1) % 4];
+            if ((a & 1) == 0)
+                out[x] = s[y];
+            else
+                out[y] = s[x];
+        }
+    }
+}
 inline void env_move(const Env& e, const uint8_t* s, int a, uint8_t* out) {
-    if (e.id == ENV_CUBE3)
+    if (e.id == ENV_CUBE4)
+        cube4_move(s, a, out);
+    else if (e.id == ENV_CUBE3)
         cube3_move(s, a, out);
     else if (e.id == ENV_LIGHTSOUT)
         lightsout_move(s, e.dim, a, out);
@@ -142,7 +184,10 @@ inline void env_move(const Env& e, const uint8_t* s, int a, uint8_t* out) {
 // Cube3::isSolved (environments.cpp:249-256), PuzzleN::isSolved (119-126)
 inline bool env_solved(const Env& e, const uint8_t* s) {
     bool ok = true;
-    if (e.id == ENV_CUBE3) {
+    if (e.id == ENV_CUBE4) {  // Cube4::isSolved (environments.cpp:355-365): every face shows one colour (sticker / 16)
+        for (int side = 0; side < 6; side++)
+            for (int i = 1; i < 16; i++) ok &= (s[side * 16 + i] / 16 == s[side * 16] / 16);
+    } else if (e.id == ENV_CUBE3) {
         for (int i = 0; i < 54; i++) ok &= (s[i] == i);
     } else if (e.id == ENV_LIGHTSOUT) {  // LightsOut::isSolved (environments.cpp:196-204) / lights_out.py:65-68
         for (int i = 0; i < e.D; i++) ok &= (s[i] == 0);

@@ -11,6 +11,7 @@
  *   cpp/environments.cpp:92-113   PuzzleN::getNextState / getNextStates
  *   cpp/environments.cpp:119-126,249-256  isSolved
  *   cpp/environments.cpp:133-208  LightsOut (move matrix, getNextState, getNextStates, isSolved)
+ *   cpp/environments.cpp:263-370  Cube4 (rotateIdxs_old / _new, getNextState, getNextStates, isSolved)
  * driven the way the reference's hot loop drives them
  * (cpp/parallel_weighted_astar.cpp:217-230: `#pragma omp parallel for` over popped nodes,
  *  one heap-allocated Environment per child).
@@ -32,10 +33,11 @@ static Environment* make_env(int env, int dim, const uint8_t* s, int D) {
     std::vector<uint8_t> v(s, s + D);
     if (env == 0) return new Cube3(v);
     if (env == 2) return new LightsOut(v, (uint8_t)dim);  // cpp/environments.cpp:156-208 (dim 7: moveMat7)
+    if (env == 3) return new Cube4(v);                    // cpp/environments.cpp:322-370
     return new PuzzleN(v, (uint8_t)dim);
 }
-static inline int env_D(int env, int dim) { return env == 0 ? 54 : dim * dim; }
-static inline int env_A(int env, int dim) { return env == 0 ? 12 : env == 2 ? dim * dim : 4; }
+static inline int env_D(int env, int dim) { return env == 0 ? 54 : env == 3 ? 96 : dim * dim; }
+static inline int env_A(int env, int dim) { return env == 0 ? 12 : env == 3 ? 24 : env == 2 ? dim * dim : 4; }
 
 extern "C" {
 

@@ -34,7 +34,7 @@ for n, k in ((1024, 1024), (1024, 5120)):
         _lib.f16x3_gemm_variant(3)
         for _ in range(3):
             _lib.f16x3_gemm(planes, whc, wlc, inv, 1.0, b, sk, True, True, want_x)
-        stamps = torch.zeros((blocks, 6), dtype=torch.int64, device="cuda")
+        stamps = torch.zeros((blocks, 8), dtype=torch.int64, device="cuda")
         _lib.check(_lib.lib().dca_f16x3_gemm_timeline(C.c_void_p(stamps.data_ptr())), "timeline")
         torch.cuda.synchronize()
         _lib.f16x3_gemm(planes, whc, wlc, inv, 1.0, b, sk, True, True, want_x)
@@ -47,6 +47,10 @@ for n, k in ((1024, 1024), (1024, 5120)):
         fill, loop, tail = us[:, 1] - us[:, 0], us[:, 2] - us[:, 1], us[:, 3] - us[:, 2]
         issue = (s[:, 5] - t0) / 100.0 - us[:, 2]   # K loop end -> wave 0 has issued its last store
         drain = us[:, 3] - (s[:, 5] - t0) / 100.0    # ... -> its stores are acknowledged
+        ghz = s[:, 6] / np.maximum(loop, 1e-3) / 1000.0  # shader cycles per microsecond of K loop -> GHz
+        # matrix-pipe cycles the K loop needs per SIMD: 2 waves x 48 MFMAs of 32x32x16 (8 passes x 4 cycles) per 32-deep K-step
+        need = (k // 32) * 2 * 48 * 32
+        util = need / np.maximum(s[:, 6], 1)
         hw = s[:, 4]
         cu_key = (hw >> 32) * 100000 + ((hw & 0xFFFFFFFF) >> 8 & 0xF) * 1000 + ((hw & 0xFFFFFFFF) >> 12 & 0x3) * 100 + ((hw & 0xFFFFFFFF) >> 13 & 0x7) * 0  # xcc, cu id, sh id (HW_ID layout varies: the key only has to separate CUs)
         cu_key = (hw >> 32) * 4096 + ((hw & 0xFFFFFFFF) >> 8 & 0xFFF)
@@ -64,6 +68,7 @@ for n, k in ((1024, 1024), (1024, 5120)):
         q = lambda a: [round(float(np.percentile(a, p)), 2) for p in (10, 50, 90)]  # noqa: E731
         print(json.dumps({"m": m, "n": n, "k": k, "tail_form": name, "tiles": int(len(s)), "launch_us": round(float(end), 1),
                           "fill_us_p10_50_90": q(fill), "kloop_us_p10_50_90": q(loop), "tail_us_p10_50_90": q(tail),
+                          "kloop_clock_ghz_p10_50_90": q(ghz), "kloop_mfma_cycle_utilisation_p10_50_90": q(util),
                           "tail_issue_us_p10_50_90": q(issue), "tail_store_drain_us_p10_50_90": q(drain),
                           "cu_slots": int(len(per_cu)), "tiles_per_cu_slot_min_max": [int(min(per_cu)), int(max(per_cu))],
                           "gap_between_tiles_on_a_cu_us_p10_50_90": q(np.array(gaps)) if gaps else None,
