@@ -132,16 +132,20 @@ def gather_ranks(x: float, world: int):
     return [float(o.item()) for o in out]
 
 
+PMC_SOURCE = {}  # kernel -> which committed PMC summary its traffic figure came from (and the episode shape it was taken at)
+
+
 def pmc_traffic(kernel: str, env: str, B: int):
     """HBM bytes per launch from the rocprofv3 PMC passes of THIS command (`tools/pmc_summary.py` writes
     profiles/r03_pmc_traffic.json from `rocprofv3 --pmc ... -- python bench.py`): counters cannot be read from inside
     the process, so the entry is matched on kernel, environment and batch size and otherwise left null."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
             continue
         if d.get("env") == env and d.get("batch_size") == B and kernel in d.get("kernels", {}):
+            PMC_SOURCE[kernel] = "profiles/%s (%s)" % (name, d.get("shape", "rocprofv3 PMC passes of bench.py at 100-step episodes"))
             return d["kernels"][kernel]
     return None
 
@@ -272,8 +276,12 @@ def run_astar(args, world, rank):
         "config": {"workload": "%s BWAS iteration on the device-resident engine, batch %d, weight %.2f, "
                                "%s semantics, heuristic = built-in 10+5*u01(hash) (engine-only, SURVEY §8d), no one-hot "
                                "rows (see engine_onehot_f32 for the north star's fused one-hot); BASELINE configs[2] "
-                               "geometry; %d episode(s) of %d timed steps on fresh test-set scrambles"
-                               % (args.env, B, w, args.semantics, leg["episodes"], args.steps),
+                               "geometry; %d episode(s) of %d timed steps on fresh test-set scrambles: the timed window is "
+                               "iterations %d..%d of each search (--warmup %d%s: a search needs 8 iterations before every pop "
+                               "is a full batch, and the engine's first 8 iterations are rebase iterations)"
+                               % (args.env, B, w, args.semantics, leg["episodes"], args.steps, leg["warmup_effective"],
+                                  leg["warmup_effective"] + args.steps - 1, args.warmup,
+                                  " raised to %d" % leg["warmup_effective"] if leg["warmup_effective"] != args.warmup else ""),
                    "env": args.env, "batch_size": B, "weight": w, "children_per_step": B * A, "semantics": args.semantics,
                    "hipgraph": not args.no_graph, "parallelism": "one search instance per GPU x%d" % world,
                    "episodes": leg["episodes"], "timed_s": leg["timed_s"],
@@ -299,6 +307,7 @@ def run_astar(args, world, rank):
         res["roofline"] = {
             "bound": "hbm", "kernel": "k_" + dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("k_" + dom, args.env, B),
+            "traffic_source": None,  # filled below: which committed PMC summary, taken at which episode shape
             "bytes_per_launch": alg_k[dom], "kernel_ms": span[dom],
             "timing": "device wall-clock stamps written by every workgroup of the launch INSIDE the replayed hipGraph "
                       "(dca_engine_profile_builtin; max end - min start, averaged over the %d iterations of one "
@@ -321,6 +330,8 @@ def run_astar(args, world, rank):
                     "probe / rank chains), not by HBM bandwidth, so its fraction of the HBM peak is low by construction — "
                     "the bandwidth-bound launch is k_expand (see engine_onehot_f32.roofline_expand)" % dom,
         }
+    if "roofline" in res:
+        res["roofline"]["traffic_source"] = PMC_SOURCE.get(res["roofline"]["kernel"])
     it_bytes = alg["per_expansion_8d"] * B
     res["roofline_iteration"] = {"bound": "hbm", "what": "whole BWAS iteration: SURVEY §8(d) bytes per expansion "
                                  "(%d B, no one-hot) x batch / ms_per_step" % alg["per_expansion_8d"],
@@ -493,7 +504,18 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
     flops = 2.0 * macs * rows
     eng.close()
     torch.cuda.empty_cache()
+    peak = (157.3 if eval_all_children else 2500.0) if dtype_name == "fp32" else (5000.0 if dtype_name == "fp8" else 2500.0)
+    issued = flops * (3.0 if (dtype_name == "fp32" and not eval_all_children) else 1.0) / (wall / steps) / 1e12
+    roof = {"bound": "mfma", "achieved": issued, "peak": peak, "unit": "TFLOP/s", "frac": issued / peak,
+            "what": "MFMA flops ISSUED per second over the whole iteration (engine launches and host hand-over included): "
+                    "2 x MACs x network rows%s / ms_per_step, against the dense peak of the pipe the layers run on"
+                    % (" x 3 (f16x3: three f16 products per fp32-accurate one)" if dtype_name == "fp32" and not eval_all_children else ""),
+            "mfma_busy_profile": {"fp32": "profiles/r04_nnet_fp32_pmc_mfma.txt", "fp8": "profiles/r03_nnet_fp8_pmc_mfma.txt"}.get(
+                dtype_name if not eval_all_children else "", None),
+            "clock_note": "the dense layers run power-limited: 1.3-1.7 GHz shader clock inside their K loops (2.4 GHz nominal), 73 % "
+                          "of the matrix pipe's issue slots filled at that clock (profiles/r04_gemm_timeline.txt)"}
     return {"value": total_exp / wall, "unit": "nodes expanded/s", "ms_per_step": wall / steps * 1e3,
+            "roofline_nnet": roof,
             "steps": steps, "timed_s": wall, "heuristic_dtype": dtype_name, "weights": "synthetic (numpy PCG64 seed 2024, BN folded)",
             "order": "eval_all_children (reference order)" if eval_all_children else "dedup_first (CLI default)",
             "layer1": "library GEMM on one-hot rows" if eval_all_children or not fast.uses_l1_kernel

@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "dca_bn_workspace_bytes", "dca_bn_train_forward", "dca_bn_train_backward",
     "dca_l1_supported", "dca_l1_kpad", "dca_l1_onehot_gemm", "dca_act_split", "dca_f16x3_gemm", "dca_split_planes", "dca_f16x3_gemm_variant",
     "dca_gemm16", "dca_gemm16_variant", "dca_gemm8", "dca_quant_e4m3", "dca_lightsout_next_state", "dca_lightsout_expand_fused",
-    "dca_head_gemv", "dca_engine_packed_state", "dca_engine_info", "dca_gemm2_skew", "dca_f16x3_gemm_timeline",
+    "dca_head_gemv", "dca_engine_packed_state", "dca_engine_info", "dca_gemm2_skew", "dca_f16x3_gemm_timeline", "dca_gemm8_mx", "dca_l1_onehot_gemm_mx",
     "dca_cube4_perm_table", "dca_cube4_next_state", "dca_cube4_prev_state", "dca_cube4_expand_fused",
     "dca_engine_set_weight_instance", "dca_engine_set_weights", "dca_engine_park_instance", "dca_engine_last_popped",
 ]
@@ -455,6 +455,40 @@ def gemm8(a: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, bias: Optional[
                           int(relu), ptr(out16), C.c_int64(n), ptr(out8), C.c_int64(n),
                           C.c_double(out8_scale if out8_scale is not None else 1.0), stream_ptr()), "dca_gemm8")
     return out16, out8
+
+
+def gemm8_mx(a: torch.Tensor, a_scale: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor, bias: Optional[torch.Tensor],
+             skip: Optional[torch.Tensor], relu: bool, want16: bool, want8: bool, out16: Optional[torch.Tensor] = None):
+    """One dense layer in the block-scaled fp8 mode (dca_gemm8_mx): a [m, k] e4m3 with a_scale [m, k/64] E8M0 bytes, w [n, k] e4m3 with
+    w_scale [n] fp32.  -> (bf16 v or None, e4m3 v blocks or None, their E8M0 scales [m, n/64] or None); `out16` may be `skip`."""
+    assert a.dtype == E4M3 and w.dtype == E4M3 and a.is_contiguous() and w.is_contiguous()
+    m, k = a.shape
+    n = w.shape[0]
+    assert a_scale.dtype == torch.uint8 and a_scale.shape == (m, k // 64) and a_scale.is_contiguous()
+    assert w.shape[1] == k and w_scale.dtype == torch.float32 and w_scale.numel() == n
+    assert bias is None or (bias.dtype == torch.float32 and bias.numel() == n)
+    assert skip is None or (skip.dtype == torch.bfloat16 and skip.shape == (m, n) and skip.is_contiguous())
+    if want16 and out16 is None:
+        out16 = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
+    out8 = torch.empty((m, n), dtype=E4M3, device=a.device) if want8 else None
+    out_sc = torch.empty((m, n // 64), dtype=torch.uint8, device=a.device) if want8 else None
+    check(lib().dca_gemm8_mx(ptr(a), ptr(a_scale), C.c_int64(m), int(k), C.c_int64(k), C.c_int64(k // 64), ptr(w), int(n), C.c_int64(k),
+                             ptr(w_scale), ptr(bias), ptr(skip), int(relu), ptr(out16), C.c_int64(n), ptr(out8), C.c_int64(n),
+                             ptr(out_sc), C.c_int64(n // 64), stream_ptr()), "dca_gemm8_mx")
+    return out16, out8, out_sc
+
+
+def l1_onehot_gemm_mx(states_nnet: torch.Tensor, depth: int, w_tiles: torch.Tensor, bias: torch.Tensor, relu: bool):
+    """Layer 1 (one bf16 weight plane) leaving as e4m3 + one E8M0 block scale per row and 64 units (dca_l1_onehot_gemm_mx)
+    -> (e4m3 [m, n_pad], uint8 [m, n_pad / 64])."""
+    x = _u8(states_nnet)
+    m, d = x.shape
+    n_pad = bias.numel()
+    out = torch.empty((m, n_pad), dtype=E4M3, device=x.device)
+    sc = torch.empty((m, n_pad // 64), dtype=torch.uint8, device=x.device)
+    check(lib().dca_l1_onehot_gemm_mx(ptr(x), C.c_int64(m), int(d), int(depth), ptr(w_tiles), C.c_int64(n_pad), ptr(bias), int(relu),
+                                      ptr(out), ptr(sc), C.c_int64(n_pad // 64), stream_ptr()), "dca_l1_onehot_gemm_mx")
+    return out, sc
 
 
 def quant_e4m3(x: torch.Tensor, scale: float) -> torch.Tensor:

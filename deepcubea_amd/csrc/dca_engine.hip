@@ -570,7 +570,7 @@ __global__ void k_root_commit(Eng E, const float* h_root) {
 // The refill kernels are only enqueued every kRefillPeriod-th iteration (they cost a few microseconds
 // even when idle), so they top FRONT up early enough to last until the next check: an iteration
 // removes at most B entries from FRONT.
-constexpr int kRefillPeriod = 8;
+constexpr int kRefillPeriod = 16;
 // what a refill / spill must leave in FRONT so that it cannot run short before the next refill check
 __device__ __forceinline__ uint32_t front_keep(const Eng& E) {
     const uint32_t floor_ = (uint32_t)(kRefillPeriod + 1) * (uint32_t)E.B;

@@ -42,12 +42,29 @@ struct Gemm8Args {
     const uint16_t* skip;  // [m, ldo16] bf16 or null
     uint16_t* out16;     // [m, ldo16] bf16 or null
     uint8_t* out8;       // [m, ldo8] e4m3 or null
-    float out8_scale;    // out8 = e4m3(sat(v * out8_scale))
+    float out8_scale;    // out8 = e4m3(sat(v * out8_scale)) — unless block scales are written (out8_scale below)
     int relu;
     int64_t m;
     int n, k;
     int64_t lda, ldw, ldo16, ldo8;
+    // block-scaled ("MX") operands and results: one E8M0 byte (value 2^(byte - 127)) per 64 consecutive K elements of a row
+    const uint8_t* a_scale;  // [m, ld_asc] (k / 64 bytes per row) or null: per-tensor scaling (scale[] carries it)
+    int64_t ld_asc;
+    uint8_t* out8_sc;        // [m, ld_osc] (n / 64 bytes per row) or null: out8 = e4m3(sat(v * out8_scale)) with the static scalar
+    int64_t ld_osc;
+    int out8_scale_ptr_set;  // (out8_sc != null: a uniform scalar the epilogue branches on)
 };
+
+// E8M0 block scale of a group whose largest magnitude is `amax`: the smallest power of two 2^e with amax * 2^-e <= 448 (the
+// largest e4m3 value), as (byte = e + 127, multiplier 2^-e).  amax = 0 (or a tiny group) takes the smallest scale.
+__device__ __forceinline__ uint32_t e8m0_of_amax(float amax, float& inv) {
+    const float t = amax * (1.0f / 448.0f);
+    const uint32_t u = __float_as_uint(t);
+    int e = (int)((u >> 23) & 0xFFu) - 127 + ((u & 0x7FFFFFu) ? 1 : 0);  // ceil(log2 t) for normal t
+    e = e < -126 ? -126 : (e > 126 ? 126 : e);
+    inv = __uint_as_float((uint32_t)(127 - e) << 23);  // 2^-e
+    return (uint32_t)(e + 127);
+}
 
 __device__ __forceinline__ uint32_t swz128b(uint32_t row, uint32_t chunk) { return row * 128u + ((chunk ^ ((row >> 1) & 7u)) << 4); }
 
@@ -74,6 +91,13 @@ __device__ __forceinline__ uint32_t pack_e4m3(float a, float b, float c, float d
 #define DCA_RD_DONE_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define DCA_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
+// MXIN: the A operand carries E8M0 block scales (one per 64 K elements of a row).  The whole K range of the tile's 256 rows
+// (k / 64 bytes a row: 4 KB at k = 1024, 20 KB at 5120) is staged into LDS behind the operand slots in the prologue — ordinary
+// loads, before the K loop, so the loop's counted LDS-DMA waits are untouched — and a lane fetches the two scales of its row
+// for a K-tile with one ds_read_u16.  gfx950's scaled MFMA multiplies a lane's 32 products by 2^(sa - 127) * 2^(sb - 127),
+// sa / sb being a byte of the lane's scale registers: both lane halves of a row pass the row's scale of the 64-deep step,
+// the weights' side passes 127 (their per-output-unit fp32 scales stay in the epilogue).
+template <bool MXIN>
 __global__ __launch_bounds__(ETHREADS, 2) void k_gemm8(const Gemm8Args p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, h = lane >> 5;
@@ -141,23 +165,39 @@ __global__ __launch_bounds__(ETHREADS, 2) void k_gemm8(const Gemm8Args p) {
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
     i32x8 av[2][2], wv0[2], wv1[2];
-    auto read_a = [&](const uint8_t* base, int u) {
+    // block scales of the A rows in `av`: bytes 0 / 1 = the two 64-deep steps of the current K-tile
+    uint32_t sa[2] = {0u, 0u};
+    const uint32_t SK = MXIN ? (uint32_t)(p.k / 64) : 0u;
+    uint8_t* lsc = lds + ELDS;
+    const uint32_t sc_row0 = ((uint32_t)wm * 128u + (uint32_t)l31) * SK;
+    auto read_a = [&](const uint8_t* base, int u, int kt) {
 #pragma unroll
-        for (int ii = 0; ii < 2; ii++)
+        for (int ii = 0; ii < 2; ii++) {
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) av[ii][ks] = frag(base + u * ESLOT + a_row0 + ii * 4096, ks);
+            if constexpr (MXIN)  // tile row = wm * 128 + (u == A23 ? 64 : 0) + ii * 32 + l31
+                sa[ii] = *reinterpret_cast<const uint16_t*>(lsc + sc_row0 + (uint32_t)((u == ES_A23 ? 64 : 0) + ii * 32) * SK + 2u * (uint32_t)kt);
+        }
     };
     auto read_b = [&](const uint8_t* base, int u, i32x8 (&wv)[2]) {
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) wv[ks] = frag(base + u * ESLOT + b_row0, ks);
     };
+#define DCA_MMA4_STEP(I0, JN, WV, KS)                                                                                    \
+    _Pragma("unroll") for (int ii = 0; ii < 2; ii++) {                                                                   \
+        if constexpr (MXIN) /* op_sel = KS: byte KS of the lane's scale register (the K-tile's two 64-deep steps) */     \
+            acc[(I0) + ii][JN] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av[ii][KS], WV[KS], acc[(I0) + ii][JN], \
+                                                                                 0, 0, KS, (int)sa[ii], 0, 127);         \
+        else                                                                                                             \
+            acc[(I0) + ii][JN] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av[ii][KS], WV[KS], acc[(I0) + ii][JN], \
+                                                                                 0, 0, 0, 0, 0, 0);                      \
+    }
 #define DCA_MMA4(I0, JN, WV)                                                                                             \
     do {                                                                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
         __builtin_amdgcn_s_setprio(1);                                                                                   \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ks++) _Pragma("unroll") for (int ii = 0; ii < 2; ii++)                \
-            acc[(I0) + ii][JN] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av[ii][ks], WV[ks], acc[(I0) + ii][JN], \
-                                                                                 0, 0, 0, 0, 0, 0);                      \
+        DCA_MMA4_STEP(I0, JN, WV, 0)                                                                                     \
+        DCA_MMA4_STEP(I0, JN, WV, 1)                                                                                     \
         __builtin_amdgcn_s_setprio(0);                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     } while (0)
@@ -172,7 +212,7 @@ __global__ __launch_bounds__(ETHREADS, 2) void k_gemm8(const Gemm8Args p) {
         const uint8_t* base = lds + b * EBUF;
         // phase 1: (A01, B0); restage A23 of kt+1; retire B1 of kt
         read_b(base, ES_B0, wv0);
-        read_a(base, ES_A01);
+        read_a(base, ES_A01, kt);
         if constexpr (N1) {
             issue(ES_A23, b ^ 1, (kt + 1) * EBK);
             DCA_VMCNT(10);
@@ -196,7 +236,7 @@ __global__ __launch_bounds__(ETHREADS, 2) void k_gemm8(const Gemm8Args p) {
         DCA_MMA4(0, 1, wv1);
         DCA_BAR();
         // phase 3: (A23, B1); restage B0 of kt+2
-        read_a(base, ES_A23);
+        read_a(base, ES_A23, kt);
         if constexpr (N2) issue(ES_B0, b, (kt + 2) * EBK);
         DCA_RD_DONE_BAR();
         DCA_MMA4(2, 1, wv1);
@@ -221,6 +261,18 @@ __global__ __launch_bounds__(ETHREADS, 2) void k_gemm8(const Gemm8Args p) {
         issue(ES_A01, 1, EBK);
         issue(ES_B0, 1, EBK);
         issue(ES_B1, 1, EBK);
+    }
+    if constexpr (MXIN) {
+        // the tile's block scales: 256 rows x SK bytes, one linear image behind the operand slots (rows past m: clamped)
+        const uint32_t words = 256u * SK / 4u;
+        for (uint32_t q = (uint32_t)t; q < words; q += ETHREADS) {
+            const uint32_t row = (q * 4u) / SK, col = (q * 4u) - row * SK;
+            int64_t gr = m0 + row;
+            gr = gr < p.m ? gr : p.m - 1;
+            *reinterpret_cast<uint32_t*>(lsc + q * 4u) = *reinterpret_cast<const uint32_t*>(p.a_scale + gr * p.ld_asc + col);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (the scale loads drain the queue once, before the loop)
+    } else if (nk > 1) {
         DCA_VMCNT(10);  // A01, B0 of tile 0 have landed
     } else {
         DCA_VMCNT(4);
@@ -238,6 +290,7 @@ __global__ __launch_bounds__(ETHREADS, 2) void k_gemm8(const Gemm8Args p) {
     }
     if (wm == 0) DCA_BAR();  // ... and the first waits for it here
 #undef DCA_MMA4
+#undef DCA_MMA4_STEP
 
     // epilogue.  Accumulator layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  Each wave
     // transposes its tile through its own 16 KB of the (now idle) LDS, 32 rows at a time: a lane then owns 4 consecutive
@@ -303,7 +356,15 @@ __global__ __launch_bounds__(ETHREADS, 2) void k_gemm8(const Gemm8Args p) {
                     *reinterpret_cast<uint2*>(p.out16 + r * p.ldo16 + colg) = ov;
                 }
                 if (p.out8) {
-                    const float s = p.out8_scale;
+                    float s = p.out8_scale;
+                    if (p.out8_scale_ptr_set) {
+                        // block scale of this row's 64 columns (the wave's slice: 16 lanes x 4 columns): largest magnitude over the
+                        // 16 lanes, the power of two that brings it into e4m3's range, one byte per (row, 64 columns)
+                        float am = fmaxf(fmaxf(fabsf(u[0]), fabsf(u[1])), fmaxf(fabsf(u[2]), fabsf(u[3])));
+                        for (int o = 8; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+                        const uint32_t sb = e8m0_of_amax(am, s);
+                        if ((lane & 15) == 0) p.out8_sc[r * p.ld_osc + (colg >> 6)] = (uint8_t)sb;
+                    }
                     *reinterpret_cast<uint32_t*>(p.out8 + r * p.ldo8 + colg) = pack_e4m3(u[0] * s, u[1] * s, u[2] * s, u[3] * s);
                 }
             } else {  // ragged right edge: element-wise
@@ -372,7 +433,7 @@ int dca_gemm8(const void* a, int64_t m, int k, int64_t lda, const void* w, int n
         DCA_HIP(hipGetDevice(&dev));
         const uint64_t bit = 1ull << (dev & 63);
         if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
-            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm8), hipFuncAttributeMaxDynamicSharedMemorySize, ELDS));
+            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm8<false>), hipFuncAttributeMaxDynamicSharedMemorySize, ELDS));
             attr_devs.fetch_or(bit, std::memory_order_release);
         }
     }
@@ -400,8 +461,77 @@ int dca_gemm8(const void* a, int64_t m, int k, int64_t lda, const void* w, int n
         set_error("dca_gemm8: too many tiles");
         return DCA_E_BADARG;
     }
-    hipLaunchKernelGGL(k_gemm8, dim3((unsigned)blocks), dim3(ETHREADS), ELDS, (hipStream_t)stream, p);
+    p.a_scale = nullptr;
+    p.ld_asc = 0;
+    p.out8_sc = nullptr;
+    p.ld_osc = 0;
+    p.out8_scale_ptr_set = 0;
+    hipLaunchKernelGGL(k_gemm8<false>, dim3((unsigned)blocks), dim3(ETHREADS), ELDS, (hipStream_t)stream, p);
     return launch_check("k_gemm8");
+}
+
+int dca_gemm8_mx(const void* a, const void* a_scale, int64_t m, int k, int64_t lda, int64_t ld_asc, const void* w, int n, int64_t ldw,
+                 const float* w_scale, const float* bias, const void* skip, int relu, void* out16, int64_t ldo16, void* out8,
+                 int64_t ldo8, void* out8_scale, int64_t ld_osc, void* stream) {
+    DCA_ARG(a && a_scale && w && w_scale && (out16 || out8) && m >= 0 && n >= 1 && k >= 256 && k % 256 == 0 && k <= 8192);
+    DCA_ARG(lda >= k && ldw >= k && lda % 16 == 0 && ldw % 16 == 0 && ld_asc >= k / 64 && ld_asc % 4 == 0);
+    DCA_ARG(((uintptr_t)a | (uintptr_t)w) % 16 == 0 && (uintptr_t)a_scale % 4 == 0);
+    DCA_ARG((!out16 && !skip) || (ldo16 >= n && ldo16 % 4 == 0 && ((uintptr_t)out16 | (uintptr_t)skip) % 8 == 0));
+    DCA_ARG((out8 != nullptr) == (out8_scale != nullptr));
+    DCA_ARG(!out8 || (ldo8 >= n && ldo8 % 4 == 0 && (uintptr_t)out8 % 4 == 0 && n % 64 == 0 && ld_osc >= n / 64));
+    {
+        const uintptr_t a0 = (uintptr_t)a, a1 = a0 + (m > 0 ? (size_t)(m - 1) * (size_t)lda + (size_t)k : 0);
+        auto overlaps = [&](const void* o, int64_t ld, size_t esz) {
+            if (!o || m == 0) return false;
+            const uintptr_t o0 = (uintptr_t)o, o1 = o0 + ((size_t)(m - 1) * (size_t)ld + (size_t)n) * esz;
+            return o0 < a1 && a0 < o1;
+        };
+        DCA_ARG(!overlaps(out8, ldo8, 1) && !overlaps(out16, ldo16, 2) && out8_scale != a_scale);
+    }
+    if (m == 0) return 0;
+    const int lds_bytes = ELDS + 256 * (k / 64);
+    {
+        static std::atomic<uint64_t> attr_devs{0};
+        int dev = 0;
+        DCA_HIP(hipGetDevice(&dev));
+        const uint64_t bit = 1ull << (dev & 63);
+        if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
+            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm8<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        ELDS + 256 * (8192 / 64)));
+            attr_devs.fetch_or(bit, std::memory_order_release);
+        }
+    }
+    Gemm8Args p;
+    p.a = reinterpret_cast<const uint8_t*>(a);
+    p.w = reinterpret_cast<const uint8_t*>(w);
+    p.scale = w_scale;
+    p.bias = bias;
+    p.skip = reinterpret_cast<const uint16_t*>(skip);
+    p.out16 = reinterpret_cast<uint16_t*>(out16);
+    p.out8 = reinterpret_cast<uint8_t*>(out8);
+    p.out8_scale = 1.f;
+    p.relu = relu;
+    p.m = m;
+    p.n = n;
+    p.k = k;
+    p.lda = lda;
+    p.ldw = ldw;
+    p.ldo16 = ldo16;
+    p.ldo8 = ldo8;
+    p.a_scale = reinterpret_cast<const uint8_t*>(a_scale);
+    p.ld_asc = ld_asc;
+    p.out8_sc = reinterpret_cast<uint8_t*>(out8_scale);
+    p.ld_osc = ld_osc;
+    p.out8_scale_ptr_set = out8_scale != nullptr ? 1 : 0;
+    const int64_t nMt = (m + EBM - 1) / EBM;
+    const int64_t nNt = (n + EBN - 1) / EBN;
+    const int64_t blocks = ((nMt + 7) / 8) * 8 * nNt;
+    if (blocks > 0x7FFFFFFFll) {
+        set_error("dca_gemm8_mx: too many tiles");
+        return DCA_E_BADARG;
+    }
+    hipLaunchKernelGGL(k_gemm8<true>, dim3((unsigned)blocks), dim3(ETHREADS), lds_bytes, (hipStream_t)stream, p);
+    return launch_check("k_gemm8<mx>");
 }
 
 int dca_quant_e4m3(const void* x, int dtype, int64_t m, int64_t n, int64_t ld, double scale, void* out, int64_t ldo, void* stream) {

@@ -50,11 +50,12 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
 
 template <int D, int DEPTH, int P,
           int OUT /*0 f32, 1 f16, 2 bf16, 3 f16x3 split (vh, vl, vh) interleaved, 4 two fp16 planes (high, then low at +m*ldo),
-                    5 e4m3 bytes (saturating)*/>
+                    5 e4m3 bytes (saturating), 6 e4m3 bytes with one E8M0 block scale per row and 64 columns (out_scale)*/>
 __global__ __launch_bounds__(kL1Threads) void k_l1_onehot_gemm(const uint8_t* __restrict__ nn, int64_t m,
                                                         const uint8_t* __restrict__ wt /*[ntile][P][KC][64][8] bf16*/,
                                                         const float* __restrict__ bias, int relu, void* __restrict__ out,
-                                                        int64_t ldo, int* __restrict__ overflow) {
+                                                        int64_t ldo, int* __restrict__ overflow,
+                                                        uint8_t* __restrict__ out_scale /*OUT 6: [m, ld_sc]*/, int64_t ld_sc) {
     using G = L1Geo<D, DEPTH>;
     extern __shared__ __attribute__((aligned(16))) uint8_t lw[];
     // weights of K-chunk ch (all planes) -> LDS, in B-fragment order [plane][k/8][column][8]
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(kL1Threads) void k_l1_onehot_gemm(const uint8_t* __
             }
         }
         // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-        if constexpr (OUT == 1 || OUT == 2 || OUT == 4 || OUT == 5) {
+        if constexpr (OUT == 1 || OUT == 2 || OUT == 4 || OUT == 5 || OUT == 6) {
             // 16-bit outputs: straight from the accumulator layout every store instruction would write 2 bytes per lane,
             // 64 contiguous bytes per row (3.1 ms for the 204 800 x 5120 planes, the fp32 output of the same tile 2.3 ms).
             // Each wave transposes 16 rows x 64 columns at a time through 4 KB of its own LDS — one word per element:
@@ -180,6 +181,8 @@ __global__ __launch_bounds__(kL1Threads) void k_l1_onehot_gemm(const uint8_t* __
                                 w = f32_to_bf16_rne(v);
                             } else if constexpr (OUT == 5) {  // e4m3fn has no infinity: saturate at +-448
                                 w = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v, -448.f), 448.f), 0.f, 0, false) & 0xFFu;
+                            } else if constexpr (OUT == 6) {  // quantised after the transposition, once the row's block scale is known
+                                w = __float_as_uint(v);
                             } else {
                                 const _Float16 hh = (_Float16)v;
                                 uint16_t hb, lb = 0;
@@ -203,6 +206,24 @@ __global__ __launch_bounds__(kL1Threads) void k_l1_onehot_gemm(const uint8_t* __
                             if (r < m)
                                 *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(out) + r * ldo + n0 + c4) =
                                     (pk.x & 0xFFu) | ((pk.y & 0xFFu) << 8) | ((pk.z & 0xFFu) << 16) | (pk.w << 24);
+                        } else if constexpr (OUT == 6) {
+                            // the workgroup's 64 columns ARE one scale block of the next layer's K: largest magnitude of the row's 64
+                            // values (16 lanes x 4), the power of two that brings it to e4m3's range, then the bytes
+                            const float u0 = __uint_as_float(pk.x), u1 = __uint_as_float(pk.y), u2 = __uint_as_float(pk.z),
+                                        u3 = __uint_as_float(pk.w);
+                            float am = fmaxf(fmaxf(fabsf(u0), fabsf(u1)), fmaxf(fabsf(u2), fabsf(u3)));
+                            for (int o = 8; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+                            const float t = am * (1.0f / 448.0f);
+                            const uint32_t tb = __float_as_uint(t);
+                            int e = (int)((tb >> 23) & 0xFFu) - 127 + ((tb & 0x7FFFFFu) ? 1 : 0);
+                            e = e < -126 ? -126 : (e > 126 ? 126 : e);
+                            const float inv = __uint_as_float((uint32_t)(127 - e) << 23);
+                            if (r < m) {
+                                uint32_t q8 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(fminf(u0 * inv, 448.f), fminf(u1 * inv, 448.f), 0, false);
+                                q8 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(fminf(u2 * inv, 448.f), fminf(u3 * inv, 448.f), (int)q8, true);
+                                *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(out) + r * ldo + n0 + c4) = q8;
+                                if ((lane & 15) == 0) out_scale[r * ld_sc + blockIdx.x] = (uint8_t)(e + 127);
+                            }
                         } else if (r < m) {
                             const u16x4 hi = {(uint16_t)pk.x, (uint16_t)pk.y, (uint16_t)pk.z, (uint16_t)pk.w};
                             uint16_t* q0 = reinterpret_cast<uint16_t*>(out) + r * ldo + n0 + c4;
@@ -257,7 +278,7 @@ __global__ __launch_bounds__(kL1Threads) void k_l1_onehot_gemm(const uint8_t* __
 
 template <int D, int DEPTH, int P>
 int launch_l1_out(const uint8_t* nn, int64_t m, const uint8_t* wt, const float* bias, int relu, void* out, int out_dtype,
-                  int64_t n_pad, int* overflow, hipStream_t s) {
+                  int64_t n_pad, int* overflow, hipStream_t s, uint8_t* out_scale = nullptr, int64_t ld_sc = 0) {
     using G = L1Geo<D, DEPTH>;
     constexpr int LDS = P * G::CHKC * 64 * 16 + (kL1Threads / 64) * 4096;  // weight tile + the waves' epilogue slices
     static_assert(LDS <= 160 * 1024, "weight tile does not fit LDS");
@@ -267,7 +288,7 @@ int launch_l1_out(const uint8_t* nn, int64_t m, const uint8_t* wt, const float* 
     do {                                                                                                             \
         auto kern = k_l1_onehot_gemm<D, DEPTH, P, OUTV>;                                                             \
         DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
-        hipLaunchKernelGGL(kern, grid, block, LDS, s, nn, m, wt, bias, relu, out, n_pad, overflow);                            \
+        hipLaunchKernelGGL(kern, grid, block, LDS, s, nn, m, wt, bias, relu, out, n_pad, overflow, out_scale, ld_sc);          \
     } while (0)
     if (out_dtype == DCA_DT_F32)
         DCA_L1_LAUNCH(0);
@@ -279,7 +300,10 @@ int launch_l1_out(const uint8_t* nn, int64_t m, const uint8_t* wt, const float* 
         DCA_L1_LAUNCH(3);
     else if (out_dtype == DCA_DT_E4M3) {
         if constexpr (P == 1) {  // (the fp8 mode keeps layer 1's weights as ONE bf16 plane: no other combination is built)
-            DCA_L1_LAUNCH(5);
+            if (out_scale != nullptr)
+                DCA_L1_LAUNCH(6);
+            else
+                DCA_L1_LAUNCH(5);
         } else {
             set_error("dca_l1_onehot_gemm: e4m3 output takes planes == 1");
             return DCA_E_BADARG;
@@ -292,9 +316,9 @@ int launch_l1_out(const uint8_t* nn, int64_t m, const uint8_t* wt, const float* 
 
 template <int D, int DEPTH>
 int launch_l1(int planes, const uint8_t* nn, int64_t m, const uint8_t* wt, const float* bias, int relu, void* out,
-              int out_dtype, int64_t n_pad, int* overflow, hipStream_t s) {
+              int out_dtype, int64_t n_pad, int* overflow, hipStream_t s, uint8_t* out_scale = nullptr, int64_t ld_sc = 0) {
     switch (planes) {
-        case 1: return launch_l1_out<D, DEPTH, 1>(nn, m, wt, bias, relu, out, out_dtype, n_pad, overflow, s);
+        case 1: return launch_l1_out<D, DEPTH, 1>(nn, m, wt, bias, relu, out, out_dtype, n_pad, overflow, s, out_scale, ld_sc);
         case 2: return launch_l1_out<D, DEPTH, 2>(nn, m, wt, bias, relu, out, out_dtype, n_pad, overflow, s);
         default: return launch_l1_out<D, DEPTH, 3>(nn, m, wt, bias, relu, out, out_dtype, n_pad, overflow, s);
     }
@@ -471,6 +495,26 @@ int dca_l1_onehot_gemm(const uint8_t* nnet_in, int64_t m, int state_dim, int dep
         case 25: return launch_l1<25, 25>(planes, nnet_in, m, wt, bias, relu, out, out_dtype, n_pad, overflow, s);
         case 36: return launch_l1<36, 36>(planes, nnet_in, m, wt, bias, relu, out, out_dtype, n_pad, overflow, s);
         default: return launch_l1<49, 49>(planes, nnet_in, m, wt, bias, relu, out, out_dtype, n_pad, overflow, s);
+    }
+}
+
+int dca_l1_onehot_gemm_mx(const uint8_t* nnet_in, int64_t m, int state_dim, int depth, const void* w_tiles, int64_t n_pad,
+                          const float* bias, int relu, void* out8, void* out_scale, int64_t ld_sc, void* stream) {
+    DCA_ARG(nnet_in && w_tiles && bias && out8 && out_scale && m >= 0 && n_pad >= 64 && n_pad % 64 == 0 && ld_sc >= n_pad / 64);
+    if (!dca_l1_supported(state_dim, depth)) {
+        set_error("dca_l1_onehot_gemm_mx: geometry (%d, %d) not instantiated", state_dim, depth);
+        return DCA_E_BADARG;
+    }
+    if (m == 0) return 0;
+    const uint8_t* wt = reinterpret_cast<const uint8_t*>(w_tiles);
+    uint8_t* sc = reinterpret_cast<uint8_t*>(out_scale);
+    hipStream_t s = (hipStream_t)stream;
+    switch (state_dim) {
+        case 54: return launch_l1<54, 6>(1, nnet_in, m, wt, bias, relu, out8, DCA_DT_E4M3, n_pad, nullptr, s, sc, ld_sc);
+        case 16: return launch_l1<16, 16>(1, nnet_in, m, wt, bias, relu, out8, DCA_DT_E4M3, n_pad, nullptr, s, sc, ld_sc);
+        case 25: return launch_l1<25, 25>(1, nnet_in, m, wt, bias, relu, out8, DCA_DT_E4M3, n_pad, nullptr, s, sc, ld_sc);
+        case 36: return launch_l1<36, 36>(1, nnet_in, m, wt, bias, relu, out8, DCA_DT_E4M3, n_pad, nullptr, s, sc, ld_sc);
+        default: return launch_l1<49, 49>(1, nnet_in, m, wt, bias, relu, out8, DCA_DT_E4M3, n_pad, nullptr, s, sc, ld_sc);
     }
 }
 

@@ -402,6 +402,22 @@ int dca_gemm16_variant(int variant);
 int dca_gemm8(const void* a, int64_t m, int k, int64_t lda, const void* w, int n, int64_t ldw, const float* scale /*[n]*/,
               const float* bias /*[n] or NULL*/, const void* skip /*bf16 [m, ldo16] or NULL*/, int relu, void* out16 /*or NULL*/,
               int64_t ldo16, void* out8 /*or NULL*/, int64_t ldo8, double out8_scale, void* stream);
+/* Block-scaled ("MX") form of the fp8 layer — what `--nnet_dtype fp8` runs: activations travel as e4m3 bytes PLUS one E8M0 scale
+ * byte (value 2^(byte - 127)) per row and 64 consecutive elements, computed where the activation is produced (the largest
+ * magnitude of the 64 values sets the power of two that brings them into e4m3's range) and applied by gfx950's scaled MFMA
+ * (v_mfma_scale_f32_32x32x64_f8f6f4: both lane halves of a row pass the row's scale of the 64-deep step; the weights pass
+ * 2^0 and keep their per-output-unit fp32 scales w_scale[n] for the epilogue).  No calibration, nothing frozen, no saturation:
+ *   v = relu?( (sum_blocks 2^(sa - 127) * a8 . w8^T)[m,n] * w_scale[n] + bias[n] (+ skip[m,n]) )
+ * a_scale [m, ld_asc] (k / 64 bytes per row; k % 256 == 0, k <= 8192); out8 / out8_scale [m, ld_osc] (n / 64 bytes per row,
+ * n % 64 == 0) = the next layer's operand and its block scales, or both NULL; out16 / skip as in dca_gemm8.
+ * dca_l1_onehot_gemm_mx: layer 1 (one bf16 weight plane, dca_l1_onehot_gemm's tiles) leaving in the same form. */
+int dca_gemm8_mx(const void* a, const void* a_scale, int64_t m, int k, int64_t lda, int64_t ld_asc, const void* w, int n,
+                 int64_t ldw, const float* w_scale /*[n]*/, const float* bias /*[n] or NULL*/,
+                 const void* skip /*bf16 [m, ldo16] or NULL*/, int relu, void* out16 /*or NULL*/, int64_t ldo16,
+                 void* out8 /*or NULL*/, int64_t ldo8, void* out8_scale /*or NULL*/, int64_t ld_osc, void* stream);
+int dca_l1_onehot_gemm_mx(const uint8_t* nnet_in /*[m, state_dim]*/, int64_t m, int state_dim, int depth, const void* w_tiles,
+                          int64_t n_pad, const float* bias /*[n_pad]*/, int relu, void* out8 /*[m, n_pad] e4m3*/,
+                          void* out_scale /*[m, ld_sc] E8M0*/, int64_t ld_sc, void* stream);
 /* x [m, n] (row stride ld; DCA_DT_F32 or DCA_DT_BF16) -> e4m3(sat(x * scale)) bytes [m, ldo]: the entry into an fp8 layer for
  * activations that did not come out of an fp8 epilogue.  n % 4 == 0. */
 int dca_quant_e4m3(const void* x, int dtype, int64_t m, int64_t n, int64_t ld, double scale, void* out, int64_t ldo, void* stream);

@@ -164,7 +164,7 @@ def test_nnet_bf16_mode_still_solves(tmp_path):
 
 
 def test_nnet_fp8_mode_still_solves(tmp_path):
-    """fp8 heuristic (Fp8Resnet: dca_gemm8 layers, calibrated on the first batch of >= 1024 rows) = explicitly non-parity mode:
+    """fp8 heuristic (Fp8Resnet: block-scaled e4m3 layers, dca_gemm8_mx) = explicitly non-parity mode:
     only validity of the solution is asserted; the mode must actually have switched to the e4m3 kernels on the way."""
     from deepcubea_amd.search_methods.engine import BwasEngine
     from deepcubea_amd.utils import nnet_utils
@@ -181,7 +181,7 @@ def test_nnet_fp8_mode_still_solves(tmp_path):
     eng = BwasEngine("cube3", 0.8, 200, max_nodes=1 << 21, packed=True)
     res = eng.solve(s[0], hfn, max_iters=3000)
     assert res["solved"]
-    assert fast.layer_scale is not None and len(fast.act_scale) == 10  # calibrated: the later batches ran on dca_gemm8
+    assert fast.scaling == "block" and fast.layer_scale is None  # block-scaled e4m3 layers (dca_gemm8_mx): nothing to calibrate
     t = s.copy()
     for a in res["moves"]:
         t = co.next_state("cube3", t, a)

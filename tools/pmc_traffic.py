@@ -10,6 +10,7 @@ import re
 import sys
 
 fd, wd, env, batch, out_txt, out_json = sys.argv[1:7]
+shape = sys.argv[7] if len(sys.argv) > 7 else "rocprofv3 PMC passes of bench.py at 100-step episodes"
 
 
 def load(d, counter):
@@ -39,6 +40,6 @@ for k, n, f, w, b in rows:
     m = re.search(r"(k_[a-z_0-9]+|expand_fused_kernel)", k)
     if m and m.group(1) not in kern:
         kern[m.group(1)] = b
-json.dump({"env": env, "batch_size": int(batch), "kernels": kern,
+json.dump({"env": env, "batch_size": int(batch), "kernels": kern, "shape": shape,
            "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `python bench.py` (tools/profile_round.sh)"},
           open(out_json, "w"), indent=1)
