@@ -438,7 +438,7 @@ def run_astar_concurrent(args, world, rank, sem, hid):
             "how": "one engine, every kernel launched once for all instances (grid.y = instance)"}
 
 
-def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool = False, gemm16: str = "library"):
+def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool = False, gemm16: str = "hip"):
     """Same loop, heuristic = ResNet(54*6 -> 5000 -> 1000 -> 4 res blocks -> 1) on PyTorch-ROCm, synthetic weights
     (numpy PCG64 seed 2024).  Default = the CLI's default path: dedup-first engine stepping (only the children that
     survive the CLOSED check are evaluated — same search, astar.py:272-282) + the padded / epilogue-fused network
@@ -787,8 +787,8 @@ def main():
             line[k] = res[k]
     if args.workload == "astar" and args.nnet_steps > 0:
         line["end_to_end_nnet"] = {"fp32": run_astar_nnet(args, world, rank, "fp32"),
-                                   "bf16": run_astar_nnet(args, world, rank, "bf16"),
-                                   "bf16_hand_written_gemm": run_astar_nnet(args, world, rank, "bf16", gemm16="hip"),
+                                   "bf16": run_astar_nnet(args, world, rank, "bf16", gemm16="hip"),
+                                   "bf16_library_gemm": run_astar_nnet(args, world, rank, "bf16", gemm16="library"),
                                    "fp8_hand_written_gemm": run_astar_nnet(args, world, rank, "fp8"),
                                    "fp32_eval_all_children": run_astar_nnet(args, world, rank, "fp32", True)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("astar", "expand"):

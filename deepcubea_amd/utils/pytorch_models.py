@@ -180,7 +180,7 @@ class FastResnet(nn.Module):
     written by the engine's pack kernel through `forward_onehot`.  fp32 is the 1e-5 parity mode."""
 
     def __init__(self, model: ResnetModel, dtype: torch.dtype = torch.float32, split: bool = True, gemm: str = "hip",
-                 gemm16: str = "library"):
+                 gemm16: str = "hip"):
         super().__init__()
         m = fold_batchnorm(model)
         self.state_dim, self.one_hot_depth = m.state_dim, m.one_hot_depth
@@ -231,11 +231,13 @@ class FastResnet(nn.Module):
         # f16 GEMM over the 3x-wide interleaved operand plus the dca_act_split glue kernel per layer (kept for comparison)
         self.gemm = gemm
         assert gemm in ("hip", "library")
-        # bf16 / fp16 (non-parity) modes.  "library" (default) = hipBLASLt GEMMs with fused bias+ReLU, plus one ReLU pass per
-        # residual block; "hip" = one dca_gemm16 launch per layer, whole tail (bias, residual add, ReLU, rounding) in the
-        # epilogue (csrc/dca_gemm16.hip).  Measured per layer at 204 800 rows, candidates taking turns
-        # (profiles/r03_gemm_bench.txt, ms, hip / library): 5120->1024 bias+ReLU 1.98 / 1.67, 1024->1024 bias+ReLU 0.54 / 0.41,
-        # 1024->1024 residual+ReLU 0.57 / 0.56 — the library's hand-scheduled assembly kernels still lead, so they stay the default.
+        # bf16 / fp16 (non-parity) modes.  "hip" (default since round 4: the product's own kernels) = one dca_gemm16 launch per
+        # layer, whole tail (bias, residual add, ReLU, rounding) in the epilogue (csrc/dca_gemm16.hip); "library" = hipBLASLt
+        # GEMMs with fused bias+ReLU, plus one ReLU pass per residual block — kept selectable and, stated plainly, still ahead:
+        # per layer at 204 800 rows, candidates taking turns (profiles/r04_gemm_bench.txt, ms, hip / library): 5120->1024
+        # bias+ReLU 1.96 / 1.68, 1024->1024 bias+ReLU 0.53 / 0.42, 1024->1024 residual+ReLU 0.56 / 0.56 (end to end 2.76e6 vs
+        # 3.09e6 nodes expanded/s).  Both sit at the chip's power limit (1.3-1.7 GHz inside the K loop, profiles/r04_gemm_timeline.txt);
+        # the library's 4-wave x 128 x 128 layout spends a third less LDS traffic per MFMA and buys its clock with it.
         self.gemm16 = gemm16
         assert gemm16 in ("hip", "library")
         # set by the split kernels when a value does not fit fp16 (|v| > 60000): that batch is redone with fp32 GEMMs
