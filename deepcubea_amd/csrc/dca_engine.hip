@@ -140,7 +140,6 @@ struct Ctl {
     // selection
     uint32_t want, bstar, shift, n_big, n_ord;
     uint32_t giant;   // this pop's threshold bin is refined across the grid by k_sel_collect (set by k_sel_scan)
-    uint32_t coop_off;  // a grid barrier found the launch not fully resident: giant bins go to k_rank's streaming path from now on (survives resets)
     uint32_t tseg;    // the segment holding the batch's last entry (= bstar unless giant)
     uint32_t pre_b, cn_star;  // entries below the threshold bin / in it (k_rank's histogram writeback)
     uint64_t sel_kmin;
@@ -214,6 +213,8 @@ struct Eng {
     uint32_t* rhist;              // histogram of BACK (refill), separate: `hist` is maintained across iterations
     uint32_t* subhist;            // [kMaxLevels][kSub] sub-bin counts of a giant threshold bin, one array per refinement level
     int coop;                     // k_sel_collect's grid is fully resident (single-instance engine): grid barriers allowed
+    uint32_t* coop_off;           // device word, set once a grid barrier found the launch NOT fully resident (the GPU is shared): giant
+                                  // bins go to k_rank's streaming path from then on.  Outside the control block: resets do not touch it
     uint64_t* part;  // [2][kCollectBlocks] per-block key ranges (min, max) of the entries k_front_rebase kept
     // scratch of the pop: every FRONT entry at or below the threshold bin, grouped by bin (bin f occupies
     // [pre[f], pre[f+1])), and — only for bins too large for LDS — the single-workgroup sub-bin ordering
@@ -500,9 +501,7 @@ __global__ void k_clear_table_list(Slot* tab, uint32_t cap, const uint32_t* __re
 __global__ void k_reset(Eng E) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Ctl* c = E.ctl;
-    const uint32_t coop_off = c->coop_off;  // a property of how the GPU is shared, not of the search
     memset(c, 0, sizeof(Ctl));
-    c->coop_off = coop_off;
     const uint8_t* s = E.state;  // node 0 = root, already copied in
     uint64_t h = hash_init(E.D);
     bool ok = true;
@@ -991,7 +990,7 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
     // f-level one tie group of up to millions of entries) is not handed to k_rank whole: k_sel_collect refines it across
     // the grid first ("giant" iteration) and k_rank only sees the few thousand entries around the batch's end.
     const uint32_t giant_limit = g_tune[3] > 0 ? (uint32_t)g_tune[3] : kGiantBinDefault;
-    const bool giant = E.coop && !c->coop_off && want != 0 && pre[s_bstar + 1] - pre[s_bstar] > giant_limit;
+    const bool giant = E.coop && !*E.coop_off && want != 0 && pre[s_bstar + 1] - pre[s_bstar] > giant_limit;
     if (giant)
         for (int i = t; i < kMaxLevels * kSub; i += 1024) E.subhist[i] = 0;
     for (int k = 0; k < kBinsPerThread; k++) {
@@ -1162,7 +1161,7 @@ struct SelParams {
 // swap's expected value is stale) or every workgroup — those polling, and those that only become resident after the early ones
 // left — sees the bit and takes the same fallback.  Nothing of the search has been modified before the first barrier.
 enum { BAR_FAIL = 0, BAR_PASS = 1, BAR_BROKEN = 2 };
-__device__ __forceinline__ int collect_grid_barrier(Ctl* c, CollectLds& L, uint32_t target, bool first) {
+__device__ __forceinline__ int collect_grid_barrier(const Eng& E, Ctl* c, CollectLds& L, uint32_t target, bool first) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave's stores / atomics have left
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1205,7 +1204,7 @@ __device__ __forceinline__ int collect_grid_barrier(Ctl* c, CollectLds& L, uint3
             __hip_atomic_store(&c->failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&c->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (res == BAR_BROKEN) {
-            __hip_atomic_store(&c->coop_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(E.coop_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         L.ok = (uint32_t)res;
     }
@@ -1279,7 +1278,7 @@ __device__ __noinline__ int collect_giant(const Eng& E, Ctl* c, CollectLds& L, c
             }
         }
     }
-    if (const int r = collect_grid_barrier(c, L, ++phase * gridDim.x, true); r != BAR_PASS) return r;
+    if (const int r = collect_grid_barrier(E, c, L, ++phase * gridDim.x, true); r != BAR_PASS) return r;
     const uint64_t gkmin = __hip_atomic_load(&c->grange.kmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint64_t gkmax = __hip_atomic_load(&c->grange.kmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t gimin = __hip_atomic_load(&c->grange.imin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1318,7 +1317,7 @@ __device__ __noinline__ int collect_giant(const Eng& E, Ctl* c, CollectLds& L, c
         uint32_t* gh = E.subhist + (size_t)lvl * kSub;
         for (uint32_t i = t; i < (uint32_t)kSub; i += 256)
             if (lh[i]) atomicAdd(&gh[i], lh[i]);
-        if (collect_grid_barrier(c, L, ++phase * gridDim.x, false) != BAR_PASS) return BAR_FAIL;
+        if (collect_grid_barrier(E, c, L, ++phase * gridDim.x, false) != BAR_PASS) return BAR_FAIL;
         // every workgroup: prefix over the level's counts, the sub-bin holding the need-th entry
         constexpr int PER = kSub / 256;
         uint32_t v[PER], sum = 0;
@@ -1562,7 +1561,7 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
         P.pre_b = L.pre[P.bstar];
         P.cn_star = L.pre[P.bstar + 1] - P.pre_b;
         const uint32_t giant_limit = g_tune[3] > 0 ? (uint32_t)g_tune[3] : kGiantBinDefault;
-        P.giant = E.coop && !c->coop_off && P.cn_star > giant_limit;
+        P.giant = E.coop && !*E.coop_off && P.cn_star > giant_limit;
         if (blockIdx.x == 0) {
             // the record k_rank (and the rest of the iteration) reads — what k_sel_scan writes in a rebase iteration
             for (uint32_t i = t; i <= (uint32_t)NBIN; i += 256) E.pre[i] = L.pre[i];
@@ -3634,6 +3633,7 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
         ALLOC(solved, N);
         ALLOC(tab, (size_t)cap);
         ALLOC(closed_slots, N);
+        ALLOC(coop_off, 16);
         E.front_cap = (uint32_t)(N + (size_t)(2 * kRefillPeriod) * Bz);
         for (int b = 0; b < 4; b++) {  // FRONT and its compaction target (0/1) + BACK and its compaction target (2/3)
             ALLOC(open_key[b], b < 2 ? (size_t)E.front_cap : N);
@@ -3671,6 +3671,7 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
             (void)hipMemset(E.fill, 0, (kSegs + 8) * sizeof(uint32_t));
             (void)hipMemset(E.subhist, 0, (size_t)kMaxLevels * kSub * sizeof(uint32_t));
             (void)hipMemset(E.child_multi, 0, M);
+            (void)hipMemset(E.coop_off, 0, 16 * sizeof(uint32_t));
             (void)hipMemset(E.ctl, 0, sizeof(Ctl));
         }
     }
@@ -4081,12 +4082,14 @@ int dca_engine_last_popped(dca_engine* e, uint8_t* states, uint8_t* flags, void*
 
 int dca_engine_info(dca_engine* e, int64_t* out, void* stream) {
     DCA_ARG(e != nullptr && out != nullptr);
-    if (int rc = fetch_ctl(e, 0, (hipStream_t)stream)) return rc;
+    uint32_t off = 0;
+    DCA_HIP(hipStreamSynchronize((hipStream_t)stream));
+    DCA_HIP(hipMemcpy(&off, e->E[0].coop_off, sizeof(off), hipMemcpyDeviceToHost));
     out[0] = (int64_t)e->collect_blocks;
     out[1] = (int64_t)e->collect_resident;
     out[2] = (int64_t)e->E[0].coop;
     out[3] = (int64_t)e->E[0].tab_cap * (int64_t)sizeof(Slot);
-    out[4] = (int64_t)e->h_ctl->coop_off;
+    out[4] = (int64_t)off;
     out[5] = out[6] = out[7] = 0;
     return 0;
 }

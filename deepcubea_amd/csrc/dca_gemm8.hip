@@ -55,6 +55,17 @@ struct Gemm8Args {
     int out8_scale_ptr_set;  // (out8_sc != null: a uniform scalar the epilogue branches on)
 };
 
+// Largest value over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), in every lane of the row: four rotate-and-max steps on
+// the VALU (row_ror 8, 4, 2, 1).  (A __shfl_xor chain is four dependent ds_bpermute round trips through the LDS crossbar: 8 us
+// per tile in the layer tail, measured — the whole cost of writing block scales.)
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xF, 0xF, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xF, 0xF, false)));
+    return v;
+}
+
 // E8M0 block scale of a group whose largest magnitude is `amax`: the smallest power of two 2^e with amax * 2^-e <= 448 (the
 // largest e4m3 value), as (byte = e + 127, multiplier 2^-e).  amax = 0 (or a tiny group) takes the smallest scale.
 __device__ __forceinline__ uint32_t e8m0_of_amax(float amax, float& inv) {
@@ -253,6 +264,25 @@ __global__ __launch_bounds__(ETHREADS, 2) void k_gemm8(const Gemm8Args p) {
         DCA_BAR();
     };
 
+    // the tile's block scales: 256 rows x SK bytes (rows past m: clamped), requested BEFORE the operand DMAs — the oldest
+    // entries of the memory queue — so that their round trip runs under the DMAs' and a counted wait retires them alone
+    // (The loads and the LDS writes of the scale words are inline asm: for a load it knows about, hipcc waits vmcnt(0) at the
+    // first use of its result while LDS-DMA is in flight — the whole prologue would drain — so the queue is counted by hand.)
+    constexpr int kScW = 16;  // words per thread at most: 256 rows x 128 scale bytes (k = 8192) / 4 / 512 threads
+    uint32_t scw[kScW];  // (prologue only: dead before the accumulators and operand registers are live)
+    if constexpr (MXIN) {
+        const uint32_t words = 256u * SK / 4u;
+#pragma unroll
+        for (int j = 0; j < kScW; j++) {
+            if ((uint32_t)j * ETHREADS >= words) continue;  // (uniform: k = 1024 takes 2 passes, k = 5120 takes 10)
+            const uint32_t q = (uint32_t)t + (uint32_t)j * ETHREADS, qc = q < words ? q : 0u;
+            const uint32_t row = (qc * 4u) / SK, col = (qc * 4u) - row * SK;
+            int64_t gr = m0 + row;
+            gr = gr < p.m ? gr : p.m - 1;
+            const uint8_t* src_sc = p.a_scale + gr * p.ld_asc + col;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(scw[j]) : "v"(src_sc) : "memory");
+        }
+    }
     issue(ES_A01, 0, 0);
     issue(ES_B0, 0, 0);
     issue(ES_B1, 0, 0);
@@ -263,16 +293,22 @@ __global__ __launch_bounds__(ETHREADS, 2) void k_gemm8(const Gemm8Args p) {
         issue(ES_B1, 1, EBK);
     }
     if constexpr (MXIN) {
-        // the tile's block scales: 256 rows x SK bytes, one linear image behind the operand slots (rows past m: clamped)
         const uint32_t words = 256u * SK / 4u;
-        for (uint32_t q = (uint32_t)t; q < words; q += ETHREADS) {
-            const uint32_t row = (q * 4u) / SK, col = (q * 4u) - row * SK;
-            int64_t gr = m0 + row;
-            gr = gr < p.m ? gr : p.m - 1;
-            *reinterpret_cast<uint32_t*>(lsc + q * 4u) = *reinterpret_cast<const uint32_t*>(p.a_scale + gr * p.ld_asc + col);
+        if (nk > 1)
+            DCA_VMCNT(14);  // the scale words (issued first) are here; the 14 DMA instructions behind them stay in flight
+        else
+            DCA_VMCNT(8);
+        const uint32_t lsc_off = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint8_t*)lsc);
+#pragma unroll
+        for (int j = 0; j < kScW; j++) {
+            if ((uint32_t)j * ETHREADS >= words) continue;
+            const uint32_t q = (uint32_t)t + (uint32_t)j * ETHREADS;
+            const uint32_t dst_off = lsc_off + (q < words ? q : (uint32_t)t) * 4u;  // (surplus lanes rewrite a word of their own: same value)
+            asm volatile("ds_write_b32 %0, %1" ::"v"(dst_off), "v"(q < words ? scw[j] : scw[0]) : "memory");
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (the scale loads drain the queue once, before the loop)
-    } else if (nk > 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the LDS image is written before the barrier below publishes it
+    }
+    if (nk > 1) {
         DCA_VMCNT(10);  // A01, B0 of tile 0 have landed
     } else {
         DCA_VMCNT(4);
@@ -360,8 +396,7 @@ __global__ __launch_bounds__(ETHREADS, 2) void k_gemm8(const Gemm8Args p) {
                     if (p.out8_scale_ptr_set) {
                         // block scale of this row's 64 columns (the wave's slice: 16 lanes x 4 columns): largest magnitude over the
                         // 16 lanes, the power of two that brings it into e4m3's range, one byte per (row, 64 columns)
-                        float am = fmaxf(fmaxf(fabsf(u[0]), fabsf(u[1])), fmaxf(fabsf(u[2]), fabsf(u[3])));
-                        for (int o = 8; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+                        const float am = row16_max(fmaxf(fmaxf(fabsf(u[0]), fabsf(u[1])), fmaxf(fabsf(u[2]), fabsf(u[3]))));
                         const uint32_t sb = e8m0_of_amax(am, s);
                         if ((lane & 15) == 0) p.out8_sc[r * p.ld_osc + (colg >> 6)] = (uint8_t)sb;
                     }

@@ -212,7 +212,11 @@ __global__ __launch_bounds__(kL1Threads) void k_l1_onehot_gemm(const uint8_t* __
                             const float u0 = __uint_as_float(pk.x), u1 = __uint_as_float(pk.y), u2 = __uint_as_float(pk.z),
                                         u3 = __uint_as_float(pk.w);
                             float am = fmaxf(fmaxf(fabsf(u0), fabsf(u1)), fmaxf(fabsf(u2), fabsf(u3)));
-                            for (int o = 8; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+                            // (over the DPP row of 16 lanes that holds this row's 64 columns: rotate-and-max on the VALU)
+                            am = fmaxf(am, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(am), 0x128, 0xF, 0xF, false)));
+                            am = fmaxf(am, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(am), 0x124, 0xF, 0xF, false)));
+                            am = fmaxf(am, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(am), 0x122, 0xF, 0xF, false)));
+                            am = fmaxf(am, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(am), 0x121, 0xF, 0xF, false)));
                             const float t = am * (1.0f / 448.0f);
                             const uint32_t tb = __float_as_uint(t);
                             int e = (int)((tb >> 23) & 0xFFu) - 127 + ((tb & 0x7FFFFFu) ? 1 : 0);

@@ -141,5 +141,6 @@ def test_updater_end_to_end_with_network(L):
     a = bellman_dev(env, st, hfn)[0]
     b = bellman_dev(env, st, hfn, onehot_dtype=torch.float32)[0]
     assert torch.equal(a, b)
+    assert Updater(env, 10, 5, hfn, 1, update_method="ASTAR").method == "ASTAR"  # (tests/test_astar_update_hip.py runs it)
     with pytest.raises(ValueError):
-        Updater(env, 10, 5, hfn, 1, update_method="ASTAR")
+        Updater(env, 10, 5, hfn, 1, update_method="BFS")  # updater.py:72-73

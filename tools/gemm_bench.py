@@ -143,6 +143,12 @@ for n, k in ((1024, 1024), (1024, 5120)) if only in ("", "e4m3") else ():
     out = skip.clone()
     cands = [("hip_bias_relu_to_e4m3", lambda: _lib.gemm8(x8, w8, sc, b32, None, True, False, 8.0)),
              ("hip_skip_relu_to_bf16_and_e4m3", lambda: _lib.gemm8(x8, w8, sc, b32, out, True, True, 8.0, out16=out))]
+    # block-scaled form (dca_gemm8_mx): E8M0 scale per row and 64 elements in, e4m3 + scales out
+    asc = torch.full((m, k // 64), 127, dtype=torch.uint8, device="cuda")
+    out_b = skip.clone()
+    cands += [("hip_mx_bias_relu_to_mx", lambda: _lib.gemm8_mx(x8, asc, w8, sc, b32, None, True, False, True)),
+              ("hip_mx_skip_relu_to_bf16_and_mx", lambda: _lib.gemm8_mx(x8, asc, w8, sc, b32, out_b, True, True, True, out16=out_b)),
+              ("hip_mx_bias_relu_to_bf16_only", lambda: _lib.gemm8_mx(x8, asc, w8, sc, b32, None, True, True, False))]
     one = torch.ones((), device="cuda")
     try:
         torch._scaled_mm(x8[:256], w8.t(), scale_a=one, scale_b=one, out_dtype=torch.bfloat16)
