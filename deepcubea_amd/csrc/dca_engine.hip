@@ -28,12 +28,12 @@
 //               histogram under a fresh binning; refills from BACK and spills to it are decided there, with hysteresis,
 //               so an iteration costs O(|FRONT| + children), independent of |OPEN|.
 //
-// One BWAS iteration = pop -> expand -> heuristic -> dedup -> push in FIVE launches (collect, rank, expand, probe, commit;
-// five more in a rebase iteration), all stream-ordered, no host round trip: counts live in a device control block (hot
+// One BWAS iteration = pop -> expand -> heuristic -> dedup -> push in FOUR launches (collect, rank, expand with the CLOSED
+// probe inside, commit; k_sel_scan's one-workgroup scan in front of them, four more in a rebase iteration), all stream-ordered, no host round trip: counts live in a device control block (hot
 // counters on their own cache lines) and every kernel sizes itself from it; the last workgroup of k_commit closes the
 // iteration and leaves the size of the next batch.  The per-iteration batch geometry is double buffered by iteration parity
-// (IterState), so the expansion launch itself closes the pop (no single-thread kernel in between).  A steady search replays
-// whole rebase periods (8 iterations) as one hipGraph.  One engine steps K independent instances at once: every kernel
+// (IterState), so the expansion launch itself closes the pop (no single-thread kernel in between).  run_builtin replays
+// chunks of up to 64 iterations as ONE hipGraph each (cached by their pattern of rebase iterations).  One engine steps K independent instances at once: every kernel
 // takes the device array of instance descriptors and picks its instance with blockIdx.y.
 //
 // Sequential-order dedup, done in parallel: children of one batch that hit the same
@@ -3141,7 +3141,13 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
     const uint32_t id = base + j;
     bool keep = false, is_new = false;
     uint32_t gj = 0, my_slot = 0;
+    // (the heuristic and the solved flag are only needed for kept children, but the keep decision of a chained child is a
+    // walk of dependent loads: requested up front, their round trip runs under it instead of behind it)
+    float h_early = 0.f;
+    uint8_t solved_early = 0;
     if (live) {
+        if (!packed) h_early = E.child_h[j];
+        solved_early = E.solved[id];
         const uint8_t fl = E.child_flags[j];
         is_new = (fl & F_NEW) != 0;
         gj = E.pop_g[j / (uint32_t)E.A] + 1u;
@@ -3185,9 +3191,9 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
     uint32_t pid_flag = 0;
     if (keep) {
         // the heuristic is only ever needed for the children that survive the CLOSED check
-        const float hraw = packed ? E.pk_h[E.kept_pos[j]] : E.child_h[j];
+        const float hraw = packed ? E.pk_h[E.kept_pos[j]] : h_early;
         const float hv = fmaxf(hraw, 0.0f);  // clip_zero (nnet_utils.py:193-194)
-        const bool ns = E.solved[id] == 0;
+        const bool ns = solved_early == 0;
         pid_flag = ns ? 0u : ID_SOLVED;
         double cost;
         if (E.sem == DCA_SEM_PY) {
@@ -3329,6 +3335,7 @@ using namespace dca;
 // more than stepping one (the reference's AStar also steps a list of instances together, astar.py:232-317).
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxInstances = 64;
+constexpr int kGraphSlots = 48, kGraphChunk = 64;
 
 struct dca_engine {
     int K;
@@ -3352,8 +3359,16 @@ struct dca_engine {
     uint8_t tab_cleared[kMaxInstances];  // the instance's CLOSED table has been cleared in full at least once
     unsigned collect_blocks;  // grid of k_sel_collect: two workgroups per CU, all resident (its giant-bin path barriers across it)
     long collect_resident;    // workgroups of k_sel_collect the device can hold at once per the occupancy query (-1: query failed)
-    hipGraph_t graph[3];   // [0] iteration without / [1] with the refill check, [2] a whole period: rebase iteration + 7 plain ones
-    hipGraphExec_t graph_exec[3];
+    // run_builtin's replayable chunks: a chunk of n <= kGraphChunk consecutive iterations is one hipGraph, keyed by its
+    // pattern of rebase iterations (bit i = iteration i of the chunk runs the refill check) — the boundary between two
+    // graph launches costs ~6 us on the device, the one between two launches inside a graph ~2
+    struct GraphSlot {
+        unsigned long long mask;
+        int n;
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+    } gslot[kGraphSlots];
+    int gslot_next;  // round-robin victim once every slot is taken
     int graph_heur;
     long host_iter;        // iterations enqueued since the last reset of instance 0 (drives the refill cadence)
     unsigned long long* d_prof;  // [P_COUNT][kProfSlots][2] device wall-clock stamps of the profiled launches
@@ -3521,13 +3536,18 @@ int enqueue_second_half(dca_engine* e, hipStream_t s) {
     return enqueue_commit(e, false, s);
 }
 
+void drop_graph_slot(dca_engine::GraphSlot& g) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+    g.exec = nullptr;
+    g.graph = nullptr;
+    g.n = 0;
+    g.mask = 0;
+}
+
 void drop_graphs(dca_engine* e) {
-    for (int g = 0; g < 3; g++) {
-        if (e->graph_exec[g]) (void)hipGraphExecDestroy(e->graph_exec[g]);
-        if (e->graph[g]) (void)hipGraphDestroy(e->graph[g]);
-        e->graph_exec[g] = nullptr;
-        e->graph[g] = nullptr;
-    }
+    for (int g = 0; g < kGraphSlots; g++) drop_graph_slot(e->gslot[g]);
+    e->gslot_next = 0;
 }
 
 int upload_engs(dca_engine* e) {
@@ -3925,39 +3945,69 @@ int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph,
         }
         return 0;
     }
-    if (e->graph_exec[0] == nullptr || e->graph_heur != heur_id) {
+    if (e->graph_heur != heur_id) {
         drop_graphs(e);
-        for (int g = 0; g < 3; g++) {
+        e->graph_heur = heur_id;
+    }
+    for (int i = 0; i < iters;) {
+        // the next chunk: up to the next period boundary first (so that a steady search replays whole periods, whose
+        // pattern repeats), then whole periods, kGraphChunk iterations at most  (knob 7: single-iteration graphs only)
+        int n = iters - i;
+        if (h_tune[7] != 0) {
+            n = 1;
+        } else if (e->host_iter < kRampIters) {
+            n = n < (int)(kRampIters - e->host_iter) ? n : (int)(kRampIters - e->host_iter);
+        } else {
+            const int to_boundary = (int)(kRefillPeriod - e->host_iter % kRefillPeriod) % kRefillPeriod;
+            if (to_boundary > 0 && n > to_boundary)
+                n = to_boundary;
+            else if (to_boundary == 0 && n > kRefillPeriod)
+                n = (n < kGraphChunk ? n : kGraphChunk) / kRefillPeriod * kRefillPeriod;
+        }
+        unsigned long long mask = 0;
+        for (int it = 0; it < n; it++)
+            if (rebase_due(e->host_iter + it)) mask |= 1ull << it;
+        dca_engine::GraphSlot* g = nullptr;
+        for (int q = 0; q < kGraphSlots && !g; q++)
+            if (e->gslot[q].exec && e->gslot[q].n == n && e->gslot[q].mask == mask) g = &e->gslot[q];
+        if (!g) {
+            for (int q = 0; q < kGraphSlots && !g; q++)
+                if (!e->gslot[q].exec) g = &e->gslot[q];
+            if (!g) {
+                g = &e->gslot[e->gslot_next];
+                e->gslot_next = (e->gslot_next + 1) % kGraphSlots;
+                drop_graph_slot(*g);
+            }
             hipStream_t cs;
             DCA_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
             hipError_t err = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
             int rc = 0;
             if (err == hipSuccess) {
-                // graph 2 = one whole rebase period (the boundary between two graph launches costs ~6 us, the one between
-                // two launches inside a graph ~2: a steady search replays periods, not single iterations)
-                const int n_it = g == 2 ? kRefillPeriod : 1;
-                for (int it = 0; it < n_it && !rc; it++) {
-                    rc = enqueue_first_half(e, heur_id, g == 1 || (g == 2 && it == 0), cs);
+                for (int it = 0; it < n && !rc; it++) {
+                    rc = enqueue_first_half(e, heur_id, (mask >> it) & 1ull, cs);
                     if (!rc) rc = enqueue_second_half(e, cs);
                 }
-                err = hipStreamEndCapture(cs, &e->graph[g]);
+                err = hipStreamEndCapture(cs, &g->graph);
             }
             (void)hipStreamDestroy(cs);
-            if (err != hipSuccess) return hip_fail(err, "hipStream capture");
-            if (rc) return rc;
-            DCA_HIP(hipGraphInstantiate(&e->graph_exec[g], e->graph[g], nullptr, nullptr, 0));
+            if (err != hipSuccess) {
+                drop_graph_slot(*g);
+                return hip_fail(err, "hipStream capture");
+            }
+            if (rc) {
+                drop_graph_slot(*g);
+                return rc;
+            }
+            if (hipError_t ierr = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0); ierr != hipSuccess) {
+                drop_graph_slot(*g);
+                return hip_fail(ierr, "hipGraphInstantiate");
+            }
+            g->n = n;
+            g->mask = mask;
         }
-        e->graph_heur = heur_id;
-    }
-    for (int i = 0; i < iters;) {
-        if (h_tune[7] == 0 && e->host_iter >= kRampIters && e->host_iter % kRefillPeriod == 0 && iters - i >= kRefillPeriod) {
-            DCA_HIP(hipGraphLaunch(e->graph_exec[2], s));  // (knob 7: single-iteration graphs only)
-            e->host_iter += kRefillPeriod;
-            i += kRefillPeriod;
-        } else {
-            DCA_HIP(hipGraphLaunch(e->graph_exec[rebase_due(e->host_iter++) ? 1 : 0], s));
-            i++;
-        }
+        DCA_HIP(hipGraphLaunch(g->exec, s));
+        e->host_iter += n;
+        i += n;
     }
     return 0;
 }

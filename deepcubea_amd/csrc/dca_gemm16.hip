@@ -28,6 +28,7 @@ namespace dca {
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int QBM = 256, QBN = 256, QBK = 64, QTHREADS = 512;
 constexpr int QIMG = 256 * QBK * 2;  // bytes of one operand image (32 KB)
@@ -68,45 +69,49 @@ __device__ __forceinline__ float from_f16(uint16_t b) {
 }
 
 // Layer tail, shared by both schedules.  Accumulator layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-template <bool BF16>
-__device__ __forceinline__ void gemm16_epilogue(const Gemm16Args& p, uint8_t* lds, f32x16 (&acc)[4][2], int64_t m0, int n0, int w,
+template <bool BF16, int NJ>
+__device__ __forceinline__ void gemm16_epilogue(const Gemm16Args& p, uint8_t* lds, f32x16 (&acc)[4][NJ], int64_t m0, int n0, int w,
                                                 int wm, int wn, int lane, int l31, int h) {
-    // Each wave transposes its tile through its own 16 KB of the (now idle) LDS, 32 rows at a time, and leaves with 8-byte accesses:
-    // a lane owns 4 consecutive columns of a row (one 8-byte skip load, one 8-byte store; 16 lanes = 128 contiguous bytes).
+    // Each wave transposes its tile (4 x NJ blocks of 32 x 32) through its own NJ * 8 KB of the (now idle) LDS, 32 rows at a
+    // time, and leaves with 8-byte accesses: a lane owns 4 consecutive columns of a row (one 8-byte skip load, one 8-byte
+    // store; 16 lanes = 128 contiguous bytes).
+    constexpr int CW = NJ * 32, LPR = CW / 4, RPP = 64 / LPR, NP = 32 / RPP;  // columns per wave, lanes per row, rows per pass, passes
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the operand stages
-    float* sl = reinterpret_cast<float*>(lds + w * 16384);
-    float bv[2];
+    float* sl = reinterpret_cast<float*>(lds + w * (CW * 32 * 4));
+    float bv[NJ];
 #pragma unroll
-    for (int jn = 0; jn < 2; jn++) {
-        const int col = n0 + wn * 64 + jn * 32 + l31;
+    for (int jn = 0; jn < NJ; jn++) {
+        const int col = n0 + wn * CW + jn * 32 + l31;
         bv[jn] = (col < p.n && p.bias) ? p.bias[col] : 0.f;
     }
-    const int c4 = (lane & 15) * 4;  // this lane's 4 columns inside the wave's 64
-    const int colg = n0 + wn * 64 + c4;
+    const int c4 = (lane % LPR) * 4;  // this lane's 4 columns inside the wave's CW
+    const int colg = n0 + wn * CW + c4;
     const bool full4 = colg + 3 < p.n;
     auto cvt_in = [](uint16_t b) { return BF16 ? from_bf16(b) : from_f16(b); };
     auto cvt_out = [](float f) { return BF16 ? to_bf16(f) : to_f16(f); };
+    // (row block as a compile-time constant: left as a loop, the 4 x NJ accumulator blocks would be indexed dynamically —
+    // the compiler then keeps all of them in scratch)
+    auto rows32 = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-#pragma unroll
-        for (int jn = 0; jn < 2; jn++)
+        for (int jn = 0; jn < NJ; jn++)
 #pragma unroll
             for (int reg = 0; reg < 16; reg++)
-                sl[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 64 + jn * 32 + l31] = acc[i][jn][reg] + bv[jn];
+                sl[((reg & 3) + 8 * (reg >> 2) + 4 * h) * CW + jn * 32 + l31] = acc[i][jn][reg] + bv[jn];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private slice: no barrier, just the wave's own writes
         const int64_t rbase = m0 + wm * 128 + i * 32;
-        uint2 sk[8];
+        uint2 sk[NP];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int64_t r = rbase + q * 4 + (lane >> 4);
+        for (int q = 0; q < NP; q++) {
+            const int64_t r = rbase + q * RPP + (lane / LPR);
             sk[q] = make_uint2(0u, 0u);
             if (p.skip && r < p.m && full4) sk[q] = *reinterpret_cast<const uint2*>(p.skip + r * p.ldo + colg);
         }
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int rl = q * 4 + (lane >> 4);
+        for (int q = 0; q < NP; q++) {
+            const int rl = q * RPP + (lane / LPR);
             const int64_t r = rbase + rl;
-            const float4 v = *reinterpret_cast<const float4*>(sl + rl * 64 + c4);
+            const float4 v = *reinterpret_cast<const float4*>(sl + rl * CW + c4);
             if (r >= p.m) continue;
             float u[4] = {v.x, v.y, v.z, v.w};
             const int64_t o = r * p.ldo + colg;
@@ -134,7 +139,11 @@ __device__ __forceinline__ void gemm16_epilogue(const Gemm16Args& p, uint8_t* ld
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slice is rewritten by the next 32 rows
-    }
+    };
+    rows32(std::integral_constant<int, 0>{});
+    rows32(std::integral_constant<int, 1>{});
+    rows32(std::integral_constant<int, 2>{});
+    rows32(std::integral_constant<int, 3>{});
 }
 
 template <bool BF16>
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16(const Gemm16Args p) {
         }
     }
 
-    gemm16_epilogue<BF16>(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h);
+    gemm16_epilogue<BF16, 2>(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h);
 }
 
 
@@ -427,7 +436,284 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16p(const Gemm16Args p) {
 #undef DCA_VMCNT
 #undef DCA_MMA8
 
-    gemm16_epilogue<BF16>(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h);
+    gemm16_epilogue<BF16, 2>(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Variant 4: the same 256 x 256 workgroup tile on FOUR waves (2 x 2), each owning 128 x 128 outputs — 4 x 4 blocks of
+// v_mfma_f32_32x32x16, 256 accumulator registers (one wave per SIMD: the whole 512-entry register file is the wave's).
+// What the shape buys over the 8-wave layouts above: a K-slice of 16 costs a wave 4 + 4 fragment reads for 16 MFMAs (0.5
+// ds_read_b128 per MFMA, against 0.75 for 4 x 2 blocks) and nothing is read twice by two waves of one SIMD.  What it
+// loses is the partner wave that covers LDS latency, so the wave pipelines itself: two fragment register sets, the reads
+// of the next 16-deep slice are in flight while the 16 MFMAs of the current one issue.
+// Staging: K-tiles of 32 (64-byte rows; swizzle chunk ^ ((row >> 2) & 3), applied on the global side of the LDS-DMA as
+// everywhere in this file), a RING OF FIVE 32 KB slots — all 160 KB of LDS.  Phase h computes K-tile h (two slices) and
+// restages the slot phase h-1 read with K-tile h+4: four phases = 4096 MFMA cycles of lead for every DMA.  One barrier
+// per phase, placed BETWEEN the two MFMA groups: behind it the wave reads the first slice of tile h+1 while the second
+// slice of tile h multiplies.
+//   RAW  vmcnt (all but the three youngest tiles have landed: tile h+1 is in) precedes the barrier of phase h; tile h+1 is
+//        first read behind it.
+//   WAR  lgkmcnt(0) precedes that barrier too: every fragment read of tile h has returned before any wave restages its
+//        slot (in phase h+1).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int WTHREADS = 256, WBK = 32;
+constexpr int WIMG = 256 * WBK * 2;  // one operand image of a K-tile: 256 rows x 64 B
+constexpr int WSLOT = 2 * WIMG;      // A | W
+constexpr int WRING = 5;
+constexpr int WLDS = WRING * WSLOT;  // 160 KB
+
+template <bool BF16>
+__global__ __launch_bounds__(WTHREADS, 1) void k_gemm16w(const Gemm16Args p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    using frag_t = typename std::conditional<BF16, b16x8, h16x8>::type;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, h = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    const int nNt = (p.n + QBN - 1) / QBN;
+    const int64_t nMt = (p.m + QBM - 1) / QBM;
+    const int64_t bid = blockIdx.x;
+    const int64_t slot_id = bid >> 3;
+    const int64_t mt = (slot_id / nNt) * 8 + (bid & 7);
+    const int nt = (int)(slot_id % nNt);
+    if (mt >= nMt) return;
+    const int64_t m0 = mt * QBM;
+    const int n0 = nt * QBN;
+
+    // DMA map: instruction q (0-7) of wave w fills rows [rb*16, rb*16 + 16) of image q >> 2, rb = (q & 3) * 4 + w; lane i
+    // lands on row i >> 2, physical chunk i & 3, and fetches logical chunk (i & 3) ^ ((row >> 2) & 3).
+    const uint16_t* src[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const uint32_t r = (uint32_t)(((q & 3) * 4 + w) * 16 + (lane >> 2));
+        const uint32_t c = (uint32_t)(lane & 3) ^ ((r >> 2) & 3u);
+        if ((q >> 2) == 0) {
+            int64_t gr = m0 + r;
+            gr = gr < p.m ? gr : p.m - 1;
+            src[q] = p.a + gr * p.lda + c * 8;
+        } else {
+            int gn = n0 + (int)r;
+            gn = gn < p.n ? gn : p.n - 1;
+            src[q] = p.w + (int64_t)gn * p.ldw + c * 8;
+        }
+    }
+    auto issue = [&](int slot, int k0) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            uint8_t* dst = lds + slot * WSLOT + (q >> 2) * WIMG + ((q & 3) * 4 + w) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + k0),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int jn = 0; jn < 4; jn++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][jn][e] = 0.f;
+
+    // fragment addresses inside a slot: row = (wave's block) * 32 + l31, logical chunk 2 s + h  ((row >> 2) & 3 == (l31 >> 2) & 3)
+    uint32_t foff[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) foff[s] = (uint32_t)l31 * 64u + (((2u * s + (uint32_t)h) ^ (((uint32_t)l31 >> 2) & 3u)) << 4);
+    const uint32_t a_row0 = (uint32_t)wm * 128u * 64u;
+    const uint32_t b_row0 = (uint32_t)WIMG + (uint32_t)wn * 128u * 64u;
+
+    // The wave has no partner to fill its issue gaps, so the phase is scheduled by hand, one non-MFMA instruction in the
+    // shadow of each MFMA (an MFMA holds the matrix pipe for 32 cycles; the wave is free to issue the next fragment read or
+    // DMA meanwhile) and every position pinned with sched_barrier:
+    //   group A, 16 MFMAs on slice 0:  the 8 fragment reads of slice 1 behind MFMAs 0-7, the 8 DMA instructions of tile
+    //            h+4 behind MFMAs 8-15;
+    //   group B, 16 MFMAs on slice 1:  MFMAs 0-7, then vmcnt + THE barrier (tile h+1 visible, this slot's reads all
+    //            returned), then the 8 reads of slice 0 of tile h+1 behind MFMAs 8-15.
+    // MFMAs run in "growing square" order over the 4 x 4 blocks — (0,0) (1,0) (0,1) (1,1) (2,0) (2,1) (0,2) (1,2) (2,2)
+    // (3,0) (3,1) (3,2) (0,3) (1,3) (2,3) (3,3) — and the fragments are read in the order that square needs them (a0 b0 a1 b1
+    // a2 b2 a3 b3), so MFMA 0 waits for the two oldest reads only.  Fragment reads are inline asm with hand-counted
+    // lgkmcnt: for loads it knows about hipcc waits lgkmcnt(0) in front of an MFMA group — the reads just issued for the
+    // next slice included.  lgkmcnt(N) before an MFMA = reads issued behind the youngest fragment it needs.
+    u32x4 fa0[4], fb0[4], fa1[4], fb1[4];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint8_t*)lds);
+    const uint32_t fo_a0 = lds0 + a_row0 + foff[0], fo_a1 = lds0 + a_row0 + foff[1];
+    const uint32_t fo_b0 = lds0 + b_row0 + foff[0], fo_b1 = lds0 + b_row0 + foff[1];
+#define DCA_SB() __builtin_amdgcn_sched_barrier(0)
+#define DCA_DSR(D, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(D) : "v"(ADDR), "i"(OFF) : "memory")
+    // read k of a slice: 0 a0, 1 b0, 2 a1, 3 b1, 4 a2, 5 b2, 6 a3, 7 b3
+#define DCA_RD(K, FA, FB, AA, AB)                                                                                  \
+    do {                                                                                                           \
+        if constexpr (((K) & 1) == 0)                                                                              \
+            DCA_DSR(FA[(K) >> 1], AA, ((K) >> 1) * 2048);                                                          \
+        else                                                                                                       \
+            DCA_DSR(FB[(K) >> 1], AB, ((K) >> 1) * 2048);                                                          \
+        DCA_SB();                                                                                                  \
+    } while (0)
+#define DCA_WL(N)                                                                                                  \
+    do {                                                                                                           \
+        asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");                                                    \
+        DCA_SB(); /* (an MFMA has no dependence on the wait: without the fence the scheduler hoists it above) */    \
+    } while (0)
+#define DCA_MM(FA, FB, I, J)                                                                                       \
+    do {                                                                                                           \
+        if constexpr (BF16)                                                                                        \
+            acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(frag_t, FA[I]),                 \
+                                                                __builtin_bit_cast(frag_t, FB[J]), acc[I][J], 0, 0, 0); \
+        else                                                                                                       \
+            acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(frag_t, FA[I]),                  \
+                                                               __builtin_bit_cast(frag_t, FB[J]), acc[I][J], 0, 0, 0); \
+        DCA_SB();                                                                                                  \
+    } while (0)
+#define DCA_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+    auto dma1 = [&](int q, int slot, int k0) {
+        uint8_t* dst = lds + slot * WSLOT + (q >> 2) * WIMG + ((q & 3) * 4 + w) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + k0),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        DCA_SB();
+    };
+
+    const int nh = p.k / WBK;
+    // one phase.  DMA: tile hh+4 exists (restage the slot phase hh-1 read); NEXT: tile hh+1 exists; VMC: DMA instructions
+    // issued behind tile hh+1 (8 per tile, three tiles at most)
+    auto phase = [&](int hh, int slot, auto dmac, auto nextc, auto vmc) {
+        constexpr bool DMA = decltype(dmac)::value, NEXT = decltype(nextc)::value;
+        constexpr int VMC = decltype(vmc)::value;
+        const uint32_t sb = (uint32_t)slot * WSLOT;
+        const uint32_t aa1 = fo_a1 + sb, ab1 = fo_b1 + sb;
+        const int dslot = slot == 0 ? WRING - 1 : slot - 1;
+        const int dk0 = (hh + 4) * WBK;
+        DCA_SB();
+        // ---- group A: slice 0 (its 8 reads were issued behind the last 8 MFMAs of the previous phase)
+        DCA_WL(6);
+        DCA_MM(fa0, fb0, 0, 0);
+        DCA_RD(0, fa1, fb1, aa1, ab1);
+        DCA_WL(6);
+        DCA_MM(fa0, fb0, 1, 0);
+        DCA_RD(1, fa1, fb1, aa1, ab1);
+        DCA_WL(6);
+        DCA_MM(fa0, fb0, 0, 1);
+        DCA_RD(2, fa1, fb1, aa1, ab1);
+        DCA_MM(fa0, fb0, 1, 1);
+        DCA_RD(3, fa1, fb1, aa1, ab1);
+        DCA_WL(7);
+        DCA_MM(fa0, fb0, 2, 0);
+        DCA_RD(4, fa1, fb1, aa1, ab1);
+        DCA_MM(fa0, fb0, 2, 1);
+        DCA_RD(5, fa1, fb1, aa1, ab1);
+        DCA_WL(8);
+        DCA_MM(fa0, fb0, 0, 2);
+        DCA_RD(6, fa1, fb1, aa1, ab1);
+        DCA_MM(fa0, fb0, 1, 2);
+        DCA_RD(7, fa1, fb1, aa1, ab1);
+        DCA_MM(fa0, fb0, 2, 2);
+        if constexpr (DMA) dma1(0, dslot, dk0);
+        DCA_WL(9);
+        DCA_MM(fa0, fb0, 3, 0);
+        if constexpr (DMA) dma1(1, dslot, dk0);
+        DCA_MM(fa0, fb0, 3, 1);
+        if constexpr (DMA) dma1(2, dslot, dk0);
+        DCA_MM(fa0, fb0, 3, 2);
+        if constexpr (DMA) dma1(3, dslot, dk0);
+        DCA_WL(8);
+        DCA_MM(fa0, fb0, 0, 3);
+        if constexpr (DMA) dma1(4, dslot, dk0);
+        DCA_MM(fa0, fb0, 1, 3);
+        if constexpr (DMA) dma1(5, dslot, dk0);
+        DCA_MM(fa0, fb0, 2, 3);
+        if constexpr (DMA) dma1(6, dslot, dk0);
+        DCA_MM(fa0, fb0, 3, 3);
+        if constexpr (DMA) dma1(7, dslot, dk0);
+        // ---- group B: slice 1
+        DCA_WL(0);  // slice 1 is in: every fragment read of this slot has returned
+        DCA_MM(fa1, fb1, 0, 0);
+        DCA_MM(fa1, fb1, 1, 0);
+        DCA_MM(fa1, fb1, 0, 1);
+        DCA_MM(fa1, fb1, 1, 1);
+        DCA_MM(fa1, fb1, 2, 0);
+        DCA_MM(fa1, fb1, 2, 1);
+        DCA_MM(fa1, fb1, 0, 2);
+        DCA_MM(fa1, fb1, 1, 2);
+        if constexpr (VMC == 24)
+            DCA_VMCNT(24);
+        else if constexpr (VMC == 16)
+            DCA_VMCNT(16);
+        else if constexpr (VMC == 8)
+            DCA_VMCNT(8);
+        else
+            DCA_VMCNT(0);
+        DCA_BAR();  // tile hh+1 has landed for everyone; nobody reads this slot any more
+        DCA_SB();
+        const int nslot = slot == WRING - 1 ? 0 : slot + 1;
+        const uint32_t sn = (uint32_t)nslot * WSLOT;
+        const uint32_t aa0 = fo_a0 + sn, ab0 = fo_b0 + sn;
+        DCA_MM(fa1, fb1, 2, 2);
+        if constexpr (NEXT) DCA_RD(0, fa0, fb0, aa0, ab0);
+        DCA_MM(fa1, fb1, 3, 0);
+        if constexpr (NEXT) DCA_RD(1, fa0, fb0, aa0, ab0);
+        DCA_MM(fa1, fb1, 3, 1);
+        if constexpr (NEXT) DCA_RD(2, fa0, fb0, aa0, ab0);
+        DCA_MM(fa1, fb1, 3, 2);
+        if constexpr (NEXT) DCA_RD(3, fa0, fb0, aa0, ab0);
+        DCA_MM(fa1, fb1, 0, 3);
+        if constexpr (NEXT) DCA_RD(4, fa0, fb0, aa0, ab0);
+        DCA_MM(fa1, fb1, 1, 3);
+        if constexpr (NEXT) DCA_RD(5, fa0, fb0, aa0, ab0);
+        DCA_MM(fa1, fb1, 2, 3);
+        if constexpr (NEXT) DCA_RD(6, fa0, fb0, aa0, ab0);
+        DCA_MM(fa1, fb1, 3, 3);
+        if constexpr (NEXT) DCA_RD(7, fa0, fb0, aa0, ab0);
+    };
+
+    issue(0, 0);
+    if (nh > 1) issue(1, WBK);
+    if (nh > 2) issue(2, 2 * WBK);
+    if (nh > 3) issue(3, 3 * WBK);
+    if (nh > 3)
+        DCA_VMCNT(24);
+    else if (nh == 3)
+        DCA_VMCNT(16);
+    else if (nh == 2)
+        DCA_VMCNT(8);
+    else
+        DCA_VMCNT(0);
+    DCA_BAR();
+    DCA_SB();
+    DCA_RD(0, fa0, fb0, fo_a0, fo_b0);
+    DCA_RD(1, fa0, fb0, fo_a0, fo_b0);
+    DCA_RD(2, fa0, fb0, fo_a0, fo_b0);
+    DCA_RD(3, fa0, fb0, fo_a0, fo_b0);
+    DCA_RD(4, fa0, fb0, fo_a0, fo_b0);
+    DCA_RD(5, fa0, fb0, fo_a0, fo_b0);
+    DCA_RD(6, fa0, fb0, fo_a0, fo_b0);
+    DCA_RD(7, fa0, fb0, fo_a0, fo_b0);
+    {
+        using T = std::true_type;
+        using F = std::false_type;
+        int slot = 0, hh = 0;
+        auto adv = [&]() {
+            slot = slot == WRING - 1 ? 0 : slot + 1;
+            hh++;
+        };
+        for (; hh + 4 < nh; adv()) phase(hh, slot, T{}, T{}, std::integral_constant<int, 24>{});
+        if (hh + 3 < nh) {
+            phase(hh, slot, F{}, T{}, std::integral_constant<int, 16>{});
+            adv();
+        }
+        if (hh + 2 < nh) {
+            phase(hh, slot, F{}, T{}, std::integral_constant<int, 8>{});
+            adv();
+        }
+        if (hh + 1 < nh) {
+            phase(hh, slot, F{}, T{}, std::integral_constant<int, 0>{});
+            adv();
+        }
+        phase(hh, slot, F{}, F{}, std::integral_constant<int, 0>{});
+    }
+#undef DCA_VMCNT
+#undef DCA_MM
+#undef DCA_WL
+#undef DCA_RD
+#undef DCA_DSR
+#undef DCA_SB
+
+    gemm16_epilogue<BF16, 4>(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h);
 }
 
 }  // namespace dca
@@ -459,9 +745,10 @@ int gemm2_launch(int mode, const Gemm2Args& p, hipStream_t s);
 
 extern "C" {
 
-/* tuning / test hook: 1 = two K-step stages, one drain + barrier per K-step; 2 (default) = the 8-phase ping-pong schedule */
+/* tuning / test hook: 1 = two K-step stages, one drain + barrier per K-step; 2 (default) = the 8-phase ping-pong schedule;
+ * 3 = 128 x 256 tiles, two workgroups per CU (dca_gemm2.hip); 4 = four waves x 128 x 128, ring of five K-tiles of 32 */
 int dca_gemm16_variant(int v) {
-    DCA_ARG(v >= 1 && v <= 3);
+    DCA_ARG(v >= 1 && v <= 4);
     g_gemm16_variant = v;
     return 0;
 }
@@ -513,6 +800,8 @@ int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int 
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16p<true>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16p<false>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
+            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16w<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WLDS));
+            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16w<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WLDS));
             attr_devs.fetch_or(bit, std::memory_order_release);
         }
     }
@@ -537,7 +826,13 @@ int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int 
         return DCA_E_BADARG;
     }
     const dim3 grid((unsigned)blocks), block(QTHREADS);
-    if (g_gemm16_variant == 2) {
+    if (g_gemm16_variant == 4) {  // four waves x (128 x 128): K-tiles of 32
+        DCA_ARG(k % WBK == 0);
+        if (dtype == DCA_DT_BF16)
+            hipLaunchKernelGGL(k_gemm16w<true>, grid, dim3(WTHREADS), WLDS, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL(k_gemm16w<false>, grid, dim3(WTHREADS), WLDS, (hipStream_t)stream, p);
+    } else if (g_gemm16_variant == 2) {
         if (dtype == DCA_DT_BF16)
             hipLaunchKernelGGL(k_gemm16p<true>, grid, block, QLDS, (hipStream_t)stream, p);
         else

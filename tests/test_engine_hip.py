@@ -225,6 +225,31 @@ def test_engine_full_size_batch_properties(L, co):
     eng.close()
 
 
+def test_graph_chunks_of_any_length_step_the_same_search(L, co):
+    """run_builtin replays chunks of iterations as one hipGraph each, cut at the rebase-period boundaries and cached by
+    their pattern of rebase iterations: any sequence of chunk lengths must walk exactly the search that one eager
+    iteration at a time walks (open / closed / generated counts after every chunk), before and after a reset."""
+    from deepcubea_amd.search_methods.engine import BwasEngine
+    root = scramble(co, "cube3", [3, 8, 1, 10, 6, 4, 11, 2, 9, 0, 7, 5, 1, 3, 10, 8, 6, 2])
+    chunks = [3, 20, 1, 37, 70, 16, 5]
+    a = BwasEngine("cube3", 0.8, 1000, max_nodes=1 << 22)
+    b = BwasEngine("cube3", 0.8, 1000, max_nodes=1 << 22)
+    for rep in range(2):
+        for eng in (a, b):
+            eng.reset(root)
+            eng.root_commit(L.heuristic_builtin(2, torch.from_numpy(root[None].copy()).cuda()))
+        for n in chunks:
+            for _ in range(n):
+                a.run_builtin(2, 1, use_graph=False)
+            b.run_builtin(2, n, use_graph=True)
+            sa, sb = a.status(), b.status()
+            for k in ("iterations", "open_size", "closed_size", "nodes_generated", "nodes_expanded", "done", "failed"):
+                assert sa[k] == sb[k], (rep, n, k, sa[k], sb[k])
+        chunks = chunks[::-1]
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("keep,fmax", [(1, 1), (40, 100), (500, 2000)])
 def test_tier_thrash_keeps_exactness(L, co, keep, fmax):
     """FRONT/BACK tiering must never change the search: with absurdly small tier sizes every iteration refills from
