@@ -456,6 +456,9 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
     model = env.get_nnet_model()  # cube3: ResnetModel(54, 6, 5000, 1000, 4, 1, True)
     load_synthetic_weights(model, 2024)
     macs = sum(m.in_features * m.out_features for m in model.modules() if isinstance(m, torch.nn.Linear))
+    fp8_scaling = "block" if dtype_name == "fp8mx" else "tensor"
+    if dtype_name == "fp8mx":
+        dtype_name = "fp8"
     dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16, "fp8": torch.bfloat16}[dtype_name]
     max_rounds = 64
     cap = max(1 << 20, (steps * max_rounds + warm + 12) * B * A + 64 * B * A // 2)
@@ -465,7 +468,7 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
                                               autocast_dtype=None if dt == torch.float32 else dt)
         eng = BwasEngine(args.env, w, B, max_nodes=cap, onehot_dtype=dt)
     else:
-        fast = (Fp8Resnet(model) if dtype_name == "fp8" else FastResnet(model, dt, gemm16=gemm16)).cuda()
+        fast = (Fp8Resnet(model, scaling=fp8_scaling) if dtype_name == "fp8" else FastResnet(model, dt, gemm16=gemm16)).cuda()
         hfn = nnet_utils.get_heuristic_fn_dev(fast, clip_zero=False, batch_size=args.nnet_batch_size)
         if fast.uses_l1_kernel:  # layer 1 = the library's one-hot MFMA kernel on the packed uint8 rows
             eng = BwasEngine(args.env, w, B, max_nodes=cap, packed=True)
@@ -516,13 +519,15 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
                           "of the matrix pipe's issue slots filled at that clock (profiles/r04_gemm_timeline.txt)"}
     return {"value": total_exp / wall, "unit": "nodes expanded/s", "ms_per_step": wall / steps * 1e3,
             "roofline_nnet": roof,
-            "steps": steps, "timed_s": wall, "heuristic_dtype": dtype_name, "weights": "synthetic (numpy PCG64 seed 2024, BN folded)",
+            "steps": steps, "timed_s": wall, "heuristic_dtype": dtype_name + (" (block-scaled, MX-64)" if dtype_name == "fp8" and fp8_scaling == "block" else ""), "weights": "synthetic (numpy PCG64 seed 2024, BN folded)",
             "order": "eval_all_children (reference order)" if eval_all_children else "dedup_first (CLI default)",
             "layer1": "library GEMM on one-hot rows" if eval_all_children or not fast.uses_l1_kernel
-            else "dca_l1_onehot_gemm (hand-written MFMA, %d bf16 plane(s)%s)" % ((1, ", e4m3 output") if dtype_name == "fp8"
+            else "dca_l1_onehot_gemm (hand-written MFMA, %d bf16 plane(s)%s)" % ((1, ", e4m3 output" + (" with E8M0 block scales" if fp8_scaling == "block" else "")) if dtype_name == "fp8"
                                                                                 else (fast.l1_planes, "")),
             "dense_layers": ("library fp32 GEMMs" if eval_all_children else "dca_f16x3_gemm (hand-written MFMA, epilogue-fused)")
-            if dtype_name == "fp32" else ("dca_gemm8 (hand-written e4m3 MFMA, dequantise + tail + requantise in the epilogue)"
+            if dtype_name == "fp32" else (("dca_gemm8_mx (hand-written scaled e4m3 MFMA, one E8M0 scale per row and 64 elements; tail + requantise in the "
+                                           "epilogue)" if fp8_scaling == "block" else
+                                           "dca_gemm8 (hand-written e4m3 MFMA, per-tensor scales; dequantise + tail + requantise in the epilogue)")
                                           if dtype_name == "fp8" else "dca_gemm16 (hand-written MFMA, epilogue-fused)"
                                           if gemm16 == "hip" else "library (hipBLASLt) GEMMs + clamp pass"),
             "network_rows_per_step": rows, "children_per_step": B * A,
@@ -531,7 +536,8 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
             "mfma_peak_tflops": (157.3 if eval_all_children else 2500.0 / 3) if dtype_name == "fp32"
             else (5000.0 if dtype_name == "fp8" else 2500.0),
             "mfma_pipe": ("f32-input MFMA" if eval_all_children else "f16/bf16 MFMA, fp32-accurate via operand splitting "
-                          "(useful flops = 1/3 of the issued ones)") if dtype_name == "fp32" else "f16/bf16 MFMA"}
+                          "(useful flops = 1/3 of the issued ones)") if dtype_name == "fp32"
+            else ("f8f6f4 MFMA (e4m3)" if dtype_name == "fp8" else "f16/bf16 MFMA")}
 
 
 def cpu_baseline_astar(args, seconds_budget: float = 20.0):
@@ -790,6 +796,7 @@ def main():
                                    "bf16": run_astar_nnet(args, world, rank, "bf16", gemm16="hip"),
                                    "bf16_library_gemm": run_astar_nnet(args, world, rank, "bf16", gemm16="library"),
                                    "fp8_hand_written_gemm": run_astar_nnet(args, world, rank, "fp8"),
+                                   "fp8_block_scaled": run_astar_nnet(args, world, rank, "fp8mx"),
                                    "fp32_eval_all_children": run_astar_nnet(args, world, rank, "fp32", True)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("astar", "expand"):
         if args.workload == "expand":

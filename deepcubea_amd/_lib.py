@@ -38,6 +38,7 @@ ABI_SYMBOLS = [
     "dca_engine_profile_builtin", "dca_engine_set_tiers", "dca_engine_debug", "dca_debug_tune", "dca_engine_status", "dca_engine_last_children", "dca_engine_solution",
     "dca_bn_workspace_bytes", "dca_bn_train_forward", "dca_bn_train_backward",
     "dca_l1_supported", "dca_l1_kpad", "dca_l1_onehot_gemm", "dca_act_split", "dca_f16x3_gemm", "dca_split_planes", "dca_f16x3_gemm_variant",
+    "dca_absmax_bits", "dca_split_planes_scaled", "dca_split_rows_scaled", "dca_split_planes_t", "dca_fill_inv_pow2",
     "dca_gemm16", "dca_gemm16_variant", "dca_gemm8", "dca_quant_e4m3", "dca_lightsout_next_state", "dca_lightsout_expand_fused",
     "dca_head_gemv", "dca_engine_packed_state", "dca_engine_info", "dca_gemm2_skew", "dca_f16x3_gemm_timeline", "dca_gemm8_mx", "dca_l1_onehot_gemm_mx",
     "dca_cube4_perm_table", "dca_cube4_next_state", "dca_cube4_prev_state", "dca_cube4_expand_fused",
@@ -334,6 +335,113 @@ def bn_train(x: torch.Tensor, bn: "torch.nn.BatchNorm1d", relu: bool, skip: Opti
             bn.running_mean.mul_(1.0 - mom).add_(mean, alpha=mom)
             bn.running_var.mul_(1.0 - mom).add_(var_u, alpha=mom)
     return y
+
+
+# ------------------------------------------------------------------------------ training step: dense layers
+def _pad64(k: int) -> int:
+    return (k + 63) // 64 * 64
+
+
+def linear_f16x3(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], scale_a: bool) -> torch.Tensor:
+    """a [m, k] fp32 . w [n, k]^T (+ bias) -> [m, n] fp32 through dca_f16x3_gemm (fp32-accurate on the f16 matrix pipes),
+    operands prepared on the spot: rows of w scaled by their own power of two (dca_split_rows_scaled), `a` by one power of two
+    for the whole tensor when scale_a (gradients; dca_absmax_bits + dca_split_planes_scaled) — activations (O(1) after
+    BatchNorm) are split as they are.  k, n % 4 == 0; K is zero-padded to a multiple of 64 inside the planes."""
+    assert a.is_cuda and a.dtype == torch.float32 and w.dtype == torch.float32 and a.dim() == 2 and w.dim() == 2
+    a, w = a.contiguous(), w.contiguous()
+    m, k = a.shape
+    n = w.shape[0]
+    assert w.shape[1] == k and k % 4 == 0 and n % 4 == 0
+    kp = _pad64(k)
+    dev = a.device
+    amax = None
+    if scale_a:
+        amax = torch.empty(1, dtype=torch.int32, device=dev)
+        check(lib().dca_absmax_bits(ptr(a), C.c_int64(m), C.c_int64(k), C.c_int64(k), ptr(amax), stream_ptr()), "dca_absmax_bits")
+    ap = torch.empty((2, m, kp), dtype=torch.float16, device=dev)
+    check(lib().dca_split_planes_scaled(ptr(a), C.c_int64(m), C.c_int64(k), C.c_int64(k), ptr(amax), ptr(ap[0]), ptr(ap[1]),
+                                        C.c_int64(kp), C.c_int64(kp), stream_ptr()), "dca_split_planes_scaled")
+    wp = torch.empty((2, n, kp), dtype=torch.float16, device=dev)
+    cs = torch.empty(n, dtype=torch.float32, device=dev)
+    check(lib().dca_split_rows_scaled(ptr(w), C.c_int64(n), C.c_int64(k), C.c_int64(k), ptr(wp[0]), ptr(wp[1]), C.c_int64(kp),
+                                      C.c_int64(kp), ptr(cs), ptr(amax), stream_ptr()), "dca_split_rows_scaled")
+    _, out = f16x3_gemm(ap, wp[0], wp[1], cs, 1.0, None if bias is None else bias.contiguous(), None, False, False, True)
+    return out
+
+
+def _absmax_bits(a: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(1, dtype=torch.int32, device=a.device)
+    check(lib().dca_absmax_bits(ptr(a), C.c_int64(a.shape[0]), C.c_int64(a.shape[1]), C.c_int64(a.shape[1]), ptr(out), stream_ptr()),
+          "dca_absmax_bits")
+    return out
+
+
+def _planes_t(a: torch.Tensor, amax: Optional[torch.Tensor]) -> torch.Tensor:
+    """planes of (a * 2^e)^T: [2, n, ceil64(m)] fp16 (dca_split_planes_t)."""
+    m, n = a.shape
+    mp = _pad64(m)
+    out = torch.empty((2, n, mp), dtype=torch.float16, device=a.device)
+    check(lib().dca_split_planes_t(ptr(a), C.c_int64(m), C.c_int64(n), C.c_int64(n), ptr(amax), ptr(out[0]), ptr(out[1]),
+                                   C.c_int64(mp), stream_ptr()), "dca_split_planes_t")
+    return out
+
+
+def weight_grad_f16x3(dy: torch.Tensor, x: torch.Tensor, amax_dy: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dy^T [n, m] . x [m, k] -> [n, k] fp32 through dca_f16x3_gemm: both operands transposed into planes (the contraction runs
+    over the batch), dy scaled by one power of two (gradients), x as it is."""
+    dy, x = dy.contiguous(), x.contiguous()
+    m, n = dy.shape
+    k = x.shape[1]
+    assert x.shape[0] == m and n % 4 == 0 and k % 4 == 0
+    if amax_dy is None:
+        amax_dy = _absmax_bits(dy)
+    a = _planes_t(dy, amax_dy)
+    w = _planes_t(x, None)
+    cs = torch.empty(k, dtype=torch.float32, device=dy.device)
+    check(lib().dca_fill_inv_pow2(ptr(cs), C.c_int64(k), ptr(amax_dy), stream_ptr()), "dca_fill_inv_pow2")
+    _, out = f16x3_gemm(a, w[0], w[1], cs, 1.0, None, None, False, False, True)
+    return out
+
+
+class _LinearTrainFn(torch.autograd.Function):
+    """nn.Linear for the training step (reference nnet_utils.py:53-118 runs it as the library's fp32 GEMMs): forward and input
+    gradient on dca_f16x3_gemm (2/3 of the layer's flops, ~3x the library's fp32 rate at fp32 accuracy).  The weight gradient
+    dy^T . x contracts over the BATCH dimension: `weight_grad_f16x3` transposes both operands while it splits them
+    (dca_split_planes_t) and is exact to the same level, but stays off by default (TRAIN_DW_F16X3: too few output tiles without
+    a split-K launch) — the library's fp32 GEMM does it."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return linear_f16x3(x, weight, bias, scale_a=False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = linear_f16x3(dy, weight.t().contiguous(), None, scale_a=True) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = weight_grad_f16x3(dy, x) if TRAIN_DW_F16X3 else dy.t().mm(x)
+        db = dy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db
+
+
+def linear_train(x: torch.Tensor, lin: "torch.nn.Linear") -> torch.Tensor:
+    """`lin(x)` inside the training step.  The f16x3 path needs the GPU, fp32, 4-element-aligned widths and enough rows to
+    fill a tile; anything else (the 1-wide output layer, the host) is F.linear."""
+    if (x.is_cuda and x.dtype == torch.float32 and lin.weight.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 256
+            and lin.in_features % 4 == 0 and lin.out_features % 4 == 0 and lin.in_features >= 64 and TRAIN_F16X3):
+        return _LinearTrainFn.apply(x, lin.weight, lin.bias)
+    return torch.nn.functional.linear(x, lin.weight, lin.bias)
+
+
+TRAIN_F16X3 = os.environ.get("DCA_TRAIN_GEMM", "f16x3") != "library"  # A/B switches (bench.py --workload train, tools/train_grad_check.py)
+# the weight gradient through the same kernel is correct (tests, tools/train_grad_check.py) but SLOWER at the training shapes
+# (12.3 vs 7.8 ms per step): dy^T . x has 16-80 output tiles of 256 x 256 for 256 CUs and a 10 000-long contraction — it
+# needs a split-K launch, which dca_f16x3_gemm does not have.  Off unless asked for.
+TRAIN_DW_F16X3 = os.environ.get("DCA_TRAIN_DW", "library") == "f16x3"
 
 
 # ------------------------------------------------------------------------------ heuristic network, layer 1

@@ -619,6 +619,151 @@ __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ 
     }
 }
 
+// ---- operands of the TRAINING step's dense layers (utils/nnet_utils.py train_nnet; reference nnet_utils.py:53-118 runs
+// nn.Linear forward / backward as the library's fp32 GEMMs).  Forward y = x . W^T and backward dx = dy . W go through
+// dca_f16x3_gemm too; what differs from inference is that nothing is prepared ahead: the weights change every step and the
+// gradients span many binades.  So every operand is scaled by a POWER OF TWO chosen from its own magnitude before it is
+// split (exact: only the exponent moves), bringing its largest element into [2^14, 2^15): the low plane of everything
+// within 2^-10 of that is a normal fp16 number, what lies below is held to 2^-39 of the largest element.  The inverse scales
+// come back through the GEMM's per-column factor.
+__device__ __forceinline__ float pow2_scale_of(uint32_t amax_bits) {
+    const int ex = (int)((amax_bits >> 23) & 0xFFu) - 127;        // floor(log2 amax) for a normal amax
+    if (ex < -100 || ex > 100) return 1.0f;                       // zero / denormal / inf / nan: leave as is
+    return __uint_as_float((uint32_t)(127 + 14 - ex) << 23);
+}
+
+// max |x| over the matrix as float bits (non-negative floats order like their bit patterns); out zeroed by the host
+__global__ __launch_bounds__(256) void k_absmax_bits(const float* __restrict__ x, int64_t m, int64_t n, int64_t ld,
+                                                     uint32_t* __restrict__ out) {
+    const int64_t n4 = n / 4, total = m * n4;
+    uint32_t mx = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / n4, c = (i - r * n4) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
+        mx = max(max(mx, __float_as_uint(fabsf(v.x))), max(__float_as_uint(fabsf(v.y)), max(__float_as_uint(fabsf(v.z)), __float_as_uint(fabsf(v.w)))));
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+    __shared__ uint32_t sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, max(max(sh[0], sh[1]), max(sh[2], sh[3])));
+}
+
+// x * 2^e -> planes, columns n..n_pad zero.  amax_bits == nullptr: no scaling.
+__global__ __launch_bounds__(256) void k_split_planes_scaled(const float* __restrict__ x, int64_t m, int64_t n, int64_t ld,
+                                                             const uint32_t* __restrict__ amax_bits, _Float16* __restrict__ oh,
+                                                             _Float16* __restrict__ ol, int64_t ldo, int64_t n_pad) {
+    const float s = amax_bits ? pow2_scale_of(*amax_bits) : 1.0f;
+    const int64_t n4 = n_pad / 4, total = m * n4;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / n4, c = (i - r * n4) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < n) v = *reinterpret_cast<const float4*>(x + r * ld + c);
+        const float u[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+        h4 hi, lo;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            hi[k] = (_Float16)u[k];
+            lo[k] = (_Float16)(u[k] - (float)hi[k]);
+        }
+        *reinterpret_cast<h4*>(oh + r * ldo + c) = hi;
+        *reinterpret_cast<h4*>(ol + r * ldo + c) = lo;
+    }
+}
+
+// one workgroup per row of w [n, k]: the row's own power-of-two scale, its planes (columns k..k_pad zero), and
+// col_scale[row] = 1 / (row scale * scale of the OTHER operand, if its |max| is given)
+__global__ __launch_bounds__(256) void k_split_rows_scaled(const float* __restrict__ w, int64_t k, int64_t ld,
+                                                           _Float16* __restrict__ oh, _Float16* __restrict__ ol, int64_t ldo,
+                                                           int64_t k_pad, float* __restrict__ col_scale,
+                                                           const uint32_t* __restrict__ other_amax_bits) {
+    const int64_t r = blockIdx.x;
+    const float* row = w + r * ld;
+    const int64_t k4 = k / 4;
+    uint32_t mx = 0;
+    for (int64_t i = threadIdx.x; i < k4; i += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(row + i * 4);
+        mx = max(max(mx, __float_as_uint(fabsf(v.x))), max(__float_as_uint(fabsf(v.y)), max(__float_as_uint(fabsf(v.z)), __float_as_uint(fabsf(v.w)))));
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+    __shared__ uint32_t sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    const float s = pow2_scale_of(max(max(sh[0], sh[1]), max(sh[2], sh[3])));
+    if (threadIdx.x == 0) {
+        const float so = other_amax_bits ? pow2_scale_of(*other_amax_bits) : 1.0f;
+        col_scale[r] = (1.0f / s) * (1.0f / so);  // powers of two: exact (2^-15-100 .. 2^+100: far inside fp32)
+    }
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    for (int64_t i = threadIdx.x; i < k_pad / 4; i += 256) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < k4) v = *reinterpret_cast<const float4*>(row + i * 4);  // (second read of the row: L2)
+        const float u[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+        h4 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            hi[q] = (_Float16)u[q];
+            lo[q] = (_Float16)(u[q] - (float)hi[q]);
+        }
+        *reinterpret_cast<h4*>(oh + r * ldo + i * 4) = hi;
+        *reinterpret_cast<h4*>(ol + r * ldo + i * 4) = lo;
+    }
+}
+
+// x [m, n] fp32 -> planes of (x * 2^e)^T: out [n][m_pad] (rows m..m_pad zero).  The weight gradient dW = dy^T . x contracts
+// over the batch dimension, which neither operand has contiguous: both are transposed on their way into planes (64 x 64
+// tiles through LDS; reads and writes in 256-byte / 128-byte row segments).
+__global__ __launch_bounds__(256) void k_split_planes_t(const float* __restrict__ x, int64_t m, int64_t n, int64_t ld,
+                                                        const uint32_t* __restrict__ amax_bits, _Float16* __restrict__ oh,
+                                                        _Float16* __restrict__ ol, int64_t ldo) {
+    __shared__ _Float16 th[64][68], tl[64][68];  // [column of x][row of x], padded: the column-wise writes below spread over banks
+    const float s = amax_bits ? pow2_scale_of(*amax_bits) : 1.0f;
+    const int64_t r0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
+    const int t = threadIdx.x;
+    {
+        const int cq = (t & 15) * 4;  // 16 lanes x float4 = one 64-column row segment
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int rr = p * 16 + (t >> 4);
+            const int64_t r = r0 + rr, c = c0 + cq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < m && c < n) v = *reinterpret_cast<const float4*>(x + r * ld + c);  // (n % 4 == 0: a float4 is in or out as a whole)
+            const float u[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const _Float16 hi = (_Float16)u[k];
+                th[cq + k][rr] = hi;
+                tl[cq + k][rr] = (_Float16)(u[k] - (float)hi);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const int rq = (t & 15) * 4;  // 16 lanes x 4 halves = one 64-row segment of an output row
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int cc = p * 16 + (t >> 4);
+            const int64_t c = c0 + cc;
+            if (c >= n) continue;
+            h4 hi, lo;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                hi[k] = th[cc][rq + k];
+                lo[k] = tl[cc][rq + k];
+            }
+            *reinterpret_cast<h4*>(oh + c * ldo + r0 + rq) = hi;  // (rows past m were staged as zeros: the pad is written too)
+            *reinterpret_cast<h4*>(ol + c * ldo + r0 + rq) = lo;
+        }
+    }
+}
+
+__global__ void k_fill_inv_pow2(float* __restrict__ out, int64_t n, const uint32_t* __restrict__ amax_bits) {
+    const float v = 1.0f / pow2_scale_of(*amax_bits);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = v;
+}
+
 }  // namespace dca
 
 using namespace dca;
@@ -766,6 +911,59 @@ int dca_split_planes(const float* x, int64_t m, int64_t n, int64_t ld, void* out
     hipLaunchKernelGGL(k_split_planes, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, m, n, ld,
                        reinterpret_cast<_Float16*>(out_h), reinterpret_cast<_Float16*>(out_l), ldo, overflow);
     return launch_check("k_split_planes");
+}
+
+int dca_absmax_bits(const float* x, int64_t m, int64_t n, int64_t ld, uint32_t* out_bits, void* stream) {
+    DCA_ARG(x && out_bits && m >= 0 && n >= 4 && n % 4 == 0 && ld >= n && ld % 4 == 0 && (uintptr_t)x % 16 == 0);
+    DCA_HIP(hipMemsetAsync(out_bits, 0, sizeof(uint32_t), (hipStream_t)stream));
+    if (m == 0) return 0;
+    int64_t blocks = (m * (n / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_absmax_bits, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, m, n, ld, out_bits);
+    return launch_check("k_absmax_bits");
+}
+
+int dca_split_planes_scaled(const float* x, int64_t m, int64_t n, int64_t ld, const uint32_t* amax_bits, void* out_h, void* out_l,
+                            int64_t ldo, int64_t n_pad, void* stream) {
+    DCA_ARG(x && out_h && out_l && m >= 0 && n >= 4 && n % 4 == 0 && ld >= n && ld % 4 == 0 && n_pad >= n && n_pad % 4 == 0 &&
+            ldo >= n_pad && ldo % 4 == 0);
+    DCA_ARG((uintptr_t)x % 16 == 0 && ((uintptr_t)out_h | (uintptr_t)out_l) % 8 == 0);
+    if (m == 0) return 0;
+    int64_t blocks = (m * (n_pad / 4) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_split_planes_scaled, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, m, n, ld, amax_bits,
+                       reinterpret_cast<_Float16*>(out_h), reinterpret_cast<_Float16*>(out_l), ldo, n_pad);
+    return launch_check("k_split_planes_scaled");
+}
+
+int dca_split_rows_scaled(const float* w, int64_t n, int64_t k, int64_t ld, void* out_h, void* out_l, int64_t ldo, int64_t k_pad,
+                          float* col_scale, const uint32_t* other_amax_bits, void* stream) {
+    DCA_ARG(w && out_h && out_l && col_scale && n >= 0 && n < (1ll << 31) && k >= 4 && k % 4 == 0 && ld >= k && ld % 4 == 0 &&
+            k_pad >= k && k_pad % 4 == 0 && ldo >= k_pad && ldo % 4 == 0);
+    DCA_ARG((uintptr_t)w % 16 == 0 && ((uintptr_t)out_h | (uintptr_t)out_l) % 8 == 0);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_split_rows_scaled, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, w, k, ld,
+                       reinterpret_cast<_Float16*>(out_h), reinterpret_cast<_Float16*>(out_l), ldo, k_pad, col_scale, other_amax_bits);
+    return launch_check("k_split_rows_scaled");
+}
+
+int dca_split_planes_t(const float* x, int64_t m, int64_t n, int64_t ld, const uint32_t* amax_bits, void* out_h, void* out_l,
+                       int64_t ldo, void* stream) {
+    const int64_t m_pad = (m + 63) / 64 * 64;
+    DCA_ARG(x && out_h && out_l && m >= 0 && n >= 4 && n % 4 == 0 && ld >= n && ld % 4 == 0 && ldo >= m_pad && ldo % 4 == 0);
+    DCA_ARG((uintptr_t)x % 16 == 0 && ((uintptr_t)out_h | (uintptr_t)out_l) % 8 == 0 && m_pad / 64 < (1ll << 31) && (n + 63) / 64 < 65536);
+    if (m == 0) return 0;
+    hipLaunchKernelGGL(k_split_planes_t, dim3((unsigned)(m_pad / 64), (unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x,
+                       m, n, ld, amax_bits, reinterpret_cast<_Float16*>(out_h), reinterpret_cast<_Float16*>(out_l), ldo);
+    return launch_check("k_split_planes_t");
+}
+
+int dca_fill_inv_pow2(float* out, int64_t n, const uint32_t* amax_bits, void* stream) {
+    DCA_ARG(out && amax_bits && n >= 0);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_fill_inv_pow2, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0,
+                       (hipStream_t)stream, out, n, amax_bits);
+    return launch_check("k_fill_inv_pow2");
 }
 
 }  // extern "C"

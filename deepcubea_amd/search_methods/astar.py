@@ -61,13 +61,17 @@ def _load_heuristic(args, env):
         nnet = nnet_utils.load_nnet("%s/model_state_dict.pt" % args.model_dir, nnet, device=device)
     nnet.to(device)
     dt_name = getattr(args, "nnet_dtype", "fp32")
-    if dt_name == "fp8" and getattr(args, "eval_all_children", False):
-        raise ValueError("--nnet_dtype fp8 runs on the dedup-first engine path only (drop --eval_all_children)")
-    dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16, "fp8": torch.bfloat16}[dt_name]
+    if dt_name in ("fp8", "fp8mx") and getattr(args, "eval_all_children", False):
+        raise ValueError("--nnet_dtype %s runs on the dedup-first engine path only (drop --eval_all_children)" % dt_name)
+    dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16, "fp8": torch.bfloat16,
+          "fp8mx": torch.bfloat16}[dt_name]
     if not getattr(args, "eval_all_children", False):
         # default: padded / epilogue-fused inference layout of the same network, fed by the dedup-first engine
         from ..utils.pytorch_models import FastResnet, Fp8Resnet
-        fast = (Fp8Resnet(nnet) if dt_name == "fp8" else FastResnet(nnet, dt)).to(device)
+        if dt_name in ("fp8", "fp8mx"):
+            fast = Fp8Resnet(nnet, scaling="block" if dt_name == "fp8mx" else "tensor").to(device)
+        else:
+            fast = FastResnet(nnet, dt).to(device)
         # layer 1 as the library's one-hot MFMA kernel: the engine then hands out uint8 rows only (stride 0 = no one-hot)
         stride = 0 if fast.uses_l1_kernel else fast.in_pad
         args._onehot_dtype = fast.onehot_dtype  # what the engine's pack kernel writes when one-hot rows are needed
@@ -112,7 +116,7 @@ def bwas_hip(args, env, states: List) -> Tuple[List[List[int]], List[List], List
         heuristic_fn, onehot_stride = _load_heuristic(args, env)
     sem = _lib.SEM_CPP if getattr(args, "semantics", "py") == "cpp" else _lib.SEM_PY
     oh = getattr(args, "_onehot_dtype", None) or {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16,
-                                                   "fp8": torch.bfloat16}[getattr(args, "nnet_dtype", "fp32")]
+                                                   "fp8": torch.bfloat16, "fp8mx": torch.bfloat16}[getattr(args, "nnet_dtype", "fp32")]
     K = max(1, int(getattr(args, "instances_per_gpu", 1)))
     eng = BwasEngine(args.env, args.weight, args.batch_size, max_nodes=_max_nodes(args, K),
                      semantics=sem, onehot_dtype=None if (onehot_stride == 0 or builtin is not None) else oh,
@@ -195,9 +199,11 @@ def build_parser() -> ArgumentParser:
                         help="node pool capacity (ids per search): a number, or auto = sized from the GPU's free HBM")
     parser.add_argument('--instances_per_gpu', type=int, default=1,
                         help="scrambles stepped together by one engine (finer per-instance sharding inside a GPU)")
-    parser.add_argument('--nnet_dtype', type=str, default="fp32", choices=["fp32", "bf16", "fp16", "fp8"],
+    parser.add_argument('--nnet_dtype', type=str, default="fp32", choices=["fp32", "bf16", "fp16", "fp8", "fp8mx"],
                         help="fp32 = parity mode (1e-5); bf16/fp16 = faster, NOT parity; fp8 = OCP e4m3 operands on the "
-                             "hand-written layer kernels (dca_gemm8), fastest, coarsest")
+                             "hand-written layer kernels (dca_gemm8), one calibrated scale per activation tensor: fastest, "
+                             "coarsest; fp8mx = the same with one E8M0 scale per row and 64 elements (nothing to "
+                             "calibrate, ~13 %% slower)")
     parser.add_argument('--fold_bn', action='store_true', default=False,
                         help="with --eval_all_children: fold BatchNorm into the Linears (always done otherwise)")
     parser.add_argument('--static_shards', action='store_true', default=False,

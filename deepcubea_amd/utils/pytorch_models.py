@@ -59,13 +59,15 @@ class ResnetModel(nn.Module):
     def _trunk_train_dev(self, x: torch.Tensor) -> torch.Tensor:
         """Training mode on the HIP device: the BatchNorms (+ residual add + ReLU) run through the library's column
         reduction kernels (csrc/dca_train.hip) — same arithmetic as `trunk`, the framework's 2-D BatchNorm kernels
-        were 41 % of the training step."""
+        were 41 % of the training step — and the Linears' forward / input-gradient GEMMs through dca_f16x3_gemm
+        (`_lib.linear_train`)."""
         from .. import _lib
-        x = _lib.bn_train(self.fc1(x), self.bn1, relu=True)
-        x = _lib.bn_train(self.fc2(x), self.bn2, relu=True)
+        lin = _lib.linear_train  # forward + input gradient on dca_f16x3_gemm (fp32-accurate), weight gradient on the library
+        x = _lib.bn_train(lin(x, self.fc1), self.bn1, relu=True)
+        x = _lib.bn_train(lin(x, self.fc2), self.bn2, relu=True)
         for blk in self.blocks:
-            h = _lib.bn_train(blk[0](x), blk[1], relu=True)
-            x = _lib.bn_train(blk[2](h), blk[3], relu=True, skip=x)
+            h = _lib.bn_train(lin(x, blk[0]), blk[1], relu=True)
+            x = _lib.bn_train(lin(h, blk[2]), blk[3], relu=True, skip=x)
         return self.fc_out(x)
 
     def trunk(self, x: torch.Tensor) -> torch.Tensor:
@@ -438,12 +440,15 @@ class Fp8Resnet(_Fp8BlockMixin, nn.Module):
     HEADROOM = 1.25
     MIN_CALIB_ROWS = 1024
 
-    def __init__(self, model: ResnetModel, scaling: str = "block"):
-        """scaling="block" (default): activations carry one E8M0 scale per row and 64 elements, computed in the epilogue
-        that produces them and applied by the scaled MFMA (dca_gemm8_mx / dca_l1_onehot_gemm_mx) — nothing is calibrated,
-        nothing is frozen, nothing saturates, whatever depth of the search the states come from.  scaling="tensor": round
-        3's arrangement — one static scale per activation tensor, calibrated on the first batch of >= 1024 real rows
-        (kept for comparison: 10 % of max|h| off the fp32 network where block scaling is within 3 %)."""
+    def __init__(self, model: ResnetModel, scaling: str = "tensor"):
+        """scaling="tensor" (default, `--nnet_dtype fp8`): one static scale per activation tensor, calibrated on the first
+        batch of >= 1024 REAL rows (see `forward`).  scaling="block" (`--nnet_dtype fp8mx`): activations carry one E8M0
+        scale per row and 64 elements, computed in the epilogue that produces them and applied by the scaled MFMA
+        (dca_gemm8_mx / dca_l1_onehot_gemm_mx) — nothing is calibrated, nothing is frozen, nothing saturates, whatever depth
+        of the search the states come from.  Measured: both sit at e4m3's own precision floor on this
+        network (max 8-10 % of max|h|, rms 2.3-2.6 %: the 3-bit mantissa, not the scaling, sets it — tools/
+        fp8_precision_floor.py), and the block-scaled layers cost 9-22 % more time (the scale traffic and the scaled
+        MFMA's operand), 3.5e6 against 4.1e6 nodes/s end to end: hence the default."""
         super().__init__()
         assert scaling in ("block", "tensor")
         self.scaling = scaling

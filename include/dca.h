@@ -425,6 +425,29 @@ int dca_quant_e4m3(const void* x, int dtype, int64_t m, int64_t n, int64_t ld, d
 int dca_split_planes(const float* x, int64_t m, int64_t n, int64_t ld, void* out_h, void* out_l, int64_t ldo,
                      int* overflow /*or NULL*/, void* stream);
 
+/* Operands of the TRAINING step's dense layers (nn.Linear forward y = x . W^T and backward dx = dy . W of
+ * utils/nnet_utils.py:53-118 through dca_f16x3_gemm; deepcubea_amd/_lib.py linear_train).  Nothing is prepared ahead here —
+ * the weights change every step, gradients span many binades — so every operand is scaled by a power of two taken from its own
+ * magnitude before it is split (exact), and the inverse scales return through the GEMM's col_scale:
+ *   dca_absmax_bits          max |x| of an fp32 matrix as float bits, into a device word (zeroed here)
+ *   dca_split_planes_scaled  x * 2^e -> fp16 planes, 2^e taking max|x| (amax_bits, from dca_absmax_bits) into [2^14, 2^15);
+ *                            amax_bits NULL = unscaled; columns n..n_pad are written as zeros (the GEMM wants k % 64 == 0)
+ *   dca_split_rows_scaled    per ROW of w [n, k]: the row's own 2^e, its planes (columns k..k_pad zero) and
+ *                            col_scale[row] = 1 / (2^e * the other operand's scale, when other_amax_bits is given)
+ * n, k, n_pad, k_pad % 4 == 0; 16-byte aligned inputs. */
+int dca_absmax_bits(const float* x, int64_t m, int64_t n, int64_t ld, uint32_t* out_bits, void* stream);
+int dca_split_planes_scaled(const float* x, int64_t m, int64_t n, int64_t ld, const uint32_t* amax_bits /*device or NULL*/,
+                            void* out_h, void* out_l, int64_t ldo, int64_t n_pad, void* stream);
+int dca_split_rows_scaled(const float* w, int64_t n, int64_t k, int64_t ld, void* out_h, void* out_l, int64_t ldo, int64_t k_pad,
+                          float* col_scale /*[n]*/, const uint32_t* other_amax_bits /*device or NULL*/, void* stream);
+/* The weight gradient dW = dy^T . x contracts over the batch dimension, which neither operand has contiguous: both are
+ * transposed on their way into planes.  dca_split_planes_t: x [m, n] -> planes of (x * 2^e)^T, [n] rows of ldo >= ceil64(m)
+ * halves, rows m..ceil64(m) zero (amax_bits as above, NULL = unscaled).  dca_fill_inv_pow2: out[0..n) = 2^-e of that scale
+ * (the GEMM's col_scale when only one operand is scaled). */
+int dca_split_planes_t(const float* x, int64_t m, int64_t n, int64_t ld, const uint32_t* amax_bits /*device or NULL*/, void* out_h,
+                       void* out_l, int64_t ldo, void* stream);
+int dca_fill_inv_pow2(float* out, int64_t n, const uint32_t* amax_bits, void* stream);
+
 /* Output layer of the cost-to-go network (utils/pytorch_models.py:83-86, fc_out: res_dim -> out_dim, out_dim = 1 for every
  * environment of the reference): out[m, n_out] = x[m, k] . w[n_out, k]^T + bias, float64 accumulation in a FIXED order (one wave
  * per row, lane-strided FMA chains, xor-butterfly fold, one rounding to fp32): a row's value does not depend on its position, on m or on the launch

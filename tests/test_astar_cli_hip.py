@@ -163,9 +163,11 @@ def test_nnet_bf16_mode_still_solves(tmp_path):
     eng.close()
 
 
-def test_nnet_fp8_mode_still_solves(tmp_path):
-    """fp8 heuristic (Fp8Resnet: block-scaled e4m3 layers, dca_gemm8_mx) = explicitly non-parity mode:
-    only validity of the solution is asserted; the mode must actually have switched to the e4m3 kernels on the way."""
+@pytest.mark.parametrize("scaling", ["tensor", "block"])
+def test_nnet_fp8_mode_still_solves(tmp_path, scaling):
+    """fp8 heuristic (Fp8Resnet: e4m3 layers, per-tensor scales = `--nnet_dtype fp8`, block scales = `fp8mx`) = explicitly
+    non-parity mode: only validity of the solution is asserted; the mode must actually have switched to the e4m3 kernels on
+    the way."""
     from deepcubea_amd.search_methods.engine import BwasEngine
     from deepcubea_amd.utils import nnet_utils
     from deepcubea_amd.utils.pytorch_models import Fp8Resnet, ResnetModel
@@ -173,7 +175,7 @@ def test_nnet_fp8_mode_still_solves(tmp_path):
     from oracle import c_oracle as co
     m = ResnetModel(54, 6, 5000, 1000, 4, 1, True)
     load_synthetic_weights(m, 3)
-    fast = Fp8Resnet(m.eval()).cuda()
+    fast = Fp8Resnet(m.eval(), scaling=scaling).cuda()
     hfn = nnet_utils.get_heuristic_fn_dev(fast)
     s = np.arange(54, dtype=np.uint8)[None]
     for a in [2, 7, 9, 4]:
@@ -181,7 +183,9 @@ def test_nnet_fp8_mode_still_solves(tmp_path):
     eng = BwasEngine("cube3", 0.8, 200, max_nodes=1 << 21, packed=True)
     res = eng.solve(s[0], hfn, max_iters=3000)
     assert res["solved"]
-    assert fast.scaling == "block" and fast.layer_scale is None  # block-scaled e4m3 layers (dca_gemm8_mx): nothing to calibrate
+    assert fast.scaling == scaling
+    # per-tensor: calibrated on the first batch of >= 1024 real rows; block-scaled (dca_gemm8_mx): nothing to calibrate
+    assert (fast.layer_scale is not None) == (scaling == "tensor")
     t = s.copy()
     for a in res["moves"]:
         t = co.next_state("cube3", t, a)

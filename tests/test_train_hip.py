@@ -52,6 +52,53 @@ def test_train_nnet_on_device_matches_reference_run(tag, bn):
         assert np.allclose(v.cpu().numpy(), g["%s:final:%s" % (tag, k)], rtol=2e-3, atol=2e-4), k
 
 
+@pytest.mark.parametrize("m,k,n", [(1000, 324, 5000), (2048, 5000, 1000), (777, 1000, 1000)])
+def test_linear_train_is_fp32_accurate_forward_and_backward(m, k, n):
+    """_lib.linear_train (nn.Linear inside the training step: forward and input gradient on dca_f16x3_gemm, operands scaled
+    by powers of two and split on the spot; weight gradient on the library) against float64.  fp32 accuracy means: as close
+    to the float64 result as torch's own fp32 nn.Linear is (factor 4 allowed), forward and all three gradients — with
+    gradients at 1e-7 scale and a 2^20 spread between rows, which an unscaled fp16 split would flush."""
+    from deepcubea_amd import _lib
+    _lib.require_gpu()
+    g = torch.Generator().manual_seed(m + k + n)
+    lin = torch.nn.Linear(k, n)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(n, k, generator=g) / k ** 0.5)
+        lin.weight[::7] *= 1e-3  # rows of very different magnitude: the per-row scales
+        lin.bias.copy_(torch.randn(n, generator=g))
+    x = torch.relu(torch.randn(m, k, generator=g)) * 2.0
+    dy = torch.randn(m, n, generator=g) * 1e-7
+    dy *= torch.exp2(-20.0 * torch.rand(m, 1, generator=g))  # per-sample gradient magnitudes over 20 binades
+    ref = torch.nn.Linear(k, n).double()
+    ref.load_state_dict({kk: v.double() for kk, v in lin.state_dict().items()})
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(dy.double())
+    lin = lin.cuda()
+
+    def run(fn):
+        lin.zero_grad()
+        xd = x.cuda().requires_grad_(True)
+        yd = fn(xd)
+        yd.backward(dy.cuda())
+        return [t.double().cpu() for t in (yd.detach(), xd.grad, lin.weight.grad, lin.bias.grad)]
+
+    ours = run(lambda t: _lib.linear_train(t, lin))
+    lib32 = run(lambda t: torch.nn.functional.linear(t, lin.weight, lin.bias))
+    want = [yr.detach(), xr.grad, ref.weight.grad, ref.bias.grad]
+    for name, o, l, w_ in zip(("y", "dx", "dw", "db"), ours, lib32, want):
+        e_ours, e_lib = float((o - w_).abs().max()), float((l - w_).abs().max())
+        scale = float(w_.abs().max())
+        assert e_ours <= max(4.0 * e_lib, 2e-7 * scale), (name, e_ours, e_lib, scale)
+    # the weight gradient through the same kernel (operands transposed while split; not the default — see _lib.TRAIN_DW_F16X3)
+    dw16 = _lib.weight_grad_f16x3(dy.cuda(), x.cuda()).double().cpu()
+    e16, e_lib = float((dw16 - want[2]).abs().max()), float((lib32[2] - want[2]).abs().max())
+    assert e16 <= max(4.0 * e_lib, 2e-7 * float(want[2].abs().max())), (e16, e_lib)
+    # per-ROW accuracy of the input gradient: a sample whose gradient is 2^-20 of the largest keeps its own digits
+    rows = (ours[1] - want[1]).abs().amax(dim=1) / want[1].abs().amax(dim=1).clamp_min(1e-300)
+    assert float(rows.max()) < 1e-3 and float(rows.median()) < 1e-5, (float(rows.max()), float(rows.median()))
+
+
 def test_avi_loop_end_to_end(tmp_path):
     """update (device) -> train -> save -> GBFS test -> target update, twice, with the reference's file layout and
     log lines (ctg_approx/avi.py:176-270)."""
