@@ -918,7 +918,7 @@ int dca_absmax_bits(const float* x, int64_t m, int64_t n, int64_t ld, uint32_t* 
     DCA_HIP(hipMemsetAsync(out_bits, 0, sizeof(uint32_t), (hipStream_t)stream));
     if (m == 0) return 0;
     int64_t blocks = (m * (n / 4) + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 768) blocks = 768;  // (one same-address atomic per workgroup: 4096 of them cost 50 us, whatever the matrix)
     hipLaunchKernelGGL(k_absmax_bits, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, m, n, ld, out_bits);
     return launch_check("k_absmax_bits");
 }

@@ -453,7 +453,7 @@ class Fp8Resnet(_Fp8BlockMixin, nn.Module):
         assert scaling in ("block", "tensor")
         self.scaling = scaling
         from .. import _lib
-        self.base = FastResnet(model, torch.bfloat16, gemm16="library")  # calibration path; also owns the folded bf16 weights
+        self.base = FastResnet(model, torch.bfloat16, gemm16="hip")  # calibration path / thin batches; also owns the folded bf16 weights
         if not self.base.uses_l1_kernel:
             raise ValueError("Fp8Resnet needs the layer-1 one-hot kernel (dca_l1_supported) for this geometry")
         b = self.base
@@ -501,15 +501,15 @@ class Fp8Resnet(_Fp8BlockMixin, nn.Module):
         """Per-tensor activation scales from a bf16 evaluation of (at most 4096 of) these rows."""
         from .. import _lib
         b = self.base
-        W, Bb = b.weights, b.biases
+        W, Bf = b.weights, b.biases_f32  # (the bf16 layers on the library's own kernel, like FastResnet(gemm16="hip"))
         x = _lib.l1_onehot_gemm(states_nnet[:4096].contiguous(), self.one_hot_depth, b.l1_tiles, b.l1_planes, b.l1_bias, True, b.dtype)
         amax = [float(x.float().abs().max())]
-        x = torch._addmm_activation(Bb[1], x, W[1].t())
+        x = _lib.gemm16(x.contiguous(), W[1], Bf[1], None, True)
         amax.append(float(x.float().abs().max()))
         for k in range(2, len(W), 2):
-            h = torch._addmm_activation(Bb[k], x, W[k].t())
+            h = _lib.gemm16(x, W[k], Bf[k], None, True)
             amax.append(float(h.float().abs().max()))
-            x = x.addmm_(h, W[k + 1].t()).relu_()
+            x = _lib.gemm16(h, W[k + 1], None, x, True, out=x)
             amax.append(float(x.float().abs().max()))
         self.act_scale = [max(a, 1e-6) * self.HEADROOM / self.E4M3_MAX for a in amax]
         dev = states_nnet.device
