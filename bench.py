@@ -278,7 +278,7 @@ def run_astar(args, world, rank):
                                "rows (see engine_onehot_f32 for the north star's fused one-hot); BASELINE configs[2] "
                                "geometry; %d episode(s) of %d timed steps on fresh test-set scrambles: the timed window is "
                                "iterations %d..%d of each search (--warmup %d%s: a search needs 8 iterations before every pop "
-                               "is a full batch, and the engine's first 8 iterations are rebase iterations)"
+                               "is a full batch, and the engine's first 8 iterations are rebase iterations; later every 16th is)"
                                % (args.env, B, w, args.semantics, leg["episodes"], args.steps, leg["warmup_effective"],
                                   leg["warmup_effective"] + args.steps - 1, args.warmup,
                                   " raised to %d" % leg["warmup_effective"] if leg["warmup_effective"] != args.warmup else ""),
@@ -324,11 +324,14 @@ def run_astar(args, world, rank):
             "sum_gap_ms": sum(v for k, v in gap.items() if not k.startswith("rank_")),
             "unprofiled_ms": leg["ms_per_step"] - sum(v for k, v in span.items() if not k.startswith("rank_"))
             - sum(v for k, v in gap.items() if not k.startswith("rank_")),  # iteration-to-iteration hand-over inside the graph chain
-            "launches_per_iteration": len([k for k in span if not k.startswith(("refill", "rank_", "sel_hist"))]),
-            "launches_every_8th_iteration_extra": 4,
+            # plain iteration: k_sel_collect (histogram scan fused in), k_rank, k_expand (+ CLOSED probe), k_commit; the
+            # sel_hist / sel_scan spans are phases of the rebase iterations' extra launches, averaged over all iterations
+            "launches_per_iteration": len([k for k in span if not k.startswith(("refill", "rank_", "sel_hist", "sel_scan"))]),
+            "launches_every_16th_iteration_extra": 5,
+            "graph_launches": "runs of iterations are replayed as chunk hipGraphs of up to 64 iterations (dca_engine_run_builtin)",
             "note": "k_%s is the longest launch of the iteration; it is bound by dependent memory round trips (hash-table "
                     "probe / rank chains), not by HBM bandwidth, so its fraction of the HBM peak is low by construction — "
-                    "the bandwidth-bound launch is k_expand (see engine_onehot_f32.roofline_expand)" % dom,
+                    "with the fp32 one-hot rows written by the same launch it is HBM-write bound (engine_onehot_f32.roofline_expand)" % dom,
         }
     if "roofline" in res:
         res["roofline"]["traffic_source"] = PMC_SOURCE.get(res["roofline"]["kernel"])
