@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "dca_engine_profile_builtin", "dca_engine_set_tiers", "dca_engine_debug", "dca_debug_tune", "dca_engine_status", "dca_engine_last_children", "dca_engine_solution",
     "dca_bn_workspace_bytes", "dca_bn_train_forward", "dca_bn_train_backward",
     "dca_l1_supported", "dca_l1_kpad", "dca_l1_onehot_gemm", "dca_act_split", "dca_f16x3_gemm", "dca_split_planes", "dca_f16x3_gemm_variant",
-    "dca_absmax_bits", "dca_split_planes_scaled", "dca_split_rows_scaled", "dca_split_planes_t", "dca_fill_inv_pow2",
+    "dca_absmax_bits", "dca_split_planes_scaled", "dca_split_rows_scaled", "dca_split_planes_t", "dca_fill_inv_pow2", "dca_f16x3_gemm_splitk",
     "dca_gemm16", "dca_gemm16_variant", "dca_gemm8", "dca_quant_e4m3", "dca_lightsout_next_state", "dca_lightsout_expand_fused",
     "dca_head_gemv", "dca_engine_packed_state", "dca_engine_info", "dca_gemm2_skew", "dca_f16x3_gemm_timeline", "dca_gemm8_mx", "dca_l1_onehot_gemm_mx",
     "dca_cube4_perm_table", "dca_cube4_next_state", "dca_cube4_prev_state", "dca_cube4_expand_fused",
@@ -342,7 +342,8 @@ def _pad64(k: int) -> int:
     return (k + 63) // 64 * 64
 
 
-def linear_f16x3(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], scale_a: bool) -> torch.Tensor:
+def linear_f16x3(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], scale_a: bool,
+                 amax: Optional[torch.Tensor] = None) -> torch.Tensor:
     """a [m, k] fp32 . w [n, k]^T (+ bias) -> [m, n] fp32 through dca_f16x3_gemm (fp32-accurate on the f16 matrix pipes),
     operands prepared on the spot: rows of w scaled by their own power of two (dca_split_rows_scaled), `a` by one power of two
     for the whole tensor when scale_a (gradients; dca_absmax_bits + dca_split_planes_scaled) — activations (O(1) after
@@ -354,10 +355,11 @@ def linear_f16x3(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
     assert w.shape[1] == k and k % 4 == 0 and n % 4 == 0
     kp = _pad64(k)
     dev = a.device
-    amax = None
-    if scale_a:
+    if scale_a and amax is None:  # (the backward pass takes max|dy| once for both of its GEMMs)
         amax = torch.empty(1, dtype=torch.int32, device=dev)
         check(lib().dca_absmax_bits(ptr(a), C.c_int64(m), C.c_int64(k), C.c_int64(k), ptr(amax), stream_ptr()), "dca_absmax_bits")
+    if not scale_a:
+        amax = None
     ap = torch.empty((2, m, kp), dtype=torch.float16, device=dev)
     check(lib().dca_split_planes_scaled(ptr(a), C.c_int64(m), C.c_int64(k), C.c_int64(k), ptr(amax), ptr(ap[0]), ptr(ap[1]),
                                         C.c_int64(kp), C.c_int64(kp), stream_ptr()), "dca_split_planes_scaled")
@@ -399,16 +401,26 @@ def weight_grad_f16x3(dy: torch.Tensor, x: torch.Tensor, amax_dy: Optional[torch
     w = _planes_t(x, None)
     cs = torch.empty(k, dtype=torch.float32, device=dy.device)
     check(lib().dca_fill_inv_pow2(ptr(cs), C.c_int64(k), ptr(amax_dy), stream_ptr()), "dca_fill_inv_pow2")
-    _, out = f16x3_gemm(a, w[0], w[1], cs, 1.0, None, None, False, False, True)
-    return out
+    # few output tiles (16-80 of 256 x 256 for 256 CUs), a batch-long contraction: split K so that the chip is full
+    mp = a.shape[2]
+    tiles = ((n + 255) // 256) * ((k + 255) // 256)
+    nk = mp // 64
+    splits = max(1, min(32, int(os.environ.get("DCA_DW_WGS", "256")) // max(tiles, 1), nk))
+    steps = (nk + splits - 1) // splits
+    splits = (nk + steps - 1) // steps  # every split gets at least one K-step
+    part = torch.empty((splits, n, k), dtype=torch.float32, device=dy.device)
+    check(lib().dca_f16x3_gemm_splitk(ptr(a[0]), ptr(a[1]), C.c_int64(n), int(mp), C.c_int64(mp), ptr(w[0]), ptr(w[1]), int(k),
+                                      C.c_int64(mp), ptr(cs), C.c_double(1.0), int(splits), ptr(part), C.c_int64(k), stream_ptr()),
+          "dca_f16x3_gemm_splitk")
+    return part[0] if splits == 1 else part.sum(0)
 
 
 class _LinearTrainFn(torch.autograd.Function):
     """nn.Linear for the training step (reference nnet_utils.py:53-118 runs it as the library's fp32 GEMMs): forward and input
     gradient on dca_f16x3_gemm (2/3 of the layer's flops, ~3x the library's fp32 rate at fp32 accuracy).  The weight gradient
     dy^T . x contracts over the BATCH dimension: `weight_grad_f16x3` transposes both operands while it splits them
-    (dca_split_planes_t) and is exact to the same level, but stays off by default (TRAIN_DW_F16X3: too few output tiles without
-    a split-K launch) — the library's fp32 GEMM does it."""
+    (dca_split_planes_t), runs the kernel's split-K form and is exact to the same level, but only draws with the library's
+    fp32 GEMM on time (TRAIN_DW_F16X3, off by default)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -420,10 +432,11 @@ class _LinearTrainFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = linear_f16x3(dy, weight.t().contiguous(), None, scale_a=True) if ctx.needs_input_grad[0] else None
+        amax = _absmax_bits(dy) if (ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and TRAIN_DW_F16X3)) else None
+        dx = linear_f16x3(dy, weight.t().contiguous(), None, scale_a=True, amax=amax) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = weight_grad_f16x3(dy, x) if TRAIN_DW_F16X3 else dy.t().mm(x)
+            dw = weight_grad_f16x3(dy, x, amax) if TRAIN_DW_F16X3 else dy.t().mm(x)
         db = dy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db
 
@@ -438,9 +451,9 @@ def linear_train(x: torch.Tensor, lin: "torch.nn.Linear") -> torch.Tensor:
 
 
 TRAIN_F16X3 = os.environ.get("DCA_TRAIN_GEMM", "f16x3") != "library"  # A/B switches (bench.py --workload train, tools/train_grad_check.py)
-# the weight gradient through the same kernel is correct (tests, tools/train_grad_check.py) but SLOWER at the training shapes
-# (12.3 vs 7.8 ms per step): dy^T . x has 16-80 output tiles of 256 x 256 for 256 CUs and a 10 000-long contraction — it
-# needs a split-K launch, which dca_f16x3_gemm does not have.  Off unless asked for.
+# the weight gradient through the same kernel (split-K on transposed planes) is correct (tests, tools/train_grad_check.py)
+# and a draw on time at the training shapes (7.68 vs 7.47 ms per step: faster GEMMs, but two operand transposes and the
+# sum of the partial products on top).  Off unless asked for.
 TRAIN_DW_F16X3 = os.environ.get("DCA_TRAIN_DW", "library") == "f16x3"
 
 

@@ -48,6 +48,8 @@ struct GemmArgs {
     _Float16 *oh, *ol;        // result planes [m, ldo] or null
     float* x_out;             // result fp32 [m, ldo] or null
     int* overflow;
+    int ksplit_steps;         // split-K (variant 3 only; 0 = off): workgroup (x, z) multiplies K-steps [z * ksplit_steps, +ksplit_steps)
+    int64_t split_stride;     //   ... and writes its partial result to x_out + z * split_stride
 };
 
 __device__ __forceinline__ uint32_t swz(uint32_t row, uint32_t chunk) { return row * 128u + ((chunk ^ ((row >> 1) & 7u)) << 4); }
@@ -402,6 +404,9 @@ __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v3(const GemmArgs p,
     if (mt >= nMt) return;
     const int64_t m0 = mt * HBM_T;
     const int n0 = nt * HBN_T;
+    // split-K (the training step's weight gradients: few output tiles, a batch-long contraction): this workgroup's K range
+    const int kt_base = p.ksplit_steps > 0 ? (int)blockIdx.y * p.ksplit_steps : 0;
+    const int64_t k_base = (int64_t)kt_base * HBK;
 
     // DMA map: instruction q (0 = high plane, 1 = low plane) of wave w fills local rows [w*16, +16) of that plane of a
     // half-tile slot; lane i lands on local row r = w*16 + (i >> 2), physical chunk i & 3, and fetches logical chunk
@@ -415,13 +420,13 @@ __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v3(const GemmArgs p,
             if (u < 2) {
                 int64_t gr = m0 + (r >> 6) * 128 + (u == PS_A23 ? 64 : 0) + (r & 63);
                 gr = gr < p.m ? gr : p.m - 1;
-                src[u][0] = p.ah + gr * p.lda + c * 8;
-                src[u][1] = p.al + gr * p.lda + c * 8;
+                src[u][0] = p.ah + gr * p.lda + c * 8 + k_base;
+                src[u][1] = p.al + gr * p.lda + c * 8 + k_base;
             } else {
                 int gn = n0 + (int)((r >> 5) * 64 + (u == PS_B1 ? 32 : 0) + (r & 31));
                 gn = gn < p.n ? gn : p.n - 1;
-                src[u][0] = p.wh + (int64_t)gn * p.ldw + c * 8;
-                src[u][1] = p.wl + (int64_t)gn * p.ldw + c * 8;
+                src[u][0] = p.wh + (int64_t)gn * p.ldw + c * 8 + k_base;
+                src[u][1] = p.wl + (int64_t)gn * p.ldw + c * 8 + k_base;
             }
         }
     }
@@ -484,7 +489,8 @@ __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v3(const GemmArgs p,
         __builtin_amdgcn_sched_barrier(0);                                                                              \
     } while (0)
 
-    const int nk = p.k / HBK;
+    const int nk_all = p.k / HBK;
+    const int nk = p.ksplit_steps > 0 ? (nk_all - kt_base < p.ksplit_steps ? nk_all - kt_base : p.ksplit_steps) : nk_all;
     // one K-step; N1 / N2: steps kt+1 / kt+2 exist (compile-time: the steady-state body is branch-free).  On entry:
     // issued = all of step kt and A01, B0, B1 of kt+1; landed and visible = A01, B0 of kt.  The vmcnt numbers count the
     // DMA instructions (2 per half-tile) issued AFTER the half-tile being waited for.
@@ -573,7 +579,13 @@ __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v3(const GemmArgs p,
 #undef DCA_RD_DONE_BAR
 #undef DCA_BAR
 
-    f16x3_epilogue(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h);
+    if (p.ksplit_steps > 0) {
+        GemmArgs q = p;
+        q.x_out = p.x_out + (int64_t)blockIdx.y * p.split_stride;
+        f16x3_epilogue(q, lds, acc, m0, n0, w, wm, wn, lane, l31, h);
+    } else {
+        f16x3_epilogue(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h);
+    }
     if constexpr (PROF) {
         const unsigned long long ts3 = wall_clock64();       // this wave has issued its last store
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and they have been acknowledged
@@ -852,6 +864,8 @@ int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t l
     p.ol = reinterpret_cast<_Float16*>(out_l);
     p.x_out = x_out;
     p.overflow = overflow;
+    p.ksplit_steps = 0;
+    p.split_stride = 0;
     // the LDS-DMA kernel leaves with 16-byte row segments: it needs 4-column-aligned outputs (every layer of the network
     // has them); anything else takes the register-staged kernel
     const bool wide_ok = ldo % 4 == 0 && ((uintptr_t)out_h | (uintptr_t)out_l) % 8 == 0 &&
@@ -900,6 +914,55 @@ int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t l
         hipLaunchKernelGGL(k_f16x3_gemm_v3<false>, dim3((unsigned)blocks), dim3(HTHREADS), HLDS, (hipStream_t)stream, p,
                            (unsigned long long*)nullptr);
     return launch_check("k_f16x3_gemm");
+}
+
+int dca_f16x3_gemm_splitk(const void* a_h, const void* a_l, int64_t m, int k, int64_t lda, const void* w_h, const void* w_l, int n,
+                          int64_t ldw, const float* col_scale, double alpha, int splits, float* partials, int64_t ldo,
+                          void* stream) {
+    DCA_ARG(a_h && a_l && w_h && w_l && partials && m >= 1 && n >= 1 && k >= GBK && k % GBK == 0 && splits >= 1 && splits <= 64);
+    DCA_ARG(lda >= k && ldw >= k && lda % 8 == 0 && ldw % 8 == 0 && ldo >= n && ldo % 4 == 0);
+    DCA_ARG(((uintptr_t)a_h | (uintptr_t)a_l | (uintptr_t)w_h | (uintptr_t)w_l | (uintptr_t)partials) % 16 == 0);
+    const int nk = k / HBK;
+    DCA_ARG((nk + splits - 1) / splits * (splits - 1) < nk);  // every split has at least one K-step (dca_f16x3_gemm_splitk_steps)
+    {
+        static std::atomic<uint64_t> attr_devs{0};
+        int dev = 0;
+        DCA_HIP(hipGetDevice(&dev));
+        const uint64_t bit = 1ull << (dev & 63);
+        if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
+            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f16x3_gemm_v3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, HLDS));
+            attr_devs.fetch_or(bit, std::memory_order_release);
+        }
+    }
+    GemmArgs p;
+    p.ah = reinterpret_cast<const _Float16*>(a_h);
+    p.al = reinterpret_cast<const _Float16*>(a_l);
+    p.wh = reinterpret_cast<const _Float16*>(w_h);
+    p.wl = reinterpret_cast<const _Float16*>(w_l);
+    p.col_scale = col_scale;
+    p.bias = nullptr;
+    p.skip = nullptr;
+    p.alpha = (float)alpha;
+    p.relu = 0;
+    p.m = m;
+    p.n = n;
+    p.k = k;
+    p.lda = lda;
+    p.ldw = ldw;
+    p.ldo = ldo;
+    p.oh = nullptr;
+    p.ol = nullptr;
+    p.x_out = partials;
+    p.overflow = nullptr;
+    p.ksplit_steps = (nk + splits - 1) / splits;
+    p.split_stride = m * ldo;
+    const int64_t nMt = (m + HBM_T - 1) / HBM_T;
+    const int64_t nNt = (n + HBN_T - 1) / HBN_T;
+    const int64_t blocks = ((nMt + 7) / 8) * 8 * nNt;
+    DCA_ARG(blocks <= 0x7FFFFFFFll);
+    hipLaunchKernelGGL(k_f16x3_gemm_v3<false>, dim3((unsigned)blocks, (unsigned)splits), dim3(HTHREADS), HLDS, (hipStream_t)stream, p,
+                       (unsigned long long*)nullptr);
+    return launch_check("k_f16x3_gemm (split-K)");
 }
 
 int dca_split_planes(const float* x, int64_t m, int64_t n, int64_t ld, void* out_h, void* out_l, int64_t ldo, int* overflow,

@@ -691,7 +691,10 @@ __global__ __launch_bounds__(WTHREADS, 1) void k_gemm16w(const Gemm16Args p) {
             slot = slot == WRING - 1 ? 0 : slot + 1;
             hh++;
         };
-        for (; hh + 4 < nh; adv()) phase(hh, slot, T{}, T{}, std::integral_constant<int, 24>{});
+        while (hh + 4 < nh) {
+            phase(hh, slot, T{}, T{}, std::integral_constant<int, 24>{});
+            adv();
+        }
         if (hh + 3 < nh) {
             phase(hh, slot, F{}, T{}, std::integral_constant<int, 16>{});
             adv();

@@ -368,6 +368,13 @@ int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t l
  * (bit-identical to 3: same products in the same order); 1 = 128 x 128 tiles staged through registers (the A/B reference; same
  * results to fp32 rounding). */
 int dca_f16x3_gemm_variant(int variant);
+/* Split-K form (the training step's weight gradients dW = dy^T . x: 16-80 output tiles, a batch-long contraction): `splits`
+ * workgroups per output tile, split z multiplies K-steps [z * ceil(nk / splits), ...) and writes alpha * col_scale * its partial
+ * product to partials[z] ([splits][m][ldo] fp32, 16-byte aligned); the caller adds the partials up in a fixed order (no
+ * atomics: deterministic).  splits must leave every split at least one 64-deep K-step. */
+int dca_f16x3_gemm_splitk(const void* a_h, const void* a_l, int64_t m, int k, int64_t lda, const void* w_h, const void* w_l, int n,
+                          int64_t ldw, const float* col_scale /*[n] or NULL*/, double alpha, int splits, float* partials,
+                          int64_t ldo, void* stream);
 /* variant 4 of dca_f16x3_gemm / variant 3 of dca_gemm16 (csrc/dca_gemm2.hip): 128 x 256 tiles on 4-wave workgroups, TWO of
  * them per CU, so that one workgroup's layer tail (output + residual traffic, matrix pipes idle) runs under the other's MFMAs;
  * three-stage LDS-DMA ring, one counted wait + one barrier per stage; results bit-identical to the 256 x 256 variants.

@@ -138,6 +138,35 @@ def test_cli_end_to_end(tmp_path, capsys, mode):
         assert res["num_nodes_generated"][i] == ref["nodes_generated"], (i, res["num_nodes_generated"][i], ref)
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16", "fp8", "fp8mx"])
+def test_cli_non_parity_dtypes_produce_valid_solutions(tmp_path, dt):
+    """`--nnet_dtype bf16 | fp16 | fp8 | fp8mx` through the CLI (argument parsing, network construction, engine wiring): the
+    non-parity modes promise valid solutions in the reference's result format, nothing about node counts."""
+    from deepcubea_amd.search_methods import astar
+    from oracle import c_oracle as co
+    scr = [[0, 5, 7], [1, 3, 8, 10], [4, 9, 2, 6]]
+    roots = []
+    for mv in scr:
+        s = np.arange(54, dtype=np.uint8)[None]
+        for a in mv:
+            s = co.next_state("cube3", s, a)
+        roots.append(s[0])
+    spath = str(tmp_path / "states.pkl")
+    _ref_pickle(spath, roots)
+    rdir = str(tmp_path / "res")
+    astar.main(["--states", spath, "--model", "synthetic:11", "--env", "cube3", "--weight", "0.8", "--batch_size", "200",
+                "--results_dir", rdir, "--language", "hip", "--nnet_batch_size", "4096", "--max_nodes", str(1 << 21),
+                "--nnet_dtype", dt])
+    sys.stdout = sys.__stdout__
+    res = data_utils.load_pickle(os.path.join(rdir, "results.pkl"))
+    assert len(res["solutions"]) == len(roots)
+    for root, soln, path in zip(roots, res["solutions"], res["paths"]):
+        s = root[None].copy()
+        for a in soln:
+            s = co.next_state("cube3", s, a)
+        assert co.is_solved("cube3", s)[0] and len(path) == len(soln) + 1
+
+
 def test_nnet_bf16_mode_still_solves(tmp_path):
     """bf16 heuristic = explicitly non-parity mode: only validity of the solution is asserted."""
     from deepcubea_amd import _lib
