@@ -3133,6 +3133,20 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
         commit_ticket(E, c);
         return;
     }
+    // The tiers' running key ranges as they stand at the START of the launch, one bound per lane 0-3 (FRONT min / max, BACK min /
+    // max), requested now and looked at near the end: a bound is only sent to its atomic if it beats this snapshot (a stale
+    // snapshot only means a few atomics that change nothing).  Read at the point of use, the load sat behind the other
+    // workgroups' atomics on that very line: 0.5 us of the launch.  Inline asm because the compiler would sink the load to its
+    // use; every lane issues it (lanes past 3 re-read lane 0's word: one request per wave) so that the register pair has ONE
+    // definition — joined with an initial value the compiler could copy it before the data is there — and it is the wave's
+    // oldest load: any later compiler-counted wait for a younger load implies this one has landed.
+    uint64_t rng_snap;
+    {
+        const uint32_t sl = threadIdx.x < 4 ? threadIdx.x : 0u;
+        const uint32_t sbuf = sl < 2 ? fb : bb;
+        const uint64_t* sp = (sl & 1) ? &c->rng[sbuf].kmax : &c->rng[sbuf].kmin;
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rng_snap) : "v"(sp) : "memory");
+    }
     for (int k = 0; k < kBinsPerThread; k++) lh[kBinsPerThread * threadIdx.x + k] = 0;
     const uint64_t bin_kmin = c->sel_kmin;
     const uint32_t bin_shift = c->shift;
@@ -3256,10 +3270,11 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
             uint64_t v = red[q][0];
             for (int w = 1; w < 16; w++) v = (q & 1) ? (red[q][w] > v ? red[q][w] : v) : (red[q][w] < v ? red[q][w] : v);
             const uint32_t buf = q < 2 ? fb : bb;
+            asm volatile("" : "+v"(rng_snap));  // (the snapshot is the wave's oldest load: long since back)
             if (q & 1) {
-                if (v > c->rng[buf].kmax) atomicMax((unsigned long long*)&c->rng[buf].kmax, (unsigned long long)v);
+                if (v > rng_snap) atomicMax((unsigned long long*)&c->rng[buf].kmax, (unsigned long long)v);
             } else {
-                if (v < c->rng[buf].kmin) atomicMin((unsigned long long*)&c->rng[buf].kmin, (unsigned long long)v);
+                if (v < rng_snap) atomicMin((unsigned long long*)&c->rng[buf].kmin, (unsigned long long)v);
             }
         }
     }
