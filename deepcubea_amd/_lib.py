@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "dca_engine_profile_builtin", "dca_engine_set_tiers", "dca_engine_debug", "dca_debug_tune", "dca_engine_status", "dca_engine_last_children", "dca_engine_solution",
     "dca_bn_workspace_bytes", "dca_bn_train_forward", "dca_bn_train_backward",
     "dca_l1_supported", "dca_l1_kpad", "dca_l1_onehot_gemm", "dca_act_split", "dca_f16x3_gemm", "dca_split_planes", "dca_f16x3_gemm_variant",
-    "dca_absmax_bits", "dca_split_planes_scaled", "dca_split_rows_scaled", "dca_split_planes_t", "dca_fill_inv_pow2", "dca_f16x3_gemm_splitk",
+    "dca_absmax_bits", "dca_split_planes_scaled", "dca_split_rows_scaled", "dca_split_planes_t", "dca_fill_inv_pow2", "dca_f16x3_gemm_splitk", "dca_engine_plan_chunk",
     "dca_gemm16", "dca_gemm16_variant", "dca_gemm8", "dca_quant_e4m3", "dca_lightsout_next_state", "dca_lightsout_expand_fused",
     "dca_head_gemv", "dca_engine_packed_state", "dca_engine_info", "dca_gemm2_skew", "dca_f16x3_gemm_timeline", "dca_gemm8_mx", "dca_l1_onehot_gemm_mx",
     "dca_cube4_perm_table", "dca_cube4_next_state", "dca_cube4_prev_state", "dca_cube4_expand_fused",

@@ -3946,6 +3946,38 @@ int dca_engine_commit_packed(dca_engine* e, const float* h, void* stream) {
     return enqueue_commit(e, true, s);
 }
 
+// The next chunk of a run of iterations that starts at iteration `host_iter` of the search: up to the next rebase-period
+// boundary first (so that a steady search replays whole periods, whose pattern repeats), then whole periods, kGraphChunk
+// iterations at most; during the ramp up to its end.  mask: bit i = iteration i of the chunk is a rebase iteration.
+static void plan_chunk(long host_iter, int remaining, bool single_only, int* n_out, unsigned long long* mask_out) {
+    int n = remaining;
+    if (single_only) {
+        n = 1;
+    } else if (host_iter < kRampIters) {
+        n = n < (int)(kRampIters - host_iter) ? n : (int)(kRampIters - host_iter);
+    } else {
+        const int to_boundary = (int)(kRefillPeriod - host_iter % kRefillPeriod) % kRefillPeriod;
+        if (to_boundary > 0 && n > to_boundary)
+            n = to_boundary;
+        else if (to_boundary == 0 && n > kRefillPeriod)
+            n = (n < kGraphChunk ? n : kGraphChunk) / kRefillPeriod * kRefillPeriod;
+    }
+    unsigned long long mask = 0;
+    for (int it = 0; it < n; it++)
+        if (rebase_due(host_iter + it)) mask |= 1ull << it;
+    *n_out = n;
+    *mask_out = mask;
+}
+
+/* host-only (no device): how dca_engine_run_builtin cuts a run into hipGraph chunks — exposed for the CPU tests */
+int dca_engine_plan_chunk(int64_t host_iter, int remaining, int* n, uint64_t* rebase_mask) {
+    DCA_ARG(host_iter >= 0 && remaining >= 1 && n != nullptr && rebase_mask != nullptr);
+    unsigned long long m = 0;
+    plan_chunk((long)host_iter, remaining, false, n, &m);
+    *rebase_mask = (uint64_t)m;
+    return 0;
+}
+
 int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph, void* stream) {
     DCA_ARG(e != nullptr && heur_id >= 0 && heur_id <= DCA_HEUR_MANHATTAN && iters >= 0);
     if (e->phase != 0) {
@@ -3965,23 +3997,9 @@ int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph,
         e->graph_heur = heur_id;
     }
     for (int i = 0; i < iters;) {
-        // the next chunk: up to the next period boundary first (so that a steady search replays whole periods, whose
-        // pattern repeats), then whole periods, kGraphChunk iterations at most  (knob 7: single-iteration graphs only)
-        int n = iters - i;
-        if (h_tune[7] != 0) {
-            n = 1;
-        } else if (e->host_iter < kRampIters) {
-            n = n < (int)(kRampIters - e->host_iter) ? n : (int)(kRampIters - e->host_iter);
-        } else {
-            const int to_boundary = (int)(kRefillPeriod - e->host_iter % kRefillPeriod) % kRefillPeriod;
-            if (to_boundary > 0 && n > to_boundary)
-                n = to_boundary;
-            else if (to_boundary == 0 && n > kRefillPeriod)
-                n = (n < kGraphChunk ? n : kGraphChunk) / kRefillPeriod * kRefillPeriod;
-        }
+        int n = 0;
         unsigned long long mask = 0;
-        for (int it = 0; it < n; it++)
-            if (rebase_due(e->host_iter + it)) mask |= 1ull << it;
+        plan_chunk(e->host_iter, iters - i, h_tune[7] != 0, &n, &mask);  // (knob 7: single-iteration graphs only)
         dca_engine::GraphSlot* g = nullptr;
         for (int q = 0; q < kGraphSlots && !g; q++)
             if (e->gslot[q].exec && e->gslot[q].n == n && e->gslot[q].mask == mask) g = &e->gslot[q];

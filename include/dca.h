@@ -249,6 +249,10 @@ int dca_engine_packed_state(dca_engine* e, int* instances_done, int* instances_f
  * iterations enqueued without any host sync (kernels no-op once the search is done).
  * use_graph != 0 replays one captured hipGraph per iteration instead of eager launches.           */
 int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph, void* stream);
+/* Host-only (no device needed): the chunk dca_engine_run_builtin would replay as ONE hipGraph for a run of `remaining`
+ * iterations starting at iteration `host_iter` of a search — its length n (<= 64: up to the next rebase-period boundary, then
+ * whole periods) and which of its iterations are rebase iterations (bit i of rebase_mask).  For tests of the cutting rule. */
+int dca_engine_plan_chunk(int64_t host_iter, int remaining, int* n, uint64_t* rebase_mask);
 /* Device-side profile of `iters` iterations of run_builtin (use_graph as there): every workgroup stamps the device wall
  * clock at entry and exit, per launch the host takes max(end) - min(start) as the launch's busy span and the distance to
  * the previous launch's end as the gap in front of it — measured INSIDE the replayed hipGraph, which HIP events between

@@ -349,3 +349,74 @@ def test_fp8_network_bookkeeping_on_the_host():
     assert float(torch.corrcoef(torch.stack([got, want]))[0, 1]) > 0.995
     with pytest.raises(RuntimeError):
         f8(x)  # no host path: the fp8 mode runs on the GPU only
+
+
+def test_graph_chunk_plan_covers_any_run_and_repeats_in_a_steady_search():
+    """dca_engine_run_builtin cuts a run of iterations into hipGraph chunks (host logic, no device): the chunks tile the run
+    exactly, never exceed 64 iterations, mark as rebase iterations exactly the first 8 of a search and every 16th after, are
+    cut at the period boundaries — and a steady search therefore replays the same few (length, pattern) graphs."""
+    from deepcubea_amd import _lib
+    L = _lib.lib()
+
+    def plan(start, run):
+        out, it, left = [], start, run
+        while left > 0:
+            n, mask = C.c_int(0), C.c_uint64(0)
+            _lib.check(L.dca_engine_plan_chunk(C.c_int64(it), int(left), C.byref(n), C.byref(mask)), "dca_engine_plan_chunk")
+            assert 1 <= n.value <= min(left, 64)
+            for i in range(n.value):
+                assert bool((mask.value >> i) & 1) == ((it + i) < 8 or (it + i) % 16 == 0), (it, i)
+            assert mask.value >> n.value == 0
+            out.append((n.value, mask.value))
+            it, left = it + n.value, left - n.value
+        return out
+
+    assert plan(0, 8) == [(8, 0xFF)]                       # the ramp: every iteration rebases
+    assert plan(8, 20) == [(8, 0), (12, 1)]                # the driver's window (bench.py --steps 20 --warmup 5): two graphs
+    assert plan(8, 200)[:2] == [(8, 0), (64, 0x0001000100010001)]
+    for start, run in [(0, 1), (0, 300), (5, 40), (16, 16), (17, 15), (17, 16), (31, 1), (100, 999), (8, 64)]:
+        chunks = plan(start, run)
+        assert sum(n for n, _ in chunks) == run
+        bounds = np.cumsum([start] + [n for n, _ in chunks])[1:-1]
+        # an interior cut sits on a period boundary (or ends the ramp), unless the run itself ends there
+        assert all(b % 16 == 0 or b == 8 for b in bounds), (start, run, chunks)
+    # a long steady search: after the first partial period every chunk is one of at most two shapes
+    assert len(set(plan(8, 5000)[1:-1])) == 1
+
+
+def test_power_of_two_operand_scaling_keeps_fp32_products_on_fp16_planes():
+    """The arithmetic behind `_lib.linear_train` (training-step GEMMs through dca_f16x3_gemm), restated in numpy: an operand is
+    multiplied by the power of two that brings its largest magnitude into [2^14, 2^15) (exact), split into hi = fp16(x) and
+    lo = fp16(x - hi); the product is xh*wh + xh*wl + xl*wh accumulated in fp32.  Against float64: elements within 2^-10 of the
+    largest keep all 22 bits of the split; smaller ones are held to 2^-39 of the largest (fp16 subnormal steps) — and an
+    UNSCALED split of 1e-7-sized gradients flushes them, which is why the scaling is there."""
+    rng = np.random.default_rng(5)
+
+    def pow2_scale(amax):
+        return 2.0 ** (14 - np.floor(np.log2(amax)))
+
+    def planes(x):
+        hi = x.astype(np.float16)
+        lo = (x - hi.astype(np.float32)).astype(np.float16)
+        return hi.astype(np.float64), lo.astype(np.float64)
+
+    g = (rng.standard_normal((64, 512)) * 1e-7 * np.exp2(-20.0 * rng.random((64, 1)))).astype(np.float32)  # gradients, 20 binades of rows
+    w = (rng.standard_normal((512, 128)) / 512 ** 0.5).astype(np.float32)
+    w[::7] *= 1e-3
+    sg = pow2_scale(np.abs(g).max())
+    sw = pow2_scale(np.abs(w).max(axis=0))  # one scale per output unit (the GEMM's rows of W^T)
+    gs, ws = (g * np.float32(sg)).astype(np.float32), (w * sw.astype(np.float32)[None, :]).astype(np.float32)
+    assert np.array_equal(gs.astype(np.float64), g.astype(np.float64) * sg)  # a power of two moves the exponent only
+    assert 2.0 ** 14 <= np.abs(gs).max() < 2.0 ** 15 and np.all((np.abs(ws).max(axis=0) >= 2.0 ** 14) & (np.abs(ws).max(axis=0) < 2.0 ** 15))
+    gh, gl = planes(gs)
+    wh, wl = planes(ws)
+    # per element: the split's error is at most 2^-22 of the element (both planes normal) or half a subnormal step
+    err = np.abs(gh + gl - gs.astype(np.float64))
+    assert np.all(err <= np.maximum(np.abs(gs) * 2.0 ** -21, 2.0 ** -25))
+    got = (gh @ wh + gh @ wl + gl @ wh) / sg / sw[None, :]
+    want = g.astype(np.float64) @ w.astype(np.float64)
+    rows = np.abs(got - want).max(axis=1) / np.abs(want).max(axis=1)
+    assert rows.max() < 1e-5 and np.median(rows) < 1e-6, (rows.max(), np.median(rows))
+    # the same split without the scaling: 1e-7-sized values sit in fp16's subnormal range (or below it)
+    uh, ul = planes(g)
+    assert np.abs(uh + ul - g.astype(np.float64)).max() / np.abs(g).max() > 1e-3
