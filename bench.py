@@ -18,7 +18,8 @@ Workloads:
                      against the same roofline, timed by device-side stamps inside the replayed hipGraph over one more
                      episode of the timed shape), `roofline_iteration` (SURVEY §8(d) bytes x batch / ms_per_step),
                      `engine_onehot_f32` (the same iteration with the fp32 one-hot rows fused into the expansion launch),
-                     `end_to_end_nnet` (the 14.7M-parameter ResNet heuristic in the loop: fp32 parity mode, bf16 on the
+                     `expand_1M` (BASELINE configs[1]: the gather kernel on 1M states, fp32 and bf16 one-hot rows, each
+                     with its HBM roofline), `end_to_end_nnet` (the 14.7M-parameter ResNet heuristic in the loop: fp32 parity mode, bf16 on the
                      library / on the hand-written layer kernel, reference order; synthetic weights — the reference's
                      checkpoints are not in the mount), `concurrent_instances`, `sharded_queue` (configs[3]'s path: 32
                      shipped puzzle15 scrambles per rank drawn from the shared work queue and searched to completion) and
@@ -94,6 +95,12 @@ def dist_setup(backend: str = "nccl"):
             if ndev:
                 torch.cuda.set_device(local % ndev)
             dist.init_process_group("gloo", rank=rank, world_size=world)
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+            if ndev and local_world > ndev:
+                # ranks share a GPU (a test box): the grid-wide refinement of giant tie bins needs every workgroup of a
+                # launch resident, which two processes on one device cannot promise each other
+                from deepcubea_amd import _lib
+                _lib.check(_lib.lib().dca_debug_tune(5, 1), "dca_debug_tune")
     elif ndev:
         torch.cuda.set_device(0)
     return world, rank, local
@@ -358,10 +365,21 @@ def run_astar(args, world, rank):
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": algo["expand"] / (sp * 1e-3) / 1e9 / HBM_PEAK_GBS}
         res["engine_onehot_f32"] = leg_o
-    if args.concurrent > 1 and args.env == "cube3":
+    if args.concurrent != "0" and args.env == "cube3":
         from deepcubea_amd import _lib
         sem = _lib.SEM_CPP if args.semantics == "cpp" else _lib.SEM_PY
-        res["concurrent_instances"] = run_astar_concurrent(args, world, rank, sem, _lib.HEUR_HASHU01)
+        sweep = {}
+        for k in [int(x) for x in args.concurrent.split(",") if int(x) > 1]:
+            sweep[str(k)] = run_astar_concurrent(args, world, rank, sem, _lib.HEUR_HASHU01, k)
+        if sweep:
+            best = max(sweep, key=lambda k: sweep[k]["value"])
+            res["concurrent_instances"] = dict(sweep[best], sweep={k: {"value": v["value"], "ms_per_step": v["ms_per_step"]}
+                                                                   for k, v in sweep.items()},
+                                               note="K searches share every launch (grid.y = instance): the CLI's "
+                                                    "--instances_per_gpu auto picks K from this kind of sweep "
+                                                    "(search_methods/astar.py:auto_instances)")
+    if args.expand_block:
+        res["expand_1M"] = expand_block(args, world, rank)
     if args.queue_states > 0:
         res["sharded_queue"] = run_sharded_queue(args, world, rank)
     return res
@@ -408,36 +426,42 @@ def run_sharded_queue(args, world, rank):
                    "refills, tie groups included)"}
 
 
-def run_astar_concurrent(args, world, rank, sem, hid):
+def run_astar_concurrent(args, world, rank, sem, hid, k):
     """k independent search instances per GPU stepped together by ONE engine (grid.y = instance; finer per-instance
     sharding, like the reference's AStar stepping a list of instances): a batch-20 000 iteration is launch/latency
     bound and leaves most of the chip idle.  Reported next to the single-instance `value`, never instead of it."""
     from deepcubea_amd import _lib
     from deepcubea_amd.search_methods.engine import BwasEngine
-    k, B, w = args.concurrent, args.batch_size, args.weight
-    steps, warm = args.steps, max(args.warmup, 8)
+    B, w = args.batch_size, args.weight
+    steps, warm = min(args.steps, 50), max(args.warmup, 8)  # (K node pools: episodes of at most 50 timed iterations)
     eng = BwasEngine("cube3", w, B, max_nodes=max(1 << 20, (steps + warm + 8) * B * 12 + (1 << 16)), semantics=sem,
                      num_instances=k)
-    for i in range(k):
-        root = test_root(rank * k + i)
-        eng.reset(root, i)
-        if sem == _lib.SEM_PY:
-            eng.root_commit(_lib.heuristic_builtin(hid, torch.from_numpy(root[None].copy()).cuda()), i)
-    eng.run_builtin(hid, warm, use_graph=not args.no_graph)
-    st0 = [eng.status(i) for i in range(k)]
-    barrier(world)
-    t0 = time.perf_counter()
-    eng.run_builtin(hid, steps, use_graph=not args.no_graph)
-    barrier(world)
-    wall = time.perf_counter() - t0
-    st1 = [eng.status(i) for i in range(k)]
-    expanded = sum(b["nodes_expanded"] - a["nodes_expanded"] for a, b in zip(st0, st1))
-    assert all(not s["failed"] and not s["done"] for s in st1)
-    wall = reduce_ranks(wall, world, "max")
-    total = reduce_ranks(float(expanded), world, "sum")
+    wall_sum, total, episodes = 0.0, 0.0, 0
+    while True:  # episodes of [reset K fresh scrambles, W untimed, K timed iterations] like the single-instance leg
+        for i in range(k):
+            root = test_root((rank + world * episodes) * k + i)
+            eng.reset(root, i)
+            if sem == _lib.SEM_PY:
+                eng.root_commit(_lib.heuristic_builtin(hid, torch.from_numpy(root[None].copy()).cuda()), i)
+        eng.run_builtin(hid, warm, use_graph=not args.no_graph)
+        st0 = [eng.status(i) for i in range(k)]
+        barrier(world)
+        t0 = time.perf_counter()
+        eng.run_builtin(hid, steps, use_graph=not args.no_graph)
+        barrier(world)
+        wall = time.perf_counter() - t0
+        st1 = [eng.status(i) for i in range(k)]
+        expanded = sum(b["nodes_expanded"] - a["nodes_expanded"] for a, b in zip(st0, st1))
+        assert all(not s["failed"] and not s["done"] for s in st1)
+        wall_sum += reduce_ranks(wall, world, "max")
+        total += reduce_ranks(float(expanded), world, "sum")
+        episodes += 1
+        if wall_sum >= MIN_TIMED_S / 2 or episodes >= 100:
+            break
     eng.close()
     torch.cuda.empty_cache()
-    return {"instances_per_gpu": k, "value": total / wall, "unit": "nodes expanded/s", "ms_per_step": wall / steps * 1e3,
+    return {"instances_per_gpu": k, "value": total / wall_sum, "unit": "nodes expanded/s",
+            "ms_per_step": wall_sum / (steps * episodes) * 1e3, "episodes": episodes, "steps_per_episode": steps,
             "how": "one engine, every kernel launched once for all instances (grid.y = instance)"}
 
 
@@ -660,12 +684,15 @@ def run_train(args, world, rank):
 # --------------------------------------------------------------------------------------------------
 # workload: expand (configs[1])
 # --------------------------------------------------------------------------------------------------
-def run_expand(args, world, rank):
+def run_expand(args, world, rank, onehot=None, steps=None, warmup=None):
     from deepcubea_amd import _lib
     n = args.n
+    onehot = onehot or args.onehot
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
     S = torch.from_numpy(synth_states(n, 54, rank)).cuda()
-    ohdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[args.onehot]
-    esz = 4 if args.onehot == "f32" else 2
+    ohdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[onehot]
+    esz = 4 if onehot == "f32" else 2
     out = {
         "children": torch.empty((n, 12, 54), dtype=torch.uint8, device="cuda"),
         "onehot": torch.empty((n * 12, 324), dtype=ohdt, device="cuda"),
@@ -677,10 +704,10 @@ def run_expand(args, world, rank):
     def step():
         _lib.expand_fused(e, d, S, out=out)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     barrier(world)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
     for a, b in ev:
         a.record()
@@ -690,20 +717,54 @@ def run_expand(args, world, rank):
     wall = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     wall = reduce_ranks(wall, world, "max")
-    total_exp = reduce_ranks(float(n * args.steps), world, "sum")
+    total_exp = reduce_ranks(float(n * steps), world, "sum")
     alg = 54 + 12 * 54 + 12 * 324 * esz  # 16 254 B (f32 one-hot) / 8 478 B (16-bit)
     achieved = alg * n / (kern_ms * 1e-3) / 1e9
+    del out, S
+    torch.cuda.empty_cache()
     return {
         "value": total_exp / wall,
-        "ms_per_step": wall / args.steps * 1e3,
+        "ms_per_step": wall / steps * 1e3,
         "config": {"workload": "cube3 fused next_state+one-hot(%s)+is_solved+hash kernel, %d synthetic states "
-                               "(BASELINE configs[1])" % (args.onehot, n), "states": n, "moves": 12,
-                   "onehot": args.onehot, "parallelism": "replica-per-gpu x%d" % world},
-        "roofline": {"bound": "hbm", "kernel": "expand_fused_kernel<cube3,%s>" % args.onehot, "achieved": achieved,
+                               "(BASELINE configs[1])" % (onehot, n), "states": n, "moves": 12,
+                   "onehot": onehot, "parallelism": "replica-per-gpu x%d" % world},
+        "roofline": {"bound": "hbm", "kernel": "expand_fused_kernel<cube3,%s>" % onehot, "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic("expand_fused_kernel<cube3,f32>", "cube3", n) if esz == 4 else None,
-                     "bytes_per_launch": alg * n, "kernel_ms": kern_ms},
+                     "traffic": expand_pmc_traffic(onehot, n),
+                     "traffic_source": PMC_SOURCE.get("expand_fused_kernel<cube3,%s>" % onehot),
+                     "bytes_per_launch": alg * n, "kernel_ms": kern_ms,
+                     "timing": "HIP events around each of the %d launches on the launch stream" % steps},
     }
+
+
+def expand_pmc_traffic(onehot: str, n: int):
+    """HBM bytes per launch of the gather kernel from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of
+    `bench.py --workload expand` (tools/profile_expand.sh -> profiles/rNN_expand_pmc_traffic.json), matched on the one-hot
+    type and the number of states; null when no pass at this shape is committed."""
+    for name in ("r05_expand_pmc_traffic.json",):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        e = d.get(onehot)
+        if e and e.get("states") == n:
+            PMC_SOURCE["expand_fused_kernel<cube3,%s>" % onehot] = "profiles/%s (%s)" % (name, d.get("shape", ""))
+            return e["hbm_bytes"]
+    return None
+
+
+def expand_block(args, world, rank):
+    """BASELINE configs[1] on the default line: the gather kernel — fused next_state + one-hot +
+    is_solved + hash over 1M synthetic cube3 states — with fp32 and bf16 one-hot rows, each with its HBM roofline."""
+    import copy
+    a = copy.copy(args)
+    a.n = 1_000_000
+    out = {}
+    for oh in ("f32", "bf16"):
+        r = run_expand(a, world, rank, onehot=oh, steps=20, warmup=3)
+        out[oh] = {"value": r["value"], "unit": "nodes expanded/s", "ms_per_launch": r["roofline"]["kernel_ms"],
+                   "states": a.n, "roofline": r["roofline"]}
+    return out
 
 
 def cpu_baseline_expand(seconds_budget: float = 12.0):
@@ -750,7 +811,10 @@ def main():
     ap.add_argument("--onehot", default="f32", choices=["f32", "bf16", "f16"], help="expand: one-hot element type")
     ap.add_argument("--no-onehot-leg", dest="onehot_leg", action="store_false",
                     help="astar: skip the engine leg with the fused fp32 one-hot rows")
-    ap.add_argument("--concurrent", type=int, default=4, help="astar: also time k concurrent instances per GPU (0/1 = skip)")
+    ap.add_argument("--concurrent", default="2,4,8,16",
+                    help="astar: also time K concurrent search instances per GPU for every K of this comma list (0 = skip)")
+    ap.add_argument("--no-expand-block", dest="expand_block", action="store_false",
+                    help="astar: skip the expand_1M block (BASELINE configs[1]: the gather kernel on 1M states)")
     ap.add_argument("--queue-states", type=int, default=32,
                     help="astar: puzzle15 test scrambles per rank drawn from the shared work queue and searched to completion "
                          "in the sharded leg (0 = skip)")
@@ -791,7 +855,8 @@ def main():
         "data": "synthetic",
         "config": res["config"],
     }
-    for k in ("roofline", "roofline_iteration", "per_rank_value", "engine_onehot_f32", "concurrent_instances", "sharded_queue"):
+    for k in ("roofline", "roofline_iteration", "per_rank_value", "engine_onehot_f32", "concurrent_instances", "sharded_queue",
+              "expand_1M"):
         if k in res:
             line[k] = res[k]
     if args.workload == "astar" and args.nnet_steps > 0:

@@ -398,9 +398,15 @@ def weight_grad_f16x3(dy: torch.Tensor, x: torch.Tensor, amax_dy: Optional[torch
     if amax_dy is None:
         amax_dy = _absmax_bits(dy)
     a = _planes_t(dy, amax_dy)
-    w = _planes_t(x, None)
+    # x is scaled by its own power of two as well: an activation beyond the fp16 range (nothing bounds the input of the
+    # first layer, or an un-normalised trunk) would otherwise become inf in its plane and NaN in the loss, silently
+    amax_x = _absmax_bits(x)
+    w = _planes_t(x, amax_x)
     cs = torch.empty(k, dtype=torch.float32, device=dy.device)
+    cs_x = torch.empty(k, dtype=torch.float32, device=dy.device)
     check(lib().dca_fill_inv_pow2(ptr(cs), C.c_int64(k), ptr(amax_dy), stream_ptr()), "dca_fill_inv_pow2")
+    check(lib().dca_fill_inv_pow2(ptr(cs_x), C.c_int64(k), ptr(amax_x), stream_ptr()), "dca_fill_inv_pow2")
+    cs = cs * cs_x  # (powers of two: exact)
     # few output tiles (16-80 of 256 x 256 for 256 CUs), a batch-long contraction: split K so that the chip is full
     mp = a.shape[2]
     tiles = ((n + 255) // 256) * ((k + 255) // 256)
@@ -426,7 +432,9 @@ class _LinearTrainFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return linear_f16x3(x, weight, bias, scale_a=False)
+        # scale_a: the activations get one power-of-two scale from their own magnitude, like the gradients (one extra pass
+        # over x; without it a value beyond 65504 turns into inf in its fp16 plane and the loss into NaN without a word)
+        return linear_f16x3(x, weight, bias, scale_a=True)
 
     @staticmethod
     def backward(ctx, dy):

@@ -2491,7 +2491,7 @@ constexpr int kEngTile = 16;  // parents per workgroup: a 20 000-parent batch th
 // and the parent's row was written an iteration ago — the tile rebuilds the representative from it (16 lanes per pending
 // comparison) and compares exactly.
 template <int ENV, int DIM, int OH, bool PROBE>
-__global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ engs, int heur_id) {
+__global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ engs, int heur_id, int write_nn) {
     const Eng& E = engs[blockIdx.y];
     using EV = EnvT<ENV, DIM>;
     using TL = Tile<ENV, DIM, kEngTile>;
@@ -2753,9 +2753,18 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
     }
 
     // child rows -> node pool (final place), network-input rows -> batch buffer: straight 16-byte copies of the
-    // staged tile (the gathers were paid once, in the per-child loop above)
+    // staged tile (the gathers were paid once, in the per-child loop above).  The network-input rows are written only when
+    // somebody reads them (write_nn): not for a built-in heuristic (evaluated above, from the tile) and not in dedup-first
+    // stepping (k_pack writes the kept children's rows from the pool) — 13 MB per batch-20 000 cube3 launch otherwise.
     __syncthreads();
-    {
+    if (!write_nn) {
+        const uint32_t tb = nchild * EV::D;
+        uint8_t* gpool = E.state + ((size_t)base + j0) * EV::D;
+        const uint32_t nfull = tb >> 4;
+        for (uint32_t q = threadIdx.x; q < nfull; q += kThreads)
+            reinterpret_cast<uint4*>(gpool)[q] = reinterpret_cast<const uint4*>(lst)[q];
+        for (uint32_t bq = (nfull << 4) + threadIdx.x; bq < tb; bq += kThreads) gpool[bq] = lst[bq];
+    } else {
         const uint32_t tb = nchild * EV::D;
         uint8_t* gpool = E.state + ((size_t)base + j0) * EV::D;
         uint8_t* gnn = E.nnet_in + (size_t)j0 * EV::D;
@@ -3426,41 +3435,42 @@ inline dim3 gxy(unsigned x, const dca_engine* e) { return dim3(x, (unsigned)e->K
 inline bool fuse_probe() { return h_tune[11] == 0; }
 
 template <int ENV, int DIM>
-int launch_expand_env(const dca_engine* e, int heur_id, bool want_oh, hipStream_t s) {
+int launch_expand_env(const dca_engine* e, int heur_id, bool want_oh, bool want_nn, hipStream_t s) {
     using TL = Tile<ENV, DIM, kEngTile>;
     const Eng& E = e->E[0];
     dim3 g = gxy((E.B + kEngTile - 1) / kEngTile, e), b(kThreads);
     // tile + tables, then the staged child rows (16 parents x A children x D bytes)
     const size_t lds = TL::LDS_BYTES + ((kEngTile * EnvT<ENV, DIM>::A * EnvT<ENV, DIM>::D + 15) / 16) * 16 + 64;  // (+ slack: the one-hot loop peeks one byte past the tile)
     const bool fuse = fuse_probe();
+    const int wnn = ((want_nn && heur_id < 0) || h_tune[12] != 0) ? 1 : 0;  // (knob 12: always write them, the round-4 behaviour, for A/B runs)
     if (E.onehot == nullptr || !want_oh) {
         if (fuse)
-            hipLaunchKernelGGL((k_expand<ENV, DIM, 0, true>), g, b, lds, s, e->d_engs, heur_id);
+            hipLaunchKernelGGL((k_expand<ENV, DIM, 0, true>), g, b, lds, s, e->d_engs, heur_id, wnn);
         else
-            hipLaunchKernelGGL((k_expand<ENV, DIM, 0, false>), g, b, lds, s, e->d_engs, heur_id);
+            hipLaunchKernelGGL((k_expand<ENV, DIM, 0, false>), g, b, lds, s, e->d_engs, heur_id, wnn);
     } else if (E.oh_dtype == DCA_DT_F32) {
         if (fuse)
-            hipLaunchKernelGGL((k_expand<ENV, DIM, 4, true>), g, b, lds, s, e->d_engs, heur_id);
+            hipLaunchKernelGGL((k_expand<ENV, DIM, 4, true>), g, b, lds, s, e->d_engs, heur_id, wnn);
         else
-            hipLaunchKernelGGL((k_expand<ENV, DIM, 4, false>), g, b, lds, s, e->d_engs, heur_id);
+            hipLaunchKernelGGL((k_expand<ENV, DIM, 4, false>), g, b, lds, s, e->d_engs, heur_id, wnn);
     } else {
         if (fuse)
-            hipLaunchKernelGGL((k_expand<ENV, DIM, 2, true>), g, b, lds, s, e->d_engs, heur_id);
+            hipLaunchKernelGGL((k_expand<ENV, DIM, 2, true>), g, b, lds, s, e->d_engs, heur_id, wnn);
         else
-            hipLaunchKernelGGL((k_expand<ENV, DIM, 2, false>), g, b, lds, s, e->d_engs, heur_id);
+            hipLaunchKernelGGL((k_expand<ENV, DIM, 2, false>), g, b, lds, s, e->d_engs, heur_id, wnn);
     }
     return launch_check("k_expand");
 }
 
-int launch_expand(const dca_engine* e, int heur_id, bool want_oh, hipStream_t s) {
+int launch_expand(const dca_engine* e, int heur_id, bool want_oh, bool want_nn, hipStream_t s) {
     const Eng& E = e->E[0];
-    if (E.env == DCA_ENV_CUBE3) return launch_expand_env<DCA_ENV_CUBE3, 0>(e, heur_id, want_oh, s);
-    if (E.env == DCA_ENV_LIGHTSOUT) return launch_expand_env<DCA_ENV_LIGHTSOUT, 7>(e, heur_id, want_oh, s);
+    if (E.env == DCA_ENV_CUBE3) return launch_expand_env<DCA_ENV_CUBE3, 0>(e, heur_id, want_oh, want_nn, s);
+    if (E.env == DCA_ENV_LIGHTSOUT) return launch_expand_env<DCA_ENV_LIGHTSOUT, 7>(e, heur_id, want_oh, want_nn, s);
     switch (E.dim) {
-        case 4: return launch_expand_env<DCA_ENV_NPUZZLE, 4>(e, heur_id, want_oh, s);
-        case 5: return launch_expand_env<DCA_ENV_NPUZZLE, 5>(e, heur_id, want_oh, s);
-        case 6: return launch_expand_env<DCA_ENV_NPUZZLE, 6>(e, heur_id, want_oh, s);
-        case 7: return launch_expand_env<DCA_ENV_NPUZZLE, 7>(e, heur_id, want_oh, s);
+        case 4: return launch_expand_env<DCA_ENV_NPUZZLE, 4>(e, heur_id, want_oh, want_nn, s);
+        case 5: return launch_expand_env<DCA_ENV_NPUZZLE, 5>(e, heur_id, want_oh, want_nn, s);
+        case 6: return launch_expand_env<DCA_ENV_NPUZZLE, 6>(e, heur_id, want_oh, want_nn, s);
+        case 7: return launch_expand_env<DCA_ENV_NPUZZLE, 7>(e, heur_id, want_oh, want_nn, s);
     }
     return DCA_E_BADARG;
 }
@@ -3505,7 +3515,7 @@ void launch_probe(const dca_engine* e, hipStream_t s) {
 
 constexpr size_t kRankLdsBytes = (size_t)kLdsEnt * 12;
 
-int enqueue_first_half(dca_engine* e, int heur_id, bool with_refill, hipStream_t s, bool want_oh = true) {
+int enqueue_first_half(dca_engine* e, int heur_id, bool with_refill, hipStream_t s, bool want_oh = true, bool want_nn = true) {
     const Eng* d = e->d_engs;
     if (with_refill) {
         hipLaunchKernelGGL(k_refill_hist, gxy(kScanGrid, e), dim3(256), 0, s, d);
@@ -3524,7 +3534,7 @@ int enqueue_first_half(dca_engine* e, int heur_id, bool with_refill, hipStream_t
     }
     hipLaunchKernelGGL(k_rank, gxy(kRankBlocks, e), dim3(RT), kRankLdsBytes, s, d);
     if (int rc = launch_check("select kernels")) return rc;
-    return launch_expand(e, heur_id, want_oh, s);
+    return launch_expand(e, heur_id, want_oh, want_nn, s);
 }
 
 // CLOSED check of the batch's children.  with_decide: the stand-alone keep decision of the dedup-first stepping
@@ -3793,8 +3803,12 @@ int dca_engine_reset_instance(dca_engine* e, int inst, const uint8_t* root, void
     memcpy(e->h_stage, root, (size_t)E.D);
     DCA_HIP(hipMemcpyAsync(E.state, e->h_stage, (size_t)E.D, hipMemcpyHostToDevice, s));
     {
-        // (an iteration abandoned between its two halves has claimed slots the list does not hold yet: clear everything)
-        const int force = (e->tab_cleared[inst] == 0 || e->phase != 0) ? 1 : 0;
+        // An iteration abandoned between its two halves has claimed slots that no instance's list holds yet (k_commit
+        // records them): EVERY instance of the engine took part in that launch, so every one of them owes a full clear at
+        // its next reset — not only the one that happens to be reset first.
+        if (e->phase != 0)
+            for (int i = 0; i < e->K; i++) e->tab_cleared[i] = 0;
+        const int force = e->tab_cleared[inst] == 0 ? 1 : 0;
         hipLaunchKernelGGL(k_init_table, dim3(4096), dim3(256), 0, s, E.tab, E.tab_cap, E.ctl, force);
         hipLaunchKernelGGL(k_clear_table_list, dim3(1024), dim3(256), 0, s, E.tab, E.tab_cap, E.closed_slots, E.ctl, force);
         e->tab_cleared[inst] = 1;
@@ -3907,7 +3921,7 @@ int dca_engine_pop_expand_packed(dca_engine* e, const uint8_t** nnet_in, const v
     }
     hipStream_t s = (hipStream_t)stream;
     DCA_HIP(hipMemsetAsync(e->pk_n, 0, 4 * sizeof(uint32_t), s));
-    if (int rc = enqueue_first_half(e, -1, rebase_due(e->host_iter++), s, false)) return rc;
+    if (int rc = enqueue_first_half(e, -1, rebase_due(e->host_iter++), s, false, false)) return rc;
     if (int rc = enqueue_dedup(e, true, s)) return rc;
     if (int rc = launch_pack(e, s)) return rc;
     DCA_HIP(hipMemcpyAsync(e->h_pk_n, e->pk_n, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -4145,6 +4159,10 @@ int dca_engine_set_weights(dca_engine* e, const double* weights, int n) {
 
 int dca_engine_park_instance(dca_engine* e, int inst, void* stream) {
     DCA_INST(e, inst);
+    if (e->phase != 0) {  // its k_commit would return early and never record the slots the expansion half claimed
+        set_error("dca_engine_park_instance between pop_expand and commit");
+        return DCA_E_STATE;
+    }
     const int32_t one = 1;
     DCA_HIP(hipStreamSynchronize((hipStream_t)stream));
     DCA_HIP(hipMemcpy(&e->E[inst].ctl->done, &one, sizeof(one), hipMemcpyHostToDevice));

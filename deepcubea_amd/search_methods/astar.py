@@ -93,6 +93,37 @@ def _max_nodes(args, instances: int) -> int:
     return BwasEngine.auto_max_nodes(args.env, args.batch_size, instances, sharers=sharding.ranks_on_my_device())
 
 
+# One batch-20 000 cube3 iteration is four dependent launches of 17-29 us that leave most of the 256 CUs idle: K searches
+# sharing every launch (grid.y = instance) raise the engine-only rate from 2.1e8 (K = 1) towards 4e8 nodes expanded/s
+# (bench.py `concurrent_instances.sweep`); with a network in the loop the iteration is MFMA-bound and K only matters
+# while one instance's children are fewer rows than a GEMM needs to fill the chip (_MIN_NNET_ROWS).
+_AUTO_CHILDREN_BUILTIN = 1_900_000   # children per launch the sweep stops gaining at (B 20 000 x 12 moves -> K = 8)
+_AUTO_MAX_INSTANCES = 16
+
+
+def auto_instances(args, env, n_states: int, builtin) -> int:
+    """`--instances_per_gpu`: the number given, or for `auto` the smallest K whose K x batch x moves children fill the
+    chip — _AUTO_CHILDREN_BUILTIN per launch for a built-in heuristic, _MIN_NNET_ROWS per network call otherwise —
+    never more than the states this rank can draw, _AUTO_MAX_INSTANCES, or what `--max_nodes` leaves room for.
+    Integer-valued built-ins (manhattan, zero) make every f-level ONE cost tie of up to millions of entries, which only a
+    single-instance engine refines with its whole grid: those searches stay at K = 1."""
+    v = str(getattr(args, "instances_per_gpu", "auto")).lower()
+    if v != "auto":
+        return max(1, int(v))
+    if builtin in (_lib.HEUR_MANHATTAN, _lib.HEUR_ZERO):
+        return 1
+    per = max(1, int(args.batch_size) * env.get_num_moves())
+    want = _AUTO_CHILDREN_BUILTIN if builtin is not None else _MIN_NNET_ROWS
+    world, _ = sharding.world_info()
+    mine = max(1, -(-int(n_states) // max(world, 1)))
+    K = max(1, min(-(-want // per), _AUTO_MAX_INSTANCES, mine))
+    if str(getattr(args, "max_nodes", "auto")).lower() == "auto":
+        # every instance owns a node pool: keep each at >= 2^27 ids (the published cube3 searches reach 6.1e7 nodes)
+        while K > 1 and BwasEngine.auto_max_nodes(args.env, args.batch_size, K, sharers=sharding.ranks_on_my_device()) < (1 << 27):
+            K -= 1
+    return K
+
+
 _BUILTIN = {"manhattan": _lib.HEUR_MANHATTAN, "zero": _lib.HEUR_ZERO, "hashu01": _lib.HEUR_HASHU01}
 
 
@@ -117,7 +148,7 @@ def bwas_hip(args, env, states: List) -> Tuple[List[List[int]], List[List], List
     sem = _lib.SEM_CPP if getattr(args, "semantics", "py") == "cpp" else _lib.SEM_PY
     oh = getattr(args, "_onehot_dtype", None) or {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16,
                                                    "fp8": torch.bfloat16, "fp8mx": torch.bfloat16}[getattr(args, "nnet_dtype", "fp32")]
-    K = max(1, int(getattr(args, "instances_per_gpu", 1)))
+    K = auto_instances(args, env, len(states), builtin)
     eng = BwasEngine(args.env, args.weight, args.batch_size, max_nodes=_max_nodes(args, K),
                      semantics=sem, onehot_dtype=None if (onehot_stride == 0 or builtin is not None) else oh,
                      num_instances=K, packed=onehot_stride is not None, onehot_stride=onehot_stride or None)
@@ -194,13 +225,21 @@ def build_parser() -> ArgumentParser:
     parser.add_argument('--debug', action='store_true', default=False, help="Set when debugging")
     # engine options
     parser.add_argument('--semantics', type=str, default="py", choices=["py", "cpp"],
-                        help="which reference search core to reproduce (astar.py vs parallel_weighted_astar.cpp)")
+                        help="which reference search core to reproduce.  py (default) = search_methods/astar.py, exact: "
+                             "pinned node for node to traces recorded from the reference.  cpp = "
+                             "cpp/parallel_weighted_astar.cpp, PARITY UNPINNED beyond four recorded answers of the "
+                             "reference binary (it needs boost and cannot be rebuilt here): moves, path cost and nodes "
+                             "generated match those; |OPEN|/|CLOSED| may differ < 1 %% under float32 cost ties")
     parser.add_argument('--max_nodes', type=str, default="auto",
                         help="node pool capacity (ids per search): a number, or auto = sized from the GPU's free HBM")
-    parser.add_argument('--instances_per_gpu', type=int, default=1,
-                        help="scrambles stepped together by one engine (finer per-instance sharding inside a GPU)")
+    parser.add_argument('--instances_per_gpu', type=str, default="auto",
+                        help="scrambles stepped together by one engine (finer per-instance sharding inside a GPU; "
+                             "astar.py:232-317 steps a list of instances the same way): a number, or auto = enough "
+                             "instances that every launch / network call has a chip-filling amount of work "
+                             "(auto_instances).  Results do not depend on it")
     parser.add_argument('--nnet_dtype', type=str, default="fp32", choices=["fp32", "bf16", "fp16", "fp8", "fp8mx"],
-                        help="fp32 = parity mode (1e-5); bf16/fp16 = faster, NOT parity; fp8 = OCP e4m3 operands on the "
+                        help="fp32 = parity mode: heuristic values within 1e-5 * max(1, |h|) of the reference's fp32 forward "
+                             "(1e-5 absolute of a float64 evaluation); bf16/fp16 = faster, NOT parity; fp8 = OCP e4m3 operands on the "
                              "hand-written layer kernels (dca_gemm8), one calibrated scale per activation tensor: fastest, "
                              "coarsest; fp8mx = the same with one E8M0 scale per row and 64 elements (nothing to "
                              "calibrate, ~13 %% slower)")

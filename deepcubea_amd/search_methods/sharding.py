@@ -34,6 +34,7 @@ def init_from_env(backend: str = "gloo") -> Tuple[int, int]:
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
         if not dist.is_initialized():
             dist.init_process_group(backend, rank=rank, world_size=world)
+        _count_sharers(world)
         if ranks_on_my_device() > 1:
             _share_gpu(rank)
     return world, rank
@@ -46,11 +47,35 @@ def ranks_on_my_device() -> int:
     HBM, and the grid-wide refinement of giant tie bins assumes it has the GPU to itself."""
     if not torch.cuda.is_available():
         return 1
-    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    if _sharers is not None:  # counted over the process group: (host, device) pairs equal to mine
+        return _sharers
+    if "LOCAL_WORLD_SIZE" not in os.environ:
+        # srun / mpirun set RANK, WORLD_SIZE and LOCAL_RANK only: WORLD_SIZE counts every NODE's ranks, so guessing from
+        # it would cut each pool to 1/nodes of its GPU.  Without a process group to ask, assume the deployment model.
+        return 1
+    local_world = int(os.environ["LOCAL_WORLD_SIZE"])
     ndev = max(1, torch.cuda.device_count())
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     mine = local_rank % ndev
     return max(1, sum(1 for r in range(local_world) if r % ndev == mine))
+
+
+_sharers: Optional[int] = None
+
+
+def _count_sharers(world: int) -> None:
+    """After the rendezvous: every rank says which device of which host it uses; the ranks whose answer equals mine share
+    my GPU.  Independent of the launcher's environment variables (torch.distributed.run, srun, mpirun)."""
+    global _sharers
+    if world <= 1 or not torch.cuda.is_available():
+        return
+    import socket
+    import torch.distributed as dist
+    mine = (socket.gethostname(), int(torch.cuda.current_device()), os.environ.get("HIP_VISIBLE_DEVICES", ""),
+            os.environ.get("CUDA_VISIBLE_DEVICES", ""))
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    _sharers = max(1, sum(1 for e in everyone if e == mine))
 
 
 _shared_noted = False

@@ -63,7 +63,11 @@ extern "C" {
 
 /* BWAS semantics: which reference implementation is reproduced */
 #define DCA_SEM_PY 0  /* search_methods/astar.py: f64 cost, FIFO ties, CLOSED starts empty */
-#define DCA_SEM_CPP 1 /* cpp/parallel_weighted_astar.cpp: f32 cost, root in CLOSED, deferred stop */
+#define DCA_SEM_CPP 1 /* cpp/parallel_weighted_astar.cpp: f32 cost, root in CLOSED, deferred stop.  PARITY UNPINNED beyond
+                         * four recorded answers of the reference binary (the binary needs boost and
+                         * cannot be rebuilt here): moves, path cost, iterations and nodes generated match them; |OPEN| /
+                         * |CLOSED| may differ < 1 % where equal float32 costs tie (std::priority_queue's tie order is
+                         * unspecified; this library breaks ties by push order).  DCA_SEM_PY is the exact one. */
 
 /* built-in deterministic heuristics (test / engine-only benchmarking) */
 #define DCA_HEUR_MOD97 0  /* f32( ((sum_i s_i*(7i+3)) mod 97) ) / 50f                        */
@@ -282,7 +286,9 @@ int dca_debug_tune(int knob, int value);
  * weight, stepped together; every popped node becomes a training target).
  *   set_weight_instance  weight of path cost of one instance (astar.py:196 `weights`), between iterations; set_weights: of the
  *                        first n instances at once (one synchronisation);
- *   park_instance        marks an instance finished (its launches become no-ops) until its next reset;
+ *   park_instance        marks an instance finished (its launches become no-ops) until its next reset; between iterations
+ *                        only (DCA_E_STATE between pop_expand and commit: the commit half records the CLOSED slots the
+ *                        expansion half claimed);
  *   last_popped          between pop_expand and commit: the parents of this pop, instance-major — states device u8
  *                        [K*batch, D], flags device u8 [K*batch]: 0 = nothing popped in that slot, 1 = popped, 2 = popped and
  *                        solved (Node.is_solved: its backup is 0, astar.py:38-40). */

@@ -236,19 +236,25 @@ def test_cli_instances_per_gpu(tmp_path):
     spath = str(tmp_path / "states.pkl")
     _ref_pickle(spath, roots)
     outs = {}
-    for k in (1, 3):
-        rdir = str(tmp_path / ("res%d" % k))
+    for k in (1, 3, "auto"):
+        rdir = str(tmp_path / ("res%s" % k))
         astar.main(["--states", spath, "--model", "synthetic:11", "--env", "cube3", "--weight", "0.8", "--batch_size",
                     "60", "--results_dir", rdir, "--nnet_batch_size", "1000", "--max_nodes", str(1 << 20),
                     "--instances_per_gpu", str(k), "--debug"])
         outs[k] = data_utils.load_pickle(os.path.join(rdir, "results.pkl"))
     for i, root in enumerate(roots):
-        for k in (1, 3):
+        for k in (1, 3, "auto"):
             s = root[None].copy()
             for a in outs[k]["solutions"][i]:
                 s = co.next_state("cube3", s, a)
             assert co.is_solved("cube3", s)[0]
         assert len(outs[1]["solutions"][i]) == len(outs[3]["solutions"][i]) == len(scr[i])
+    # results.pkl does not depend on K: same moves, same node counts, same paths — only the per-state
+    # wall times differ.  `auto` (the default) steps all five together here: 60 x 12 children per instance fill nothing.
+    for k in (3, "auto"):
+        assert outs[k]["solutions"] == outs[1]["solutions"]
+        assert outs[k]["num_nodes_generated"] == outs[1]["num_nodes_generated"]
+        assert [len(p) for p in outs[k]["paths"]] == [len(p) for p in outs[1]["paths"]]
 
 
 def test_cli_two_ranks_sharded(tmp_path):
@@ -289,3 +295,32 @@ def test_cli_two_ranks_sharded(tmp_path):
             s = co.next_state("cube3", s, a)
         assert co.is_solved("cube3", s)[0] and len(res["solutions"][i]) == len(scr[i])
     assert os.path.isfile(os.path.join(rdir, "output.txt"))  # rank 0's log (the states it drew from the shared queue)
+
+
+def test_bench_two_ranks_real_engine_over_gloo():
+    """The N > 1 path of bench.py with the REAL engine (tests/test_bench_cpu.py only drives `selftest`):
+    `bench.py --gpus 2` re-executes itself under torch.distributed.run, two ranks (sharing GPU 0 here, one GPU each on a
+    multi-GPU node), every rank its own search replica on its own scrambles, the timing barrier / max / sum over gloo, and
+    the sharded leg drawing 2 x 2 puzzle15 scrambles from the shared work queue.  Same launch pattern as the reference's
+    per-GPU fan-out (nnet_utils.py:292-301)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "5", "--warmup",
+           "2", "--nnet-steps", "0", "--no-cpu-baseline", "--concurrent", "0", "--queue-states", "2", "--no-expand-block"]
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-8000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]  # rank 0 prints ONE JSON line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 5 and j["scaling"] == "weak" and j["unit"] == "nodes expanded/s"
+    assert len(j["per_rank_value"]) == 2 and all(v > 0 for v in j["per_rank_value"])
+    # value = nodes expanded by BOTH ranks / max-over-ranks time: no less than either rank alone could report
+    assert j["value"] >= 0.9 * max(j["per_rank_value"]) and j["value"] <= 1.1 * sum(j["per_rank_value"])
+    assert j["config"]["parallelism"].endswith("x2")
+    q = j["sharded_queue"]
+    assert q["states"] == 4 and len(q["states_per_rank"]) == 2 and sum(q["states_per_rank"]) == 4
+    assert "roofline" in j and "engine_onehot_f32" in j

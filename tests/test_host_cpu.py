@@ -420,3 +420,23 @@ def test_power_of_two_operand_scaling_keeps_fp32_products_on_fp16_planes():
     # the same split without the scaling: 1e-7-sized values sit in fp16's subnormal range (or below it)
     uh, ul = planes(g)
     assert np.abs(uh + ul - g.astype(np.float64)).max() / np.abs(g).max() > 1e-3
+
+
+def test_auto_instances_rule():
+    """--instances_per_gpu auto (search_methods/astar.py:auto_instances): enough instances that a launch / a network call
+    has a chip-filling amount of work, bounded by the states at hand; tie-heavy integer built-ins stay single-instance."""
+    from types import SimpleNamespace as NS
+    from deepcubea_amd import _lib
+    from deepcubea_amd.search_methods import astar
+    from deepcubea_amd.utils import env_utils
+    env = env_utils.get_environment("cube3")
+    mk = lambda **kw: NS(env="cube3", max_nodes=str(1 << 20), instances_per_gpu="auto", **kw)
+    assert astar.auto_instances(mk(batch_size=20000), env, 1000, None) == 1          # 240 000 rows per call already
+    assert astar.auto_instances(mk(batch_size=10000), env, 1000, None) == 2          # train.sh's batch: two fill a GEMM
+    assert astar.auto_instances(mk(batch_size=20000), env, 1000, _lib.HEUR_HASHU01) == 8
+    assert astar.auto_instances(mk(batch_size=20000), env, 3, _lib.HEUR_HASHU01) == 3  # never more than the states at hand
+    assert astar.auto_instances(mk(batch_size=100), env, 1000, _lib.HEUR_HASHU01) == 16
+    assert astar.auto_instances(mk(batch_size=10000), env_utils.get_environment("puzzle15"), 500, _lib.HEUR_MANHATTAN) == 1
+    a = mk(batch_size=20000)
+    a.instances_per_gpu = "5"
+    assert astar.auto_instances(a, env, 1000, None) == 5

@@ -222,8 +222,31 @@ def test_heuristic_tolerance_at_trained_network_magnitudes(L, nets):
     # measured on the MI355X (r02): module 1.02e-5, folded 1.15e-5, FastResnet native fp32 1.37e-5 — the library's fp32 GEMMs
     # themselves sit AT the 1e-5 line at this magnitude — and the f16x3 parity mode 8.3e-6: the CLI default is the path
     # held to the north star's 1e-5 here; the plain fp32 paths get the fp32 noise floor of |h| = 29 (2e-5)
+    # THE TOLERANCE, stated once (also in DESIGN §2 and in `--nnet_dtype`'s help): against the
+    # REFERENCE's fp32 values a device heuristic must be within  1e-5 * max(1, |h|)  — the north star's 1e-5 where |h| is
+    # O(1), and 1e-5 relative where trained outputs reach 20-30 (one fp32 ulp of 25 is 1.9e-6; the reference's own fp32
+    # forward sits 6.3e-6 from the float64 value of its weights, so two correct fp32 evaluations can be 1.3e-5 apart).
+    # Against the float64 yardstick the CLI-default path is held to 1e-5 ABSOLUTE.  Measured values are printed and bounded
+    # by the regression guard 2e-5 absolute, so the stated tolerance is never the only thing between a change and a drift.
+    hmax = float(np.max(np.abs(y32)))
+    tol_ref = 1e-5 * max(1.0, hmax)
     for name, (e64, e32) in errs.items():
         assert e64 <= (1e-5 if "f16x3" in name else 2e-5), (name, e64)
-        assert e32 <= 2e-5, (name, e32)
+        assert e32 <= tol_ref and e32 <= 2e-5, (name, e32, tol_ref)
     f = paths["fast_f16x3 (CLI default)"]
     assert f.split and f.split_fallbacks == 0
+    # the same network the way the engine's dedup-first stepping calls it: uint8 rows through the heuristic closure, the
+    # batch padded to a multiple of 1024 rows with stale rows behind the valid ones (engine.step: `nn[:n]`) — a state's
+    # value must not depend on the padding, and stays inside the same tolerance at |h| ~ 25
+    from deepcubea_amd.utils import nnet_utils
+    hfn = nnet_utils.get_heuristic_fn_dev(f, clip_zero=False, batch_size=1 << 17)
+    rows = x.shape[0]
+    assert x.dtype == torch.uint8
+    pad = (rows + 1023) // 1024 * 1024 + 1024
+    xp = torch.randint(0, 6, (pad, x.shape[1]), dtype=torch.uint8, device="cuda")
+    xp[:rows] = x
+    hp = hfn(xp)[:rows].double().cpu().numpy().reshape(-1)
+    e64p, e32p = float(np.max(np.abs(hp - y64))), float(np.max(np.abs(hp - y32)))
+    print("engine packed path (rows padded to %d): vs float64 %.3e, vs reference fp32 %.3e (tolerance %.3e)" % (pad, e64p, e32p, tol_ref))
+    assert e64p <= 1e-5 and e32p <= tol_ref and e32p <= 2e-5
+    assert np.array_equal(hp, f(x)[:, 0].double().cpu().numpy())  # bit-identical to the unpadded evaluation

@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/${tag}_prof
 mkdir -p $out/summary
 cd /tmp; export TMPDIR=/tmp
-BENCH="python $R/bench.py --nnet-steps 0 --no-cpu-baseline --concurrent 0 --queue-states 0 --profile-iters 0 --steps $steps --warmup 5"
+BENCH="python $R/bench.py --nnet-steps 0 --no-cpu-baseline --concurrent 0 --queue-states 0 --no-expand-block --profile-iters 0 --steps $steps --warmup 5"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/astar_stats -o astar -- $BENCH > $out/astar_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/astar_fetch -o astar -- $BENCH --no-onehot-leg > $out/astar_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/astar_write -o astar -- $BENCH --no-onehot-leg > $out/astar_write.log 2>&1
