@@ -184,12 +184,14 @@ def run_selftest(args, world, rank):
 # --------------------------------------------------------------------------------------------------
 def engine_bytes(env: str, B: int, onehot_bytes: int):
     """Algorithmic bytes per launch of the iteration's kernels and SURVEY §8(d)'s per-expansion
-    figure for the whole iteration: n^2-free, each array the kernel must touch counted once."""
+    figure for the whole iteration: n^2-free, each array the kernel must touch counted once.  The colour-index
+    (network-input) rows are not part of it: with a built-in heuristic nobody reads them and the launch no longer writes
+    them (round 5; they were 13 MB of the 43.5 MB counted for this launch in round 4)."""
     D = STATE_DIM[env]
     A = 12 if env == "cube3" else 4
     depth = 6 if env == "cube3" else D
     M = B * A
-    per_child_expand = 2 * D + 8 + 4 + 4 + 4 + 1 + 1 + 1 + D * depth * onehot_bytes
+    per_child_expand = D + 8 + 4 + 4 + 4 + 1 + 1 + 1 + D * depth * onehot_bytes
     return {
         "expand": B * (D + 4 + 4) + M * per_child_expand,
         # hash 8, own row D, slot compare-and-swap 16 + 8, chain hook 8, next/slot/v0/flags 13, representative's row

@@ -193,7 +193,8 @@ def test_avi_update_one_million_puzzle48_states(L, co):
 def test_heuristic_tolerance_at_trained_network_magnitudes(L, nets):
     """|h| = 21..29: one float32 ulp is 1.9e-6, the reference's own fp32 forward is 6.3e-6 away from the float64
     evaluation of its weights.  Every device path must stay within the north star's 1e-5 of that float64 yardstick
-    (absolute), and within 2e-5 of the reference's fp32 values (two fp32-accurate evaluations can sit on opposite sides)."""
+    (absolute); the CLI-default path is ALSO within 1e-5 absolute of the reference's fp32 values (the tolerance block below
+    states what each path is held to)."""
     from deepcubea_amd.utils.pytorch_models import FastResnet, ResnetModel, fold_batchnorm
     from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
     net = ResnetModel(54, 6, 5000, 1000, 4, 1, True)
@@ -222,17 +223,21 @@ def test_heuristic_tolerance_at_trained_network_magnitudes(L, nets):
     # measured on the MI355X (r02): module 1.02e-5, folded 1.15e-5, FastResnet native fp32 1.37e-5 — the library's fp32 GEMMs
     # themselves sit AT the 1e-5 line at this magnitude — and the f16x3 parity mode 8.3e-6: the CLI default is the path
     # held to the north star's 1e-5 here; the plain fp32 paths get the fp32 noise floor of |h| = 29 (2e-5)
-    # THE TOLERANCE, stated once (also in DESIGN §2 and in `--nnet_dtype`'s help): against the
-    # REFERENCE's fp32 values a device heuristic must be within  1e-5 * max(1, |h|)  — the north star's 1e-5 where |h| is
-    # O(1), and 1e-5 relative where trained outputs reach 20-30 (one fp32 ulp of 25 is 1.9e-6; the reference's own fp32
-    # forward sits 6.3e-6 from the float64 value of its weights, so two correct fp32 evaluations can be 1.3e-5 apart).
-    # Against the float64 yardstick the CLI-default path is held to 1e-5 ABSOLUTE.  Measured values are printed and bounded
-    # by the regression guard 2e-5 absolute, so the stated tolerance is never the only thing between a change and a drift.
+    # THE TOLERANCE, stated once (also in DESIGN §2 and in `--nnet_dtype`'s help):
+    #   * the CLI-default path (f16x3 parity mode) is within the north star's 1e-5 ABSOLUTE of the REFERENCE's fp32 values
+    #     even at trained magnitudes |h| = 21..29 (measured on the MI355X, r05: 9.54e-6; one fp32 ulp of 25 is 1.9e-6), and
+    #     within 1e-5 absolute of the float64 yardstick (8.92e-6);
+    #   * the plain fp32-GEMM paths (the reference's own module on the device, BN-folded, FastResnet split=False — none of
+    #     them the default) are held to 1e-5 * max(1, |h|) relative-to-magnitude, with a 2e-5 absolute regression guard:
+    #     the library's fp32 GEMMs sit AT the 1e-5 line here (1.14e-5 .. 1.34e-5 vs the reference's fp32 values; the
+    #     reference's own fp32 forward is 6.3e-6 from float64, so two correct fp32 evaluations can be 1.3e-5 apart).
     hmax = float(np.max(np.abs(y32)))
     tol_ref = 1e-5 * max(1.0, hmax)
     for name, (e64, e32) in errs.items():
-        assert e64 <= (1e-5 if "f16x3" in name else 2e-5), (name, e64)
-        assert e32 <= tol_ref and e32 <= 2e-5, (name, e32, tol_ref)
+        if "f16x3" in name:
+            assert e64 <= 1e-5 and e32 <= 1e-5, (name, e64, e32)
+        else:
+            assert e64 <= 2e-5 and e32 <= tol_ref and e32 <= 2e-5, (name, e64, e32, tol_ref)
     f = paths["fast_f16x3 (CLI default)"]
     assert f.split and f.split_fallbacks == 0
     # the same network the way the engine's dedup-first stepping calls it: uint8 rows through the heuristic closure, the
@@ -247,6 +252,6 @@ def test_heuristic_tolerance_at_trained_network_magnitudes(L, nets):
     xp[:rows] = x
     hp = hfn(xp)[:rows].double().cpu().numpy().reshape(-1)
     e64p, e32p = float(np.max(np.abs(hp - y64))), float(np.max(np.abs(hp - y32)))
-    print("engine packed path (rows padded to %d): vs float64 %.3e, vs reference fp32 %.3e (tolerance %.3e)" % (pad, e64p, e32p, tol_ref))
-    assert e64p <= 1e-5 and e32p <= tol_ref and e32p <= 2e-5
+    print("engine packed path (rows padded to %d): vs float64 %.3e, vs reference fp32 %.3e (tolerance 1e-5 absolute)" % (pad, e64p, e32p))
+    assert e64p <= 1e-5 and e32p <= 1e-5
     assert np.array_equal(hp, f(x)[:, 0].double().cpu().numpy())  # bit-identical to the unpadded evaluation
