@@ -34,6 +34,7 @@ constexpr int QBM = 256, QBN = 256, QBK = 64, QTHREADS = 512;
 constexpr int QIMG = 256 * QBK * 2;  // bytes of one operand image (32 KB)
 constexpr int QSTAGE = 2 * QIMG;     // A, W
 constexpr int QLDS = 2 * QSTAGE;     // two stages: 128 KB
+constexpr int QLDS_PS = QLDS + 8 * 4096;  // variant 5: + a wave-private 4 KB each for the tail's piece exchange (160 KB)
 
 struct Gemm16Args {
     const uint16_t* a;   // [m, lda]
@@ -45,16 +46,24 @@ struct Gemm16Args {
     int64_t m;
     int n, k;
     int64_t lda, ldw, ldo;
+    unsigned long long* prof;  // diagnostics (variant 5): per tile {start, K loop done, tail done} on the 100 MHz wall clock
+    int skew_us;               // diagnostics (variant 5): workgroup j of an XCD starts (j % 8) * skew_us / 8 late
 };
 
 __device__ __forceinline__ uint32_t swz128(uint32_t row, uint32_t chunk) { return row * 128u + ((chunk ^ ((row >> 1) & 7u)) << 4); }
 
-__device__ __forceinline__ uint16_t to_bf16(float f) {  // round to nearest even (what torch does); NaN stays NaN
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// round to nearest even (what torch does), NaN stays NaN: gfx950's v_cvt_pk_bf16_f32 — one instruction per two values where
+// the integer sequence (NaN test, bias add, shift) took six per value: ~700 VALU instructions per wave and tile
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+    uint32_t u;
+    __builtin_memcpy(&u, &b, 4);
+    return u;
 }
+__device__ __forceinline__ uint16_t to_bf16(float f) { return (uint16_t)(pack_bf16x2(f, 0.f) & 0xFFFFu); }
 __device__ __forceinline__ float from_bf16(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 __device__ __forceinline__ uint16_t to_f16(float f) {
     const _Float16 h = (_Float16)f;
@@ -127,8 +136,13 @@ __device__ __forceinline__ void gemm16_epilogue(const Gemm16Args& p, uint8_t* ld
                     for (int e = 0; e < 4; e++) u[e] = fmaxf(u[e], 0.f);
                 }
                 uint2 ov;
-                ov.x = (uint32_t)cvt_out(u[0]) | ((uint32_t)cvt_out(u[1]) << 16);
-                ov.y = (uint32_t)cvt_out(u[2]) | ((uint32_t)cvt_out(u[3]) << 16);
+                if constexpr (BF16) {
+                    ov.x = pack_bf16x2(u[0], u[1]);
+                    ov.y = pack_bf16x2(u[2], u[3]);
+                } else {
+                    ov.x = (uint32_t)cvt_out(u[0]) | ((uint32_t)cvt_out(u[1]) << 16);
+                    ov.y = (uint32_t)cvt_out(u[2]) | ((uint32_t)cvt_out(u[3]) << 16);
+                }
                 *reinterpret_cast<uint2*>(p.out + o) = ov;
             } else {  // ragged right edge: element-wise
                 for (int e = 0; e < 4 && colg + e < p.n; e++) {
@@ -719,11 +733,367 @@ __global__ __launch_bounds__(WTHREADS, 1) void k_gemm16w(const Gemm16Args p) {
     gemm16_epilogue<BF16, 4>(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Variant 5 (round 5): the ping-pong K loop of variant 2 inside a PERSISTENT workgroup with a register-only layer tail.
+// What the profile of variant 2 said (profiles/r04_gemm_timeline.txt): per 256 x 256 tile at K = 1024 the K loop takes
+// ~26 us and everything around it ~15 — 3.6 us until the first operands have landed, 10-12 us of tail (accumulators through
+// LDS, skip rows in four dependent round trips, stores), 1.6 us until the CU's next workgroup starts.  None of that needs the
+// matrix pipe, and none of it overlapped with anything.  Three changes, same products in the same order:
+//   * OPERAND ROLES SWAPPED in the MFMA: the weight fragment is the instruction's A operand, the activation fragment its B
+//     operand, so D[i][j] has j = lane & 31 = the activation ROW and i (the register index) = the output column.  A lane
+//     then owns a piece of ONE output row — and which physical weight row feeds MFMA row i is free to choose (it is only
+//     the source address of an LDS-DMA piece): sigma() below makes a lane's 8 consecutive accumulator registers 8
+//     CONSECUTIVE output columns (16 bytes of bf16) and the two lane halves adjacent.  The whole tail — bias, skip, ReLU,
+//     rounding, store — runs on registers: one 16-byte skip load and one 16-byte store per 8 values, no LDS, no barrier.
+//   * PERSISTENT: gridDim = CUs; a workgroup walks tiles slot = j + t * (grid / 8) of its XCD (same XCD mapping as before:
+//     the N tiles of one M tile share that XCD's L2).  No per-tile launch gap, no re-derivation of the maps.
+//   * CROSS-TILE PREFETCH: the tail does not touch the LDS, so the first seven half-tiles of the NEXT tile are requested
+//     before the tail starts and land under it; the next K loop starts with its operands in place.
+// vmcnt bookkeeping: loads and stores retire in issue order (one counter, gfx9 family), so the counted waits of the K loop
+// stay correct with the tail's loads / stores in the queue: everything older than the N youngest entries has completed, and
+// the N youngest are always DMA pieces of the K loop itself (N <= 10 < pieces issued since the tail).  They are merely a
+// little stricter than necessary in a tile's first phases (they also wait for the tail's stores to be acknowledged).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int sigma16(int jn, int i) {
+    // MFMA row i = r + 8 q + 4 h (r = reg & 3, q = reg >> 2, h = lane half)  ->  column inside the wave's 64:
+    // (jn * 2 + (q >> 1)) * 16 + h * 8 + (q & 1) * 4 + r
+    const int r = i & 3, hh = (i >> 2) & 1, q = i >> 3;
+    return (jn * 2 + (q >> 1)) * 16 + hh * 8 + (q & 1) * 4 + r;
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(QTHREADS, 2) void k_gemm16ps(const Gemm16Args p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    using frag_t = typename std::conditional<BF16, b16x8, h16x8>::type;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, h = lane >> 5;
+    const int wm = w >> 2, wn = w & 3;
+    const int nNt = (p.n + QBN - 1) / QBN;
+    const int64_t nMt = (p.m + QBM - 1) / QBM;
+    const int64_t slots = ((nMt + 7) / 8) * nNt;  // per XCD
+    const int xcd = (int)(blockIdx.x & 7);
+    const int64_t stride = gridDim.x >> 3;
+    const int nk = p.k / QBK;
+
+    const uint16_t* src[4][2];
+    auto set_src = [&](int64_t m0, int n0) {
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const uint32_t r = (uint32_t)((q * 8 + w) * 8 + (lane >> 3));
+                const uint32_t c = (uint32_t)(lane & 7) ^ ((r >> 1) & 7u);
+                if (u < 2) {
+                    int64_t gr = m0 + (r >> 6) * 128 + (u == PS_A23 ? 64 : 0) + (r & 63);
+                    gr = gr < p.m ? gr : p.m - 1;
+                    src[u][q] = p.a + gr * p.lda + c * 8;
+                } else {
+                    int gn = n0 + (int)(r >> 5) * 64 + sigma16(u == PS_B1 ? 1 : 0, (int)(r & 31));
+                    gn = gn < p.n ? gn : p.n - 1;
+                    src[u][q] = p.w + (int64_t)gn * p.ldw + c * 8;
+                }
+            }
+    };
+    auto issue = [&](int u, int buf, int k0) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            uint8_t* dst = lds + buf * PBUF + u * PSLOT + (q * 8 + w) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[u][q] + k0),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+    auto prologue = [&]() {  // all of K-tile 0 and A01, B0, B1 of K-tile 1
+        issue(PS_A01, 0, 0);
+        issue(PS_B0, 0, 0);
+        issue(PS_B1, 0, 0);
+        issue(PS_A23, 0, 0);
+        if (nk > 1) {
+            issue(PS_A01, 1, QBK);
+            issue(PS_B0, 1, QBK);
+            issue(PS_B1, 1, QBK);
+        }
+    };
+    auto tile_of = [&](int64_t slot, int64_t& m0, int& n0) -> bool {
+        if (slot >= slots) return false;
+        const int64_t mt = (slot / nNt) * 8 + xcd;
+        m0 = mt * QBM;
+        n0 = (int)(slot % nNt) * QBN;
+        return true;
+    };
+    // first tile of this workgroup with rows inside the matrix (slots of an XCD whose M tile lies past the edge are skipped)
+    auto next_tile = [&](int64_t& slot, int64_t& m0, int& n0) -> bool {
+        for (;; slot += stride) {
+            if (!tile_of(slot, m0, n0)) return false;
+            if (m0 < p.m) return true;
+        }
+    };
+
+    uint32_t foff[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) foff[s] = swz128((uint32_t)l31, 2u * s + (uint32_t)h);
+    const uint32_t a_row0 = (uint32_t)wm * 64u * 128u;
+    const uint32_t b_row0 = (uint32_t)wn * 32u * 128u;
+
+    f32x16 acc[4][2];
+    frag_t av[2][4], wv0[4], wv1[4];
+    auto read_a = [&](const uint8_t* base, int u) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ii++)
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+                av[ii][s] = *reinterpret_cast<const frag_t*>(base + u * PSLOT + a_row0 + ii * 4096 + foff[s]);
+    };
+    auto read_b = [&](const uint8_t* base, int u, frag_t (&wv)[4]) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) wv[s] = *reinterpret_cast<const frag_t*>(base + u * PSLOT + b_row0 + foff[s]);
+    };
+    // (weight fragment = A operand, activation fragment = B operand: see the header)
+#define DCA_MMA8(I0, JN, WV)                                                                                          \
+    do {                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        __builtin_amdgcn_s_setprio(1);                                                                                \
+        _Pragma("unroll") for (int s = 0; s < 4; s++) _Pragma("unroll") for (int ii = 0; ii < 2; ii++) {              \
+            if constexpr (BF16)                                                                                       \
+                acc[(I0) + ii][JN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WV[s], av[ii][s], acc[(I0) + ii][JN], 0, 0, 0); \
+            else                                                                                                      \
+                acc[(I0) + ii][JN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WV[s], av[ii][s], acc[(I0) + ii][JN], 0, 0, 0);  \
+        }                                                                                                             \
+        __builtin_amdgcn_s_setprio(0);                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+    } while (0)
+#define DCA_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+    auto tile = [&](int kt, auto n1c, auto n2c) {  // one K-tile: identical to variant 2's
+        constexpr bool N1 = decltype(n1c)::value, N2 = decltype(n2c)::value;
+        const int b = kt & 1;
+        const uint8_t* base = lds + b * PBUF;
+        read_b(base, PS_B0, wv0);
+        read_a(base, PS_A01);
+        if constexpr (N1) {
+            issue(PS_A23, b ^ 1, (kt + 1) * QBK);
+            DCA_VMCNT(10);
+        } else {
+            DCA_VMCNT(2);
+        }
+        DCA_RD_DONE_BAR();
+        DCA_MMA8(0, 0, wv0);
+        DCA_BAR();
+        read_b(base, PS_B1, wv1);
+        if constexpr (N2) {
+            issue(PS_A01, b, (kt + 2) * QBK);
+            DCA_VMCNT(10);
+        } else if constexpr (N1) {
+            DCA_VMCNT(8);
+        } else {
+            DCA_VMCNT(0);
+        }
+        DCA_RD_DONE_BAR();
+        DCA_MMA8(0, 1, wv1);
+        DCA_BAR();
+        read_a(base, PS_A23);
+        if constexpr (N2) issue(PS_B0, b, (kt + 2) * QBK);
+        DCA_RD_DONE_BAR();
+        DCA_MMA8(2, 1, wv1);
+        DCA_BAR();
+        if constexpr (N2) {
+            issue(PS_B1, b, (kt + 2) * QBK);
+            DCA_VMCNT(10);
+        } else if constexpr (N1) {
+            DCA_VMCNT(4);
+        }
+        DCA_RD_DONE_BAR();
+        DCA_MMA8(2, 0, wv0);
+        DCA_BAR();
+    };
+
+    auto cvt_in = [](uint32_t b) { return BF16 ? from_bf16((uint16_t)b) : from_f16((uint16_t)b); };
+    auto cvt_out = [](float f) { return (uint32_t)(BF16 ? to_bf16(f) : to_f16(f)); };
+    const bool al16 = ((p.ldo & 7) == 0) && (((uintptr_t)p.out | (uintptr_t)p.skip) & 15) == 0;
+    const bool bal16 = ((uintptr_t)p.bias & 15) == 0;
+
+    int64_t slot = blockIdx.x >> 3, m0 = 0;
+    int n0 = 0;
+    bool have = next_tile(slot, m0, n0);
+    if (!have) return;
+    if (p.skew_us > 0) {  // (diagnostic: take the CUs' tiles out of lockstep)
+        const unsigned long long t0 = wall_clock64();
+        const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 7) * (unsigned long long)p.skew_us * 100ull / 8ull;
+        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
+    set_src(m0, n0);
+    prologue();
+    int64_t tcount = 0;
+    while (have) {
+        if (p.prof && t == 0) p.prof[(tcount * gridDim.x + blockIdx.x) * 4 + 0] = wall_clock64();
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int jn = 0; jn < 2; jn++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[i][jn][e] = 0.f;
+        // A01, B0 of K-tile 0 have landed (everything older than the 10 youngest pieces: B1 A23 of tile 0, A01 B0 B1 of tile 1)
+        if (nk > 1)
+            DCA_VMCNT(10);
+        else
+            DCA_VMCNT(4);
+        DCA_BAR();
+        if (wm == 1) DCA_BAR();  // the second wave row runs one barrier behind the first
+        {
+            int kt = 0;
+            for (; kt + 2 < nk; kt++) tile(kt, std::true_type{}, std::true_type{});
+            if (kt + 1 < nk) {
+                tile(kt, std::true_type{}, std::false_type{});
+                kt++;
+            }
+            tile(kt, std::false_type{}, std::false_type{});
+        }
+        if (wm == 0) DCA_BAR();  // ... and the first waits for it here: nobody reads the operand slots any more
+        if (p.prof && t == 0) p.prof[(tcount * gridDim.x + blockIdx.x) * 4 + 1] = wall_clock64();
+        const int64_t cm0 = m0;
+        const int cn0 = n0;
+        // bias of this lane's 4 x 8 columns: requested first, so that it lands under the address work and DMA issue below
+        float bv[4][8];
+        {
+            const int colb = cn0 + wn * 64 + h * 8;
+#pragma unroll
+            for (int X = 0; X < 4; X++) {
+                const int col = colb + X * 16;
+                if (p.bias && col + 7 < p.n && bal16) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col), b1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
+                    bv[X][0] = b0.x, bv[X][1] = b0.y, bv[X][2] = b0.z, bv[X][3] = b0.w;
+                    bv[X][4] = b1.x, bv[X][5] = b1.y, bv[X][6] = b1.z, bv[X][7] = b1.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) bv[X][e] = (p.bias && col + e < p.n) ? p.bias[col + e] : 0.f;
+                }
+            }
+        }
+        slot += stride;
+        have = next_tile(slot, m0, n0);
+        if (have) {
+            set_src(m0, n0);
+            prologue();  // lands under the tail below
+        }
+        // ---- the layer tail.  Lane (l31, h), accumulator block (i, jn), registers 8 x .. 8 x + 7 are 8 consecutive columns
+        //      (one 16-byte piece c16 = X * 2 + h, X = jn * 2 + x, of the wave's 128-byte row segment) of row
+        //      cm0 + wm * 128 + i * 32 + l31.  A store with one ROW per lane costs a CU 3.5 us per 128 KB tile, one with 8
+        //      lanes per 128-byte row segment 1.0 (tools/store_pattern_probe.hip), so the packed pieces of a 32-row block
+        //      change hands inside the wave first — through a wave-private 4 KB of the LDS that the operand slots do not
+        //      use (no barrier, no conflict with the prefetch above): lane (4 g + x, h) ends up with piece x * 2 + h of rows
+        //      4 g .. 4 g + 3.  Skip rows come in by the same route, the other way round.
+        uint8_t* tl = lds + 2 * PBUF + w * 4096;
+        const int tg = l31 >> 2, tx = l31 & 3;
+        auto tl_addr = [&](int row, int c16) { return tl + row * 128 + ((c16 ^ (row & 7)) << 4); };
+        const int colw = cn0 + wn * 64;
+        auto load_skip = [&](int i, u32x4 (&sk)[4]) {  // coalesced: piece tx * 2 + h of rows 4 tg + j
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int64_t r = cm0 + wm * 128 + i * 32 + 4 * tg + j;
+                const int col = colw + (tx * 2 + h) * 8;
+                sk[j] = u32x4{0u, 0u, 0u, 0u};
+                if (p.skip && r < p.m && col < p.n) {
+                    const uint16_t* sp = p.skip + r * p.ldo + col;
+                    if (col + 7 < p.n) {
+                        if (al16) {
+                            sk[j] = *reinterpret_cast<const u32x4*>(sp);
+                        } else {
+                            const uint2 lo = *reinterpret_cast<const uint2*>(sp), hi = *reinterpret_cast<const uint2*>(sp + 4);
+                            sk[j] = u32x4{lo.x, lo.y, hi.x, hi.y};
+                        }
+                    } else {  // ragged right edge: element-wise
+                        uint32_t e16[8];
+#pragma unroll
+                        for (int e = 0; e < 8; e++) e16[e] = col + e < p.n ? (uint32_t)sp[e] : 0u;
+                        sk[j] = u32x4{e16[0] | (e16[1] << 16), e16[2] | (e16[3] << 16), e16[4] | (e16[5] << 16), e16[6] | (e16[7] << 16)};
+                    }
+                }
+            }
+        };
+        auto rows32 = [&](auto ic, const u32x4 (&sk)[4]) {
+            constexpr int i = decltype(ic)::value;
+            u32x4 mine[4];  // this lane's own row: skip pieces X * 2 + h
+            if (p.skip) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) *reinterpret_cast<u32x4*>(tl_addr(4 * tg + j, tx * 2 + h)) = sk[j];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int X = 0; X < 4; X++) mine[X] = *reinterpret_cast<const u32x4*>(tl_addr(l31, X * 2 + h));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+#pragma unroll
+            for (int X = 0; X < 4; X++) {
+                float u[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) u[e] = acc[i][X >> 1][8 * (X & 1) + e] + bv[X][e];
+                if (p.skip) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) u[e] += cvt_in((mine[X][e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) u[e] = fmaxf(u[e], 0.f);
+                }
+                u32x4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if constexpr (BF16)
+                        ov[e] = pack_bf16x2(u[2 * e], u[2 * e + 1]);
+                    else
+                        ov[e] = cvt_out(u[2 * e]) | (cvt_out(u[2 * e + 1]) << 16);
+                }
+                *reinterpret_cast<u32x4*>(tl_addr(l31, X * 2 + h)) = ov;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            u32x4 q[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) q[j] = *reinterpret_cast<const u32x4*>(tl_addr(4 * tg + j, tx * 2 + h));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the slice is rewritten by the next block)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int64_t r = cm0 + wm * 128 + i * 32 + 4 * tg + j;
+                const int col = colw + (tx * 2 + h) * 8;
+                if (r >= p.m || col >= p.n) continue;
+                uint16_t* op = p.out + r * p.ldo + col;
+                if (col + 7 < p.n) {
+                    if (al16) {
+                        *reinterpret_cast<u32x4*>(op) = q[j];
+                    } else {
+                        *reinterpret_cast<uint2*>(op) = make_uint2(q[j][0], q[j][1]);
+                        *reinterpret_cast<uint2*>(op + 4) = make_uint2(q[j][2], q[j][3]);
+                    }
+                } else {  // ragged right edge: element-wise
+                    for (int e = 0; e < 8 && col + e < p.n; e++) op[e] = (uint16_t)((q[j][e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+                }
+            }
+        };
+        {   // skip rows of block i + 1 are in flight while block i is worked on
+            u32x4 ska[4], skb[4];
+            load_skip(0, ska);
+            load_skip(1, skb);
+            rows32(std::integral_constant<int, 0>{}, ska);
+            load_skip(2, ska);
+            rows32(std::integral_constant<int, 1>{}, skb);
+            load_skip(3, skb);
+            rows32(std::integral_constant<int, 2>{}, ska);
+            rows32(std::integral_constant<int, 3>{}, skb);
+        }
+        if (p.prof && t == 0) {
+            p.prof[(tcount * gridDim.x + blockIdx.x) * 4 + 2] = wall_clock64();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            p.prof[(tcount * gridDim.x + blockIdx.x) * 4 + 3] = wall_clock64();
+        }
+        tcount++;
+    }
+#undef DCA_VMCNT
+#undef DCA_MMA8
+}
+
 }  // namespace dca
 
 using namespace dca;
 
 static int g_gemm16_variant = 2;
+static unsigned long long* g_gemm16_prof = nullptr;
+static int g_gemm16_skew_us = 0;
 
 namespace dca {
 // csrc/dca_gemm2.hip: the two-workgroups-per-CU kernels (variant 3 here, variant 4 of dca_f16x3_gemm)
@@ -750,8 +1120,16 @@ extern "C" {
 
 /* tuning / test hook: 1 = two K-step stages, one drain + barrier per K-step; 2 (default) = the 8-phase ping-pong schedule;
  * 3 = 128 x 256 tiles, two workgroups per CU (dca_gemm2.hip); 4 = four waves x 128 x 128, ring of five K-tiles of 32 */
+/* diagnostics of variant 5: knob 1 = device buffer for per-tile wall-clock stamps (4 x u64 per tile and workgroup; 0 = off),
+ * knob 2 = start skew in microseconds */
+int dca_gemm16_debug(int knob, long long value) {
+    if (knob == 1) g_gemm16_prof = reinterpret_cast<unsigned long long*>((uintptr_t)value);
+    if (knob == 2) g_gemm16_skew_us = (int)value;
+    return 0;
+}
+
 int dca_gemm16_variant(int v) {
-    DCA_ARG(v >= 1 && v <= 4);
+    DCA_ARG(v >= 1 && v <= 5);
     g_gemm16_variant = v;
     return 0;
 }
@@ -803,6 +1181,8 @@ int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int 
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16p<true>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16p<false>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
+            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16ps<true>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS_PS));
+            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16ps<false>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS_PS));
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16w<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WLDS));
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16w<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WLDS));
             attr_devs.fetch_or(bit, std::memory_order_release);
@@ -821,6 +1201,8 @@ int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int 
     p.lda = lda;
     p.ldw = ldw;
     p.ldo = ldo;
+    p.prof = g_gemm16_prof;
+    p.skew_us = g_gemm16_skew_us;
     const int64_t nMt = (m + QBM - 1) / QBM;
     const int64_t nNt = (n + QBN - 1) / QBN;
     const int64_t blocks = ((nMt + 7) / 8) * 8 * nNt;
@@ -829,7 +1211,21 @@ int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int 
         return DCA_E_BADARG;
     }
     const dim3 grid((unsigned)blocks), block(QTHREADS);
-    if (g_gemm16_variant == 4) {  // four waves x (128 x 128): K-tiles of 32
+    if (g_gemm16_variant == 5) {  // persistent: one workgroup per CU (a multiple of 8: the XCD mapping), never more than tiles
+        static int cus = 0;
+        if (cus == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            DCA_HIP(hipGetDevice(&dev));
+            DCA_HIP(hipGetDeviceProperties(&prop, dev));
+            cus = prop.multiProcessorCount > 8 ? (prop.multiProcessorCount / 8) * 8 : 8;
+        }
+        const unsigned g = (unsigned)(blocks < cus ? blocks : cus);
+        if (dtype == DCA_DT_BF16)
+            hipLaunchKernelGGL(k_gemm16ps<true>, dim3(g), block, QLDS_PS, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL(k_gemm16ps<false>, dim3(g), block, QLDS_PS, (hipStream_t)stream, p);
+    } else if (g_gemm16_variant == 4) {  // four waves x (128 x 128): K-tiles of 32
         DCA_ARG(k % WBK == 0);
         if (dtype == DCA_DT_BF16)
             hipLaunchKernelGGL(k_gemm16w<true>, grid, dim3(WTHREADS), WLDS, (hipStream_t)stream, p);

@@ -97,7 +97,7 @@ def _max_nodes(args, instances: int) -> int:
 # sharing every launch (grid.y = instance) raise the engine-only rate from 2.1e8 (K = 1) towards 4e8 nodes expanded/s
 # (bench.py `concurrent_instances.sweep`); with a network in the loop the iteration is MFMA-bound and K only matters
 # while one instance's children are fewer rows than a GEMM needs to fill the chip (_MIN_NNET_ROWS).
-_AUTO_CHILDREN_BUILTIN = 1_900_000   # children per launch the sweep stops gaining at (B 20 000 x 12 moves -> K = 8)
+_AUTO_CHILDREN_BUILTIN = 3_800_000   # children per launch the sweep still gains up to (B 20 000 x 12 moves -> K = 16: 4.0e8)
 _AUTO_MAX_INSTANCES = 16
 
 

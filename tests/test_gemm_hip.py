@@ -157,7 +157,7 @@ def test_f16x3_schedules_agree_bit_for_bit_under_load():
 # ---------------------------------------------------------------------------------------------------------------------
 # dca_gemm16 (csrc/dca_gemm16.hip): the same layer in the non-parity 16-bit modes, tail in the epilogue
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[1, 2, 3, 4], ids=["two_stage", "eight_phase", "two_wg_per_cu_128x256", "four_waves_128x128"])
+@pytest.fixture(params=[1, 2, 3, 4, 5], ids=["two_stage", "eight_phase", "two_wg_per_cu_128x256", "four_waves_128x128", "persistent"])
 def variant16(request):
     from deepcubea_amd import _lib
     _lib.gemm16_variant(request.param)
@@ -228,7 +228,7 @@ def test_gemm16_schedules_agree_bit_for_bit_under_load(dt):
         _lib.gemm16_variant(1)
         want = _lib.gemm16(a, w, bias, None, True)
         try:
-            for v in (2, 3, 4):  # 3: 128 x 256 tiles, two workgroups per CU (csrc/dca_gemm2.hip); 4: four waves x 128 x 128, ring of five K-tiles of 32
+            for v in (2, 3, 4, 5):  # 5: persistent workgroups, register-only tail; 3: 128 x 256 tiles, two workgroups per CU (csrc/dca_gemm2.hip); 4: four waves x 128 x 128, ring of five K-tiles of 32
                 _lib.gemm16_variant(v)
                 for _ in range(reps):
                     got = _lib.gemm16(a, w, bias, None, True)
@@ -237,6 +237,9 @@ def test_gemm16_schedules_agree_bit_for_bit_under_load(dt):
             _lib.gemm16_variant(1)
             want = _lib.gemm16(a, w, None, skip, True)
             _lib.gemm16_variant(3)
+            got = _lib.gemm16(a, w, None, skip, True)
+            assert torch.equal(got, want)
+            _lib.gemm16_variant(5)
             got = _lib.gemm16(a, w, None, skip, True)
             assert torch.equal(got, want)
             got = _lib.gemm16(a, w, None, skip, True, out=skip)  # in place: the residual stream

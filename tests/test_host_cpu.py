@@ -433,7 +433,7 @@ def test_auto_instances_rule():
     mk = lambda **kw: NS(env="cube3", max_nodes=str(1 << 20), instances_per_gpu="auto", **kw)
     assert astar.auto_instances(mk(batch_size=20000), env, 1000, None) == 1          # 240 000 rows per call already
     assert astar.auto_instances(mk(batch_size=10000), env, 1000, None) == 2          # train.sh's batch: two fill a GEMM
-    assert astar.auto_instances(mk(batch_size=20000), env, 1000, _lib.HEUR_HASHU01) == 8
+    assert astar.auto_instances(mk(batch_size=20000), env, 1000, _lib.HEUR_HASHU01) == 16
     assert astar.auto_instances(mk(batch_size=20000), env, 3, _lib.HEUR_HASHU01) == 3  # never more than the states at hand
     assert astar.auto_instances(mk(batch_size=100), env, 1000, _lib.HEUR_HASHU01) == 16
     assert astar.auto_instances(mk(batch_size=10000), env_utils.get_environment("puzzle15"), 500, _lib.HEUR_MANHATTAN) == 1

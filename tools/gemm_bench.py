@@ -116,10 +116,8 @@ for dt, nm in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")) if only in (""
                 return _lib.gemm16(x, w, None, out, True, out=out) if with_skip else _lib.gemm16(x, w, b32, None, True)
             return run
 
-        res = interleaved([("hip4w_bias_relu", hip16(4, False)), ("hip4w_skip_relu", hip16(4, True)),
-                           ("hip2_bias_relu", hip16(3, False)), ("hip2_skip_relu", hip16(3, True)),
+        res = interleaved([("hip_persistent_bias_relu", hip16(5, False)), ("hip_persistent_skip_relu", hip16(5, True)),
                            ("hip_bias_relu", hip16(2, False)), ("hip_skip_relu", hip16(2, True)),
-                           ("hip_two_stage_bias_relu", hip16(1, False)), ("hip_two_stage_skip_relu", hip16(1, True)),
                            ("library_bias_relu", lambda: torch._addmm_activation(bdt, x, w.t())),
                            ("library_skip_relu", lambda: out2.addmm_(x, w.t()).relu_())])
         _lib.gemm16_variant(2)
