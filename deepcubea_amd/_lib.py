@@ -38,9 +38,9 @@ ABI_SYMBOLS = [
     "dca_engine_profile_builtin", "dca_engine_set_tiers", "dca_engine_debug", "dca_debug_tune", "dca_engine_status", "dca_engine_last_children", "dca_engine_solution",
     "dca_bn_workspace_bytes", "dca_bn_train_forward", "dca_bn_train_backward",
     "dca_l1_supported", "dca_l1_kpad", "dca_l1_onehot_gemm", "dca_act_split", "dca_f16x3_gemm", "dca_split_planes", "dca_f16x3_gemm_variant",
-    "dca_absmax_bits", "dca_split_planes_scaled", "dca_split_rows_scaled", "dca_split_planes_t", "dca_fill_inv_pow2", "dca_f16x3_gemm_splitk", "dca_engine_plan_chunk",
+    "dca_absmax_bits", "dca_split_planes_scaled", "dca_split_rows_scaled", "dca_fill_inv_pow2", "dca_engine_plan_chunk",
     "dca_gemm16", "dca_gemm16_variant", "dca_gemm8", "dca_quant_e4m3", "dca_lightsout_next_state", "dca_lightsout_expand_fused",
-    "dca_head_gemv", "dca_engine_packed_state", "dca_engine_info", "dca_gemm2_skew", "dca_f16x3_gemm_timeline", "dca_gemm8_mx", "dca_l1_onehot_gemm_mx",
+    "dca_head_gemv", "dca_engine_packed_state", "dca_engine_info", "dca_gemm8_mx", "dca_l1_onehot_gemm_mx",
     "dca_cube4_perm_table", "dca_cube4_next_state", "dca_cube4_prev_state", "dca_cube4_expand_fused",
     "dca_engine_set_weight_instance", "dca_engine_set_weights", "dca_engine_park_instance", "dca_engine_last_popped",
 ]
@@ -378,55 +378,12 @@ def _absmax_bits(a: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def _planes_t(a: torch.Tensor, amax: Optional[torch.Tensor]) -> torch.Tensor:
-    """planes of (a * 2^e)^T: [2, n, ceil64(m)] fp16 (dca_split_planes_t)."""
-    m, n = a.shape
-    mp = _pad64(m)
-    out = torch.empty((2, n, mp), dtype=torch.float16, device=a.device)
-    check(lib().dca_split_planes_t(ptr(a), C.c_int64(m), C.c_int64(n), C.c_int64(n), ptr(amax), ptr(out[0]), ptr(out[1]),
-                                   C.c_int64(mp), stream_ptr()), "dca_split_planes_t")
-    return out
-
-
-def weight_grad_f16x3(dy: torch.Tensor, x: torch.Tensor, amax_dy: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """dy^T [n, m] . x [m, k] -> [n, k] fp32 through dca_f16x3_gemm: both operands transposed into planes (the contraction runs
-    over the batch), dy scaled by one power of two (gradients), x as it is."""
-    dy, x = dy.contiguous(), x.contiguous()
-    m, n = dy.shape
-    k = x.shape[1]
-    assert x.shape[0] == m and n % 4 == 0 and k % 4 == 0
-    if amax_dy is None:
-        amax_dy = _absmax_bits(dy)
-    a = _planes_t(dy, amax_dy)
-    # x is scaled by its own power of two as well: an activation beyond the fp16 range (nothing bounds the input of the
-    # first layer, or an un-normalised trunk) would otherwise become inf in its plane and NaN in the loss, silently
-    amax_x = _absmax_bits(x)
-    w = _planes_t(x, amax_x)
-    cs = torch.empty(k, dtype=torch.float32, device=dy.device)
-    cs_x = torch.empty(k, dtype=torch.float32, device=dy.device)
-    check(lib().dca_fill_inv_pow2(ptr(cs), C.c_int64(k), ptr(amax_dy), stream_ptr()), "dca_fill_inv_pow2")
-    check(lib().dca_fill_inv_pow2(ptr(cs_x), C.c_int64(k), ptr(amax_x), stream_ptr()), "dca_fill_inv_pow2")
-    cs = cs * cs_x  # (powers of two: exact)
-    # few output tiles (16-80 of 256 x 256 for 256 CUs), a batch-long contraction: split K so that the chip is full
-    mp = a.shape[2]
-    tiles = ((n + 255) // 256) * ((k + 255) // 256)
-    nk = mp // 64
-    splits = max(1, min(32, int(os.environ.get("DCA_DW_WGS", "256")) // max(tiles, 1), nk))
-    steps = (nk + splits - 1) // splits
-    splits = (nk + steps - 1) // steps  # every split gets at least one K-step
-    part = torch.empty((splits, n, k), dtype=torch.float32, device=dy.device)
-    check(lib().dca_f16x3_gemm_splitk(ptr(a[0]), ptr(a[1]), C.c_int64(n), int(mp), C.c_int64(mp), ptr(w[0]), ptr(w[1]), int(k),
-                                      C.c_int64(mp), ptr(cs), C.c_double(1.0), int(splits), ptr(part), C.c_int64(k), stream_ptr()),
-          "dca_f16x3_gemm_splitk")
-    return part[0] if splits == 1 else part.sum(0)
-
-
 class _LinearTrainFn(torch.autograd.Function):
     """nn.Linear for the training step (reference nnet_utils.py:53-118 runs it as the library's fp32 GEMMs): forward and input
     gradient on dca_f16x3_gemm (2/3 of the layer's flops, ~3x the library's fp32 rate at fp32 accuracy).  The weight gradient
-    dy^T . x contracts over the BATCH dimension: `weight_grad_f16x3` transposes both operands while it splits them
-    (dca_split_planes_t), runs the kernel's split-K form and is exact to the same level, but only draws with the library's
-    fp32 GEMM on time (TRAIN_DW_F16X3, off by default)."""
+    dy^T . x contracts over the BATCH dimension and stays on the library's fp32 GEMM: a split-K form of the f16x3 kernel on
+    operands transposed while they are split was built in round 4, exact to the same level and only a draw on time (faster
+    GEMMs, but two transposes and the sum of the partials on top) — deleted in round 5."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -440,11 +397,11 @@ class _LinearTrainFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
-        amax = _absmax_bits(dy) if (ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and TRAIN_DW_F16X3)) else None
+        amax = _absmax_bits(dy) if ctx.needs_input_grad[0] else None
         dx = linear_f16x3(dy, weight.t().contiguous(), None, scale_a=True, amax=amax) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = weight_grad_f16x3(dy, x, amax) if TRAIN_DW_F16X3 else dy.t().mm(x)
+            dw = dy.t().mm(x)
         db = dy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db
 
@@ -459,11 +416,6 @@ def linear_train(x: torch.Tensor, lin: "torch.nn.Linear") -> torch.Tensor:
 
 
 TRAIN_F16X3 = os.environ.get("DCA_TRAIN_GEMM", "f16x3") != "library"  # A/B switches (bench.py --workload train, tools/train_grad_check.py)
-# the weight gradient through the same kernel (split-K on transposed planes) is correct (tests, tools/train_grad_check.py)
-# and a draw on time at the training shapes (7.68 vs 7.47 ms per step: faster GEMMs, but two operand transposes and the
-# sum of the partial products on top).  Off unless asked for.
-TRAIN_DW_F16X3 = os.environ.get("DCA_TRAIN_DW", "library") == "f16x3"
-
 
 # ------------------------------------------------------------------------------ heuristic network, layer 1
 def l1_supported(state_dim: int, depth: int) -> bool:
@@ -645,19 +597,13 @@ def head_gemv(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) ->
     return out
 
 
-def gemm2_skew(sixteenths: int) -> None:
-    """Tuning hook of the two-workgroups-per-CU kernels (csrc/dca_gemm2.hip): start-up skew of every CU's second workgroup in
-    1/16ths of a tile's K-loop time (default 8; 0 = none)."""
-    check(lib().dca_gemm2_skew(int(sixteenths)), "dca_gemm2_skew")
-
-
 def gemm16_variant(v: int) -> None:
-    """Tuning / test hook: 3 = 128 x 256 tiles, two workgroups per CU (csrc/dca_gemm2.hip); 2 = 8-phase ping-pong schedule on
-    256 x 256 tiles, 1 = two-stage loop (one drain + barrier per K-step).  Bit-identical results."""
+    """Test hook: 3 (default) = ping-pong schedule, swapped operand roles, lean tail per layer form; 2 = the same schedule with
+    the general tail; 1 = two-stage loop (one drain + barrier per K-step).  Bit-identical results."""
     check(lib().dca_gemm16_variant(int(v)), "dca_gemm16_variant")
 
 
 def f16x3_gemm_variant(v: int) -> None:
-    """Tuning / test hook: 4 = 128 x 256 tiles, two workgroups per CU (csrc/dca_gemm2.hip), 3 = LDS-DMA 256x256 kernel on the
-    ping-pong schedule, 2 = the same tile with two whole-K-step stages (2, 3, 4 bit-identical), 1 = register-staged 128x128 kernel."""
+    """Test hook: 3 (default) = LDS-DMA 256x256 kernel on the ping-pong schedule, 2 = the same tile with two whole-K-step
+    stages (bit-identical)."""
     check(lib().dca_f16x3_gemm_variant(int(v)), "dca_f16x3_gemm_variant")

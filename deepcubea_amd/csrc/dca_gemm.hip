@@ -30,9 +30,7 @@ namespace dca {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int GBM = 128, GBN = 128, GBK = 64, GTHREADS = 256;
-constexpr int GIMG = GBM * GBK * 2;     // bytes of one operand image (16 KB)
-constexpr int GLDS = 4 * GIMG;          // A high, A low, W high, W low
+constexpr int GBK = 64;  // K granularity of the planes (operands are padded to it)
 
 struct GemmArgs {
     const _Float16 *ah, *al;  // activation planes [m, lda]
@@ -48,137 +46,9 @@ struct GemmArgs {
     _Float16 *oh, *ol;        // result planes [m, ldo] or null
     float* x_out;             // result fp32 [m, ldo] or null
     int* overflow;
-    int ksplit_steps;         // split-K (variant 3 only; 0 = off): workgroup (x, z) multiplies K-steps [z * ksplit_steps, +ksplit_steps)
-    int64_t split_stride;     //   ... and writes its partial result to x_out + z * split_stride
 };
 
 __device__ __forceinline__ uint32_t swz(uint32_t row, uint32_t chunk) { return row * 128u + ((chunk ^ ((row >> 1) & 7u)) << 4); }
-
-__global__ __launch_bounds__(GTHREADS, 2) void k_f16x3_gemm_v1(const GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, h = lane >> 5;
-    const int wm = w >> 1, wn = w & 1;
-    // workgroup -> output tile: the N tiles of one M tile sit on one XCD (workgroup b runs on XCD b % 8)
-    const int nNt = (p.n + GBN - 1) / GBN;
-    const int64_t nMt = (p.m + GBM - 1) / GBM;
-    const int64_t bid = blockIdx.x;
-    const int64_t slot = bid >> 3;
-    const int64_t mt = (slot / nNt) * 8 + (bid & 7);
-    const int nt = (int)(slot % nNt);
-    if (mt >= nMt) return;
-    const int64_t m0 = mt * GBM;
-    const int n0 = nt * GBN;
-
-    // staging map: an image is 128 rows x 8 chunks of 16 B; thread t moves chunks q*256 + t (row = slot / 8: eight
-    // neighbouring lanes read one row's 128 contiguous bytes)
-    uint4 pre[4][4];
-    const uint32_t srow = (uint32_t)t >> 3, schunk = (uint32_t)t & 7u;
-    auto load_tile = [&](int k0) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t r = srow + 32u * q;
-            const int64_t gr = m0 + r;
-            const int gn = n0 + (int)r;
-            const uint4 z = make_uint4(0, 0, 0, 0);
-            if (gr < p.m) {
-                const int64_t o = gr * p.lda + k0 + schunk * 8;
-                pre[0][q] = *reinterpret_cast<const uint4*>(p.ah + o);
-                pre[1][q] = *reinterpret_cast<const uint4*>(p.al + o);
-            } else {
-                pre[0][q] = z;
-                pre[1][q] = z;
-            }
-            if (gn < p.n) {
-                const int64_t o = (int64_t)gn * p.ldw + k0 + schunk * 8;
-                pre[2][q] = *reinterpret_cast<const uint4*>(p.wh + o);
-                pre[3][q] = *reinterpret_cast<const uint4*>(p.wl + o);
-            } else {
-                pre[2][q] = z;
-                pre[3][q] = z;
-            }
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t off = swz(srow + 32u * q, schunk);
-#pragma unroll
-            for (int img = 0; img < 4; img++) *reinterpret_cast<uint4*>(lds + img * GIMG + off) = pre[img][q];
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int jn = 0; jn < 2; jn++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][jn][e] = 0.f;
-
-    const int nk = p.k / GBK;
-    load_tile(0);
-    for (int kt = 0; kt < nk; kt++) {
-        store_tile();
-        __syncthreads();
-        if (kt + 1 < nk) load_tile((kt + 1) * GBK);  // in flight under this step's MFMAs
-#pragma unroll
-        for (int s = 0; s < GBK / 16; s++) {
-            const uint32_t c = 2u * s + (uint32_t)h;
-            f16x8 ah[2], al[2], wh[2], wl[2];
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const uint32_t off = swz((uint32_t)(wm * 64 + i * 32 + l31), c);
-                ah[i] = *reinterpret_cast<const f16x8*>(lds + off);
-                al[i] = *reinterpret_cast<const f16x8*>(lds + GIMG + off);
-            }
-#pragma unroll
-            for (int jn = 0; jn < 2; jn++) {
-                const uint32_t off = swz((uint32_t)(wn * 64 + jn * 32 + l31), c);
-                wh[jn] = *reinterpret_cast<const f16x8*>(lds + 2 * GIMG + off);
-                wl[jn] = *reinterpret_cast<const f16x8*>(lds + 3 * GIMG + off);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int jn = 0; jn < 2; jn++) {
-                    // small terms first, then the leading product: x.w = xl.wh + xh.wl + xh.wh
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[jn], acc[i][jn], 0, 0, 0);
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[jn], acc[i][jn], 0, 0, 0);
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[jn], acc[i][jn], 0, 0, 0);
-                }
-        }
-        __syncthreads();
-    }
-
-    // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    bool ovf = false;
-#pragma unroll
-    for (int jn = 0; jn < 2; jn++) {
-        const int col = n0 + wn * 64 + jn * 32 + l31;
-        if (col >= p.n) continue;
-        const float cs = p.col_scale ? p.alpha * p.col_scale[col] : p.alpha;
-        const float bv = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int reg = 0; reg < 16; reg++) {
-                const int64_t r = m0 + wm * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                if (r >= p.m) continue;
-                const int64_t o = r * p.ldo + col;
-                float u = acc[i][jn][reg] * cs + bv;
-                if (p.skip) u += p.skip[o];
-                if (p.relu) u = fmaxf(u, 0.f);
-                if (p.x_out) p.x_out[o] = u;
-                if (p.oh) {
-                    ovf |= !(fabsf(u) <= 60000.0f);  // beyond fp16 (or NaN): the caller redoes the batch in fp32
-                    const _Float16 hh = (_Float16)u;
-                    p.oh[o] = hh;
-                    p.ol[o] = (_Float16)(u - (float)hh);
-                }
-            }
-    }
-    if (ovf && p.overflow) *p.overflow = 1;
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // v2 (default): 256 x 256 outputs per workgroup, 8 waves as 2 (M) x 4 (N), each wave 4 x 2 tiles of 32x32x16 (128
@@ -189,8 +59,8 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_f16x3_gemm_v1(const GemmArgs p)
 // linearly, so the image stays linear in LDS and the XOR swizzle that makes the ds_read_b128 fragment reads
 // conflict-free (chunk ^ ((row >> 2) & 3) for 64-byte rows) is applied to each lane's GLOBAL source address instead:
 // the four lanes of a row still read one contiguous 64-byte segment, in permuted order.
-// (v1 above — 128 x 128 tile, register staging, two barriers per K-step — measured 620 TF on the MFMA pipe; it stays as
-// the A/B reference, dca_f16x3_gemm_variant(1).)
+// (Round 1's first cut — 128 x 128 tiles, register staging, two barriers per K-step — measured 620 TF on the MFMA pipe and
+// was deleted in round 5.)
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int HBM_T = 256, HBN_T = 256, HBK = 32, HTHREADS = 512;
 constexpr int HIMG = 256 * HBK * 2;   // bytes of one operand image (16 KB)
@@ -386,14 +256,9 @@ constexpr int PS_A01 = 0, PS_A23 = 1, PS_B0 = 2, PS_B1 = 3;
 #define DCA_RD_DONE_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define DCA_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
-// PROF: four wall-clock stamps per workgroup (entry, first operands landed, K loop done, tail done) into p.overflow's
-// neighbour array — tools/gemm_timeline.py; never launched by the library's own paths
-template <bool PROF>
-__global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v3(const GemmArgs p, unsigned long long* __restrict__ stamps) {
+__global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v3(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, h = lane >> 5;
-    unsigned long long ts0 = 0;
-    if constexpr (PROF) ts0 = wall_clock64();
     const int wm = w >> 2, wn = w & 3;
     const int nNt = (p.n + HBN_T - 1) / HBN_T;
     const int64_t nMt = (p.m + HBM_T - 1) / HBM_T;
@@ -404,9 +269,6 @@ __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v3(const GemmArgs p,
     if (mt >= nMt) return;
     const int64_t m0 = mt * HBM_T;
     const int n0 = nt * HBN_T;
-    // split-K (the training step's weight gradients: few output tiles, a batch-long contraction): this workgroup's K range
-    const int kt_base = p.ksplit_steps > 0 ? (int)blockIdx.y * p.ksplit_steps : 0;
-    const int64_t k_base = (int64_t)kt_base * HBK;
 
     // DMA map: instruction q (0 = high plane, 1 = low plane) of wave w fills local rows [w*16, +16) of that plane of a
     // half-tile slot; lane i lands on local row r = w*16 + (i >> 2), physical chunk i & 3, and fetches logical chunk
@@ -420,13 +282,13 @@ __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v3(const GemmArgs p,
             if (u < 2) {
                 int64_t gr = m0 + (r >> 6) * 128 + (u == PS_A23 ? 64 : 0) + (r & 63);
                 gr = gr < p.m ? gr : p.m - 1;
-                src[u][0] = p.ah + gr * p.lda + c * 8 + k_base;
-                src[u][1] = p.al + gr * p.lda + c * 8 + k_base;
+                src[u][0] = p.ah + gr * p.lda + c * 8;
+                src[u][1] = p.al + gr * p.lda + c * 8;
             } else {
                 int gn = n0 + (int)((r >> 5) * 64 + (u == PS_B1 ? 32 : 0) + (r & 31));
                 gn = gn < p.n ? gn : p.n - 1;
-                src[u][0] = p.wh + (int64_t)gn * p.ldw + c * 8 + k_base;
-                src[u][1] = p.wl + (int64_t)gn * p.ldw + c * 8 + k_base;
+                src[u][0] = p.wh + (int64_t)gn * p.ldw + c * 8;
+                src[u][1] = p.wl + (int64_t)gn * p.ldw + c * 8;
             }
         }
     }
@@ -490,7 +352,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v3(const GemmArgs p,
     } while (0)
 
     const int nk_all = p.k / HBK;
-    const int nk = p.ksplit_steps > 0 ? (nk_all - kt_base < p.ksplit_steps ? nk_all - kt_base : p.ksplit_steps) : nk_all;
+    const int nk = nk_all;
     // one K-step; N1 / N2: steps kt+1 / kt+2 exist (compile-time: the steady-state body is branch-free).  On entry:
     // issued = all of step kt and A01, B0, B1 of kt+1; landed and visible = A01, B0 of kt.  The vmcnt numbers count the
     // DMA instructions (2 per half-tile) issued AFTER the half-tile being waited for.
@@ -554,11 +416,6 @@ __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v3(const GemmArgs p,
         DCA_VMCNT(4);
     }
     DCA_BAR();
-    unsigned long long ts1 = 0, ts2 = 0, cy1 = 0, cy2 = 0;
-    if constexpr (PROF) {
-        ts1 = wall_clock64();
-        cy1 = clock64();  // shader-clock cycles: with the wall clock, the clock the K loop actually ran at
-    }
     if (wm == 1) DCA_BAR();  // the second wave row runs one barrier behind the first from here on
     {
         int kt = 0;
@@ -570,41 +427,12 @@ __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v3(const GemmArgs p,
         step(kt, std::false_type{}, std::false_type{});
     }
     if (wm == 0) DCA_BAR();  // ... and the first waits for it here
-    if constexpr (PROF) {
-        ts2 = wall_clock64();
-        cy2 = clock64();
-    }
 #undef DCA_MMA12
 #undef DCA_VMCNT
 #undef DCA_RD_DONE_BAR
 #undef DCA_BAR
 
-    if (p.ksplit_steps > 0) {
-        GemmArgs q = p;
-        q.x_out = p.x_out + (int64_t)blockIdx.y * p.split_stride;
-        f16x3_epilogue(q, lds, acc, m0, n0, w, wm, wn, lane, l31, h);
-    } else {
-        f16x3_epilogue(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h);
-    }
-    if constexpr (PROF) {
-        const unsigned long long ts3 = wall_clock64();       // this wave has issued its last store
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and they have been acknowledged
-        if (t == 0) {
-            unsigned long long* q = stamps + (size_t)blockIdx.x * 8;
-            q[6] = cy2 - cy1;
-            q[7] = 0;
-            q[0] = ts0;
-            q[1] = ts1;
-            q[2] = ts2;
-            q[5] = ts3;
-            q[3] = wall_clock64();
-            uint32_t xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            uint32_t hwid;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            q[4] = ((unsigned long long)xcc << 32) | hwid;
-        }
-    }
+    f16x3_epilogue(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h);
 }
 
 // fp32 [m, n] (row stride ld) -> its two fp16 planes (and the overflow flag): the entry into an f16x3 layer for
@@ -723,54 +551,6 @@ __global__ __launch_bounds__(256) void k_split_rows_scaled(const float* __restri
     }
 }
 
-// x [m, n] fp32 -> planes of (x * 2^e)^T: out [n][m_pad] (rows m..m_pad zero).  The weight gradient dW = dy^T . x contracts
-// over the batch dimension, which neither operand has contiguous: both are transposed on their way into planes (64 x 64
-// tiles through LDS; reads and writes in 256-byte / 128-byte row segments).
-__global__ __launch_bounds__(256) void k_split_planes_t(const float* __restrict__ x, int64_t m, int64_t n, int64_t ld,
-                                                        const uint32_t* __restrict__ amax_bits, _Float16* __restrict__ oh,
-                                                        _Float16* __restrict__ ol, int64_t ldo) {
-    __shared__ _Float16 th[64][68], tl[64][68];  // [column of x][row of x], padded: the column-wise writes below spread over banks
-    const float s = amax_bits ? pow2_scale_of(*amax_bits) : 1.0f;
-    const int64_t r0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
-    const int t = threadIdx.x;
-    {
-        const int cq = (t & 15) * 4;  // 16 lanes x float4 = one 64-column row segment
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const int rr = p * 16 + (t >> 4);
-            const int64_t r = r0 + rr, c = c0 + cq;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < m && c < n) v = *reinterpret_cast<const float4*>(x + r * ld + c);  // (n % 4 == 0: a float4 is in or out as a whole)
-            const float u[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const _Float16 hi = (_Float16)u[k];
-                th[cq + k][rr] = hi;
-                tl[cq + k][rr] = (_Float16)(u[k] - (float)hi);
-            }
-        }
-    }
-    __syncthreads();
-    {
-        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-        const int rq = (t & 15) * 4;  // 16 lanes x 4 halves = one 64-row segment of an output row
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const int cc = p * 16 + (t >> 4);
-            const int64_t c = c0 + cc;
-            if (c >= n) continue;
-            h4 hi, lo;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                hi[k] = th[cc][rq + k];
-                lo[k] = tl[cc][rq + k];
-            }
-            *reinterpret_cast<h4*>(oh + c * ldo + r0 + rq) = hi;  // (rows past m were staged as zeros: the pad is written too)
-            *reinterpret_cast<h4*>(ol + c * ldo + r0 + rq) = lo;
-        }
-    }
-}
-
 __global__ void k_fill_inv_pow2(float* __restrict__ out, int64_t n, const uint32_t* __restrict__ amax_bits) {
     const float v = 1.0f / pow2_scale_of(*amax_bits);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = v;
@@ -781,45 +561,15 @@ __global__ void k_fill_inv_pow2(float* __restrict__ out, int64_t n, const uint32
 using namespace dca;
 
 static int g_gemm_variant = 3;
-static unsigned long long* g_gemm_stamps = nullptr;  // diagnostics: device [blocks][5] u64 (dca_f16x3_gemm_timeline)
-
-namespace dca {
-// csrc/dca_gemm2.hip: the two-workgroups-per-CU kernels (variant 4 here, variant 3 of dca_gemm16)
-struct Gemm2Args {
-    const uint16_t *a, *a2, *w, *w2;
-    int64_t m;
-    int n, k;
-    int64_t lda, ldw, ldo;
-    const float* col_scale;
-    const float* bias;
-    const void* skip;
-    float alpha;
-    int relu;
-    uint16_t *oh, *ol;
-    float* x_out;
-    int* overflow;
-    int skew_ticks;
-    int cus;
-};
-int gemm2_launch(int mode, const Gemm2Args& p, hipStream_t s);
-}  // namespace dca
 
 extern "C" {
 
-/* tuning / test hook: 1 = the register-staged 128 x 128 kernel, 2 = the LDS-DMA 256 x 256 kernel with two whole-K-step stages,
+/* test hook: 2 = the LDS-DMA 256 x 256 kernel with two whole-K-step stages (the reference the race screens compare against),
  * 3 (default) = the same tile on the ping-pong / half-tile schedule (bit-identical to 2; measured at 204 800 x 1024, candidates
  * taking turns: k = 1024 1.42 vs 1.47 ms, k = 5120 5.67 vs 6.07 ms) */
 int dca_f16x3_gemm_variant(int v) {
-    DCA_ARG(v >= 1 && v <= 4);
+    DCA_ARG(v == 2 || v == 3);
     g_gemm_variant = v;
-    return 0;
-}
-
-/* diagnostics (tools/gemm_timeline.py): the next variant-3 launches write six u64 per workgroup into `stamps` (device):
- * wall clock (100 MHz) at entry, when the first operands have landed, at the end of the K loop, when the tile's stores have
- * been acknowledged, and (XCC id << 32 | HW_ID).  NULL switches it off. */
-int dca_f16x3_gemm_timeline(void* stamps) {
-    g_gemm_stamps = reinterpret_cast<unsigned long long*>(stamps);
     return 0;
 }
 
@@ -830,6 +580,8 @@ int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t l
     DCA_ARG(lda >= k && ldw >= k && lda % 8 == 0 && ldw % 8 == 0 && ldo >= n);
     DCA_ARG((out_h != nullptr) == (out_l != nullptr) && (out_h != nullptr || x_out != nullptr));
     DCA_ARG(((uintptr_t)a_h | (uintptr_t)a_l | (uintptr_t)w_h | (uintptr_t)w_l) % 16 == 0);
+    // the kernels leave with 16-byte row segments: 4-column-aligned outputs (every layer of the network has them)
+    DCA_ARG(ldo % 4 == 0 && ((uintptr_t)out_h | (uintptr_t)out_l) % 8 == 0 && ((uintptr_t)x_out | (uintptr_t)skip) % 16 == 0);
     if (m == 0) return 0;
     {   // the dynamic-LDS limit is a per-device function attribute: set it once for every device this process uses
         static std::atomic<uint64_t> attr_devs{0};
@@ -837,10 +589,8 @@ int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t l
         DCA_HIP(hipGetDevice(&dev));
         const uint64_t bit = 1ull << (dev & 63);
         if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
-            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f16x3_gemm_v1), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS));
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f16x3_gemm_v2), hipFuncAttributeMaxDynamicSharedMemorySize, HLDS));
-            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f16x3_gemm_v3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, HLDS));
-            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f16x3_gemm_v3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, HLDS));
+            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f16x3_gemm_v3), hipFuncAttributeMaxDynamicSharedMemorySize, HLDS));
             attr_devs.fetch_or(bit, std::memory_order_release);
         }
     }
@@ -864,105 +614,18 @@ int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t l
     p.ol = reinterpret_cast<_Float16*>(out_l);
     p.x_out = x_out;
     p.overflow = overflow;
-    p.ksplit_steps = 0;
-    p.split_stride = 0;
-    // the LDS-DMA kernel leaves with 16-byte row segments: it needs 4-column-aligned outputs (every layer of the network
-    // has them); anything else takes the register-staged kernel
-    const bool wide_ok = ldo % 4 == 0 && ((uintptr_t)out_h | (uintptr_t)out_l) % 8 == 0 &&
-                         ((uintptr_t)x_out | (uintptr_t)skip) % 16 == 0;
-    const int variant = (g_gemm_variant >= 2 && wide_ok) ? g_gemm_variant : 1;
-    if (variant == 4) {  // 128 x 256 tiles, 4 waves, two workgroups per CU (csrc/dca_gemm2.hip); bit-identical to 2 and 3
-        Gemm2Args q;
-        q.a = reinterpret_cast<const uint16_t*>(a_h);
-        q.a2 = reinterpret_cast<const uint16_t*>(a_l);
-        q.w = reinterpret_cast<const uint16_t*>(w_h);
-        q.w2 = reinterpret_cast<const uint16_t*>(w_l);
-        q.m = m;
-        q.n = n;
-        q.k = k;
-        q.lda = lda;
-        q.ldw = ldw;
-        q.ldo = ldo;
-        q.col_scale = col_scale;
-        q.bias = bias;
-        q.skip = skip;
-        q.alpha = (float)alpha;
-        q.relu = relu;
-        q.oh = reinterpret_cast<uint16_t*>(out_h);
-        q.ol = reinterpret_cast<uint16_t*>(out_l);
-        q.x_out = x_out;
-        q.overflow = overflow;
-        q.skew_ticks = 0;
-        q.cus = 0;
-        return gemm2_launch(0, q, (hipStream_t)stream);
-    }
-    const int bm = variant == 1 ? GBM : HBM_T, bn = variant == 1 ? GBN : HBN_T;
-    const int64_t nMt = (m + bm - 1) / bm;
-    const int64_t nNt = (n + bn - 1) / bn;
+    const int64_t nMt = (m + HBM_T - 1) / HBM_T;
+    const int64_t nNt = (n + HBN_T - 1) / HBN_T;
     const int64_t blocks = ((nMt + 7) / 8) * 8 * nNt;
     if (blocks > 0x7FFFFFFFll) {
         set_error("dca_f16x3_gemm: too many tiles");
         return DCA_E_BADARG;
     }
-    if (variant == 1)
-        hipLaunchKernelGGL(k_f16x3_gemm_v1, dim3((unsigned)blocks), dim3(GTHREADS), GLDS, (hipStream_t)stream, p);
-    else if (variant == 2)
+    if (g_gemm_variant == 2)
         hipLaunchKernelGGL(k_f16x3_gemm_v2, dim3((unsigned)blocks), dim3(HTHREADS), HLDS, (hipStream_t)stream, p);
-    else if (g_gemm_stamps != nullptr)
-        hipLaunchKernelGGL(k_f16x3_gemm_v3<true>, dim3((unsigned)blocks), dim3(HTHREADS), HLDS, (hipStream_t)stream, p, g_gemm_stamps);
     else
-        hipLaunchKernelGGL(k_f16x3_gemm_v3<false>, dim3((unsigned)blocks), dim3(HTHREADS), HLDS, (hipStream_t)stream, p,
-                           (unsigned long long*)nullptr);
+        hipLaunchKernelGGL(k_f16x3_gemm_v3, dim3((unsigned)blocks), dim3(HTHREADS), HLDS, (hipStream_t)stream, p);
     return launch_check("k_f16x3_gemm");
-}
-
-int dca_f16x3_gemm_splitk(const void* a_h, const void* a_l, int64_t m, int k, int64_t lda, const void* w_h, const void* w_l, int n,
-                          int64_t ldw, const float* col_scale, double alpha, int splits, float* partials, int64_t ldo,
-                          void* stream) {
-    DCA_ARG(a_h && a_l && w_h && w_l && partials && m >= 1 && n >= 1 && k >= GBK && k % GBK == 0 && splits >= 1 && splits <= 64);
-    DCA_ARG(lda >= k && ldw >= k && lda % 8 == 0 && ldw % 8 == 0 && ldo >= n && ldo % 4 == 0);
-    DCA_ARG(((uintptr_t)a_h | (uintptr_t)a_l | (uintptr_t)w_h | (uintptr_t)w_l | (uintptr_t)partials) % 16 == 0);
-    const int nk = k / HBK;
-    DCA_ARG((nk + splits - 1) / splits * (splits - 1) < nk);  // every split has at least one K-step (dca_f16x3_gemm_splitk_steps)
-    {
-        static std::atomic<uint64_t> attr_devs{0};
-        int dev = 0;
-        DCA_HIP(hipGetDevice(&dev));
-        const uint64_t bit = 1ull << (dev & 63);
-        if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
-            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f16x3_gemm_v3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, HLDS));
-            attr_devs.fetch_or(bit, std::memory_order_release);
-        }
-    }
-    GemmArgs p;
-    p.ah = reinterpret_cast<const _Float16*>(a_h);
-    p.al = reinterpret_cast<const _Float16*>(a_l);
-    p.wh = reinterpret_cast<const _Float16*>(w_h);
-    p.wl = reinterpret_cast<const _Float16*>(w_l);
-    p.col_scale = col_scale;
-    p.bias = nullptr;
-    p.skip = nullptr;
-    p.alpha = (float)alpha;
-    p.relu = 0;
-    p.m = m;
-    p.n = n;
-    p.k = k;
-    p.lda = lda;
-    p.ldw = ldw;
-    p.ldo = ldo;
-    p.oh = nullptr;
-    p.ol = nullptr;
-    p.x_out = partials;
-    p.overflow = nullptr;
-    p.ksplit_steps = (nk + splits - 1) / splits;
-    p.split_stride = m * ldo;
-    const int64_t nMt = (m + HBM_T - 1) / HBM_T;
-    const int64_t nNt = (n + HBN_T - 1) / HBN_T;
-    const int64_t blocks = ((nMt + 7) / 8) * 8 * nNt;
-    DCA_ARG(blocks <= 0x7FFFFFFFll);
-    hipLaunchKernelGGL(k_f16x3_gemm_v3<false>, dim3((unsigned)blocks, (unsigned)splits), dim3(HTHREADS), HLDS, (hipStream_t)stream, p,
-                       (unsigned long long*)nullptr);
-    return launch_check("k_f16x3_gemm (split-K)");
 }
 
 int dca_split_planes(const float* x, int64_t m, int64_t n, int64_t ld, void* out_h, void* out_l, int64_t ldo, int* overflow,
@@ -1008,17 +671,6 @@ int dca_split_rows_scaled(const float* w, int64_t n, int64_t k, int64_t ld, void
     hipLaunchKernelGGL(k_split_rows_scaled, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, w, k, ld,
                        reinterpret_cast<_Float16*>(out_h), reinterpret_cast<_Float16*>(out_l), ldo, k_pad, col_scale, other_amax_bits);
     return launch_check("k_split_rows_scaled");
-}
-
-int dca_split_planes_t(const float* x, int64_t m, int64_t n, int64_t ld, const uint32_t* amax_bits, void* out_h, void* out_l,
-                       int64_t ldo, void* stream) {
-    const int64_t m_pad = (m + 63) / 64 * 64;
-    DCA_ARG(x && out_h && out_l && m >= 0 && n >= 4 && n % 4 == 0 && ld >= n && ld % 4 == 0 && ldo >= m_pad && ldo % 4 == 0);
-    DCA_ARG((uintptr_t)x % 16 == 0 && ((uintptr_t)out_h | (uintptr_t)out_l) % 8 == 0 && m_pad / 64 < (1ll << 31) && (n + 63) / 64 < 65536);
-    if (m == 0) return 0;
-    hipLaunchKernelGGL(k_split_planes_t, dim3((unsigned)(m_pad / 64), (unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x,
-                       m, n, ld, amax_bits, reinterpret_cast<_Float16*>(out_h), reinterpret_cast<_Float16*>(out_l), ldo);
-    return launch_check("k_split_planes_t");
 }
 
 int dca_fill_inv_pow2(float* out, int64_t n, const uint32_t* amax_bits, void* stream) {

@@ -8,8 +8,9 @@
 // bias, residual add, ReLU and the rounding to the 16-bit output ride in the epilogue: activations cross HBM once in
 // each direction, 2 bytes per element.
 //
-// Two schedules over the same tile (dca_gemm16_variant): variant 1 below — two whole K-step stages — and variant 2, the
-// default, further down: the ping-pong schedule over half-tile slots (its header has the derivation).
+// Three kernels over the same tile (dca_gemm16_variant): variant 1 below — two whole K-step stages, the plain reference —,
+// variant 2 further down: the ping-pong schedule over half-tile slots (its header has the derivation) with the general tail,
+// and variant 3, the default: that schedule with swapped operand roles and a lean tail for the network's own layer forms.
 // Tiling (the f16x3 kernel's, dca_gemm.hip, with one operand plane instead of two): workgroup = 256 x 256 outputs, 8
 // waves as 2 (M) x 4 (N), each wave 4 x 2 tiles of v_mfma_f32_32x32x16_{bf16,f16} (128 accumulator VGPRs, 32 MFMAs per
 // K-step of 64).  The two operand images of a K-step (256 rows x 128 B each = 64 KB) are filled by
@@ -34,7 +35,6 @@ constexpr int QBM = 256, QBN = 256, QBK = 64, QTHREADS = 512;
 constexpr int QIMG = 256 * QBK * 2;  // bytes of one operand image (32 KB)
 constexpr int QSTAGE = 2 * QIMG;     // A, W
 constexpr int QLDS = 2 * QSTAGE;     // two stages: 128 KB
-constexpr int QLDS_PS = QLDS + 8 * 4096;  // variant 5: + a wave-private 4 KB each for the tail's piece exchange (160 KB)
 
 struct Gemm16Args {
     const uint16_t* a;   // [m, lda]
@@ -46,8 +46,6 @@ struct Gemm16Args {
     int64_t m;
     int n, k;
     int64_t lda, ldw, ldo;
-    unsigned long long* prof;  // diagnostics (variant 5): per tile {start, K loop done, tail done} on the 100 MHz wall clock
-    int skew_us;               // diagnostics (variant 5): workgroup j of an XCD starts (j % 8) * skew_us / 8 late
 };
 
 __device__ __forceinline__ uint32_t swz128(uint32_t row, uint32_t chunk) { return row * 128u + ((chunk ^ ((row >> 1) & 7u)) << 4); }
@@ -454,306 +452,37 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16p(const Gemm16Args p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Variant 4: the same 256 x 256 workgroup tile on FOUR waves (2 x 2), each owning 128 x 128 outputs — 4 x 4 blocks of
-// v_mfma_f32_32x32x16, 256 accumulator registers (one wave per SIMD: the whole 512-entry register file is the wave's).
-// What the shape buys over the 8-wave layouts above: a K-slice of 16 costs a wave 4 + 4 fragment reads for 16 MFMAs (0.5
-// ds_read_b128 per MFMA, against 0.75 for 4 x 2 blocks) and nothing is read twice by two waves of one SIMD.  What it
-// loses is the partner wave that covers LDS latency, so the wave pipelines itself: two fragment register sets, the reads
-// of the next 16-deep slice are in flight while the 16 MFMAs of the current one issue.
-// Staging: K-tiles of 32 (64-byte rows; swizzle chunk ^ ((row >> 2) & 3), applied on the global side of the LDS-DMA as
-// everywhere in this file), a RING OF FIVE 32 KB slots — all 160 KB of LDS.  Phase h computes K-tile h (two slices) and
-// restages the slot phase h-1 read with K-tile h+4: four phases = 4096 MFMA cycles of lead for every DMA.  One barrier
-// per phase, placed BETWEEN the two MFMA groups: behind it the wave reads the first slice of tile h+1 while the second
-// slice of tile h multiplies.
-//   RAW  vmcnt (all but the three youngest tiles have landed: tile h+1 is in) precedes the barrier of phase h; tile h+1 is
-//        first read behind it.
-//   WAR  lgkmcnt(0) precedes that barrier too: every fragment read of tile h has returned before any wave restages its
-//        slot (in phase h+1).
-// ---------------------------------------------------------------------------------------------------------------------
-constexpr int WTHREADS = 256, WBK = 32;
-constexpr int WIMG = 256 * WBK * 2;  // one operand image of a K-tile: 256 rows x 64 B
-constexpr int WSLOT = 2 * WIMG;      // A | W
-constexpr int WRING = 5;
-constexpr int WLDS = WRING * WSLOT;  // 160 KB
-
-template <bool BF16>
-__global__ __launch_bounds__(WTHREADS, 1) void k_gemm16w(const Gemm16Args p) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    using frag_t = typename std::conditional<BF16, b16x8, h16x8>::type;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, h = lane >> 5;
-    const int wm = w >> 1, wn = w & 1;
-    const int nNt = (p.n + QBN - 1) / QBN;
-    const int64_t nMt = (p.m + QBM - 1) / QBM;
-    const int64_t bid = blockIdx.x;
-    const int64_t slot_id = bid >> 3;
-    const int64_t mt = (slot_id / nNt) * 8 + (bid & 7);
-    const int nt = (int)(slot_id % nNt);
-    if (mt >= nMt) return;
-    const int64_t m0 = mt * QBM;
-    const int n0 = nt * QBN;
-
-    // DMA map: instruction q (0-7) of wave w fills rows [rb*16, rb*16 + 16) of image q >> 2, rb = (q & 3) * 4 + w; lane i
-    // lands on row i >> 2, physical chunk i & 3, and fetches logical chunk (i & 3) ^ ((row >> 2) & 3).
-    const uint16_t* src[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const uint32_t r = (uint32_t)(((q & 3) * 4 + w) * 16 + (lane >> 2));
-        const uint32_t c = (uint32_t)(lane & 3) ^ ((r >> 2) & 3u);
-        if ((q >> 2) == 0) {
-            int64_t gr = m0 + r;
-            gr = gr < p.m ? gr : p.m - 1;
-            src[q] = p.a + gr * p.lda + c * 8;
-        } else {
-            int gn = n0 + (int)r;
-            gn = gn < p.n ? gn : p.n - 1;
-            src[q] = p.w + (int64_t)gn * p.ldw + c * 8;
-        }
-    }
-    auto issue = [&](int slot, int k0) {
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            uint8_t* dst = lds + slot * WSLOT + (q >> 2) * WIMG + ((q & 3) * 4 + w) * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + k0),
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
-    };
-
-    f32x16 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int jn = 0; jn < 4; jn++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][jn][e] = 0.f;
-
-    // fragment addresses inside a slot: row = (wave's block) * 32 + l31, logical chunk 2 s + h  ((row >> 2) & 3 == (l31 >> 2) & 3)
-    uint32_t foff[2];
-#pragma unroll
-    for (int s = 0; s < 2; s++) foff[s] = (uint32_t)l31 * 64u + (((2u * s + (uint32_t)h) ^ (((uint32_t)l31 >> 2) & 3u)) << 4);
-    const uint32_t a_row0 = (uint32_t)wm * 128u * 64u;
-    const uint32_t b_row0 = (uint32_t)WIMG + (uint32_t)wn * 128u * 64u;
-
-    // The wave has no partner to fill its issue gaps, so the phase is scheduled by hand, one non-MFMA instruction in the
-    // shadow of each MFMA (an MFMA holds the matrix pipe for 32 cycles; the wave is free to issue the next fragment read or
-    // DMA meanwhile) and every position pinned with sched_barrier:
-    //   group A, 16 MFMAs on slice 0:  the 8 fragment reads of slice 1 behind MFMAs 0-7, the 8 DMA instructions of tile
-    //            h+4 behind MFMAs 8-15;
-    //   group B, 16 MFMAs on slice 1:  MFMAs 0-7, then vmcnt + THE barrier (tile h+1 visible, this slot's reads all
-    //            returned), then the 8 reads of slice 0 of tile h+1 behind MFMAs 8-15.
-    // MFMAs run in "growing square" order over the 4 x 4 blocks — (0,0) (1,0) (0,1) (1,1) (2,0) (2,1) (0,2) (1,2) (2,2)
-    // (3,0) (3,1) (3,2) (0,3) (1,3) (2,3) (3,3) — and the fragments are read in the order that square needs them (a0 b0 a1 b1
-    // a2 b2 a3 b3), so MFMA 0 waits for the two oldest reads only.  Fragment reads are inline asm with hand-counted
-    // lgkmcnt: for loads it knows about hipcc waits lgkmcnt(0) in front of an MFMA group — the reads just issued for the
-    // next slice included.  lgkmcnt(N) before an MFMA = reads issued behind the youngest fragment it needs.
-    u32x4 fa0[4], fb0[4], fa1[4], fb1[4];
-    const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint8_t*)lds);
-    const uint32_t fo_a0 = lds0 + a_row0 + foff[0], fo_a1 = lds0 + a_row0 + foff[1];
-    const uint32_t fo_b0 = lds0 + b_row0 + foff[0], fo_b1 = lds0 + b_row0 + foff[1];
-#define DCA_SB() __builtin_amdgcn_sched_barrier(0)
-#define DCA_DSR(D, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(D) : "v"(ADDR), "i"(OFF) : "memory")
-    // read k of a slice: 0 a0, 1 b0, 2 a1, 3 b1, 4 a2, 5 b2, 6 a3, 7 b3
-#define DCA_RD(K, FA, FB, AA, AB)                                                                                  \
-    do {                                                                                                           \
-        if constexpr (((K) & 1) == 0)                                                                              \
-            DCA_DSR(FA[(K) >> 1], AA, ((K) >> 1) * 2048);                                                          \
-        else                                                                                                       \
-            DCA_DSR(FB[(K) >> 1], AB, ((K) >> 1) * 2048);                                                          \
-        DCA_SB();                                                                                                  \
-    } while (0)
-#define DCA_WL(N)                                                                                                  \
-    do {                                                                                                           \
-        asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");                                                    \
-        DCA_SB(); /* (an MFMA has no dependence on the wait: without the fence the scheduler hoists it above) */    \
-    } while (0)
-#define DCA_MM(FA, FB, I, J)                                                                                       \
-    do {                                                                                                           \
-        if constexpr (BF16)                                                                                        \
-            acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(frag_t, FA[I]),                 \
-                                                                __builtin_bit_cast(frag_t, FB[J]), acc[I][J], 0, 0, 0); \
-        else                                                                                                       \
-            acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(frag_t, FA[I]),                  \
-                                                               __builtin_bit_cast(frag_t, FB[J]), acc[I][J], 0, 0, 0); \
-        DCA_SB();                                                                                                  \
-    } while (0)
-#define DCA_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
-    auto dma1 = [&](int q, int slot, int k0) {
-        uint8_t* dst = lds + slot * WSLOT + (q >> 2) * WIMG + ((q & 3) * 4 + w) * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + k0),
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        DCA_SB();
-    };
-
-    const int nh = p.k / WBK;
-    // one phase.  DMA: tile hh+4 exists (restage the slot phase hh-1 read); NEXT: tile hh+1 exists; VMC: DMA instructions
-    // issued behind tile hh+1 (8 per tile, three tiles at most)
-    auto phase = [&](int hh, int slot, auto dmac, auto nextc, auto vmc) {
-        constexpr bool DMA = decltype(dmac)::value, NEXT = decltype(nextc)::value;
-        constexpr int VMC = decltype(vmc)::value;
-        const uint32_t sb = (uint32_t)slot * WSLOT;
-        const uint32_t aa1 = fo_a1 + sb, ab1 = fo_b1 + sb;
-        const int dslot = slot == 0 ? WRING - 1 : slot - 1;
-        const int dk0 = (hh + 4) * WBK;
-        DCA_SB();
-        // ---- group A: slice 0 (its 8 reads were issued behind the last 8 MFMAs of the previous phase)
-        DCA_WL(6);
-        DCA_MM(fa0, fb0, 0, 0);
-        DCA_RD(0, fa1, fb1, aa1, ab1);
-        DCA_WL(6);
-        DCA_MM(fa0, fb0, 1, 0);
-        DCA_RD(1, fa1, fb1, aa1, ab1);
-        DCA_WL(6);
-        DCA_MM(fa0, fb0, 0, 1);
-        DCA_RD(2, fa1, fb1, aa1, ab1);
-        DCA_MM(fa0, fb0, 1, 1);
-        DCA_RD(3, fa1, fb1, aa1, ab1);
-        DCA_WL(7);
-        DCA_MM(fa0, fb0, 2, 0);
-        DCA_RD(4, fa1, fb1, aa1, ab1);
-        DCA_MM(fa0, fb0, 2, 1);
-        DCA_RD(5, fa1, fb1, aa1, ab1);
-        DCA_WL(8);
-        DCA_MM(fa0, fb0, 0, 2);
-        DCA_RD(6, fa1, fb1, aa1, ab1);
-        DCA_MM(fa0, fb0, 1, 2);
-        DCA_RD(7, fa1, fb1, aa1, ab1);
-        DCA_MM(fa0, fb0, 2, 2);
-        if constexpr (DMA) dma1(0, dslot, dk0);
-        DCA_WL(9);
-        DCA_MM(fa0, fb0, 3, 0);
-        if constexpr (DMA) dma1(1, dslot, dk0);
-        DCA_MM(fa0, fb0, 3, 1);
-        if constexpr (DMA) dma1(2, dslot, dk0);
-        DCA_MM(fa0, fb0, 3, 2);
-        if constexpr (DMA) dma1(3, dslot, dk0);
-        DCA_WL(8);
-        DCA_MM(fa0, fb0, 0, 3);
-        if constexpr (DMA) dma1(4, dslot, dk0);
-        DCA_MM(fa0, fb0, 1, 3);
-        if constexpr (DMA) dma1(5, dslot, dk0);
-        DCA_MM(fa0, fb0, 2, 3);
-        if constexpr (DMA) dma1(6, dslot, dk0);
-        DCA_MM(fa0, fb0, 3, 3);
-        if constexpr (DMA) dma1(7, dslot, dk0);
-        // ---- group B: slice 1
-        DCA_WL(0);  // slice 1 is in: every fragment read of this slot has returned
-        DCA_MM(fa1, fb1, 0, 0);
-        DCA_MM(fa1, fb1, 1, 0);
-        DCA_MM(fa1, fb1, 0, 1);
-        DCA_MM(fa1, fb1, 1, 1);
-        DCA_MM(fa1, fb1, 2, 0);
-        DCA_MM(fa1, fb1, 2, 1);
-        DCA_MM(fa1, fb1, 0, 2);
-        DCA_MM(fa1, fb1, 1, 2);
-        if constexpr (VMC == 24)
-            DCA_VMCNT(24);
-        else if constexpr (VMC == 16)
-            DCA_VMCNT(16);
-        else if constexpr (VMC == 8)
-            DCA_VMCNT(8);
-        else
-            DCA_VMCNT(0);
-        DCA_BAR();  // tile hh+1 has landed for everyone; nobody reads this slot any more
-        DCA_SB();
-        const int nslot = slot == WRING - 1 ? 0 : slot + 1;
-        const uint32_t sn = (uint32_t)nslot * WSLOT;
-        const uint32_t aa0 = fo_a0 + sn, ab0 = fo_b0 + sn;
-        DCA_MM(fa1, fb1, 2, 2);
-        if constexpr (NEXT) DCA_RD(0, fa0, fb0, aa0, ab0);
-        DCA_MM(fa1, fb1, 3, 0);
-        if constexpr (NEXT) DCA_RD(1, fa0, fb0, aa0, ab0);
-        DCA_MM(fa1, fb1, 3, 1);
-        if constexpr (NEXT) DCA_RD(2, fa0, fb0, aa0, ab0);
-        DCA_MM(fa1, fb1, 3, 2);
-        if constexpr (NEXT) DCA_RD(3, fa0, fb0, aa0, ab0);
-        DCA_MM(fa1, fb1, 0, 3);
-        if constexpr (NEXT) DCA_RD(4, fa0, fb0, aa0, ab0);
-        DCA_MM(fa1, fb1, 1, 3);
-        if constexpr (NEXT) DCA_RD(5, fa0, fb0, aa0, ab0);
-        DCA_MM(fa1, fb1, 2, 3);
-        if constexpr (NEXT) DCA_RD(6, fa0, fb0, aa0, ab0);
-        DCA_MM(fa1, fb1, 3, 3);
-        if constexpr (NEXT) DCA_RD(7, fa0, fb0, aa0, ab0);
-    };
-
-    issue(0, 0);
-    if (nh > 1) issue(1, WBK);
-    if (nh > 2) issue(2, 2 * WBK);
-    if (nh > 3) issue(3, 3 * WBK);
-    if (nh > 3)
-        DCA_VMCNT(24);
-    else if (nh == 3)
-        DCA_VMCNT(16);
-    else if (nh == 2)
-        DCA_VMCNT(8);
-    else
-        DCA_VMCNT(0);
-    DCA_BAR();
-    DCA_SB();
-    DCA_RD(0, fa0, fb0, fo_a0, fo_b0);
-    DCA_RD(1, fa0, fb0, fo_a0, fo_b0);
-    DCA_RD(2, fa0, fb0, fo_a0, fo_b0);
-    DCA_RD(3, fa0, fb0, fo_a0, fo_b0);
-    DCA_RD(4, fa0, fb0, fo_a0, fo_b0);
-    DCA_RD(5, fa0, fb0, fo_a0, fo_b0);
-    DCA_RD(6, fa0, fb0, fo_a0, fo_b0);
-    DCA_RD(7, fa0, fb0, fo_a0, fo_b0);
-    {
-        using T = std::true_type;
-        using F = std::false_type;
-        int slot = 0, hh = 0;
-        auto adv = [&]() {
-            slot = slot == WRING - 1 ? 0 : slot + 1;
-            hh++;
-        };
-        while (hh + 4 < nh) {
-            phase(hh, slot, T{}, T{}, std::integral_constant<int, 24>{});
-            adv();
-        }
-        if (hh + 3 < nh) {
-            phase(hh, slot, F{}, T{}, std::integral_constant<int, 16>{});
-            adv();
-        }
-        if (hh + 2 < nh) {
-            phase(hh, slot, F{}, T{}, std::integral_constant<int, 8>{});
-            adv();
-        }
-        if (hh + 1 < nh) {
-            phase(hh, slot, F{}, T{}, std::integral_constant<int, 0>{});
-            adv();
-        }
-        phase(hh, slot, F{}, F{}, std::integral_constant<int, 0>{});
-    }
-#undef DCA_VMCNT
-#undef DCA_MM
-#undef DCA_WL
-#undef DCA_RD
-#undef DCA_DSR
-#undef DCA_SB
-
-    gemm16_epilogue<BF16, 4>(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h);
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Variant 5 (round 5): the ping-pong K loop of variant 2 inside a PERSISTENT workgroup with a register-only layer tail.
-// What the profile of variant 2 said (profiles/r04_gemm_timeline.txt): per 256 x 256 tile at K = 1024 the K loop takes
-// ~26 us and everything around it ~15 — 3.6 us until the first operands have landed, 10-12 us of tail (accumulators through
-// LDS, skip rows in four dependent round trips, stores), 1.6 us until the CU's next workgroup starts.  None of that needs the
-// matrix pipe, and none of it overlapped with anything.  Three changes, same products in the same order:
+// Variant 3 (round 5, the default): the ping-pong K loop of variant 2 with a LEAN layer tail for the network's own layer
+// forms, relu(a . w^T + bias) and relu(a . w^T + bias + skip), on whole tiles.
+// What the measurements said (profiles/r05_gemm16_*.txt; tools/gemm16_probe.py, tools/store_pattern_probe.hip):
+//   * the tail was bound by its own INSTRUCTIONS, not by HBM: rounding to bf16 in software (six integer instructions per
+//     value) alone cost 4.5 us of a 40 us tile — v_cvt_pk_bf16_f32 does two values per instruction (all variants now);
+//     the accumulator-layout tail of variants 1 / 2 further issues 128 ds_write_b32 + 32 ds_read_b128 + 32 eight-byte
+//     stores per wave, every one behind run-time tests for the ragged cases: ~4200 instructions per wave and tile;
+//   * a store with one ROW per lane costs a CU 3.5 us per 128 KB tile however few CUs store at the time, one with 8 lanes
+//     per 128-byte row segment 1.0 us.
+// Three changes, same products in the same order (bit-identical to variants 1 / 2 — the race screen in tests/):
 //   * OPERAND ROLES SWAPPED in the MFMA: the weight fragment is the instruction's A operand, the activation fragment its B
-//     operand, so D[i][j] has j = lane & 31 = the activation ROW and i (the register index) = the output column.  A lane
-//     then owns a piece of ONE output row — and which physical weight row feeds MFMA row i is free to choose (it is only
-//     the source address of an LDS-DMA piece): sigma() below makes a lane's 8 consecutive accumulator registers 8
-//     CONSECUTIVE output columns (16 bytes of bf16) and the two lane halves adjacent.  The whole tail — bias, skip, ReLU,
-//     rounding, store — runs on registers: one 16-byte skip load and one 16-byte store per 8 values, no LDS, no barrier.
-//   * PERSISTENT: gridDim = CUs; a workgroup walks tiles slot = j + t * (grid / 8) of its XCD (same XCD mapping as before:
-//     the N tiles of one M tile share that XCD's L2).  No per-tile launch gap, no re-derivation of the maps.
-//   * CROSS-TILE PREFETCH: the tail does not touch the LDS, so the first seven half-tiles of the NEXT tile are requested
-//     before the tail starts and land under it; the next K loop starts with its operands in place.
-// vmcnt bookkeeping: loads and stores retire in issue order (one counter, gfx9 family), so the counted waits of the K loop
-// stay correct with the tail's loads / stores in the queue: everything older than the N youngest entries has completed, and
-// the N youngest are always DMA pieces of the K loop itself (N <= 10 < pieces issued since the tail).  They are merely a
-// little stricter than necessary in a tile's first phases (they also wait for the tail's stores to be acknowledged).
+//     operand, so D[i][j] has j = lane & 31 = the activation ROW and i (the register index) = the output column.  Which
+//     physical weight row feeds MFMA row i is free to choose (it is only the source address of an LDS-DMA piece): sigma16()
+//     makes a lane's 8 consecutive accumulator registers 8 CONSECUTIVE output columns.  Bias, ReLU and the rounding then work
+//     on register octets, and a lane leaves with packed 16-byte PIECES instead of 4-byte words.
+//   * PIECE EXCHANGE: the four pieces a lane holds of its own row change hands inside the wave through a wave-private 4 KB
+//     of LDS (4 ds_write_b128 + 4 ds_read_b128 per 32 rows) so that lane (4 g + x, h) stores piece x * 2 + h of rows
+//     4 g .. 4 g + 3: 8 lanes per 128-byte row segment.  Skip rows come in by the same route, the other way round.
+//   * NO RUN-TIME CASES in the tail: the kernel is compiled per form (skip or not; bias and ReLU always), takes whole
+//     256 x 256 tiles with 16-byte aligned rows only, and the host hands everything else — other forms, the ragged right /
+//     bottom strips of a layer — to variant 2.  ~520 instructions per wave and tile.
+// Measured (204 800 rows, candidates taking turns, profiles/r05_gemm_bench.txt): K = 1024 0.450 / 0.499 ms (bias / residual
+// form) against 0.491 / 0.529 for variant 2 and 0.376 / 0.562 for the library; K = 5120 1.93 / 1.98 against 1.92 / 1.97 and
+// 1.67 / 1.88.
+// Built on top of this, measured, and DELETED again in the same round: the PERSISTENT form the round-4 review asked for — one
+// workgroup per CU walking its XCD's tiles, the exchange slices behind the operand slots (160 KB of LDS), the first seven
+// half-tiles of the next tile requested before the tail so that they land under it.  Bit-identical, 0.454 / 0.500 ms at
+// K = 1024 and 1.90 / 1.94 at K = 5120: nothing at K = 1024, 1.6 % at K = 5120 (profiles/r05_gemm16_timeline.txt).  Why: the
+// prefetch (112 KB) and the tail's stores (128 KB) share the CU's one memory pipe, which moves ~15-20 B/clk with every CU
+// active — the tail got 7.4 us long instead of disappearing — and the K loop itself runs at that same fetch rate (64 KB per
+// K-tile in ~1.75 us), not at the matrix pipe's.
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int sigma16(int jn, int i) {
     // MFMA row i = r + 8 q + 4 h (r = reg & 3, q = reg >> 2, h = lane half)  ->  column inside the wave's 64:
@@ -762,38 +491,142 @@ __device__ __forceinline__ int sigma16(int jn, int i) {
     return (jn * 2 + (q >> 1)) * 16 + hh * 8 + (q & 1) * 4 + r;
 }
 
+
 template <bool BF16>
-__global__ __launch_bounds__(QTHREADS, 2) void k_gemm16ps(const Gemm16Args p) {
+__device__ __forceinline__ uint32_t pack16x2(float lo, float hi) {
+    if constexpr (BF16)
+        return pack_bf16x2(lo, hi);
+    else
+        return (uint32_t)to_f16(lo) | ((uint32_t)to_f16(hi) << 16);
+}
+template <bool BF16>
+__device__ __forceinline__ float lo16(uint32_t v) {
+    if constexpr (BF16)
+        return __uint_as_float(v << 16);
+    else
+        return from_f16((uint16_t)(v & 0xFFFFu));
+}
+template <bool BF16>
+__device__ __forceinline__ float hi16(uint32_t v) {
+    if constexpr (BF16)
+        return __uint_as_float(v & 0xFFFF0000u);
+    else
+        return from_f16((uint16_t)(v >> 16));
+}
+
+// Tail of a FULL tile.  tl: this wave's 4 KB exchange slice; rows cm0 + wm*128 .. +128, columns cn0 + wn*64 .. +64.
+template <bool BF16, bool SKIP, bool RELU>
+__device__ __forceinline__ void gemm16_tail_full(const Gemm16Args& p, uint8_t* tl, f32x16 (&acc)[4][2], int64_t cm0, int cn0, int wm,
+                                                 int wn, int l31, int h) {
+    const int tg = l31 >> 2, tx = l31 & 3;
+    const uint32_t a_own = (uint32_t)l31 * 128u;  // + ((c16 ^ (row & 7)) << 4)
+    auto own_addr = [&](int X) { return tl + a_own + ((uint32_t)(((X * 2 + h) ^ (l31 & 7))) << 4); };
+    auto quad_addr = [&](int j) {
+        const int row = 4 * tg + j;
+        return tl + row * 128 + ((uint32_t)(((tx * 2 + h) ^ (row & 7))) << 4);
+    };
+    const int colw = cn0 + wn * 64;
+    {   // bias of this lane's 4 x 8 columns, added in place (this kernel serves the network's layer forms: bias is there)
+        const float* bp = p.bias + colw + h * 8;
+#pragma unroll
+        for (int X = 0; X < 4; X++) {
+            const float4 b0 = *reinterpret_cast<const float4*>(bp + X * 16), b1 = *reinterpret_cast<const float4*>(bp + X * 16 + 4);
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc[i][X >> 1][8 * (X & 1) + e] += bb[e];
+            __builtin_amdgcn_sched_barrier(0);  // (left alone, the scheduler hoists every load of the tail to its top and spills)
+        }
+    }
+    // this lane's pieces in the coalesced arrangement: piece tx * 2 + h of rows 4 tg + j of a 32-row block
+    const int64_t rq = cm0 + wm * 128 + 4 * tg;
+    const int64_t goff = rq * p.ldo + colw + (tx * 2 + h) * 8;
+    u32x4 sk[2][4];
+    auto load_skip = [&](int i, u32x4 (&s4)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) s4[j] = *reinterpret_cast<const u32x4*>(p.skip + goff + (int64_t)(i * 32 + j) * p.ldo);
+    };
+    if constexpr (SKIP) load_skip(0, sk[0]);
+    auto rows32 = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SKIP) {
+            if constexpr (i + 1 < 4) load_skip(i + 1, sk[(i + 1) & 1]);  // in flight while this block is worked on
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) *reinterpret_cast<u32x4*>(quad_addr(j)) = sk[i & 1][j];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            u32x4 mine[4];
+#pragma unroll
+            for (int X = 0; X < 4; X++) mine[X] = *reinterpret_cast<const u32x4*>(own_addr(X));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int X = 0; X < 4; X++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    acc[i][X >> 1][8 * (X & 1) + 2 * e] += lo16<BF16>(mine[X][e]);
+                    acc[i][X >> 1][8 * (X & 1) + 2 * e + 1] += hi16<BF16>(mine[X][e]);
+                }
+        }
+#pragma unroll
+        for (int X = 0; X < 4; X++) {
+            u32x4 ov;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float a = acc[i][X >> 1][8 * (X & 1) + 2 * e], b = acc[i][X >> 1][8 * (X & 1) + 2 * e + 1];
+                if constexpr (RELU) {
+                    a = fmaxf(a, 0.f);
+                    b = fmaxf(b, 0.f);
+                }
+                ov[e] = pack16x2<BF16>(a, b);
+            }
+            *reinterpret_cast<u32x4*>(own_addr(X)) = ov;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        u32x4 q[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) q[j] = *reinterpret_cast<const u32x4*>(quad_addr(j));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the slice is rewritten by the next block)
+#pragma unroll
+        for (int j = 0; j < 4; j++) *reinterpret_cast<u32x4*>(p.out + goff + (int64_t)(i * 32 + j) * p.ldo) = q[j];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    rows32(std::integral_constant<int, 0>{});
+    rows32(std::integral_constant<int, 1>{});
+    rows32(std::integral_constant<int, 2>{});
+    rows32(std::integral_constant<int, 3>{});
+}
+
+template <bool BF16, bool SKIP>
+__global__ __launch_bounds__(QTHREADS, 2) void k_gemm16s(const Gemm16Args p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     using frag_t = typename std::conditional<BF16, b16x8, h16x8>::type;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, h = lane >> 5;
     const int wm = w >> 2, wn = w & 3;
-    const int nNt = (p.n + QBN - 1) / QBN;
-    const int64_t nMt = (p.m + QBM - 1) / QBM;
-    const int64_t slots = ((nMt + 7) / 8) * nNt;  // per XCD
-    const int xcd = (int)(blockIdx.x & 7);
-    const int64_t stride = gridDim.x >> 3;
+    const int nNt = p.n / QBN;  // (m, n: multiples of the tile)
+    const int64_t slot = blockIdx.x >> 3;
+    const int64_t m0 = ((slot / nNt) * 8 + (blockIdx.x & 7)) * QBM;  // the N tiles of one M tile sit on one XCD
+    const int n0 = (int)(slot % nNt) * QBN;
+    if (m0 >= p.m) return;
     const int nk = p.k / QBK;
 
+    // (full tiles only — the host hands the ragged edges of a layer to variant 2: no clamping, no per-element tests)
     const uint16_t* src[4][2];
-    auto set_src = [&](int64_t m0, int n0) {
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+    for (int u = 0; u < 4; u++)
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const uint32_t r = (uint32_t)((q * 8 + w) * 8 + (lane >> 3));
-                const uint32_t c = (uint32_t)(lane & 7) ^ ((r >> 1) & 7u);
-                if (u < 2) {
-                    int64_t gr = m0 + (r >> 6) * 128 + (u == PS_A23 ? 64 : 0) + (r & 63);
-                    gr = gr < p.m ? gr : p.m - 1;
-                    src[u][q] = p.a + gr * p.lda + c * 8;
-                } else {
-                    int gn = n0 + (int)(r >> 5) * 64 + sigma16(u == PS_B1 ? 1 : 0, (int)(r & 31));
-                    gn = gn < p.n ? gn : p.n - 1;
-                    src[u][q] = p.w + (int64_t)gn * p.ldw + c * 8;
-                }
+        for (int q = 0; q < 2; q++) {
+            const uint32_t r = (uint32_t)((q * 8 + w) * 8 + (lane >> 3));
+            const uint32_t c = (uint32_t)(lane & 7) ^ ((r >> 1) & 7u);
+            if (u < 2) {
+                const int64_t gr = m0 + (r >> 6) * 128 + (u == PS_A23 ? 64 : 0) + (r & 63);
+                src[u][q] = p.a + gr * p.lda + c * 8;
+            } else {
+                const int gn = n0 + (int)(r >> 5) * 64 + sigma16(u == PS_B1 ? 1 : 0, (int)(r & 31));
+                src[u][q] = p.w + (int64_t)gn * p.ldw + c * 8;
             }
-    };
+        }
     auto issue = [&](int u, int buf, int k0) {
 #pragma unroll
         for (int q = 0; q < 2; q++) {
@@ -802,32 +635,6 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16ps(const Gemm16Args p) {
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
-    auto prologue = [&]() {  // all of K-tile 0 and A01, B0, B1 of K-tile 1
-        issue(PS_A01, 0, 0);
-        issue(PS_B0, 0, 0);
-        issue(PS_B1, 0, 0);
-        issue(PS_A23, 0, 0);
-        if (nk > 1) {
-            issue(PS_A01, 1, QBK);
-            issue(PS_B0, 1, QBK);
-            issue(PS_B1, 1, QBK);
-        }
-    };
-    auto tile_of = [&](int64_t slot, int64_t& m0, int& n0) -> bool {
-        if (slot >= slots) return false;
-        const int64_t mt = (slot / nNt) * 8 + xcd;
-        m0 = mt * QBM;
-        n0 = (int)(slot % nNt) * QBN;
-        return true;
-    };
-    // first tile of this workgroup with rows inside the matrix (slots of an XCD whose M tile lies past the edge are skipped)
-    auto next_tile = [&](int64_t& slot, int64_t& m0, int& n0) -> bool {
-        for (;; slot += stride) {
-            if (!tile_of(slot, m0, n0)) return false;
-            if (m0 < p.m) return true;
-        }
-    };
-
     uint32_t foff[4];
 #pragma unroll
     for (int s = 0; s < 4; s++) foff[s] = swz128((uint32_t)l31, 2u * s + (uint32_t)h);
@@ -905,184 +712,38 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16ps(const Gemm16Args p) {
         DCA_BAR();
     };
 
-    auto cvt_in = [](uint32_t b) { return BF16 ? from_bf16((uint16_t)b) : from_f16((uint16_t)b); };
-    auto cvt_out = [](float f) { return (uint32_t)(BF16 ? to_bf16(f) : to_f16(f)); };
-    const bool al16 = ((p.ldo & 7) == 0) && (((uintptr_t)p.out | (uintptr_t)p.skip) & 15) == 0;
-    const bool bal16 = ((uintptr_t)p.bias & 15) == 0;
-
-    int64_t slot = blockIdx.x >> 3, m0 = 0;
-    int n0 = 0;
-    bool have = next_tile(slot, m0, n0);
-    if (!have) return;
-    if (p.skew_us > 0) {  // (diagnostic: take the CUs' tiles out of lockstep)
-        const unsigned long long t0 = wall_clock64();
-        const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 7) * (unsigned long long)p.skew_us * 100ull / 8ull;
-        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int jn = 0; jn < 2; jn++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][jn][e] = 0.f;
+    issue(PS_A01, 0, 0);
+    issue(PS_B0, 0, 0);
+    issue(PS_B1, 0, 0);
+    issue(PS_A23, 0, 0);
+    if (nk > 1) {
+        issue(PS_A01, 1, QBK);
+        issue(PS_B0, 1, QBK);
+        issue(PS_B1, 1, QBK);
+        DCA_VMCNT(10);  // A01, B0 of tile 0 have landed
+    } else {
+        DCA_VMCNT(4);
     }
-    set_src(m0, n0);
-    prologue();
-    int64_t tcount = 0;
-    while (have) {
-        if (p.prof && t == 0) p.prof[(tcount * gridDim.x + blockIdx.x) * 4 + 0] = wall_clock64();
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int jn = 0; jn < 2; jn++)
-#pragma unroll
-                for (int e = 0; e < 16; e++) acc[i][jn][e] = 0.f;
-        // A01, B0 of K-tile 0 have landed (everything older than the 10 youngest pieces: B1 A23 of tile 0, A01 B0 B1 of tile 1)
-        if (nk > 1)
-            DCA_VMCNT(10);
-        else
-            DCA_VMCNT(4);
-        DCA_BAR();
-        if (wm == 1) DCA_BAR();  // the second wave row runs one barrier behind the first
-        {
-            int kt = 0;
-            for (; kt + 2 < nk; kt++) tile(kt, std::true_type{}, std::true_type{});
-            if (kt + 1 < nk) {
-                tile(kt, std::true_type{}, std::false_type{});
-                kt++;
-            }
-            tile(kt, std::false_type{}, std::false_type{});
+    DCA_BAR();
+    if (wm == 1) DCA_BAR();  // the second wave row runs one barrier behind the first from here on
+    {
+        int kt = 0;
+        for (; kt + 2 < nk; kt++) tile(kt, std::true_type{}, std::true_type{});
+        if (kt + 1 < nk) {
+            tile(kt, std::true_type{}, std::false_type{});
+            kt++;
         }
-        if (wm == 0) DCA_BAR();  // ... and the first waits for it here: nobody reads the operand slots any more
-        if (p.prof && t == 0) p.prof[(tcount * gridDim.x + blockIdx.x) * 4 + 1] = wall_clock64();
-        const int64_t cm0 = m0;
-        const int cn0 = n0;
-        // bias of this lane's 4 x 8 columns: requested first, so that it lands under the address work and DMA issue below
-        float bv[4][8];
-        {
-            const int colb = cn0 + wn * 64 + h * 8;
-#pragma unroll
-            for (int X = 0; X < 4; X++) {
-                const int col = colb + X * 16;
-                if (p.bias && col + 7 < p.n && bal16) {
-                    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col), b1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
-                    bv[X][0] = b0.x, bv[X][1] = b0.y, bv[X][2] = b0.z, bv[X][3] = b0.w;
-                    bv[X][4] = b1.x, bv[X][5] = b1.y, bv[X][6] = b1.z, bv[X][7] = b1.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; e++) bv[X][e] = (p.bias && col + e < p.n) ? p.bias[col + e] : 0.f;
-                }
-            }
-        }
-        slot += stride;
-        have = next_tile(slot, m0, n0);
-        if (have) {
-            set_src(m0, n0);
-            prologue();  // lands under the tail below
-        }
-        // ---- the layer tail.  Lane (l31, h), accumulator block (i, jn), registers 8 x .. 8 x + 7 are 8 consecutive columns
-        //      (one 16-byte piece c16 = X * 2 + h, X = jn * 2 + x, of the wave's 128-byte row segment) of row
-        //      cm0 + wm * 128 + i * 32 + l31.  A store with one ROW per lane costs a CU 3.5 us per 128 KB tile, one with 8
-        //      lanes per 128-byte row segment 1.0 (tools/store_pattern_probe.hip), so the packed pieces of a 32-row block
-        //      change hands inside the wave first — through a wave-private 4 KB of the LDS that the operand slots do not
-        //      use (no barrier, no conflict with the prefetch above): lane (4 g + x, h) ends up with piece x * 2 + h of rows
-        //      4 g .. 4 g + 3.  Skip rows come in by the same route, the other way round.
-        uint8_t* tl = lds + 2 * PBUF + w * 4096;
-        const int tg = l31 >> 2, tx = l31 & 3;
-        auto tl_addr = [&](int row, int c16) { return tl + row * 128 + ((c16 ^ (row & 7)) << 4); };
-        const int colw = cn0 + wn * 64;
-        auto load_skip = [&](int i, u32x4 (&sk)[4]) {  // coalesced: piece tx * 2 + h of rows 4 tg + j
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int64_t r = cm0 + wm * 128 + i * 32 + 4 * tg + j;
-                const int col = colw + (tx * 2 + h) * 8;
-                sk[j] = u32x4{0u, 0u, 0u, 0u};
-                if (p.skip && r < p.m && col < p.n) {
-                    const uint16_t* sp = p.skip + r * p.ldo + col;
-                    if (col + 7 < p.n) {
-                        if (al16) {
-                            sk[j] = *reinterpret_cast<const u32x4*>(sp);
-                        } else {
-                            const uint2 lo = *reinterpret_cast<const uint2*>(sp), hi = *reinterpret_cast<const uint2*>(sp + 4);
-                            sk[j] = u32x4{lo.x, lo.y, hi.x, hi.y};
-                        }
-                    } else {  // ragged right edge: element-wise
-                        uint32_t e16[8];
-#pragma unroll
-                        for (int e = 0; e < 8; e++) e16[e] = col + e < p.n ? (uint32_t)sp[e] : 0u;
-                        sk[j] = u32x4{e16[0] | (e16[1] << 16), e16[2] | (e16[3] << 16), e16[4] | (e16[5] << 16), e16[6] | (e16[7] << 16)};
-                    }
-                }
-            }
-        };
-        auto rows32 = [&](auto ic, const u32x4 (&sk)[4]) {
-            constexpr int i = decltype(ic)::value;
-            u32x4 mine[4];  // this lane's own row: skip pieces X * 2 + h
-            if (p.skip) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) *reinterpret_cast<u32x4*>(tl_addr(4 * tg + j, tx * 2 + h)) = sk[j];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int X = 0; X < 4; X++) mine[X] = *reinterpret_cast<const u32x4*>(tl_addr(l31, X * 2 + h));
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-#pragma unroll
-            for (int X = 0; X < 4; X++) {
-                float u[8];
-#pragma unroll
-                for (int e = 0; e < 8; e++) u[e] = acc[i][X >> 1][8 * (X & 1) + e] + bv[X][e];
-                if (p.skip) {
-#pragma unroll
-                    for (int e = 0; e < 8; e++) u[e] += cvt_in((mine[X][e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
-                }
-                if (p.relu) {
-#pragma unroll
-                    for (int e = 0; e < 8; e++) u[e] = fmaxf(u[e], 0.f);
-                }
-                u32x4 ov;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    if constexpr (BF16)
-                        ov[e] = pack_bf16x2(u[2 * e], u[2 * e + 1]);
-                    else
-                        ov[e] = cvt_out(u[2 * e]) | (cvt_out(u[2 * e + 1]) << 16);
-                }
-                *reinterpret_cast<u32x4*>(tl_addr(l31, X * 2 + h)) = ov;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            u32x4 q[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) q[j] = *reinterpret_cast<const u32x4*>(tl_addr(4 * tg + j, tx * 2 + h));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the slice is rewritten by the next block)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int64_t r = cm0 + wm * 128 + i * 32 + 4 * tg + j;
-                const int col = colw + (tx * 2 + h) * 8;
-                if (r >= p.m || col >= p.n) continue;
-                uint16_t* op = p.out + r * p.ldo + col;
-                if (col + 7 < p.n) {
-                    if (al16) {
-                        *reinterpret_cast<u32x4*>(op) = q[j];
-                    } else {
-                        *reinterpret_cast<uint2*>(op) = make_uint2(q[j][0], q[j][1]);
-                        *reinterpret_cast<uint2*>(op + 4) = make_uint2(q[j][2], q[j][3]);
-                    }
-                } else {  // ragged right edge: element-wise
-                    for (int e = 0; e < 8 && col + e < p.n; e++) op[e] = (uint16_t)((q[j][e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
-                }
-            }
-        };
-        {   // skip rows of block i + 1 are in flight while block i is worked on
-            u32x4 ska[4], skb[4];
-            load_skip(0, ska);
-            load_skip(1, skb);
-            rows32(std::integral_constant<int, 0>{}, ska);
-            load_skip(2, ska);
-            rows32(std::integral_constant<int, 1>{}, skb);
-            load_skip(3, skb);
-            rows32(std::integral_constant<int, 2>{}, ska);
-            rows32(std::integral_constant<int, 3>{}, skb);
-        }
-        if (p.prof && t == 0) {
-            p.prof[(tcount * gridDim.x + blockIdx.x) * 4 + 2] = wall_clock64();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            p.prof[(tcount * gridDim.x + blockIdx.x) * 4 + 3] = wall_clock64();
-        }
-        tcount++;
+        tile(kt, std::false_type{}, std::false_type{});
     }
+    if (wm == 0) DCA_BAR();  // ... and the first waits for it here: nobody reads the operand slots any more
+    // the tail's piece exchange uses the first 32 KB of the (now idle) operand slots, 4 KB per wave
+    gemm16_tail_full<BF16, SKIP, true>(p, lds + w * 4096, acc, m0, n0, wm, wn, l31, h);
 #undef DCA_VMCNT
 #undef DCA_MMA8
 }
@@ -1091,45 +752,22 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16ps(const Gemm16Args p) {
 
 using namespace dca;
 
-static int g_gemm16_variant = 2;
-static unsigned long long* g_gemm16_prof = nullptr;
-static int g_gemm16_skew_us = 0;
+static int g_gemm16_variant = 3;
 
-namespace dca {
-// csrc/dca_gemm2.hip: the two-workgroups-per-CU kernels (variant 3 here, variant 4 of dca_f16x3_gemm)
-struct Gemm2Args {
-    const uint16_t *a, *a2, *w, *w2;
-    int64_t m;
-    int n, k;
-    int64_t lda, ldw, ldo;
-    const float* col_scale;
-    const float* bias;
-    const void* skip;
-    float alpha;
-    int relu;
-    uint16_t *oh, *ol;
-    float* x_out;
-    int* overflow;
-    int skew_ticks;
-    int cus;
-};
-int gemm2_launch(int mode, const Gemm2Args& p, hipStream_t s);
-}  // namespace dca
+// the lean-tail kernel serving one of the network's layer forms: relu(a . w^T + bias) or relu(a . w^T + bias + skip)
+static const void* lean_kernel(int bf16, int skip) {
+    static const void* tab[4] = {reinterpret_cast<const void*>(k_gemm16s<false, false>), reinterpret_cast<const void*>(k_gemm16s<true, false>),
+                                 reinterpret_cast<const void*>(k_gemm16s<false, true>), reinterpret_cast<const void*>(k_gemm16s<true, true>)};
+    return tab[(bf16 ? 1 : 0) | (skip ? 2 : 0)];
+}
 
 extern "C" {
 
-/* tuning / test hook: 1 = two K-step stages, one drain + barrier per K-step; 2 (default) = the 8-phase ping-pong schedule;
- * 3 = 128 x 256 tiles, two workgroups per CU (dca_gemm2.hip); 4 = four waves x 128 x 128, ring of five K-tiles of 32 */
-/* diagnostics of variant 5: knob 1 = device buffer for per-tile wall-clock stamps (4 x u64 per tile and workgroup; 0 = off),
- * knob 2 = start skew in microseconds */
-int dca_gemm16_debug(int knob, long long value) {
-    if (knob == 1) g_gemm16_prof = reinterpret_cast<unsigned long long*>((uintptr_t)value);
-    if (knob == 2) g_gemm16_skew_us = (int)value;
-    return 0;
-}
-
+/* test hook: 1 = two K-step stages, one drain + barrier per K-step (the reference the race screens compare against); 2 = the
+ * 8-phase ping-pong schedule with the general tail (what ragged strips and other layer forms always run on); 3 (default) = the
+ * same schedule with operand roles swapped and the lean tail for the network's layer forms */
 int dca_gemm16_variant(int v) {
-    DCA_ARG(v >= 1 && v <= 5);
+    DCA_ARG(v >= 1 && v <= 3);
     g_gemm16_variant = v;
     return 0;
 }
@@ -1146,31 +784,6 @@ int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int 
         DCA_ARG(!(o0 < a1 && a0 < o1));
     }
     if (m == 0) return 0;
-    if (g_gemm16_variant == 3) {  // 128 x 256 tiles, 4 waves, two workgroups per CU (csrc/dca_gemm2.hip); bit-identical to 1 and 2
-        Gemm2Args q;
-        q.a = reinterpret_cast<const uint16_t*>(a);
-        q.a2 = nullptr;
-        q.w = reinterpret_cast<const uint16_t*>(w);
-        q.w2 = nullptr;
-        q.m = m;
-        q.n = n;
-        q.k = k;
-        q.lda = lda;
-        q.ldw = ldw;
-        q.ldo = ldo;
-        q.col_scale = nullptr;
-        q.bias = bias;
-        q.skip = skip;
-        q.alpha = 1.f;
-        q.relu = relu;
-        q.oh = reinterpret_cast<uint16_t*>(out);
-        q.ol = nullptr;
-        q.x_out = nullptr;
-        q.overflow = nullptr;
-        q.skew_ticks = 0;
-        q.cus = 0;
-        return gemm2_launch(dtype == DCA_DT_BF16 ? 1 : 2, q, (hipStream_t)stream);
-    }
     {   // the dynamic-LDS limit is a per-device function attribute: set it once for every device this process uses
         static std::atomic<uint64_t> attr_devs{0};
         int dev = 0;
@@ -1181,10 +794,7 @@ int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int 
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16p<true>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16p<false>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
-            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16ps<true>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS_PS));
-            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16ps<false>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS_PS));
-            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16w<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WLDS));
-            DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16w<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WLDS));
+            for (int f = 0; f < 4; f++) DCA_HIP(hipFuncSetAttribute(lean_kernel(f & 1, f >> 1), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
             attr_devs.fetch_or(bit, std::memory_order_release);
         }
     }
@@ -1201,48 +811,69 @@ int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int 
     p.lda = lda;
     p.ldw = ldw;
     p.ldo = ldo;
-    p.prof = g_gemm16_prof;
-    p.skew_us = g_gemm16_skew_us;
-    const int64_t nMt = (m + QBM - 1) / QBM;
-    const int64_t nNt = (n + QBN - 1) / QBN;
-    const int64_t blocks = ((nMt + 7) / 8) * 8 * nNt;
-    if (blocks > 0x7FFFFFFFll) {
-        set_error("dca_gemm16: too many tiles");
-        return DCA_E_BADARG;
-    }
-    const dim3 grid((unsigned)blocks), block(QTHREADS);
-    if (g_gemm16_variant == 5) {  // persistent: one workgroup per CU (a multiple of 8: the XCD mapping), never more than tiles
-        static int cus = 0;
-        if (cus == 0) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            DCA_HIP(hipGetDevice(&dev));
-            DCA_HIP(hipGetDeviceProperties(&prop, dev));
-            cus = prop.multiProcessorCount > 8 ? (prop.multiProcessorCount / 8) * 8 : 8;
+    hipStream_t s = (hipStream_t)stream;
+    // one workgroup per 256 x 256 tile, any shape, any form (variants 1, 2)
+    auto launch_generic = [&](const Gemm16Args& q, int variant) -> int {
+        const int64_t nMt = (q.m + QBM - 1) / QBM;
+        const int64_t nNt = (q.n + QBN - 1) / QBN;
+        const int64_t blocks = ((nMt + 7) / 8) * 8 * nNt;
+        if (blocks > 0x7FFFFFFFll) {
+            set_error("dca_gemm16: too many tiles");
+            return DCA_E_BADARG;
         }
-        const unsigned g = (unsigned)(blocks < cus ? blocks : cus);
-        if (dtype == DCA_DT_BF16)
-            hipLaunchKernelGGL(k_gemm16ps<true>, dim3(g), block, QLDS_PS, (hipStream_t)stream, p);
-        else
-            hipLaunchKernelGGL(k_gemm16ps<false>, dim3(g), block, QLDS_PS, (hipStream_t)stream, p);
-    } else if (g_gemm16_variant == 4) {  // four waves x (128 x 128): K-tiles of 32
-        DCA_ARG(k % WBK == 0);
-        if (dtype == DCA_DT_BF16)
-            hipLaunchKernelGGL(k_gemm16w<true>, grid, dim3(WTHREADS), WLDS, (hipStream_t)stream, p);
-        else
-            hipLaunchKernelGGL(k_gemm16w<false>, grid, dim3(WTHREADS), WLDS, (hipStream_t)stream, p);
-    } else if (g_gemm16_variant == 2) {
-        if (dtype == DCA_DT_BF16)
-            hipLaunchKernelGGL(k_gemm16p<true>, grid, block, QLDS, (hipStream_t)stream, p);
-        else
-            hipLaunchKernelGGL(k_gemm16p<false>, grid, block, QLDS, (hipStream_t)stream, p);
-    } else {
-        if (dtype == DCA_DT_BF16)
-            hipLaunchKernelGGL(k_gemm16<true>, grid, block, QLDS, (hipStream_t)stream, p);
-        else
-            hipLaunchKernelGGL(k_gemm16<false>, grid, block, QLDS, (hipStream_t)stream, p);
+        const dim3 grid((unsigned)blocks), block(QTHREADS);
+        if (variant == 1) {
+            if (dtype == DCA_DT_BF16)
+                hipLaunchKernelGGL(k_gemm16<true>, grid, block, QLDS, s, q);
+            else
+                hipLaunchKernelGGL(k_gemm16<false>, grid, block, QLDS, s, q);
+        } else {
+            if (dtype == DCA_DT_BF16)
+                hipLaunchKernelGGL(k_gemm16p<true>, grid, block, QLDS, s, q);
+            else
+                hipLaunchKernelGGL(k_gemm16p<false>, grid, block, QLDS, s, q);
+        }
+        return 0;
+    };
+    if (g_gemm16_variant < 3) {
+        if (int rc = launch_generic(p, g_gemm16_variant)) return rc;
+        return launch_check("k_gemm16");
     }
-    return launch_check("k_gemm16");
+    // Variant 3 — the lean-tail kernel — serves the network's own layer forms, relu(a . w^T + bias (+ skip)), on whole tiles
+    // with 16-byte aligned rows; any other form goes to variant 2, and so do the ragged right and bottom strips of a layer
+    // (none in the network's own shapes: widths are padded to 1024 / 5120, row counts to 1024) — the same products in the same
+    // order either way.
+    const bool lean = relu && bias && (ldo % 8 == 0) && (((uintptr_t)out | (uintptr_t)skip | (uintptr_t)bias) % 16 == 0);
+    const int64_t mf = lean ? (m / QBM) * QBM : 0;
+    const int nf = lean ? (n / QBN) * QBN : 0;
+    if (mf > 0 && nf > 0) {
+        Gemm16Args q = p;
+        q.m = mf;
+        q.n = nf;
+        const int64_t nMt = mf / QBM, nNt = nf / QBN;
+        const int64_t blocks = ((nMt + 7) / 8) * 8 * nNt;
+        if (blocks > 0x7FFFFFFFll) {
+            set_error("dca_gemm16: too many tiles");
+            return DCA_E_BADARG;
+        }
+        void* kargs[] = {&q};
+        DCA_HIP(hipLaunchKernel(lean_kernel(dtype == DCA_DT_BF16, skip != nullptr), dim3((unsigned)blocks), dim3(QTHREADS), kargs, QLDS, s));
+    }
+    auto strip = [&](int64_t r0, int64_t rows, int c0, int cols) -> int {  // rows [r0, r0 + rows) x columns [c0, c0 + cols)
+        if (rows <= 0 || cols <= 0) return 0;
+        Gemm16Args q = p;
+        q.a = p.a + r0 * lda;
+        q.w = p.w + (int64_t)c0 * ldw;
+        q.bias = p.bias ? p.bias + c0 : nullptr;
+        q.skip = p.skip ? p.skip + r0 * ldo + c0 : nullptr;
+        q.out = p.out + r0 * ldo + c0;
+        q.m = rows;
+        q.n = cols;
+        return launch_generic(q, 2);
+    };
+    if (int rc = strip(0, mf, nf, n - nf)) return rc;  // right strip beside the full tiles
+    if (int rc = strip(mf, m - mf, 0, n)) return rc;   // bottom strip, full width
+    return launch_check("k_gemm16s");
 }
 
 }  // extern "C"

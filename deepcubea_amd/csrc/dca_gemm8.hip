@@ -79,12 +79,18 @@ __device__ __forceinline__ uint32_t e8m0_of_amax(float amax, float& inv) {
 
 __device__ __forceinline__ uint32_t swz128b(uint32_t row, uint32_t chunk) { return row * 128u + ((chunk ^ ((row >> 1) & 7u)) << 4); }
 
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {  // round to nearest even; NaN stays NaN
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+typedef __bf16 g8_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float g8_f32x2 __attribute__((ext_vector_type(2)));
+// round to nearest even, NaN stays NaN: gfx950's v_cvt_pk_bf16_f32, two values per instruction (the integer sequence it
+// replaces took six per value — a visible share of the layer tail, csrc/dca_gemm16.hip)
+__device__ __forceinline__ uint32_t f32_to_bf16x2(float lo, float hi) {
+    const g8_f32x2 v = {lo, hi};
+    const g8_bf16x2 b = __builtin_convertvector(v, g8_bf16x2);
+    uint32_t u;
+    __builtin_memcpy(&u, &b, 4);
+    return u;
 }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return (uint16_t)(f32_to_bf16x2(f, 0.f) & 0xFFFFu); }
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
 // four floats -> four e4m3 bytes (round to nearest even, saturating at +-448: e4m3fn has no infinity)
@@ -387,8 +393,8 @@ __global__ __launch_bounds__(ETHREADS, 2) void k_gemm8(const Gemm8Args p) {
                 }
                 if (p.out16) {
                     uint2 ov;
-                    ov.x = (uint32_t)f32_to_bf16(u[0]) | ((uint32_t)f32_to_bf16(u[1]) << 16);
-                    ov.y = (uint32_t)f32_to_bf16(u[2]) | ((uint32_t)f32_to_bf16(u[3]) << 16);
+                    ov.x = f32_to_bf16x2(u[0], u[1]);
+                    ov.y = f32_to_bf16x2(u[2], u[3]);
                     *reinterpret_cast<uint2*>(p.out16 + r * p.ldo16 + colg) = ov;
                 }
                 if (p.out8) {

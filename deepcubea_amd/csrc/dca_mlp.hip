@@ -43,9 +43,14 @@ struct L1Geo {
     static constexpr int MWC = (CH_STEPS * 16 + 31) / 32;  // one-hot mask words per row and chunk
 };
 
-__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
-    uint32_t u = __float_as_uint(f);
-    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {  // gfx950's v_cvt_pk_bf16_f32 (round to nearest even)
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = {f, 0.f};
+    const bf2 b = __builtin_convertvector(v, bf2);
+    uint32_t u;
+    __builtin_memcpy(&u, &b, 4);
+    return (uint16_t)(u & 0xFFFFu);
 }
 
 template <int D, int DEPTH, int P,

@@ -71,7 +71,7 @@ def _load_heuristic(args, env):
         if dt_name in ("fp8", "fp8mx"):
             fast = Fp8Resnet(nnet, scaling="block" if dt_name == "fp8mx" else "tensor").to(device)
         else:
-            fast = FastResnet(nnet, dt).to(device)
+            fast = FastResnet(nnet, dt, gemm16=getattr(args, "gemm16", "hip")).to(device)
         # layer 1 as the library's one-hot MFMA kernel: the engine then hands out uint8 rows only (stride 0 = no one-hot)
         stride = 0 if fast.uses_l1_kernel else fast.in_pad
         args._onehot_dtype = fast.onehot_dtype  # what the engine's pack kernel writes when one-hot rows are needed
@@ -243,6 +243,9 @@ def build_parser() -> ArgumentParser:
                              "hand-written layer kernels (dca_gemm8), one calibrated scale per activation tensor: fastest, "
                              "coarsest; fp8mx = the same with one E8M0 scale per row and 64 elements (nothing to "
                              "calibrate, ~13 %% slower)")
+    parser.add_argument('--gemm16', type=str, default="hip", choices=["hip", "library"],
+                        help="--nnet_dtype bf16 / fp16: dense layers on the hand-written dca_gemm16 kernel (default) or on the "
+                             "library's (hipBLASLt) GEMMs")
     parser.add_argument('--fold_bn', action='store_true', default=False,
                         help="with --eval_all_children: fold BatchNorm into the Linears (always done otherwise)")
     parser.add_argument('--static_shards', action='store_true', default=False,

@@ -235,11 +235,11 @@ class FastResnet(nn.Module):
         assert gemm in ("hip", "library")
         # bf16 / fp16 (non-parity) modes.  "hip" (default since round 4: the product's own kernels) = one dca_gemm16 launch per
         # layer, whole tail (bias, residual add, ReLU, rounding) in the epilogue (csrc/dca_gemm16.hip); "library" = hipBLASLt
-        # GEMMs with fused bias+ReLU, plus one ReLU pass per residual block — kept selectable and, stated plainly, still ahead:
-        # per layer at 204 800 rows, candidates taking turns (profiles/r04_gemm_bench.txt, ms, hip / library): 5120->1024
-        # bias+ReLU 1.96 / 1.68, 1024->1024 bias+ReLU 0.53 / 0.42, 1024->1024 residual+ReLU 0.56 / 0.56 (end to end 2.76e6 vs
-        # 3.09e6 nodes expanded/s).  Both sit at the chip's power limit (1.3-1.7 GHz inside the K loop, profiles/r04_gemm_timeline.txt);
-        # the library's 4-wave x 128 x 128 layout spends a third less LDS traffic per MFMA and buys its clock with it.
+        # GEMMs with fused bias+ReLU, plus one ReLU pass per residual block — selectable from the CLI (`--gemm16 library`).
+        # Per layer at 204 800 rows, candidates taking turns (profiles/r05_gemm_bench.txt, ms, hip / library): 1024->1024
+        # residual+ReLU 0.50 / 0.56 (ahead), 1024->1024 bias+ReLU 0.45 / 0.38, 5120->1024 bias+ReLU 1.93 / 1.67 (behind).
+        # What bounds both is the operand stream from L2 into the LDS (64 KB per K-tile of a 256 x 256 tile, ~15-20 B/clk/CU
+        # with every CU fetching) and, on random operands, the power limit; csrc/dca_gemm16.hip has the measurements.
         self.gemm16 = gemm16
         assert gemm16 in ("hip", "library")
         # set by the split kernels when a value does not fit fp16 (|v| > 60000): that batch is redone with fp32 GEMMs

@@ -373,28 +373,11 @@ int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t l
                    int64_t ldw, const float* col_scale /*[n] or NULL*/, double alpha, const float* bias /*[n] or NULL*/,
                    const float* skip /*[m, ldo] fp32 or NULL*/, int relu, void* out_h, void* out_l, float* x_out, int64_t ldo,
                    int* overflow, void* stream);
-/* tuning / test hook: 3 (default) = 256 x 256 tiles filled by LDS-DMA on the ping-pong / half-tile schedule (two wave groups one
- * barrier apart, the DMA queue never drained); 2 = the same tile with two whole-K-step stages and one drain + barrier per K-step
- * (bit-identical to 3: same products in the same order); 1 = 128 x 128 tiles staged through registers (the A/B reference; same
- * results to fp32 rounding). */
+/* test hook: 3 (default) = 256 x 256 tiles filled by LDS-DMA on the ping-pong / half-tile schedule (two wave groups one barrier
+ * apart, the DMA queue never drained); 2 = the same tile with two whole-K-step stages and one drain + barrier per K-step
+ * (bit-identical to 3: same products in the same order — what the race screens in tests/ compare against).  ldo % 4 == 0,
+ * out_h / out_l 8-byte and x_out / skip 16-byte aligned. */
 int dca_f16x3_gemm_variant(int variant);
-/* Split-K form (the training step's weight gradients dW = dy^T . x: 16-80 output tiles, a batch-long contraction): `splits`
- * workgroups per output tile, split z multiplies K-steps [z * ceil(nk / splits), ...) and writes alpha * col_scale * its partial
- * product to partials[z] ([splits][m][ldo] fp32, 16-byte aligned); the caller adds the partials up in a fixed order (no
- * atomics: deterministic).  splits must leave every split at least one 64-deep K-step. */
-int dca_f16x3_gemm_splitk(const void* a_h, const void* a_l, int64_t m, int k, int64_t lda, const void* w_h, const void* w_l, int n,
-                          int64_t ldw, const float* col_scale /*[n] or NULL*/, double alpha, int splits, float* partials,
-                          int64_t ldo, void* stream);
-/* variant 4 of dca_f16x3_gemm / variant 3 of dca_gemm16 (csrc/dca_gemm2.hip): 128 x 256 tiles on 4-wave workgroups, TWO of
- * them per CU, so that one workgroup's layer tail (output + residual traffic, matrix pipes idle) runs under the other's MFMAs;
- * three-stage LDS-DMA ring, one counted wait + one barrier per stage; results bit-identical to the 256 x 256 variants.
- * dca_gemm2_skew: start-up skew of every CU's second workgroup in 1/16ths of a tile's K-loop time (default 8; 0 = none). */
-int dca_gemm2_skew(int sixteenths);
-/* diagnostics (tools/gemm_timeline.py): while `stamps` (device u64 [workgroups][8]) is set, variant-3 launches of
- * dca_f16x3_gemm record per workgroup the 100 MHz wall clock [0] at entry, [1] when the first operands have landed, [2] at the
- * end of the K loop, [5] when wave 0 has issued its last store, [3] when its stores have been acknowledged, and
- * [4] (XCC id << 32 | HW_ID), [6] shader-clock cycles of the K loop ([2] - [1] in core cycles: the clock it ran at).  NULL: off. */
-int dca_f16x3_gemm_timeline(void* stamps);
 
 /* The same layer in the NON-parity 16-bit modes (`--nnet_dtype bf16 | fp16`; replaces the library GEMM + separate clamp pass of
  * utils/pytorch_models.py:57-86 as PyTorch runs it): out = relu?( a . w^T + bias (+ skip) ), operands and result in `dtype`
@@ -405,9 +388,11 @@ int dca_f16x3_gemm_timeline(void* stamps);
 int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int n, int64_t ldw, int dtype,
                const float* bias /*[n] or NULL*/, const void* skip /*[m, ldo] or NULL*/, int relu, void* out, int64_t ldo,
                void* stream);
-/* tuning / test hook: 2 (default) = the 8-phase schedule (two wave groups one barrier apart, half-tile staging, the DMA
- * queue never drained); 1 = two whole K-step stages with one drain + barrier per K-step (the A/B reference).  Bit-identical
- * results (same accumulation order). */
+/* test hook: 3 (default) = the 8-phase schedule (two wave groups one barrier apart, half-tile staging, the DMA queue never
+ * drained) with the MFMA operand roles swapped and a lean tail compiled per layer form — relu(a . w^T + bias (+ skip)) on whole
+ * 256 x 256 tiles with 16-byte aligned rows; other forms and the ragged strips of a layer run on 2 = the same schedule with the
+ * general tail; 1 = two whole K-step stages with one drain + barrier per K-step (the plain reference of the race screens).
+ * Bit-identical results (same products, same accumulation order). */
 int dca_gemm16_variant(int variant);
 
 /* The same layer in the NON-parity fp8 mode (`--nnet_dtype fp8`; csrc/dca_gemm8.hip): OCP e4m3 operands a [m, lda] / w [n, ldw]
@@ -457,12 +442,7 @@ int dca_split_planes_scaled(const float* x, int64_t m, int64_t n, int64_t ld, co
                             void* out_h, void* out_l, int64_t ldo, int64_t n_pad, void* stream);
 int dca_split_rows_scaled(const float* w, int64_t n, int64_t k, int64_t ld, void* out_h, void* out_l, int64_t ldo, int64_t k_pad,
                           float* col_scale /*[n]*/, const uint32_t* other_amax_bits /*device or NULL*/, void* stream);
-/* The weight gradient dW = dy^T . x contracts over the batch dimension, which neither operand has contiguous: both are
- * transposed on their way into planes.  dca_split_planes_t: x [m, n] -> planes of (x * 2^e)^T, [n] rows of ldo >= ceil64(m)
- * halves, rows m..ceil64(m) zero (amax_bits as above, NULL = unscaled).  dca_fill_inv_pow2: out[0..n) = 2^-e of that scale
- * (the GEMM's col_scale when only one operand is scaled). */
-int dca_split_planes_t(const float* x, int64_t m, int64_t n, int64_t ld, const uint32_t* amax_bits /*device or NULL*/, void* out_h,
-                       void* out_l, int64_t ldo, void* stream);
+/* dca_fill_inv_pow2: out[0..n) = 2^-e of the power-of-two scale dca_split_planes_scaled derives from amax_bits. */
 int dca_fill_inv_pow2(float* out, int64_t n, const uint32_t* amax_bits, void* stream);
 
 /* Output layer of the cost-to-go network (utils/pytorch_models.py:83-86, fc_out: res_dim -> out_dim, out_dim = 1 for every

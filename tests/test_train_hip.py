@@ -90,10 +90,6 @@ def test_linear_train_is_fp32_accurate_forward_and_backward(m, k, n):
         e_ours, e_lib = float((o - w_).abs().max()), float((l - w_).abs().max())
         scale = float(w_.abs().max())
         assert e_ours <= max(4.0 * e_lib, 2e-7 * scale), (name, e_ours, e_lib, scale)
-    # the weight gradient through the same kernel (operands transposed while split; not the default — see _lib.TRAIN_DW_F16X3)
-    dw16 = _lib.weight_grad_f16x3(dy.cuda(), x.cuda()).double().cpu()
-    e16, e_lib = float((dw16 - want[2]).abs().max()), float((lib32[2] - want[2]).abs().max())
-    assert e16 <= max(4.0 * e_lib, 2e-7 * float(want[2].abs().max())), (e16, e_lib)
     # per-ROW accuracy of the input gradient: a sample whose gradient is 2^-20 of the largest keeps its own digits
     rows = (ours[1] - want[1]).abs().amax(dim=1) / want[1].abs().amax(dim=1).clamp_min(1e-300)
     assert float(rows.max()) < 1e-3 and float(rows.median()) < 1e-5, (float(rows.max()), float(rows.median()))
@@ -103,7 +99,7 @@ def test_linear_train_is_fp32_accurate_forward_and_backward(m, k, n):
 def test_linear_train_survives_activations_beyond_the_fp16_range():
     """the forward used to split activations into fp16 planes unscaled — a value past 65504 became inf and the
     loss NaN without a diagnostic.  Activations now carry a power-of-two scale from their own magnitude (like the
-    gradients): outputs and all gradients stay finite and fp32-accurate with inputs of 3e5, forward and weight gradient."""
+    gradients): outputs and all gradients stay finite and fp32-accurate with inputs of 3e5."""
     from deepcubea_amd import _lib
     _lib.require_gpu()
     g = torch.Generator().manual_seed(5)
@@ -125,11 +121,6 @@ def test_linear_train_survives_activations_beyond_the_fp16_range():
     y32 = torch.nn.functional.linear(x.cuda(), lin.weight, lin.bias).double().cpu()
     e_ours, e_lib = float((yd.detach().double().cpu() - yr.detach()).abs().max()), float((y32 - yr.detach()).abs().max())
     assert e_ours <= max(4.0 * e_lib, 2e-7 * float(yr.abs().max())), (e_ours, e_lib)
-    dw16 = _lib.weight_grad_f16x3(dy.cuda(), x.cuda()).double().cpu()
-    assert torch.isfinite(dw16).all()
-    e16 = float((dw16 - ref.weight.grad).abs().max())
-    e_lib = float((dy.cuda().t().mm(x.cuda()).double().cpu() - ref.weight.grad).abs().max())
-    assert e16 <= max(4.0 * e_lib, 2e-7 * float(ref.weight.grad.abs().max())), (e16, e_lib)
 
 
 def test_avi_loop_end_to_end(tmp_path):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""What bounds the bf16 dense layer?  Times dca_gemm16 variants 2 (per-tile workgroups, LDS tail) and 5 (persistent,
-register tail) and the library GEMM on (a) random operands, (b) ALL-ZERO operands (same instructions, same bytes, no
+"""What bounds the bf16 dense layer?  Times dca_gemm16 variants 2 (general tail) and 3 (lean tail, the default) and the
+library GEMM on (a) random operands, (b) ALL-ZERO operands (same instructions, same bytes, no
 switching activity in the matrix pipe: if the chip is power-limited the zero run clocks higher) and (c) a sweep over K
 (tail-dominated ... K-loop-dominated).   python tools/gemm16_probe.py [rows]"""
 import json
@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 from deepcubea_amd import _lib  # noqa: E402
 
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 204800
-variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["2", "5"])]
+variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["2", "3"])]
 dt = torch.bfloat16
 
 
@@ -67,4 +67,4 @@ for k in (64, 256, 1024, 2048, 5120):
         print(json.dumps({"k": k, "operands": fill, "ms": res, "tflops": {a: round(flops / t / 1e9, 1) for a, t in res.items()}}))
         del x, w
         torch.cuda.empty_cache()
-_lib.gemm16_variant(2)
+_lib.gemm16_variant(3)

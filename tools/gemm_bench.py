@@ -75,17 +75,7 @@ for n, k in ((1024, 1024), (1024, 5120)) if only in ("", "f16x3") else ():
             return _lib.f16x3_gemm(planes, whc, wlc, inv, 1.0, b, None, True, True, want_x)
         return run
 
-    def hip_skew(v, sk):
-        def run():
-            _lib.gemm2_skew(sk)
-            r = hip_layer(v)()
-            _lib.gemm2_skew(8)
-            return r
-        return run
-
-    res = interleaved([("hip_v4", hip_layer(4)), ("hip_v3", hip_layer(3)), ("hip_v4_noskew", hip_skew(4, 0)),
-                       ("hip_v4_planes_only", hip_noskip(4, False)), ("hip_v3_planes_only", hip_noskip(3, False)),
-                       ("hip_v2", hip_layer(2)), ("hip_v1", hip_layer(1)),
+    res = interleaved([("hip_v3", hip_layer(3)), ("hip_v3_planes_only", hip_noskip(3, False)), ("hip_v2", hip_layer(2)),
                        ("library_gemm_plus_glue", lib_layer),
                        ("library_gemm_only", lambda: torch.mm(a3, w3.t(), out_dtype=torch.float32))])
     _lib.f16x3_gemm_variant(3)
@@ -113,14 +103,14 @@ for dt, nm in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")) if only in (""
         def hip16(v, with_skip):
             def run():
                 _lib.gemm16_variant(v)
-                return _lib.gemm16(x, w, None, out, True, out=out) if with_skip else _lib.gemm16(x, w, b32, None, True)
+                return _lib.gemm16(x, w, b32, out, True, out=out) if with_skip else _lib.gemm16(x, w, b32, None, True)
             return run
 
-        res = interleaved([("hip_persistent_bias_relu", hip16(5, False)), ("hip_persistent_skip_relu", hip16(5, True)),
-                           ("hip_bias_relu", hip16(2, False)), ("hip_skip_relu", hip16(2, True)),
+        res = interleaved([("hip_bias_relu", hip16(3, False)), ("hip_skip_relu", hip16(3, True)),
+                           ("hip_general_tail_bias_relu", hip16(2, False)), ("hip_general_tail_skip_relu", hip16(2, True)),
                            ("library_bias_relu", lambda: torch._addmm_activation(bdt, x, w.t())),
                            ("library_skip_relu", lambda: out2.addmm_(x, w.t()).relu_())])
-        _lib.gemm16_variant(2)
+        _lib.gemm16_variant(3)
         for name, ms in res.items():
             row[name + "_ms"], row[name + "_tflops"] = round(ms, 4), round(flops / ms / 1e9, 1)
         print(json.dumps(row))

@@ -27,7 +27,6 @@ def make(seed=2024):
 
 def grads(mode, x, y):
     _lib.TRAIN_F16X3 = mode != "library"
-    _lib.TRAIN_DW_F16X3 = mode == "f16x3"
     _, net = make()
     if mode == "float64":  # the yardstick: the whole step in double precision (torch's own kernels)
         net = net.double()
@@ -67,14 +66,13 @@ def main():
     res = {"one_step_loss_float64": l_r}
     import re
     noise = re.compile(r"(fc1|fc2|blocks\.\d\.[02])\.bias")  # a Linear bias in front of BatchNorm: analytically zero gradient
-    for mode in ("f16x3", "f16x3_dw_library", "library"):
+    for mode in ("f16x3", "library"):  # (f16x3: forward + input-gradient GEMMs on dca_f16x3_gemm, weight gradient on the library)
         l_a, g_a = grads(mode, x[:B], y[:B])
         err = {k: float((g_a[k] - g_r[k]).abs().max()) / max(float(g_r[k].abs().max()), 1e-300) for k in g_a if not noise.fullmatch(k)}
         top = sorted(err.items(), key=lambda kv: -kv[1])[:3]
         res[mode] = {"loss": l_a, "grad_error_vs_float64_over_max_grad": {"worst": top, "median": float(np.median(list(err.values()))),
                                                                          "mean": float(np.mean(list(err.values())))}}
     print(json.dumps(res))
-    _lib.TRAIN_DW_F16X3 = True
     ta, tb = trajectory("f16x3", x, y, 30, B), trajectory("library", x, y, 30, B)
     tb2 = trajectory("library", x, y, 30, B)
     print(json.dumps({"loss_f16x3": [round(v, 5) for v in ta], "loss_library": [round(v, 5) for v in tb],
