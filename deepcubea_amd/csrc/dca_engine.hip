@@ -192,6 +192,13 @@ constexpr int kProfSlots = 1024;
 // diagnostics: knobs a tuning run can flip without a rebuild (dca_debug_tune); 0 = the shipped behaviour
 __device__ int g_tune[16];
 #define kTinyBin ((uint32_t)(g_tune[9] > 0 ? g_tune[9] : kTinyBinDefault))
+// workgroups of k_rank that share one large bin (each reads and counts all of it, then scatters / orders / emits its own run of
+// sub-bins): one per 1024 entries, at most 8 — the callers clamp.  (One per 512 or 256 entries — 3 to 6 workgroups on the
+// 1250-1950-entry threshold bin instead of 2 — changes nothing: the bin's workgroups spend their time in the chain load ->
+// count -> scatter -> order, not in the share of the scatter that shrinks; profiles/r05_engine_ab.txt.)
+__device__ __forceinline__ uint32_t rank_shares(uint32_t cn) {
+    return cn <= (uint32_t)(512 * 16) ? (cn + 1023u) / 1024u : 1u;  // (512 * 16 = kLdsEnt: larger bins stream through one workgroup)
+}
 
 struct Eng {
     int env, dim, D, A, B, sem, oh_dtype, depth;
@@ -1003,7 +1010,7 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const Eng* __restrict__ engs,
             // the segments that replace a giant threshold bin are listed by k_sel_collect
             if (cn > kTinyBin && !(giant && bin == s_bstar)) {
                 // a bin that fits k_rank's LDS path is shared between up to eight workgroups (about a thousand entries each)
-                uint32_t G = cn <= (uint32_t)kLdsEnt ? (cn + 1023u) / 1024u : 1u;
+                uint32_t G = rank_shares(cn);
                 G = G > 8u ? 8u : G;
                 const uint32_t at = atomicAdd(&s_nbig, G);
                 for (uint32_t g = 0; g < G; g++) E.big_list[at + g] = bin | (g << 16) | (G << 20);
@@ -1373,7 +1380,7 @@ __device__ __noinline__ int collect_giant(const Eng& E, Ctl* c, CollectLds& L, c
             const uint32_t cn = sg == 0 ? below : subpre[sg] - subpre[sg - 1];
             if (sg > 0) E.pre[seg0 + sg] = pre_b + below + subpre[sg];
             if (cn > kTinyBin) {
-                uint32_t G = cn <= (uint32_t)kLdsEnt ? (cn + 1023u) / 1024u : 1u;
+                uint32_t G = rank_shares(cn);
                 G = G > 8u ? 8u : G;
                 const uint32_t at = atomicAdd(&L.nb, G);
                 for (uint32_t g = 0; g < G; g++) E.big_list[at + g] = (bstar + sg) | (g << 16) | (G << 20);
@@ -1576,7 +1583,7 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
                 if (cn > 256) atomicMax(&L.st_n, cn);
                 if (cn > (uint32_t)kSortCap) atomicAdd(&L.nz_n, 1u);
                 if (cn > kTinyBin && !(P.giant && bin == P.bstar)) {
-                    uint32_t G = cn <= (uint32_t)kLdsEnt ? (cn + 1023u) / 1024u : 1u;
+                    uint32_t G = rank_shares(cn);
                     G = G > 8u ? 8u : G;
                     const uint32_t at = atomicAdd(&L.nb, G);
                     for (uint32_t g = 0; g < G; g++) E.big_list[at + g] = bin | (g << 16) | (G << 20);
@@ -1617,7 +1624,7 @@ __global__ __launch_bounds__(256) void k_sel_collect(const Eng* __restrict__ eng
         // threshold bin is an ordinary (large) bin again, streamed by one workgroup there.
         if (blockIdx.x == 0 && t == 0) {
             const uint32_t cn = P.cn_star;
-            uint32_t G = cn <= (uint32_t)kLdsEnt ? (cn + 1023u) / 1024u : 1u;
+            uint32_t G = rank_shares(cn);
             G = G > 8u ? 8u : G;
             const uint32_t at = c->n_big;
             if (cn > kTinyBin) {
@@ -3238,6 +3245,23 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
     uint32_t* const ctr[3] = {&c->open_n[fb].v, &c->open_n[bb].v, &c->closed_n.v};
     uint32_t pos[3];
     block_reserveK<1024, 3>(cnt, ctr, pos, sh);
+    // This workgroup's pushes per selection bin -> FRONT's histogram (block_reserveK's barriers have ordered the LDS counts).
+    // In a young search nearly every child lies below the histogram horizon and a workgroup's 1024 children touch 600-900
+    // different bins: 235 workgroups x that many device-scope atomics were 10 of this launch's 23 us (iterations 8-27 — the
+    // window a 20-step bench episode lives in; tools/engine_probe.py @13=1 times the launch without them, profiles/
+    // r05_engine_ab.txt) — and they sat at the very END of the launch, behind everything else.  So: two bins per atomic (a
+    // 64-bit add on an aligned pair of 32-bit counters: no carry, counts stay below 2^31), issued HERE, as soon as the counts
+    // are complete, so that their trip to the memory side runs under the scattered stores and the range fold below.
+    static_assert(kBinsPerThread % 2 == 0, "bins are flushed in aligned pairs");
+    if (kBinsPerThread * threadIdx.x < hbin && !(g_tune[13] & 1)) {  // (knob 13 bit 0, diagnostics: timing without the flush)
+#pragma unroll
+        for (int k = 0; k < kBinsPerThread; k += 2) {
+            const uint32_t v0 = lh[kBinsPerThread * threadIdx.x + k], v1 = lh[kBinsPerThread * threadIdx.x + k + 1];
+            if (v0 | v1)
+                atomicAdd(reinterpret_cast<unsigned long long*>(&E.hist[kBinsPerThread * threadIdx.x + k]),
+                          (unsigned long long)v0 | ((unsigned long long)v1 << 32));
+        }
+    }
     if (is_new && pos[2] < E.max_nodes) E.closed_slots[pos[2]] = my_slot;  // what the next reset clears (k_clear_table_list)
     if (tof) {
         if (pos[0] < E.front_cap) {
@@ -3280,18 +3304,14 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
             for (int w = 1; w < 16; w++) v = (q & 1) ? (red[q][w] > v ? red[q][w] : v) : (red[q][w] < v ? red[q][w] : v);
             const uint32_t buf = q < 2 ? fb : bb;
             asm volatile("" : "+v"(rng_snap));  // (the snapshot is the wave's oldest load: long since back)
-            if (q & 1) {
+            if (g_tune[13] & 2) {  // (knob 13 bit 1, diagnostics: timing without the range atomics)
+            } else if (q & 1) {
                 if (v > rng_snap) atomicMax((unsigned long long*)&c->rng[buf].kmax, (unsigned long long)v);
             } else {
                 if (v < rng_snap) atomicMin((unsigned long long*)&c->rng[buf].kmin, (unsigned long long)v);
             }
         }
     }
-    if (kBinsPerThread * threadIdx.x < hbin)
-        for (int k = 0; k < kBinsPerThread; k++) {
-            const uint32_t v = lh[kBinsPerThread * threadIdx.x + k];
-            if (v) atomicAdd(&E.hist[kBinsPerThread * threadIdx.x + k], v);
-        }
     commit_ticket(E, c);
 }
 
@@ -3614,6 +3634,9 @@ int dca_engine_create_multi(dca_engine** out, int env, int dim, double weight, i
     const int depth = env == DCA_ENV_NPUZZLE ? D : 6;
     const int64_t Mll = (int64_t)batch_size * A;
     DCA_ARG(max_nodes >= Mll + 16 && max_nodes <= 0x7FFFFF00ll);
+    // CLOSED slots: the power of two at or above 2 per node id.  (A 256 MiB instead of a 512 MiB table at the bench shape —
+    // the size of the Infinity Cache — changes nothing: k_expand 28.1 us either way, profiles/r05_engine_ab.txt.  The probe is
+    // bound by the memory-side atomics' rate, not by where the slots live.)
     uint64_t cap = 1024;
     while (cap < 2ull * (uint64_t)max_nodes) cap <<= 1;
     if (cap > 0x80000000ull) {
