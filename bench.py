@@ -146,7 +146,7 @@ def pmc_traffic(kernel: str, env: str, B: int):
     """HBM bytes per launch from the rocprofv3 PMC passes of THIS command (`tools/pmc_summary.py` writes
     profiles/r03_pmc_traffic.json from `rocprofv3 --pmc ... -- python bench.py`): counters cannot be read from inside
     the process, so the entry is matched on kernel, environment and batch size and otherwise left null."""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):

@@ -3315,6 +3315,15 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
     commit_ticket(E, c);
 }
 
+// per-instance weights of path cost from a device array (dca_engine_set_weights_dev): stream-ordered, no host involvement
+__global__ void k_set_weights(Eng* __restrict__ engs, const double* __restrict__ w, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        engs[i].w = w[i];
+        engs[i].wf = (float)w[i];
+    }
+}
+
 // The parents of the last pop (between pop_expand and commit): their state rows, and per parent 1 = popped, 2 = popped and
 // solved, 0 = slot unused (short batch, instance finished).  What an ASTAR update backs up (updater.py:44-50: every popped
 // node of every instance gets a training target).
@@ -4190,6 +4199,53 @@ int dca_engine_park_instance(dca_engine* e, int inst, void* stream) {
     DCA_HIP(hipStreamSynchronize((hipStream_t)stream));
     DCA_HIP(hipMemcpy(&e->E[inst].ctl->done, &one, sizeof(one), hipMemcpyHostToDevice));
     return 0;
+}
+
+/* The batched, synchronisation-free forms an ASTAR update steps thousands of batch-1 searches with (updater.py:36-54; ADVICE
+ * r04: a host round trip per instance and per step made that update launch- and sync-bound). */
+int dca_engine_reset_many(dca_engine* e, const uint8_t* roots_dev, int n, void* stream) {
+    DCA_ARG(e != nullptr && roots_dev != nullptr && n >= 0 && n <= e->K);
+    hipStream_t s = (hipStream_t)stream;
+    if (e->phase != 0)  // (an abandoned half iteration: see dca_engine_reset_instance)
+        for (int i = 0; i < e->K; i++) e->tab_cleared[i] = 0;
+    for (int i = 0; i < e->K; i++) {
+        Eng& E = e->E[i];
+        if (i >= n) {  // parked: every launch of this instance is a no-op until it is reset again
+            DCA_HIP(hipMemsetD32Async((hipDeviceptr_t)&E.ctl->done, 1, 1, s));
+            continue;
+        }
+        DCA_HIP(hipMemcpyAsync(E.state, roots_dev + (size_t)i * (size_t)E.D, (size_t)E.D, hipMemcpyDeviceToDevice, s));
+        const int force = e->tab_cleared[i] == 0 ? 1 : 0;
+        // (both are enqueued, one of them returns at once — see clear_by_list; grids sized for the table: these are small searches)
+        const unsigned g_all = (unsigned)std::min<uint64_t>(4096, ((uint64_t)E.tab_cap + 255) / 256);
+        const unsigned g_list = (unsigned)std::min<uint64_t>(1024, ((uint64_t)E.tab_cap / 8 + 255) / 256);
+        hipLaunchKernelGGL(k_init_table, dim3(g_all), dim3(256), 0, s, E.tab, E.tab_cap, E.ctl, force);
+        hipLaunchKernelGGL(k_clear_table_list, dim3(g_list ? g_list : 1), dim3(256), 0, s, E.tab, E.tab_cap, E.closed_slots, E.ctl, force);
+        e->tab_cleared[i] = 1;
+        hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, s, E);
+        DCA_HIP(hipMemsetAsync(E.child_multi, 0, (size_t)E.M, s));
+    }
+    e->phase = 0;
+    e->host_iter = 0;
+    return launch_check("k_reset (many)");
+}
+
+int dca_engine_root_commit_many(dca_engine* e, const float* h_roots_dev, int n, void* stream) {
+    DCA_ARG(e != nullptr && n >= 0 && n <= e->K);
+    if (e->E[0].sem != DCA_SEM_PY) return 0;
+    DCA_ARG(h_roots_dev != nullptr || n == 0);
+    for (int i = 0; i < n; i++) hipLaunchKernelGGL(k_root_commit, dim3(1), dim3(64), 0, (hipStream_t)stream, e->E[i], h_roots_dev + i);
+    return launch_check("k_root_commit (many)");
+}
+
+int dca_engine_set_weights_dev(dca_engine* e, const double* weights_dev, int n, void* stream) {
+    DCA_ARG(e != nullptr && weights_dev != nullptr && n >= 1 && n <= e->K);
+    if (e->phase != 0) {
+        set_error("dca_engine_set_weights_dev between pop_expand and commit");
+        return DCA_E_STATE;
+    }
+    hipLaunchKernelGGL(k_set_weights, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, e->d_engs, weights_dev, n);
+    return launch_check("k_set_weights");
 }
 
 int dca_engine_last_popped(dca_engine* e, uint8_t* states, uint8_t* flags, void* stream) {

@@ -70,27 +70,36 @@ constexpr int HLDS = 2 * HSTAGE;      // two stages: 128 KB
 __device__ __forceinline__ uint32_t swz64(uint32_t row, uint32_t chunk) { return row * 64u + ((chunk ^ ((row >> 2) & 3u)) << 4); }
 
 // Layer tail of the 256 x 256 kernels (shared by the two-stage and the ping-pong schedule).
-__device__ __forceinline__ void f16x3_epilogue(const GemmArgs& p, uint8_t* lds, f32x16 (&acc)[4][2], int64_t m0, int n0, int w, int wm,
-                                               int wn, int lane, int l31, int h) {
-    // epilogue.  The accumulator layout (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) would make
+// MODE < 0: any shape, any form, every option tested at run time.  MODE >= 0 (bit 0 skip, bit 1 fp32 output, bit 2 planes): the
+// same tail compiled for ONE of the network's layer forms on a tile that lies inside the matrix, with scale, bias and ReLU —
+// no per-row / per-element tests left (round 5: the general tail is ~7400 instructions per wave, most of them branches around
+// cases the network's own shapes never take; csrc/dca_gemm16.hip has the measurements that led here).
+template <int MODE>
+__device__ __forceinline__ void f16x3_epilogue_as(const GemmArgs& p, uint8_t* lds, const f32x16 (&acc)[4][2], int64_t m0, int n0, int w,
+                                                  int wm, int wn, int lane, int l31, int h) {
+    // The accumulator layout (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) would make
     // every store a 4-byte (fp32) or 2-byte (planes) column access — measured 1.8 ms per layer, more than the K loop.  So
     // each wave transposes its tile through its own 16 KB of the (now idle) LDS, 32 rows at a time, and leaves with
     // 16-byte accesses: a lane owns 4 consecutive columns of a row — one float4 skip load, one float4 store, two 8-byte
     // plane stores; 16 lanes cover a row's 256 contiguous bytes.
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the operand stages
+    constexpr bool G = MODE < 0;  // general
+    const bool has_skip = G ? p.skip != nullptr : (MODE & 1) != 0;
+    const bool has_x = G ? p.x_out != nullptr : (MODE & 2) != 0;
+    const bool has_planes = G ? p.oh != nullptr : (MODE & 4) != 0;
+    const bool relu = G ? p.relu != 0 : true;
     float* sl = reinterpret_cast<float*>(lds + w * 16384);
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     float cs[2], bv[2];
 #pragma unroll
     for (int jn = 0; jn < 2; jn++) {
         const int col = n0 + wn * 64 + jn * 32 + l31;
-        const bool cv = col < p.n;
-        cs[jn] = cv ? (p.col_scale ? p.alpha * p.col_scale[col] : p.alpha) : 0.f;
-        bv[jn] = (cv && p.bias) ? p.bias[col] : 0.f;
+        const bool cv = G ? col < p.n : true;
+        cs[jn] = cv ? ((G ? p.col_scale != nullptr : true) ? p.alpha * p.col_scale[col] : p.alpha) : 0.f;
+        bv[jn] = (cv && (G ? p.bias != nullptr : true)) ? p.bias[col] : 0.f;
     }
     const int c4 = (lane & 15) * 4;              // this lane's 4 columns inside the wave's 64
     const int colg = n0 + wn * 64 + c4;
-    const bool full4 = colg + 3 < p.n;
+    const bool full4 = G ? colg + 3 < p.n : true;
     bool ovf = false;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -106,37 +115,37 @@ __device__ __forceinline__ void f16x3_epilogue(const GemmArgs& p, uint8_t* lds, 
         for (int q = 0; q < 8; q++) {
             const int64_t r = rbase + q * 4 + (lane >> 4);
             sk[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.skip && r < p.m && full4) sk[q] = *reinterpret_cast<const float4*>(p.skip + r * p.ldo + colg);
+            if (has_skip && (G ? (r < p.m && full4) : true)) sk[q] = *reinterpret_cast<const float4*>(p.skip + r * p.ldo + colg);
         }
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int rl = q * 4 + (lane >> 4);
             const int64_t r = rbase + rl;
             const float4 v = *reinterpret_cast<const float4*>(sl + rl * 64 + c4);
-            if (r >= p.m) continue;
+            if (G && r >= p.m) continue;
             float u[4] = {v.x + sk[q].x, v.y + sk[q].y, v.z + sk[q].z, v.w + sk[q].w};
             const int64_t o = r * p.ldo + colg;
             if (full4) {
                 h4 hi, lo;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    if (p.relu) u[e] = fmaxf(u[e], 0.f);
+                    if (relu) u[e] = fmaxf(u[e], 0.f);
                     ovf |= !(fabsf(u[e]) <= 60000.0f);
                     hi[e] = (_Float16)u[e];
                     lo[e] = (_Float16)(u[e] - (float)hi[e]);
                 }
-                if (p.x_out) *reinterpret_cast<float4*>(p.x_out + o) = make_float4(u[0], u[1], u[2], u[3]);
-                if (p.oh) {
+                if (has_x) *reinterpret_cast<float4*>(p.x_out + o) = make_float4(u[0], u[1], u[2], u[3]);
+                if (has_planes) {
                     *reinterpret_cast<h4*>(p.oh + o) = hi;
                     *reinterpret_cast<h4*>(p.ol + o) = lo;
                 }
             } else {  // ragged right edge (n not a multiple of 4 columns here): element-wise
                 for (int e = 0; e < 4 && colg + e < p.n; e++) {
-                    float ue = u[e] + (p.skip ? p.skip[o + e] : 0.f);
-                    if (p.relu) ue = fmaxf(ue, 0.f);
+                    float ue = u[e] + (has_skip ? p.skip[o + e] : 0.f);
+                    if (relu) ue = fmaxf(ue, 0.f);
                     ovf |= !(fabsf(ue) <= 60000.0f);
-                    if (p.x_out) p.x_out[o + e] = ue;
-                    if (p.oh) {
+                    if (has_x) p.x_out[o + e] = ue;
+                    if (has_planes) {
                         const _Float16 hh = (_Float16)ue;
                         p.oh[o + e] = hh;
                         p.ol[o + e] = (_Float16)(ue - (float)hh);
@@ -146,7 +155,22 @@ __device__ __forceinline__ void f16x3_epilogue(const GemmArgs& p, uint8_t* lds, 
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slice is rewritten by the next 32 rows
     }
-    if (ovf && p.oh && p.overflow) *p.overflow = 1;
+    if (ovf && has_planes && p.overflow) *p.overflow = 1;
+}
+
+__device__ __forceinline__ void f16x3_epilogue(const GemmArgs& p, uint8_t* lds, f32x16 (&acc)[4][2], int64_t m0, int n0, int w, int wm,
+                                               int wn, int lane, int l31, int h) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the operand stages
+    // the network's own layer forms on a tile inside the matrix (uniform over the workgroup) take a tail compiled for them
+    const bool inside = m0 + HBM_T <= p.m && n0 + HBN_T <= p.n && p.relu && p.col_scale && p.bias;
+    const int mode = inside ? ((p.skip ? 1 : 0) | (p.x_out ? 2 : 0) | (p.oh ? 4 : 0)) : -1;
+    switch (mode) {
+        case 4: f16x3_epilogue_as<4>(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h); break;  // planes only (first layer of a block)
+        case 6: f16x3_epilogue_as<6>(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h); break;  // planes + fp32 (the 5120 -> 1024 layer)
+        case 7: f16x3_epilogue_as<7>(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h); break;  // residual: skip in, planes + fp32 out
+        case 3: f16x3_epilogue_as<3>(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h); break;  // last block: skip in, fp32 out
+        default: f16x3_epilogue_as<-1>(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h); break;
+    }
 }
 
 __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v2(const GemmArgs p) {

@@ -36,7 +36,7 @@ from ..utils import data_utils, env_utils, nnet_utils
 
 
 # (flag, type | "flag", default | REQUIRED, help) — names, types and defaults are the reference's (avi.py:21-97; pinned by
-# tests/golden/cli_flags.json), `--seed` is the only addition
+# tests/golden/cli_flags.json); `--seed` and `--max_seconds` are the only additions
 REQUIRED = object()
 _OPTIONS = (
     ("env", str, REQUIRED, "Environment"),
@@ -60,6 +60,7 @@ _OPTIONS = (
     ("update_num", int, 0, "Update number"),
     ("save_dir", str, "saved_models", "Director to which to save model"),
     ("seed", int, 0, "seed of the device state generator (shards are disjoint)"),
+    ("max_seconds", float, 0.0, "stop after the update that crosses this much wall time (0 = run to --max_itrs)"),
 )
 
 
@@ -168,7 +169,11 @@ def main(argv=None):
         model = nn.parallel.DistributedDataParallel(nnet, device_ids=[device.index])
     local_batch = max(args_dict['batch_size'] // world, 1)
 
+    t_start = time.time()
     while itr < args_dict['max_itrs']:
+        if args_dict['max_seconds'] > 0 and time.time() - t_start >= args_dict['max_seconds']:
+            print("Time budget of %.0f s used (%i iterations, update number %i)" % (args_dict['max_seconds'], itr, update_num))
+            break
         # update (targets from the target network)
         hfn = target_heuristic(args_dict['targ_dir'], env, device, args_dict['update_nnet_batch_size'])
         states_nnet, outputs = do_update(args_dict["back_max"], update_num, env, args_dict['max_update_steps'],

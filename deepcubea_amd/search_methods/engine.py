@@ -151,6 +151,25 @@ class BwasEngine:
         w = np.ascontiguousarray(weights, dtype=np.float64)
         _lib.check(_lib.lib().dca_engine_set_weights(self._h, w.ctypes.data_as(C.c_void_p), int(w.size)), "dca_engine_set_weights")
 
+    def reset_many(self, roots_dev: torch.Tensor) -> None:
+        """Instances 0..n-1 restart from the rows of a DEVICE tensor [n, D] uint8, the others are parked; nothing synchronises."""
+        assert roots_dev.is_cuda and roots_dev.dtype == torch.uint8 and roots_dev.is_contiguous()
+        assert roots_dev.dim() == 2 and roots_dev.shape[1] == self.state_dim and roots_dev.shape[0] <= self.num_instances
+        _lib.check(_lib.lib().dca_engine_reset_many(self._h, _lib.ptr(roots_dev), int(roots_dev.shape[0]), _lib.stream_ptr()),
+                   "dca_engine_reset_many")
+
+    def root_commit_many(self, h_roots: torch.Tensor) -> None:
+        h = h_roots.to(torch.float32).contiguous().view(-1)
+        _lib.check(_lib.lib().dca_engine_root_commit_many(self._h, _lib.ptr(h), int(h.numel()), _lib.stream_ptr()),
+                   "dca_engine_root_commit_many")
+
+    def set_weights_dev(self, weights_dev: torch.Tensor) -> None:
+        """Weights of path cost of instances 0..n-1 from a device float64 tensor (stream-ordered, no host sync)."""
+        w = weights_dev.to(torch.float64).contiguous().view(-1)
+        assert w.is_cuda and 1 <= w.numel() <= self.num_instances
+        _lib.check(_lib.lib().dca_engine_set_weights_dev(self._h, _lib.ptr(w), int(w.numel()), _lib.stream_ptr()),
+                   "dca_engine_set_weights_dev")
+
     def park(self, instance: int) -> None:
         """Mark an instance finished (its launches are no-ops) until it is reset again."""
         _lib.check(_lib.lib().dca_engine_park_instance(self._h, int(instance), _lib.stream_ptr()), "dca_engine_park_instance")

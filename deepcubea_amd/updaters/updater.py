@@ -110,19 +110,24 @@ def gbfs_update_dev(states: torch.Tensor, env, num_steps: int, heuristic_fn_dev:
 
 def astar_update_dev(states: torch.Tensor, env, num_steps: int, heuristic_fn_dev: Callable,
                      weights: Optional[np.ndarray] = None, generator: Optional[np.random.Generator] = None,
-                     instances_per_launch: int = 64, engine=None, onehot_dtype=None):
+                     instances_per_launch: int = 64, engine=None, onehot_dtype=None, engines_in_rotation: Optional[int] = None):
     """updater.py:36-54 astar_update on the device: one batch-1 weighted A* per training state (`AStar(states, env,
     heuristic_fn, weights)` with weights ~ U[0, 1), one per instance), `num_steps` steps (`astar.step(heuristic_fn, 1)`:
     every unsolved instance pops its cheapest node, expands it, the network scores ALL children, the CLOSED check drops
     duplicates, the rest is pushed), then `Node.compute_bellman` on every popped node: 0 for a solved node, else
     min over its children of (transition cost 1 + the child's heuristic, clipped at 0 like the update's heuristic servers,
     avi.py:213).  The searches are the engine's (libdca_hip.so, PY semantics: float64 cost = w * g + h, (cost, push count)
-    order, sequential CLOSED rule), up to `instances_per_launch` of them sharing every launch (grid.y = instance) and ONE
-    network call per step.  Each group of `instances_per_launch` states is one `astar_update` call of the reference (its
-    `update_runner` cuts the states into `update_batch_size` pieces the same way, updater.py:62-71), including how that call
-    pairs weights with instances: `AStar.step` zips `self.weights` with the instances that have not found a goal yet
-    (astar.py:262-263, 279-281), so once an instance has finished, the j-th REMAINING instance searches with weights[j]
-    — reproduced here step by step (the fixtures recorded from the reference depend on it).
+    order, sequential CLOSED rule), up to `instances_per_launch` of them sharing every launch (grid.y = instance).
+    Each group of `instances_per_launch` states is one `astar_update` call of the reference (its `update_runner` cuts the
+    states into `update_batch_size` pieces the same way, updater.py:62-71), including how that call pairs weights with
+    instances: `AStar.step` zips `self.weights` with the instances that have not found a goal yet (astar.py:262-263,
+    279-281), so once an instance has finished, the j-th REMAINING instance searches with weights[j] — reproduced here step
+    by step (the fixtures recorded from the reference depend on it), ON THE DEVICE: rank among the live instances by a
+    prefix sum of the done flags, `dca_engine_set_weights_dev`.
+    Nothing in the stepping loop talks to the host (one device synchronisation per step and instance made a
+    500 000-state update launch- and sync-bound): groups restart from device rows (`reset_many`), `engines_in_rotation`
+    engines are stepped side by side and their children scored by ONE network call per step (R x K x moves rows instead of
+    K x moves: 64 x 12 rows do not fill a GEMM), popped nodes are collected unfiltered and compacted once at the end.
     -> (states_update u8 [T, D], cost_to_go f32 [T], is_solved bool [n]) in the reference's order: instance-major, each
     instance's popped nodes in pop order (misc_utils.flatten(astar.get_popped_nodes())).
     onehot_dtype: the closure wants one-hot rows (a network whose first layer has no uint8 kernel, e.g. lightsout7's): the
@@ -136,58 +141,77 @@ def astar_update_dev(states: torch.Tensor, env, num_steps: int, heuristic_fn_dev
     weights = np.asarray(weights, np.float64)
     assert weights.shape == (n,)
     K = max(1, min(int(instances_per_launch), 64, n))
-    own = engine is None
-    if own:
+    if engine is not None:
+        engines = [engine]
+    else:
+        # enough engines side by side that one network call sees ~65 000 rows (never more than the states need)
+        R = engines_in_rotation if engines_in_rotation else max(1, min(16, (1 << 16) // max(K * A, 1), -(-n // K)))
         # ids: the root, then <= A + 15 per step (a batch's ids start on a multiple of 16)
-        engine = BwasEngine(env.env_name, 0.0, 1, max_nodes=64 + num_steps * (A + 16) + A + 16, num_instances=K,
-                            onehot_dtype=onehot_dtype)
-    eng = engine
-    assert eng.batch_size == 1 and eng.num_instances >= K
-    Kc = eng.num_instances
-    roots_np = states.cpu().numpy()
+        engines = [BwasEngine(env.env_name, 0.0, 1, max_nodes=64 + num_steps * (A + 16) + A + 16, num_instances=K,
+                              onehot_dtype=onehot_dtype) for _ in range(R)]
+    assert all(e.batch_size == 1 and e.num_instances >= K for e in engines)
+    Kc = engines[0].num_instances
+    R = len(engines)
+    w_all = torch.from_numpy(weights).to(dev)
+    states = states.contiguous()
     out_states: List[torch.Tensor] = []
     out_ctg: List[torch.Tensor] = []
     out_inst: List[torch.Tensor] = []
+    out_live: List[torch.Tensor] = []
     found = torch.zeros(n, dtype=torch.bool, device=dev)
-    for g0 in range(0, n, Kc):
-        k = min(Kc, n - g0)
-        for i in range(k):
-            eng.reset(roots_np[g0 + i], i)
-        for i in range(k, Kc):
-            eng.park(i)
+    zeros_tail = torch.zeros(Kc, dtype=torch.float64, device=dev)
+    for s0 in range(0, n, R * Kc):
+        # the engines of this round and their slices of the states: (engine, first state, instances in use)
+        groups = [(engines[r], s0 + r * Kc, min(Kc, n - (s0 + r * Kc))) for r in range(R) if s0 + r * Kc < n]
+        tot = sum(k for _, _, k in groups)
+        for eng, lo, k in groups:
+            eng.reset_many(states[lo:lo + k])
         # root nodes: heuristic of all roots in one call (astar.py:246-249 add_heuristic_and_cost(root_nodes, ...))
-        root_nn = _lib.nnet_input(env._env_id, env._dim, states[g0:g0 + k].contiguous())
-        h_root = heuristic_fn_dev(root_nn).to(torch.float32)
-        for i in range(k):
-            eng.root_commit(h_root[i:i + 1], i)
-        inst_ids = torch.arange(g0, g0 + Kc, device=dev)
-        done_host = np.zeros(k, bool)  # instances that have popped a goal: no longer stepped (astar.py:262-263)
-        for _ in range(num_steps):
-            w_step = np.zeros(Kc, np.float64)
-            alive = np.flatnonzero(~done_host)
-            if alive.size == 0:
-                break
-            w_step[alive] = weights[g0:g0 + alive.size]  # zip(self.weights, remaining instances): positional (astar.py:279-281)
-            eng.set_weights(w_step)
-            nn, oh = eng.pop_expand()
-            h = (heuristic_fn_dev(oh, True) if oh is not None else heuristic_fn_dev(nn)).to(torch.float32).contiguous()
-            popped, flags = eng.last_popped()  # [Kc, D], [Kc]
-            live = flags[:k] != 0
-            if bool(live.any()):
+        root_nn = _lib.nnet_input(env._env_id, env._dim, states[s0:s0 + tot])
+        h_root = heuristic_fn_dev(root_nn).to(torch.float32).view(-1)
+        for eng, lo, k in groups:
+            eng.root_commit_many(h_root[lo - s0:lo - s0 + k])
+        done = torch.zeros(tot, dtype=torch.bool, device=dev)  # instances that have popped a goal: no longer stepped (astar.py:262-263)
+        for step in range(num_steps):
+            nns, ohs = [], []
+            for eng, lo, k in groups:
+                # zip(self.weights, remaining instances): positional (astar.py:279-281) — the j-th live instance gets weights[j]
+                alive = ~done[lo - s0:lo - s0 + k]
+                rank = torch.cumsum(alive.to(torch.int64), 0) - 1
+                w_step = torch.where(alive, w_all[lo:lo + k][rank.clamp_min(0)], zeros_tail[:k])
+                eng.set_weights_dev(torch.cat([w_step, zeros_tail[:Kc - k]]) if k < Kc else w_step)
+                nn, oh = eng.pop_expand()
+                nns.append(nn)
+                ohs.append(oh)
+            if ohs[0] is not None:
+                h_all = heuristic_fn_dev(ohs[0] if len(ohs) == 1 else torch.cat(ohs), True)
+            else:
+                h_all = heuristic_fn_dev(nns[0] if len(nns) == 1 else torch.cat(nns))
+            h_all = h_all.to(torch.float32).contiguous().view(len(groups), Kc * A)
+            for gi, (eng, lo, k) in enumerate(groups):
+                h = h_all[gi].contiguous()
+                popped, flags = eng.last_popped()  # [Kc, D], [Kc]
+                fk = flags[:k]
                 hk = torch.clamp_min(h.view(Kc, A)[:k], 0.0)
                 backup = 1.0 + hk.min(dim=1).values           # tc + node_c.heuristic, min over the children (astar.py:43-44)
-                backup = torch.where(flags[:k] == 2, torch.zeros_like(backup), backup)  # a solved node backs up to 0
-                out_states.append(popped[:k][live])
-                out_ctg.append(backup[live])
-                out_inst.append(inst_ids[:k][live])
-                found[g0:g0 + k] |= flags[:k] == 2
-            eng.commit(h)
-            done_host |= (flags[:k] == 2).cpu().numpy()
-    if own:
-        eng.close()
+                backup = torch.where(fk == 2, torch.zeros_like(backup), backup)  # a solved node backs up to 0
+                out_states.append(popped[:k])
+                out_ctg.append(backup)
+                out_inst.append(torch.arange(lo, lo + k, device=dev))
+                out_live.append(fk != 0)
+                solved_now = fk == 2
+                found[lo:lo + k] |= solved_now
+                done[lo - s0:lo - s0 + k] |= solved_now
+                eng.commit(h)
+            if step % 8 == 7 and step + 1 < num_steps and bool(done.all()):  # (one look at the host every 8 steps)
+                break
+    if engine is None:
+        for e in engines:
+            e.close()
     if not out_states:
         return (torch.zeros((0, D), dtype=torch.uint8, device=dev), torch.zeros(0, dtype=torch.float32, device=dev), found)
-    su, cg, inst = torch.cat(out_states), torch.cat(out_ctg), torch.cat(out_inst)
+    live = torch.cat(out_live)
+    su, cg, inst = torch.cat(out_states)[live], torch.cat(out_ctg)[live], torch.cat(out_inst)[live]
     order = torch.sort(inst, stable=True).indices  # instance-major, pops in step order
     return su[order], cg[order], found
 

@@ -296,6 +296,16 @@ int dca_engine_set_weight_instance(dca_engine* e, int inst, double weight);
 int dca_engine_set_weights(dca_engine* e, const double* weights /*host [n], instances 0..n-1*/, int n);
 int dca_engine_park_instance(dca_engine* e, int inst, void* stream);
 int dca_engine_last_popped(dca_engine* e, uint8_t* states, uint8_t* flags, void* stream);
+/* The same controls without a host round trip, for stepping thousands of batch-1 searches (one ASTAR update = up to 5e5 of
+ * them, updater.py:36-54): everything is enqueued on `stream`, nothing synchronises.
+ *   reset_many        instances 0..n-1 restart from roots_dev (device u8 [n, D]; NOT range-checked — the rows come from the
+ *                     library's own generator), instances n..K-1 are parked;
+ *   root_commit_many  h_roots_dev: device float [n], the heuristic of the n roots;
+ *   set_weights_dev   weights of path cost of instances 0..n-1 from a device double [n]; they hold until the next host-side
+ *                     dca_engine_set_weight(s) / profile call re-uploads the host's copy of the instance table. */
+int dca_engine_reset_many(dca_engine* e, const uint8_t* roots_dev, int n, void* stream);
+int dca_engine_root_commit_many(dca_engine* e, const float* h_roots_dev, int n, void* stream);
+int dca_engine_set_weights_dev(dca_engine* e, const double* weights_dev, int n, void* stream);
 /* facts about an engine (host int64[8]): [0] workgroups of k_sel_collect's grid, [1] how many of them the device holds at once
  * according to hipOccupancyMaxActiveBlocksPerMultiprocessor (-1: query failed), [2] 1 if the grid-wide refinement of giant tie
  * bins (grid barriers; needs [1] >= [0]) was enabled at creation, [3] bytes of the CLOSED table, [4] 1 once a grid barrier

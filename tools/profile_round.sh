@@ -3,7 +3,7 @@
 # (engine legs), HBM traffic of its kernels from separate FETCH_SIZE / WRITE_SIZE passes (never combined with trace
 # domains), kernel stats + MFMA-busy counters of the heuristic network.  Raw output under gpurun_out/<tag>_prof/, the
 # summaries to copy into profiles/ under gpurun_out/<tag>_prof/summary/.
-tag=${1:-r04}
+tag=${1:-r05}
 steps=${2:-20}   # episode shape of the PMC / stats passes: the driver's flags (--steps 20 --warmup 5) by default
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/${tag}_prof
