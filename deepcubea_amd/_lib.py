@@ -80,7 +80,7 @@ def lib() -> C.CDLL:
         _lib.dca_bn_workspace_bytes.restype = C.c_int64
         _lib.dca_bn_workspace_bytes.argtypes = [C.c_int64]
         _lib.dca_engine_destroy.restype = None
-        if _lib.dca_abi_version() != 2:
+        if _lib.dca_abi_version() != 3:
             raise DcaError("libdca_hip.so ABI version mismatch")
     return _lib
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DCA_ABI_VERSION 2
+#define DCA_ABI_VERSION 3
 
 /* library error codes (negative; positive values are hipError_t) */
 #define DCA_E_BADARG (-1)
@@ -302,7 +302,7 @@ int dca_engine_last_popped(dca_engine* e, uint8_t* states, uint8_t* flags, void*
  *                     library's own generator), instances n..K-1 are parked;
  *   root_commit_many  h_roots_dev: device float [n], the heuristic of the n roots;
  *   set_weights_dev   weights of path cost of instances 0..n-1 from a device double [n]; they hold until the next host-side
- *                     dca_engine_set_weight(s) / profile call re-uploads the host's copy of the instance table. */
+ *                     dca_engine_set_weights / dca_engine_set_weight_instance / profile call re-uploads the host's copy of the instance table. */
 int dca_engine_reset_many(dca_engine* e, const uint8_t* roots_dev, int n, void* stream);
 int dca_engine_root_commit_many(dca_engine* e, const float* h_roots_dev, int n, void* stream);
 int dca_engine_set_weights_dev(dca_engine* e, const double* weights_dev, int n, void* stream);
