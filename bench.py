@@ -479,7 +479,10 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
     from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
     from deepcubea_amd.utils import env_utils
     B, w = args.batch_size, args.weight
-    steps, warm = args.nnet_steps, 2  # `steps` timed iterations per round, rounds repeated until MIN_TIMED_S were timed
+    # `steps` timed iterations per round, rounds repeated until MIN_TIMED_S were timed; one whole round untimed first: the rows
+    # handed to the network change from step to step (padded to 1024), and a first-time shape costs the caching allocator a
+    # device allocation — seen as a one-off ~130 ms stall inside the first timed round of some runs (fp32 leg: 28 instead of 17 ms)
+    steps, warm = args.nnet_steps, 2 + args.nnet_steps
     env = env_utils.get_environment(args.env)
     A = env.get_num_moves()
     model = env.get_nnet_model()  # cube3: ResnetModel(54, 6, 5000, 1000, 4, 1, True)
@@ -560,6 +563,8 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
                                           if dtype_name == "fp8" else "dca_gemm16 (hand-written MFMA, epilogue-fused)"
                                           if gemm16 == "hip" else "library (hipBLASLt) GEMMs + clamp pass"),
             "network_rows_per_step": rows, "children_per_step": B * A,
+            # fp32 parity mode: batches whose activations left the fp16 range and were redone with fp32 GEMMs (0 expected)
+            "split_fallbacks": None if eval_all_children else getattr(fast, "split_fallbacks", None),
             "heuristic_tflops_per_gpu": flops / (wall / steps) / 1e12,
             # fp32 default path = f16x3 split layers: 3 f16 MFMA flops per useful flop -> ceiling 2500/3 "fp32-equivalent"
             "mfma_peak_tflops": (157.3 if eval_all_children else 2500.0 / 3) if dtype_name == "fp32"

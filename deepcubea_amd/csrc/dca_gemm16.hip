@@ -470,7 +470,7 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16p(const Gemm16Args p) {
 //   * PIECE EXCHANGE: the four pieces a lane holds of its own row change hands inside the wave through a wave-private 4 KB
 //     of LDS (4 ds_write_b128 + 4 ds_read_b128 per 32 rows) so that lane (4 g + x, h) stores piece x * 2 + h of rows
 //     4 g .. 4 g + 3: 8 lanes per 128-byte row segment.  Skip rows come in by the same route, the other way round.
-//   * NO RUN-TIME CASES in the tail: the kernel is compiled per form (skip or not; bias and ReLU always), takes whole
+//   * NO RUN-TIME CASES in the tail: the kernel is compiled per form (skip or not, bias or not; ReLU always), takes whole
 //     256 x 256 tiles with 16-byte aligned rows only, and the host hands everything else — other forms, the ragged right /
 //     bottom strips of a layer — to variant 2.  ~520 instructions per wave and tile.
 // Measured (204 800 rows, candidates taking turns, profiles/r05_gemm_bench.txt): K = 1024 0.450 / 0.499 ms (bias / residual
@@ -515,7 +515,7 @@ __device__ __forceinline__ float hi16(uint32_t v) {
 }
 
 // Tail of a FULL tile.  tl: this wave's 4 KB exchange slice; rows cm0 + wm*128 .. +128, columns cn0 + wn*64 .. +64.
-template <bool BF16, bool SKIP, bool RELU>
+template <bool BF16, bool SKIP, bool RELU, bool BIAS>
 __device__ __forceinline__ void gemm16_tail_full(const Gemm16Args& p, uint8_t* tl, f32x16 (&acc)[4][2], int64_t cm0, int cn0, int wm,
                                                  int wn, int l31, int h) {
     const int tg = l31 >> 2, tx = l31 & 3;
@@ -526,7 +526,7 @@ __device__ __forceinline__ void gemm16_tail_full(const Gemm16Args& p, uint8_t* t
         return tl + row * 128 + ((uint32_t)(((tx * 2 + h) ^ (row & 7))) << 4);
     };
     const int colw = cn0 + wn * 64;
-    {   // bias of this lane's 4 x 8 columns, added in place (this kernel serves the network's layer forms: bias is there)
+    if constexpr (BIAS) {  // bias of this lane's 4 x 8 columns, added in place
         const float* bp = p.bias + colw + h * 8;
 #pragma unroll
         for (int X = 0; X < 4; X++) {
@@ -598,7 +598,7 @@ __device__ __forceinline__ void gemm16_tail_full(const Gemm16Args& p, uint8_t* t
     rows32(std::integral_constant<int, 3>{});
 }
 
-template <bool BF16, bool SKIP>
+template <bool BF16, bool SKIP, bool BIAS>
 __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16s(const Gemm16Args p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     using frag_t = typename std::conditional<BF16, b16x8, h16x8>::type;
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16s(const Gemm16Args p) {
     }
     if (wm == 0) DCA_BAR();  // ... and the first waits for it here: nobody reads the operand slots any more
     // the tail's piece exchange uses the first 32 KB of the (now idle) operand slots, 4 KB per wave
-    gemm16_tail_full<BF16, SKIP, true>(p, lds + w * 4096, acc, m0, n0, wm, wn, l31, h);
+    gemm16_tail_full<BF16, SKIP, true, BIAS>(p, lds + w * 4096, acc, m0, n0, wm, wn, l31, h);
 #undef DCA_VMCNT
 #undef DCA_MMA8
 }
@@ -754,11 +754,15 @@ using namespace dca;
 
 static int g_gemm16_variant = 3;
 
-// the lean-tail kernel serving one of the network's layer forms: relu(a . w^T + bias) or relu(a . w^T + bias + skip)
-static const void* lean_kernel(int bf16, int skip) {
-    static const void* tab[4] = {reinterpret_cast<const void*>(k_gemm16s<false, false>), reinterpret_cast<const void*>(k_gemm16s<true, false>),
-                                 reinterpret_cast<const void*>(k_gemm16s<false, true>), reinterpret_cast<const void*>(k_gemm16s<true, true>)};
-    return tab[(bf16 ? 1 : 0) | (skip ? 2 : 0)];
+// the lean-tail kernel serving one of the network's layer forms: relu(a . w^T (+ bias) (+ skip)) — FastResnet folds the second
+// bias of a residual block into the weights (a constant-one input unit), so its residual layers come without a bias
+static const void* lean_kernel(int bf16, int skip, int bias) {
+    static const void* tab[8] = {
+        reinterpret_cast<const void*>(k_gemm16s<false, false, false>), reinterpret_cast<const void*>(k_gemm16s<true, false, false>),
+        reinterpret_cast<const void*>(k_gemm16s<false, true, false>),  reinterpret_cast<const void*>(k_gemm16s<true, true, false>),
+        reinterpret_cast<const void*>(k_gemm16s<false, false, true>),  reinterpret_cast<const void*>(k_gemm16s<true, false, true>),
+        reinterpret_cast<const void*>(k_gemm16s<false, true, true>),   reinterpret_cast<const void*>(k_gemm16s<true, true, true>)};
+    return tab[(bf16 ? 1 : 0) | (skip ? 2 : 0) | (bias ? 4 : 0)];
 }
 
 extern "C" {
@@ -794,7 +798,7 @@ int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int 
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16p<true>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
             DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm16p<false>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
-            for (int f = 0; f < 4; f++) DCA_HIP(hipFuncSetAttribute(lean_kernel(f & 1, f >> 1), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
+            for (int f = 0; f < 8; f++) DCA_HIP(hipFuncSetAttribute(lean_kernel(f & 1, (f >> 1) & 1, f >> 2), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
             attr_devs.fetch_or(bit, std::memory_order_release);
         }
     }
@@ -839,11 +843,11 @@ int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int 
         if (int rc = launch_generic(p, g_gemm16_variant)) return rc;
         return launch_check("k_gemm16");
     }
-    // Variant 3 — the lean-tail kernel — serves the network's own layer forms, relu(a . w^T + bias (+ skip)), on whole tiles
+    // Variant 3 — the lean-tail kernel — serves the network's own layer forms, relu(a . w^T (+ bias) (+ skip)), on whole tiles
     // with 16-byte aligned rows; any other form goes to variant 2, and so do the ragged right and bottom strips of a layer
     // (none in the network's own shapes: widths are padded to 1024 / 5120, row counts to 1024) — the same products in the same
     // order either way.
-    const bool lean = relu && bias && (ldo % 8 == 0) && (((uintptr_t)out | (uintptr_t)skip | (uintptr_t)bias) % 16 == 0);
+    const bool lean = relu && (ldo % 8 == 0) && (((uintptr_t)out | (uintptr_t)skip | (uintptr_t)bias) % 16 == 0);
     const int64_t mf = lean ? (m / QBM) * QBM : 0;
     const int nf = lean ? (n / QBN) * QBN : 0;
     if (mf > 0 && nf > 0) {
@@ -857,7 +861,7 @@ int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int 
             return DCA_E_BADARG;
         }
         void* kargs[] = {&q};
-        DCA_HIP(hipLaunchKernel(lean_kernel(dtype == DCA_DT_BF16, skip != nullptr), dim3((unsigned)blocks), dim3(QTHREADS), kargs, QLDS, s));
+        DCA_HIP(hipLaunchKernel(lean_kernel(dtype == DCA_DT_BF16, skip != nullptr, bias != nullptr), dim3((unsigned)blocks), dim3(QTHREADS), kargs, QLDS, s));
     }
     auto strip = [&](int64_t r0, int64_t rows, int c0, int cols) -> int {  // rows [r0, r0 + rows) x columns [c0, c0 + cols)
         if (rows <= 0 || cols <= 0) return 0;

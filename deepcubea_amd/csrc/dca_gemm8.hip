@@ -108,6 +108,105 @@ __device__ __forceinline__ uint32_t pack_e4m3(float a, float b, float c, float d
 #define DCA_RD_DONE_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define DCA_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
+// Layer tail.  MODE < 0: any shape, any form, block-scaled results included, every option tested at run time.  MODE >= 0 (bit 0
+// skip, bit 1 bf16 output, bit 2 e4m3 output with the static scale, bit 3 bias): the same tail compiled for ONE of the network's
+// layer forms on a tile inside the matrix, with ReLU — no per-row / per-element tests left (round 5; the 1024-wide e4m3 layers
+// spend 40-50 % of their time in this tail, csrc/dca_gemm16.hip has the measurements that led here).
+template <int MODE>
+__device__ __forceinline__ void gemm8_tail_as(const Gemm8Args& p, uint8_t* lds, const f32x16 (&acc)[4][2], int64_t m0, int n0, int w, int wm,
+                                              int wn, int lane, int l31, int h) {
+    constexpr bool G = MODE < 0;
+    const bool has_skip = G ? p.skip != nullptr : (MODE & 1) != 0;
+    const bool has16 = G ? p.out16 != nullptr : (MODE & 2) != 0;
+    const bool has8 = G ? p.out8 != nullptr : (MODE & 4) != 0;
+    const bool has_bias = G ? p.bias != nullptr : (MODE & 8) != 0;
+    const bool relu = G ? p.relu != 0 : true;
+    // Accumulator layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  Each wave
+    // transposes its tile through its own 16 KB of the (now idle) LDS, 32 rows at a time: a lane then owns 4 consecutive
+    // columns of a row — one 8-byte skip load, one 8-byte bf16 store, one 4-byte e4m3 store.
+    float* sl = reinterpret_cast<float*>(lds + w * 16384);
+    float sc[2], bv[2];
+#pragma unroll
+    for (int jn = 0; jn < 2; jn++) {
+        const int col = n0 + wn * 64 + jn * 32 + l31;
+        sc[jn] = (G ? col < p.n : true) ? p.scale[col] : 0.f;
+        bv[jn] = ((G ? col < p.n : true) && has_bias) ? p.bias[col] : 0.f;
+    }
+    const int c4 = (lane & 15) * 4;  // this lane's 4 columns inside the wave's 64
+    const int colg = n0 + wn * 64 + c4;
+    const bool full4 = G ? colg + 3 < p.n : true;
+    // residual rows: the loads of round i+1 are issued before round i is worked on (two register sets), so only the first
+    // round waits a full memory latency — the waits between rounds would otherwise add up (4 x ~1.5 us per tile)
+    uint2 sk[2][8];
+    auto load_skip = [&](int i, uint2 (&dst)[8]) {
+        const int64_t rb = m0 + wm * 128 + i * 32;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int64_t r = rb + q * 4 + (lane >> 4);
+            dst[q] = make_uint2(0u, 0u);
+            if (has_skip && (G ? (r < p.m && full4) : true)) dst[q] = *reinterpret_cast<const uint2*>(p.skip + r * p.ldo16 + colg);
+        }
+    };
+    if (has_skip) load_skip(0, sk[0]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int jn = 0; jn < 2; jn++)
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++)
+                sl[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 64 + jn * 32 + l31] = acc[i][jn][reg] * sc[jn] + bv[jn];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private slice: no barrier, just the wave's own writes
+        const int64_t rbase = m0 + wm * 128 + i * 32;
+        if (has_skip && i + 1 < 4) load_skip(i + 1, sk[(i + 1) & 1]);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int rl = q * 4 + (lane >> 4);
+            const int64_t r = rbase + rl;
+            const float4 v = *reinterpret_cast<const float4*>(sl + rl * 64 + c4);
+            if (G && r >= p.m) continue;
+            float u[4] = {v.x, v.y, v.z, v.w};
+            if (full4) {
+                if (has_skip) {
+                    const uint2 s2 = sk[i & 1][q];
+                    u[0] += bf16_to_f32((uint16_t)(s2.x & 0xFFFFu));
+                    u[1] += bf16_to_f32((uint16_t)(s2.x >> 16));
+                    u[2] += bf16_to_f32((uint16_t)(s2.y & 0xFFFFu));
+                    u[3] += bf16_to_f32((uint16_t)(s2.y >> 16));
+                }
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) u[e] = fmaxf(u[e], 0.f);
+                }
+                if (has16) {
+                    uint2 ov;
+                    ov.x = f32_to_bf16x2(u[0], u[1]);
+                    ov.y = f32_to_bf16x2(u[2], u[3]);
+                    *reinterpret_cast<uint2*>(p.out16 + r * p.ldo16 + colg) = ov;
+                }
+                if (has8) {
+                    float s = p.out8_scale;
+                    if (G && p.out8_scale_ptr_set) {
+                        // block scale of this row's 64 columns (the wave's slice: 16 lanes x 4 columns): largest magnitude over the
+                        // 16 lanes, the power of two that brings it into e4m3's range, one byte per (row, 64 columns)
+                        const float am = row16_max(fmaxf(fmaxf(fabsf(u[0]), fabsf(u[1])), fmaxf(fabsf(u[2]), fabsf(u[3]))));
+                        const uint32_t sb = e8m0_of_amax(am, s);
+                        if ((lane & 15) == 0) p.out8_sc[r * p.ld_osc + (colg >> 6)] = (uint8_t)sb;
+                    }
+                    *reinterpret_cast<uint32_t*>(p.out8 + r * p.ldo8 + colg) = pack_e4m3(u[0] * s, u[1] * s, u[2] * s, u[3] * s);
+                }
+            } else {  // ragged right edge: element-wise
+                for (int e = 0; e < 4 && colg + e < p.n; e++) {
+                    float ue = u[e] + (p.skip ? bf16_to_f32(p.skip[r * p.ldo16 + colg + e]) : 0.f);
+                    if (p.relu) ue = fmaxf(ue, 0.f);
+                    if (p.out16) p.out16[r * p.ldo16 + colg + e] = f32_to_bf16(ue);
+                    if (p.out8) p.out8[r * p.ldo8 + colg + e] = (uint8_t)(pack_e4m3(ue * p.out8_scale, 0.f, 0.f, 0.f) & 0xFFu);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slice is rewritten by the next 32 rows
+    }
+}
+
 // MXIN: the A operand carries E8M0 block scales (one per 64 K elements of a row).  The whole K range of the tile's 256 rows
 // (k / 64 bytes a row: 4 KB at k = 1024, 20 KB at 5120) is staged into LDS behind the operand slots in the prologue — ordinary
 // loads, before the K loop, so the loop's counted LDS-DMA waits are untouched — and a lane fetches the two scales of its row
@@ -334,90 +433,21 @@ __global__ __launch_bounds__(ETHREADS, 2) void k_gemm8(const Gemm8Args p) {
 #undef DCA_MMA4
 #undef DCA_MMA4_STEP
 
-    // epilogue.  Accumulator layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  Each wave
-    // transposes its tile through its own 16 KB of the (now idle) LDS, 32 rows at a time: a lane then owns 4 consecutive
-    // columns of a row — one 8-byte skip load, one 8-byte bf16 store, one 4-byte e4m3 store.
+    // the layer tail: the network's own forms on a tile inside the matrix (uniform over the workgroup) take a tail compiled for
+    // them; everything else — ragged edges, block-scaled results, no ReLU — the general one
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the operand slots
-    float* sl = reinterpret_cast<float*>(lds + w * 16384);
-    float sc[2], bv[2];
-#pragma unroll
-    for (int jn = 0; jn < 2; jn++) {
-        const int col = n0 + wn * 64 + jn * 32 + l31;
-        sc[jn] = col < p.n ? p.scale[col] : 0.f;
-        bv[jn] = (col < p.n && p.bias) ? p.bias[col] : 0.f;
-    }
-    const int c4 = (lane & 15) * 4;  // this lane's 4 columns inside the wave's 64
-    const int colg = n0 + wn * 64 + c4;
-    const bool full4 = colg + 3 < p.n;
-    // residual rows: the loads of round i+1 are issued before round i is worked on (two register sets), so only the first
-    // round waits a full memory latency — the waits between rounds would otherwise add up (4 x ~1.5 us per tile)
-    uint2 sk[2][8];
-    auto load_skip = [&](int i, uint2 (&dst)[8]) {
-        const int64_t rb = m0 + wm * 128 + i * 32;
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int64_t r = rb + q * 4 + (lane >> 4);
-            dst[q] = make_uint2(0u, 0u);
-            if (p.skip && r < p.m && full4) dst[q] = *reinterpret_cast<const uint2*>(p.skip + r * p.ldo16 + colg);
+    {
+        const bool inside = m0 + EBM <= p.m && n0 + EBN <= p.n && p.relu && !p.out8_scale_ptr_set;
+        const int mode = inside ? ((p.skip ? 1 : 0) | (p.out16 ? 2 : 0) | (p.out8 ? 4 : 0) | (p.bias ? 8 : 0)) : -1;
+        switch (mode) {
+            case 12: gemm8_tail_as<12>(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h); break;  // bias + ReLU -> e4m3
+            case 14: gemm8_tail_as<14>(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h); break;  // bias + ReLU -> bf16 and e4m3 (the 5120 -> 1024 layer)
+            case 15: gemm8_tail_as<15>(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h); break;  // bias + skip + ReLU -> bf16 and e4m3
+            case 11: gemm8_tail_as<11>(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h); break;  // last block: bias + skip + ReLU -> bf16
+            case 7: gemm8_tail_as<7>(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h); break;    // skip + ReLU -> bf16 and e4m3 (no bias)
+            case 3: gemm8_tail_as<3>(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h); break;    // skip + ReLU -> bf16 (no bias)
+            default: gemm8_tail_as<-1>(p, lds, acc, m0, n0, w, wm, wn, lane, l31, h); break;
         }
-    };
-    load_skip(0, sk[0]);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-#pragma unroll
-        for (int jn = 0; jn < 2; jn++)
-#pragma unroll
-            for (int reg = 0; reg < 16; reg++)
-                sl[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 64 + jn * 32 + l31] = acc[i][jn][reg] * sc[jn] + bv[jn];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private slice: no barrier, just the wave's own writes
-        const int64_t rbase = m0 + wm * 128 + i * 32;
-        if (i + 1 < 4) load_skip(i + 1, sk[(i + 1) & 1]);
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int rl = q * 4 + (lane >> 4);
-            const int64_t r = rbase + rl;
-            const float4 v = *reinterpret_cast<const float4*>(sl + rl * 64 + c4);
-            if (r >= p.m) continue;
-            float u[4] = {v.x, v.y, v.z, v.w};
-            if (full4) {
-                if (p.skip) {
-                    const uint2 s2 = sk[i & 1][q];
-                    u[0] += bf16_to_f32((uint16_t)(s2.x & 0xFFFFu));
-                    u[1] += bf16_to_f32((uint16_t)(s2.x >> 16));
-                    u[2] += bf16_to_f32((uint16_t)(s2.y & 0xFFFFu));
-                    u[3] += bf16_to_f32((uint16_t)(s2.y >> 16));
-                }
-                if (p.relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; e++) u[e] = fmaxf(u[e], 0.f);
-                }
-                if (p.out16) {
-                    uint2 ov;
-                    ov.x = f32_to_bf16x2(u[0], u[1]);
-                    ov.y = f32_to_bf16x2(u[2], u[3]);
-                    *reinterpret_cast<uint2*>(p.out16 + r * p.ldo16 + colg) = ov;
-                }
-                if (p.out8) {
-                    float s = p.out8_scale;
-                    if (p.out8_scale_ptr_set) {
-                        // block scale of this row's 64 columns (the wave's slice: 16 lanes x 4 columns): largest magnitude over the
-                        // 16 lanes, the power of two that brings it into e4m3's range, one byte per (row, 64 columns)
-                        const float am = row16_max(fmaxf(fmaxf(fabsf(u[0]), fabsf(u[1])), fmaxf(fabsf(u[2]), fabsf(u[3]))));
-                        const uint32_t sb = e8m0_of_amax(am, s);
-                        if ((lane & 15) == 0) p.out8_sc[r * p.ld_osc + (colg >> 6)] = (uint8_t)sb;
-                    }
-                    *reinterpret_cast<uint32_t*>(p.out8 + r * p.ldo8 + colg) = pack_e4m3(u[0] * s, u[1] * s, u[2] * s, u[3] * s);
-                }
-            } else {  // ragged right edge: element-wise
-                for (int e = 0; e < 4 && colg + e < p.n; e++) {
-                    float ue = u[e] + (p.skip ? bf16_to_f32(p.skip[r * p.ldo16 + colg + e]) : 0.f);
-                    if (p.relu) ue = fmaxf(ue, 0.f);
-                    if (p.out16) p.out16[r * p.ldo16 + colg + e] = f32_to_bf16(ue);
-                    if (p.out8) p.out8[r * p.ldo8 + colg + e] = (uint8_t)(pack_e4m3(ue * p.out8_scale, 0.f, 0.f, 0.f) & 0xFFu);
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slice is rewritten by the next 32 rows
     }
 }
 #undef DCA_VMCNT

@@ -81,9 +81,30 @@ __global__ __launch_bounds__(kL1Threads) void k_l1_onehot_gemm(const uint8_t* __
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int64_t n0 = (int64_t)blockIdx.x * 64;
+    // LEAN (round 5; 16-bit and e4m3 outputs): the MFMA's operand roles are swapped — weights = A operand, one-hot rows = B
+    // operand — so that a lane holds a piece of ONE output row, and the weight column that feeds MFMA row i is chosen (bits 2
+    // and 3 of the fragment's column index swapped: the same 32 chunks per lane group, still conflict-free) such that a
+    // lane's 8 consecutive accumulator registers are 8 CONSECUTIVE output columns: bias, ReLU and the rounding work on
+    // register octets, packed pieces change hands through the wave's 4 KB of LDS, 8 lanes store one row segment.  The
+    // accumulator-layout tail it replaces (one LDS word per element: 128 ds_write_b32 + 16 ds_read_b128 + 16 eight-byte
+    // stores per wave and 64 x 64 tile) was half the kernel's time with one weight plane (csrc/dca_gemm16.hip has the story).
+    constexpr bool LEAN = OUT == 1 || OUT == 2 || OUT == 4 || OUT == 5;
+    const int wcol = LEAN ? ((l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1)) : l31;
     float bv[2];
     bv[0] = bias[n0 + l31];
     bv[1] = bias[n0 + 32 + l31];
+    // LEAN: the bias of a lane's 4 x 8 columns (piece X: columns X * 16 + h * 8 .. + 8).  With ONE weight plane the kernel must
+    // stay at 128 VGPRs — two workgroups per CU: 0.92 vs 1.08 ms per 204 800 x 5120 layer — so the bias is fetched per piece in
+    // the tail (two 16-byte loads that hit L1, hidden by the other workgroup); with two or three planes the weight tile leaves room
+    // for one workgroup per CU anyway and the 32 registers are free: held across the K loop (per-piece loads: 2.47 vs 2.09 ms).
+    constexpr bool BIAS_REGS = LEAN && P > 1;
+    float bq[BIAS_REGS ? 4 : 1][8];
+    if constexpr (BIAS_REGS) {
+#pragma unroll
+        for (int X = 0; X < 4; X++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) bq[X][e] = bias[n0 + X * 16 + h * 8 + e];
+    }
     for (int64_t chunk = blockIdx.y; chunk * kL1Rows < m; chunk += gridDim.y) {
         const int64_t rw = chunk * kL1Rows + wv * 64;  // first row of this wave
         // (with K-chunking every wave takes part in the staging barriers, rows or not)
@@ -153,13 +174,104 @@ __global__ __launch_bounds__(kL1Threads) void k_l1_onehot_gemm(const uint8_t* __
 #pragma unroll
                     for (int jn = 0; jn < 2; jn++) {
                         const bf16x8 b = *reinterpret_cast<const bf16x8*>(
-                            lw + ((size_t)((p * G::CHKC + 2 * s + h) * 64 + jn * 32 + l31)) * 16);
-                        acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b, acc[0][jn], 0, 0, 0);
-                        acc[1][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b, acc[1][jn], 0, 0, 0);
+                            lw + ((size_t)((p * G::CHKC + 2 * s + h) * 64 + jn * 32 + wcol)) * 16);
+                        if constexpr (LEAN) {  // weights = the instruction's A operand: D[i][j] has j = lane & 31 = the state's row
+                            acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a[0], acc[0][jn], 0, 0, 0);
+                            acc[1][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a[1], acc[1][jn], 0, 0, 0);
+                        } else {
+                            acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b, acc[0][jn], 0, 0, 0);
+                            acc[1][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b, acc[1][jn], 0, 0, 0);
+                        }
                     }
                 }
             }
         }
+        if constexpr (LEAN) {
+            // lane (l31, h), block (i, jn), registers 8 x .. 8 x + 7  ->  row rw + 32 i + l31, columns n0 + (jn * 2 + x) * 16 + h * 8 .. + 8
+            uint8_t* tl = lw + G::CHKC * P * 64 * 16 + wv * 4096;
+            const int tg = l31 >> 2, tx = l31 & 3;
+            constexpr int PB = OUT == 5 ? 8 : 16;        // bytes of a packed piece (8 values)
+            constexpr int RB = 8 * PB;                   // bytes of a row of the wave's 64 columns
+            auto addr = [&](int row, int c16) { return tl + row * RB + ((c16 ^ (row & 7)) * PB); };
+            bool ovf = false;
+            constexpr int NPASS = OUT == 4 ? 2 : 1;      // two fp16 planes: the high halves, then the low halves
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+#pragma unroll
+                for (int pass = 0; pass < NPASS; pass++) {
+#pragma unroll
+                    for (int X = 0; X < 4; X++) {
+                        float bb[8];
+                        if constexpr (BIAS_REGS) {
+#pragma unroll
+                            for (int e = 0; e < 8; e++) bb[e] = bq[X][e];
+                        } else {
+                            const float4 b0 = *reinterpret_cast<const float4*>(bias + n0 + X * 16 + h * 8);
+                            const float4 b1 = *reinterpret_cast<const float4*>(bias + n0 + X * 16 + h * 8 + 4);
+                            bb[0] = b0.x, bb[1] = b0.y, bb[2] = b0.z, bb[3] = b0.w, bb[4] = b1.x, bb[5] = b1.y, bb[6] = b1.z, bb[7] = b1.w;
+                        }
+                        float u[8];
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            float v = acc[i][X >> 1][8 * (X & 1) + e] + bb[e];
+                            if (relu) v = fmaxf(v, 0.f);
+                            if constexpr (OUT == 4) ovf |= !(fabsf(v) <= 60000.0f);
+                            u[e] = v;
+                        }
+                        if constexpr (OUT == 5) {  // e4m3fn has no infinity: saturate at +-448
+                            uint32_t w0 = 0, w1 = 0;
+                            auto sat = [](float f) { return fminf(fmaxf(f, -448.f), 448.f); };
+                            w0 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(sat(u[0]), sat(u[1]), 0, false);
+                            w0 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(sat(u[2]), sat(u[3]), (int)w0, true);
+                            w1 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(sat(u[4]), sat(u[5]), 0, false);
+                            w1 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(sat(u[6]), sat(u[7]), (int)w1, true);
+                            *reinterpret_cast<uint2*>(addr(l31, X * 2 + h)) = make_uint2(w0, w1);
+                        } else {
+                            uint32_t w[4];
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const float a0 = u[2 * e], a1 = u[2 * e + 1];
+                                if constexpr (OUT == 2) {
+                                    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                                    typedef float f2 __attribute__((ext_vector_type(2)));
+                                    const f2 vv = {a0, a1};
+                                    const bf2 bb2 = __builtin_convertvector(vv, bf2);
+                                    __builtin_memcpy(&w[e], &bb2, 4);
+                                } else {
+                                    _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+                                    if (OUT == 4 && pass == 1) {  // the low plane: what the high halves left over
+                                        h0 = (_Float16)(a0 - (float)h0);
+                                        h1 = (_Float16)(a1 - (float)h1);
+                                    }
+                                    uint16_t c0, c1;
+                                    __builtin_memcpy(&c0, &h0, 2);
+                                    __builtin_memcpy(&c1, &h1, 2);
+                                    w[e] = (uint32_t)c0 | ((uint32_t)c1 << 16);
+                                }
+                            }
+                            *reinterpret_cast<uint4*>(addr(l31, X * 2 + h)) = make_uint4(w[0], w[1], w[2], w[3]);
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private slice: only the wave's own writes
+                    // lane (4 g + x, h) leaves with piece x * 2 + h of rows 4 g .. 4 g + 3: 8 lanes per row segment
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int64_t r = rw + 32 * i + 4 * tg + j;
+                        const int c16 = tx * 2 + h;
+                        if constexpr (OUT == 5) {
+                            const uint2 q = *reinterpret_cast<const uint2*>(addr(4 * tg + j, c16));
+                            if (r < m) *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(out) + r * ldo + n0 + c16 * 8) = q;
+                        } else {
+                            const uint4 q = *reinterpret_cast<const uint4*>(addr(4 * tg + j, c16));
+                            uint16_t* q0 = reinterpret_cast<uint16_t*>(out) + r * ldo + n0 + c16 * 8 + (pass ? m * ldo : 0);
+                            if (r < m) *reinterpret_cast<uint4*>(q0) = q;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads are done before the slice is rewritten
+                }
+            }
+            if (OUT == 4 && ovf && overflow) *overflow = 1;
+        } else
         // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
         if constexpr (OUT == 1 || OUT == 2 || OUT == 4 || OUT == 5 || OUT == 6) {
             // 16-bit outputs: straight from the accumulator layout every store instruction would write 2 bytes per lane,
