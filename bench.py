@@ -545,10 +545,11 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
             "what": "MFMA flops ISSUED per second over the whole iteration (engine launches and host hand-over included): "
                     "2 x MACs x network rows%s / ms_per_step, against the dense peak of the pipe the layers run on"
                     % (" x 3 (f16x3: three f16 products per fp32-accurate one)" if dtype_name == "fp32" and not eval_all_children else ""),
-            "mfma_busy_profile": {"fp32": "profiles/r04_nnet_fp32_pmc_mfma.txt", "fp8": "profiles/r03_nnet_fp8_pmc_mfma.txt"}.get(
+            "mfma_busy_profile": {"fp32": "profiles/r05_nnet_fp32_pmc_mfma.txt", "fp8": "profiles/r05_nnet_fp8_pmc_mfma.txt"}.get(
                 dtype_name if not eval_all_children else "", None),
-            "clock_note": "the dense layers run power-limited: 1.3-1.7 GHz shader clock inside their K loops (2.4 GHz nominal), 73 % "
-                          "of the matrix pipe's issue slots filled at that clock (profiles/r04_gemm_timeline.txt)"}
+            "clock_note": "the dense layers run power-limited on random operands (1.3-1.7 GHz shader clock inside their K loops, 2.4 GHz "
+                          "nominal: profiles/r04_gemm_timeline.txt) and fetch-bound on the L2 -> LDS operand stream "
+                          "(profiles/r05_gemm16_probe.txt: all-zero operands run 32 % faster, the library's kernel 6 %)"}
     return {"value": total_exp / wall, "unit": "nodes expanded/s", "ms_per_step": wall / steps * 1e3,
             "roofline_nnet": roof,
             "steps": steps, "timed_s": wall, "heuristic_dtype": dtype_name + (" (block-scaled, MX-64)" if dtype_name == "fp8" and fp8_scaling == "block" else ""), "weights": "synthetic (numpy PCG64 seed 2024, BN folded)",
