@@ -440,3 +440,15 @@ def test_auto_instances_rule():
     a = mk(batch_size=20000)
     a.instances_per_gpu = "5"
     assert astar.auto_instances(a, env, 1000, None) == 5
+
+
+def test_graft_entry_build_passes_on_this_box():
+    """`__graft_entry__.build()` is the driver's "does it build" check (hipcc cross-compiles without a GPU): it must succeed here —
+    including its own assertion on the library's ABI version, which round 5 bumped without touching that file until the GPU box's
+    smoke test said so."""
+    import importlib
+    ge = importlib.import_module("__graft_entry__")
+    ge.build()
+    from deepcubea_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "dca.h")).read()
+    assert "#define DCA_ABI_VERSION %d" % _lib.lib().dca_abi_version() in hdr
