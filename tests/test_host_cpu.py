@@ -452,3 +452,39 @@ def test_graft_entry_build_passes_on_this_box():
     from deepcubea_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "dca.h")).read()
     assert "#define DCA_ABI_VERSION %d" % _lib.lib().dca_abi_version() in hdr
+
+
+def test_ranks_sharing_a_gpu_are_not_guessed_from_world_size(monkeypatch):
+    """launchers that set RANK / WORLD_SIZE / LOCAL_RANK but no LOCAL_WORLD_SIZE (srun, mpirun) made every rank of a
+    multi-node job believe WORLD_SIZE / devices ranks share its GPU — node pools cut to 1/nodes of the HBM, grid-wide tie
+    refinement off.  Without LOCAL_WORLD_SIZE (and without a process group to count over) the deployment model is assumed: one
+    rank per GPU; with it, the local ranks are mapped onto the visible devices; a count taken over the process group wins."""
+    import torch
+    from deepcubea_amd.search_methods import sharding
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(sharding, "_sharers", None)
+    monkeypatch.setenv("WORLD_SIZE", "32")   # four nodes of eight
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    assert sharding.ranks_on_my_device() == 1
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert sharding.ranks_on_my_device() == 1
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)  # a test box: eight local ranks on one GPU
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    assert sharding.ranks_on_my_device() == 8
+    monkeypatch.setattr(sharding, "_sharers", 2)  # counted over the process group: (host, device) pairs equal to mine
+    assert sharding.ranks_on_my_device() == 2
+
+
+def test_bench_reads_the_committed_pmc_traffic_of_this_round():
+    """bench.py's `roofline.traffic` figures come from the rocprofv3 PMC passes committed under profiles/ (counters cannot be read
+    inside the timed process): the engine kernels' and the gather kernel's entries of round 5 are there and name their source."""
+    import importlib
+    bench = importlib.import_module("bench")
+    t = bench.pmc_traffic("k_expand", "cube3", 20000)
+    assert t is not None and 3e7 < t < 1.2e8 and bench.PMC_SOURCE["k_expand"].startswith("profiles/r05_pmc_traffic.json")
+    for oh, alg in (("f32", 16_254_000_000), ("bf16", 8_478_000_000)):
+        b = bench.expand_pmc_traffic(oh, 1_000_000)
+        assert b is not None and alg <= b <= 1.03 * alg, (oh, b)  # no re-reads: measured traffic = algorithmic bytes (+ hash / solved)
+    assert bench.expand_pmc_traffic("f32", 12345) is None
