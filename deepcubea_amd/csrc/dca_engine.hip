@@ -44,6 +44,7 @@
 #include <string.h>
 
 #include <new>
+#include <vector>
 
 #include "dca_common.h"
 #include "dca_tile.h"
@@ -3316,11 +3317,13 @@ __global__ __launch_bounds__(1024) void k_commit(const Eng* __restrict__ engs, i
 }
 
 // per-instance weights of path cost from a device array (dca_engine_set_weights_dev): stream-ordered, no host involvement
+// The host setters refuse weights < 0 or NaN (DCA_E_BADARG); a stream-ordered launch cannot refuse, so it clamps them to 0.
 __global__ void k_set_weights(Eng* __restrict__ engs, const double* __restrict__ w, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        engs[i].w = w[i];
-        engs[i].wf = (float)w[i];
+        const double v = w[i] >= 0.0 ? w[i] : 0.0;  // (NaN fails the comparison)
+        engs[i].w = v;
+        engs[i].wf = (float)v;
     }
 }
 
@@ -3409,6 +3412,7 @@ struct dca_engine {
     float* pk_h;
     int64_t pk_rows;       // rows packed by the last dca_engine_pop_expand_packed
     int phase;             // 0 idle, 1 between pop_expand and commit, 2 between pop_expand_packed and commit_packed
+    bool w_dev;            // the device copy holds weights the host mirror has not seen (dca_engine_set_weights_dev)
     uint8_t tab_cleared[kMaxInstances];  // the instance's CLOSED table has been cleared in full at least once
     unsigned collect_blocks;  // grid of k_sel_collect: two workgroups per CU, all resident (its giant-bin path barriers across it)
     long collect_resident;    // workgroups of k_sel_collect the device can hold at once per the occupancy query (-1: query failed)
@@ -3604,7 +3608,24 @@ void drop_graphs(dca_engine* e) {
     e->gslot_next = 0;
 }
 
+// dca_engine_set_weights_dev writes w / wf of the DEVICE copy only (stream-ordered, no host involvement: ADVICE r05).  Before
+// the host mirror is used as a whole — any upload, any host-side weight setter — the device's weights are read back into it, so
+// that a later upload cannot revert them.  (Kernels that take an Eng by value from the mirror read w only as w * 0 at the root.)
+int pull_dev_weights(dca_engine* e) {
+    if (!e->w_dev) return 0;
+    DCA_HIP(hipDeviceSynchronize());
+    std::vector<Eng> tmp((size_t)e->K);
+    DCA_HIP(hipMemcpy(tmp.data(), e->d_engs, sizeof(Eng) * (size_t)e->K, hipMemcpyDeviceToHost));
+    for (int i = 0; i < e->K; i++) {
+        e->E[i].w = tmp[(size_t)i].w;
+        e->E[i].wf = tmp[(size_t)i].wf;
+    }
+    e->w_dev = false;
+    return 0;
+}
+
 int upload_engs(dca_engine* e) {
+    if (int rc = pull_dev_weights(e)) return rc;
     DCA_HIP(hipMemcpy(e->d_engs, e->E, sizeof(Eng) * (size_t)e->K, hipMemcpyHostToDevice));
     return 0;
 }
@@ -4168,6 +4189,7 @@ int dca_engine_set_weight_instance(dca_engine* e, int inst, double weight) {
         set_error("dca_engine_set_weight_instance between pop_expand and commit");
         return DCA_E_STATE;
     }
+    if (int rc = pull_dev_weights(e)) return rc;  // (the other instances may carry device-set weights)
     e->E[inst].w = weight;
     e->E[inst].wf = (float)weight;
     DCA_HIP(hipDeviceSynchronize());  // (no launch may still be reading the instance array)
@@ -4180,8 +4202,9 @@ int dca_engine_set_weights(dca_engine* e, const double* weights, int n) {
         set_error("dca_engine_set_weights between pop_expand and commit");
         return DCA_E_STATE;
     }
+    for (int i = 0; i < n; i++) DCA_ARG(weights[i] >= 0.0);
+    if (int rc = pull_dev_weights(e)) return rc;  // (instances n..K-1 may carry device-set weights)
     for (int i = 0; i < n; i++) {
-        DCA_ARG(weights[i] >= 0.0);
         e->E[i].w = weights[i];
         e->E[i].wf = (float)weights[i];
     }
@@ -4245,6 +4268,7 @@ int dca_engine_set_weights_dev(dca_engine* e, const double* weights_dev, int n, 
         return DCA_E_STATE;
     }
     hipLaunchKernelGGL(k_set_weights, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, e->d_engs, weights_dev, n);
+    e->w_dev = true;
     return launch_check("k_set_weights");
 }
 

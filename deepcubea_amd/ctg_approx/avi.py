@@ -171,7 +171,12 @@ def main(argv=None):
 
     t_start = time.time()
     while itr < args_dict['max_itrs']:
-        if args_dict['max_seconds'] > 0 and time.time() - t_start >= args_dict['max_seconds']:
+        stop = args_dict['max_seconds'] > 0 and time.time() - t_start >= args_dict['max_seconds']
+        if world > 1:  # rank 0's clock decides for everybody: a rank that left alone would strand the others in a collective
+            flag = torch.tensor([int(stop)], dtype=torch.int32, device=device)
+            torch.distributed.broadcast(flag, 0)
+            stop = bool(flag.item())
+        if stop:
             print("Time budget of %.0f s used (%i iterations, update number %i)" % (args_dict['max_seconds'], itr, update_num))
             break
         # update (targets from the target network)

@@ -117,10 +117,13 @@ def auto_instances(args, env, n_states: int, builtin) -> int:
     world, _ = sharding.world_info()
     mine = max(1, -(-int(n_states) // max(world, 1)))
     K = max(1, min(-(-want // per), _AUTO_MAX_INSTANCES, mine))
-    if str(getattr(args, "max_nodes", "auto")).lower() == "auto":
-        # every instance owns a node pool: keep each at >= 2^27 ids (the published cube3 searches reach 6.1e7 nodes)
-        while K > 1 and BwasEngine.auto_max_nodes(args.env, args.batch_size, K, sharers=sharding.ranks_on_my_device()) < (1 << 27):
-            K -= 1
+    # every instance owns a node pool.  `--max_nodes auto`: keep each at >= 2^27 ids (the published cube3 searches reach
+    # 6.1e7 nodes); an explicit `--max_nodes N` is ids PER SEARCH and is passed through unchanged, so K shrinks until K
+    # pools of N ids fit this rank's share of the HBM (a command that fitted at K = 1 must not fail because of `auto`)
+    v = str(getattr(args, "max_nodes", "auto")).lower()
+    need = (1 << 27) if v == "auto" else int(v)
+    while K > 1 and BwasEngine.auto_max_nodes(args.env, args.batch_size, K, sharers=sharding.ranks_on_my_device()) < need:
+        K -= 1
     return K
 
 

@@ -63,16 +63,32 @@ def ranks_on_my_device() -> int:
 _sharers: Optional[int] = None
 
 
+def _device_identity() -> tuple:
+    """(host, PHYSICAL identity of the current device).  Slurm / srun on AMD bind GPUs through ROCR_VISIBLE_DEVICES: every
+    task then sees its GPU as device 0 with HIP_ / CUDA_VISIBLE_DEVICES unset, so an index plus those two variables would make
+    all ranks of a node compare equal.  The device's UUID — or its PCI address — says which GPU it is whatever
+    the masking; the index and all three masks are only the last resort when the runtime reports neither."""
+    import socket
+    dev = int(torch.cuda.current_device())
+    props = torch.cuda.get_device_properties(dev)
+    uuid = getattr(props, "uuid", None)
+    if uuid is not None and str(uuid).strip("0-") != "":
+        return (socket.gethostname(), "uuid", str(uuid))
+    pci = tuple(getattr(props, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    if pci[1] is not None:
+        return (socket.gethostname(), "pci", pci)
+    return (socket.gethostname(), "index", dev, os.environ.get("ROCR_VISIBLE_DEVICES", ""),
+            os.environ.get("HIP_VISIBLE_DEVICES", ""), os.environ.get("CUDA_VISIBLE_DEVICES", ""))
+
+
 def _count_sharers(world: int) -> None:
     """After the rendezvous: every rank says which device of which host it uses; the ranks whose answer equals mine share
     my GPU.  Independent of the launcher's environment variables (torch.distributed.run, srun, mpirun)."""
     global _sharers
     if world <= 1 or not torch.cuda.is_available():
         return
-    import socket
     import torch.distributed as dist
-    mine = (socket.gethostname(), int(torch.cuda.current_device()), os.environ.get("HIP_VISIBLE_DEVICES", ""),
-            os.environ.get("CUDA_VISIBLE_DEVICES", ""))
+    mine = _device_identity()
     everyone = [None] * world
     dist.all_gather_object(everyone, mine)
     _sharers = max(1, sum(1 for e in everyone if e == mine))

@@ -301,8 +301,11 @@ int dca_engine_last_popped(dca_engine* e, uint8_t* states, uint8_t* flags, void*
  *   reset_many        instances 0..n-1 restart from roots_dev (device u8 [n, D]; NOT range-checked — the rows come from the
  *                     library's own generator), instances n..K-1 are parked;
  *   root_commit_many  h_roots_dev: device float [n], the heuristic of the n roots;
- *   set_weights_dev   weights of path cost of instances 0..n-1 from a device double [n]; they hold until the next host-side
- *                     dca_engine_set_weights / dca_engine_set_weight_instance / profile call re-uploads the host's copy of the instance table. */
+ *   set_weights_dev   weights of path cost of instances 0..n-1 from a device double [n] (stream-ordered, nothing
+ *                     synchronises); they hold until a host-side dca_engine_set_weights / dca_engine_set_weight_instance
+ *                     names the same instance: every call that re-uploads the host's copy of the instance table (set_tiers,
+ *                     the profile calls, the host setters) first reads the device's weights back into it.  A weight < 0 or
+ *                     NaN — which the host setters refuse with DCA_E_BADARG — is clamped to 0 by the launch. */
 int dca_engine_reset_many(dca_engine* e, const uint8_t* roots_dev, int n, void* stream);
 int dca_engine_root_commit_many(dca_engine* e, const float* h_roots_dev, int n, void* stream);
 int dca_engine_set_weights_dev(dca_engine* e, const double* weights_dev, int n, void* stream);

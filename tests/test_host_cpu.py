@@ -422,14 +422,20 @@ def test_power_of_two_operand_scaling_keeps_fp32_products_on_fp16_planes():
     assert np.abs(uh + ul - g.astype(np.float64)).max() / np.abs(g).max() > 1e-3
 
 
-def test_auto_instances_rule():
+def test_auto_instances_rule(monkeypatch):
     """--instances_per_gpu auto (search_methods/astar.py:auto_instances): enough instances that a launch / a network call
-    has a chip-filling amount of work, bounded by the states at hand; tie-heavy integer built-ins stay single-instance."""
+    has a chip-filling amount of work, bounded by the states at hand and by the HBM the K node pools need; tie-heavy integer
+    built-ins stay single-instance."""
     from types import SimpleNamespace as NS
     from deepcubea_amd import _lib
     from deepcubea_amd.search_methods import astar
+    from deepcubea_amd.search_methods.engine import BwasEngine
     from deepcubea_amd.utils import env_utils
     env = env_utils.get_environment("cube3")
+    hbm = [288 << 30]  # an empty MI355X; auto_max_nodes itself needs the device (torch.cuda.mem_get_info)
+    monkeypatch.setattr(BwasEngine, "auto_max_nodes", staticmethod(
+        lambda env_name, batch_size, num_instances=1, fraction=0.8, sharers=1:
+        min(int(hbm[0] // sharers * fraction) // (BwasEngine.bytes_per_node(env_name) * num_instances), 0x7FFFFF00 // 2)))
     mk = lambda **kw: NS(env="cube3", max_nodes=str(1 << 20), instances_per_gpu="auto", **kw)
     assert astar.auto_instances(mk(batch_size=20000), env, 1000, None) == 1          # 240 000 rows per call already
     assert astar.auto_instances(mk(batch_size=10000), env, 1000, None) == 2          # train.sh's batch: two fill a GEMM
@@ -440,6 +446,20 @@ def test_auto_instances_rule():
     a = mk(batch_size=20000)
     a.instances_per_gpu = "5"
     assert astar.auto_instances(a, env, 1000, None) == 5
+    # an explicit --max_nodes is ids PER SEARCH and every instance owns a pool — `auto` must not turn a command
+    # that fitted at K = 1 into K pools that do not fit.  8e8 ids x ~200 B = 160 GB: one pool fits 288 GB, two do not
+    big = mk(batch_size=10000)
+    big.max_nodes = "800000000"
+    assert astar.auto_instances(big, env, 1000, None) == 1
+    assert astar.auto_instances(mk(batch_size=20000, ), env, 1000, _lib.HEUR_HASHU01) == 16  # 2^20 ids x 16: no constraint
+    mid = mk(batch_size=20000)
+    mid.max_nodes = str(1 << 27)   # 16 pools of 2^27 ids = 430 GB: the largest K whose pools fit 80 % of the HBM
+    k = astar.auto_instances(mid, env, 1000, _lib.HEUR_HASHU01)
+    assert 1 < k < 16 and BwasEngine.auto_max_nodes("cube3", 20000, k) >= (1 << 27) > BwasEngine.auto_max_nodes("cube3", 20000, k + 1)
+    hbm[0] = 36 << 30                # an eighth of the device (eight ranks sharing it): --max_nodes auto keeps pools >= 2^27 ids
+    auto = mk(batch_size=20000)
+    auto.max_nodes = "auto"
+    assert astar.auto_instances(auto, env, 1000, _lib.HEUR_HASHU01) == 1
 
 
 def test_graft_entry_build_passes_on_this_box():
@@ -475,6 +495,31 @@ def test_ranks_sharing_a_gpu_are_not_guessed_from_world_size(monkeypatch):
     assert sharding.ranks_on_my_device() == 8
     monkeypatch.setattr(sharding, "_sharers", 2)  # counted over the process group: (host, device) pairs equal to mine
     assert sharding.ranks_on_my_device() == 2
+
+
+def test_sharers_are_counted_by_physical_device_not_by_index(monkeypatch):
+    """under srun on AMD every task sees ITS GPU as device 0 (ROCR_VISIBLE_DEVICES binding, HIP_ / CUDA_VISIBLE_DEVICES
+    unset): an (index, masks) key made all ranks of a node compare equal.  The key is the device's UUID (or PCI address)."""
+    from types import SimpleNamespace as NS
+    import torch
+    from deepcubea_amd.search_methods import sharding
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda d: NS(uuid="GPU-aaaa", pci_bus_id=5))
+    a = sharding._device_identity()
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda d: NS(uuid="GPU-bbbb", pci_bus_id=6))
+    b = sharding._device_identity()
+    assert a != b and a[1] == "uuid"            # two tasks, both "device 0", two GPUs
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda d: NS(pci_domain_id=0, pci_bus_id=5, pci_device_id=0))
+    c = sharding._device_identity()
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda d: NS(pci_domain_id=0, pci_bus_id=6, pci_device_id=0))
+    assert c != sharding._device_identity() and c[1] == "pci"
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda d: NS())   # a runtime that reports neither
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "3")
+    d = sharding._device_identity()
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "4")
+    assert d != sharding._device_identity() and d[1] == "index"
 
 
 def test_bench_reads_the_committed_pmc_traffic_of_this_round():

@@ -7,16 +7,20 @@ the first N shipped `data/puzzle15/test` states with the network that came out, 
 report against (a) the optimal lengths shipped with the test set and (b) the published per-state results of the
 reference's fully trained network (results/puzzle15/output.txt, kept as a fixture).
 
-    python tools/avi_e2e.py [train_seconds] [n_states] [states_per_update] [save_dir]
-"""
+    python tools/avi_e2e.py [train_seconds] [n_states] [states_per_update] [save_dir] [epochs_per_update]
+
+Seeds are fixed (torch / numpy / random / the device state generator), so a rerun on the same build repeats the schedule up to
+the order of floating-point atomics."""
 import json
 import os
 import pickle
+import random
 import sys
 import tempfile
 import time
 
 import numpy as np
+import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -30,7 +34,11 @@ env = "puzzle15"
 train_s = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 spu = int(sys.argv[3]) if len(sys.argv) > 3 else 3_000_000
-save = sys.argv[4] if len(sys.argv) > 4 else tempfile.mkdtemp()
+save = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] != "-" else tempfile.mkdtemp()
+epochs = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+torch.manual_seed(0)
+np.random.seed(0)
+random.seed(0)
 B = 10000  # train.sh:18
 t0 = time.time()
 # the reference's own line (train.sh:18: 50 M states per update, 5000 steps of 10 000) scaled to the budget: `spu` states and
@@ -38,12 +46,13 @@ t0 = time.time()
 # updates is what the budget has to buy (the reference ran ~200)
 avi.main(["--env", env, "--states_per_update", str(spu), "--batch_size", str(B), "--nnet_name", env, "--max_itrs", "100000000",
           "--loss_thresh", "0.1", "--back_max", "500", "--num_test", "1000", "--save_dir", save, "--max_seconds", str(train_s),
-          "--update_nnet_batch_size", "100000", "--debug"])
+          "--update_nnet_batch_size", "100000", "--epochs_per_update", str(epochs), "--seed", "0", "--debug"])
 train_wall = time.time() - t0
 itr = pickle.load(open(os.path.join(save, env, "current", "train_itr.pkl"), "rb"))
 upd = pickle.load(open(os.path.join(save, env, "current", "update_num.pkl"), "rb"))
 print("\nTRAINED %s" % json.dumps({"seconds": round(train_wall, 1), "train_iterations": int(itr), "target_updates": int(upd),
-                                  "states_per_update": spu, "batch_size": B}))
+                                  "states_per_update": spu, "epochs_per_update": epochs,
+                                  "adam_steps_per_update": epochs * -(-spu // B), "batch_size": B}))
 
 g = np.load(os.path.join(ROOT, "tests", "golden", "golden.npz"))
 states = g[env + "_test_states"][:n]
