@@ -24,7 +24,8 @@ HEUR_MOD97, HEUR_KNUTH3, HEUR_HASHU01, HEUR_ZERO, HEUR_MANHATTAN = 0, 1, 2, 3, 4
 
 _TORCH_DT = {torch.float32: DT_F32, torch.float16: DT_F16, torch.bfloat16: DT_BF16}
 
-# every symbol include/dca.h declares (tests check the library exports all of them)
+# every symbol include/dca.h (the product ABI) and include/dca_debug.h (test / tuning / profiling hooks) declare
+# (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "dca_abi_version", "dca_last_error", "dca_cube3_perm_table", "dca_npuzzle_swap_table",
     "dca_cube3_next_state", "dca_cube3_prev_state", "dca_npuzzle_next_state", "dca_npuzzle_prev_state",

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/dca.h"
+#include "../../include/dca_debug.h"
 
 namespace dca {
 

@@ -253,35 +253,9 @@ int dca_engine_packed_state(dca_engine* e, int* instances_done, int* instances_f
  * iterations enqueued without any host sync (kernels no-op once the search is done).
  * use_graph != 0 replays one captured hipGraph per iteration instead of eager launches.           */
 int dca_engine_run_builtin(dca_engine* e, int heur_id, int iters, int use_graph, void* stream);
-/* Host-only (no device needed): the chunk dca_engine_run_builtin would replay as ONE hipGraph for a run of `remaining`
- * iterations starting at iteration `host_iter` of a search — its length n (<= 64: up to the next rebase-period boundary, then
- * whole periods) and which of its iterations are rebase iterations (bit i of rebase_mask).  For tests of the cutting rule. */
-int dca_engine_plan_chunk(int64_t host_iter, int remaining, int* n, uint64_t* rebase_mask);
-/* Device-side profile of `iters` iterations of run_builtin (use_graph as there): every workgroup stamps the device wall
- * clock at entry and exit, per launch the host takes max(end) - min(start) as the launch's busy span and the distance to
- * the previous launch's end as the gap in front of it — measured INSIDE the replayed hipGraph, which HIP events between
- * eager launches cannot do.  span_ms / gap_ms: host float[DCA_PROF_SLOTS], summed milliseconds over the iterations
- * (gap_ms may be NULL).  Slots: 0 refill_hist 1 refill_scan 2 refill_move 3 sel_hist (= the FRONT rebase pass; 0-3 only in
- * rebase iterations: every 8th, and the first twelve after a reset) 4 sel_scan 5 sel_collect 6 rank 7 expand 8 probe 9 decide
- * 10 pack (dedup-first stepping only) 11 commit; 12 / 13 = the two halves of the rank launch (small-bin pass, large-bin
- * workgroups), 14-17 = phases of the large-bin path (load + range, count + prefix, scatter, order) as envelopes over the
- * workgroups — for tuning.  Synchronises every iteration.                                                            */
-#define DCA_PROF_SLOTS 18
-int dca_engine_profile_builtin(dca_engine* e, int heur_id, int iters, int use_graph, float* span_ms /*host [DCA_PROF_SLOTS]*/,
-                               float* gap_ms /*host [DCA_PROF_SLOTS] or NULL*/, void* stream);
 /* synchronises the stream */
 int dca_engine_status(dca_engine* e, dca_status* out, void* stream);
 int dca_engine_status_instance(dca_engine* e, int inst, dca_status* out, void* stream);
-/* test / tuning hook: FRONT-tier hysteresis in entries (defaults 32*B / 96*B); results never depend on it */
-int dca_engine_set_tiers(dca_engine* e, int64_t front_keep, int64_t front_max);
-/* internals of the last iteration for diagnostics (host double[16]; layout in dca_engine.hip); synchronises */
-int dca_engine_debug(dca_engine* e, double* out /*host [16]*/, void* stream);
-/* diagnostics: flips a tuning knob of the engine kernels process-wide (0 = shipped behaviour); never needed in production.
- * knob 0: extra log2 of sub-bins per large bin in k_rank; 1: sub-bin size above which a sub-bin is refined on its own;
- * 2: BACK squeeze mark (1/1024ths of max_nodes); 3: threshold-bin size above which the grid refines the bin; 4: workgroups of
- * k_sel_collect, 5: grid-wide refinement off, 6: k_sel_scan in every iteration, 7: single-iteration graphs only (4-7 host side,
- * set before the engine is created / first stepped); 9: largest bin k_rank orders a thread per entry; 0-15 accepted.      */
-int dca_debug_tune(int knob, int value);
 /* ASTAR updates (updaters/updater.py:36-54 of the reference: one batch-1 search per training state, each with its own random
  * weight, stepped together; every popped node becomes a training target).
  *   set_weight_instance  weight of path cost of one instance (astar.py:196 `weights`), between iterations; set_weights: of the
@@ -386,11 +360,6 @@ int dca_f16x3_gemm(const void* a_h, const void* a_l, int64_t m, int k, int64_t l
                    int64_t ldw, const float* col_scale /*[n] or NULL*/, double alpha, const float* bias /*[n] or NULL*/,
                    const float* skip /*[m, ldo] fp32 or NULL*/, int relu, void* out_h, void* out_l, float* x_out, int64_t ldo,
                    int* overflow, void* stream);
-/* test hook: 3 (default) = 256 x 256 tiles filled by LDS-DMA on the ping-pong / half-tile schedule (two wave groups one barrier
- * apart, the DMA queue never drained); 2 = the same tile with two whole-K-step stages and one drain + barrier per K-step
- * (bit-identical to 3: same products in the same order — what the race screens in tests/ compare against).  ldo % 4 == 0,
- * out_h / out_l 8-byte and x_out / skip 16-byte aligned. */
-int dca_f16x3_gemm_variant(int variant);
 
 /* The same layer in the NON-parity 16-bit modes (`--nnet_dtype bf16 | fp16`; replaces the library GEMM + separate clamp pass of
  * utils/pytorch_models.py:57-86 as PyTorch runs it): out = relu?( a . w^T + bias (+ skip) ), operands and result in `dtype`
@@ -401,12 +370,6 @@ int dca_f16x3_gemm_variant(int variant);
 int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int n, int64_t ldw, int dtype,
                const float* bias /*[n] or NULL*/, const void* skip /*[m, ldo] or NULL*/, int relu, void* out, int64_t ldo,
                void* stream);
-/* test hook: 3 (default) = the 8-phase schedule (two wave groups one barrier apart, half-tile staging, the DMA queue never
- * drained) with the MFMA operand roles swapped and a lean tail compiled per layer form — relu(a . w^T + bias (+ skip)) on whole
- * 256 x 256 tiles with 16-byte aligned rows; other forms and the ragged strips of a layer run on 2 = the same schedule with the
- * general tail; 1 = two whole K-step stages with one drain + barrier per K-step (the plain reference of the race screens).
- * Bit-identical results (same products, same accumulation order). */
-int dca_gemm16_variant(int variant);
 
 /* The same layer in the NON-parity fp8 mode (`--nnet_dtype fp8`; csrc/dca_gemm8.hip): OCP e4m3 operands a [m, lda] / w [n, ldw]
  * (bytes; k % 128 == 0, lda / ldw % 16 == 0), fp32 accumulation on v_mfma_f32_32x32x64_f8f6f4, and the whole tail in the epilogue:

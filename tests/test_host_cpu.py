@@ -14,8 +14,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_loads_and_exports_every_declared_symbol():
     from deepcubea_amd import _lib
+    # the product ABI (include/dca.h) and the test / tuning / profiling hooks kept apart from it (include/dca_debug.h)
     hdr = open(os.path.join(ROOT, "include", "dca.h")).read()
-    declared = sorted(set(re.findall(r"\b(dca_[a-z0-9_]+)\s*\(", hdr)) - {"dca_engine"})
+    dbg = open(os.path.join(ROOT, "include", "dca_debug.h")).read()
+    product = set(re.findall(r"\b(dca_[a-z0-9_]+)\s*\(", hdr)) - {"dca_engine"}
+    hooks = set(re.findall(r"\b(dca_[a-z0-9_]+)\s*\(", dbg)) - {"dca_engine"}
+    assert not (product & hooks) and not any("debug" in n or "variant" in n or "profile" in n for n in product)
+    declared = sorted(product | hooks)
     assert sorted(_lib.ABI_SYMBOLS) == declared
     L = C.CDLL(_lib.LIB_PATH)
     for name in declared:
