@@ -8,11 +8,13 @@
                                      deterministic weights (same recipe as make_golden.py:det_weights /
                                      deepcubea_amd.utils.synthetic_weights), 64 random tile permutations -> fp32 outputs
   puzzle24_resnet_seed2027_{x,y}     same for NPuzzle(5)
-  cube3_big_seed2028_{x,y32,y64,out_scale,out_shift}
+  cube3_big_seed{2028,2029,2030}_{x,y32,y64,out_scale,out_shift}
                                      cube3 architecture whose fc_out is rescaled so that the outputs sit at trained-network
                                      magnitudes (|h| ~ 20-30, where fp32 has the least headroom for the 1e-5 tolerance):
                                      y32 = the reference's fp32 forward, y64 = the same module evaluated in float64
                                      (SURVEY §7.3's protocol: both implementations are judged against the fp64 evaluation).
+  puzzle48_big_seed2031_{...}        the puzzle48 network the same way at ITS trained magnitudes (|h| ~ 100-300: one fp32 ulp is
+                                     1.5e-5 .. 3e-5 there, so the tolerance is 1e-5 * max(1, |h|), not 1e-5 absolute).
 Only data is written (inputs + the reference's outputs); the weights are regenerated from the seed on both sides.
 """
 import os
@@ -96,27 +98,40 @@ def main():
         out["%s_resnet_seed%d_x" % (name, seed)] = x
         out["%s_resnet_seed%d_y" % (name, seed)] = y.astype(np.float32)
         print(name, "outputs", y[:4], "max|y|", np.abs(y).max())
-    # trained-network magnitudes: rescale fc_out (weights * s, bias + t) so the outputs land in ~[20, 30]
-    net = Cube3().get_nnet_model()
-    det_weights(net, 2028)
-    net.eval()
-    x = (synth_states(512, 54, 13) // 9).astype(np.uint8)
-    with torch.no_grad():
-        y0 = net(torch.tensor(x)).numpy()[:, 0]
-    s = np.float32(4.0 / max(float(np.abs(y0 - y0.mean()).max()), 1e-6))  # spread +-4 around ...
-    t = np.float32(25.0)                                                   # ... 25
-    with torch.no_grad():
-        net.fc_out.weight.mul_(float(s))
-        net.fc_out.bias.mul_(float(s)).add_(float(t) - float(s) * float(y0.mean()))
-        y32 = net(torch.tensor(x)).numpy()[:, 0]
-    y64 = forward_fp64({k: v.numpy() for k, v in net.state_dict().items()}, x, 6)
-    print("cube3_big: y32 range", y32.min(), y32.max(), " reference fp32 vs its own fp64 evaluation: max abs",
-          np.abs(y32.astype(np.float64) - y64).max())
-    out["cube3_big_seed2028_x"] = x
-    out["cube3_big_seed2028_y32"] = y32.astype(np.float32)
-    out["cube3_big_seed2028_y64"] = y64.astype(np.float64)
-    out["cube3_big_seed2028_out_scale"] = np.array(s, np.float32)
-    out["cube3_big_seed2028_out_shift"] = np.array(np.float32(float(t) - float(s) * float(y0.mean())), np.float32)
+    # trained-network magnitudes: rescale fc_out (weights * s, bias + t) so the outputs land around `centre` +- `spread`.
+    # cube3: |h| ~ 21-29 (the published cube3 cost-to-go tops out at 26), three weight seeds (one seed with
+    # 4.6 % headroom under 1e-5 is one data point).  puzzle48: its trained cost-to-go is O(100-300) — one fp32 ulp there is
+    # 1.5e-5..3e-5, so NO fp32 evaluation (the reference's own included) can be within 1e-5 ABSOLUTE of another one; the
+    # tolerance there is 1e-5 * max(1, |h|) and the fixture shows what the reference's fp32 forward itself does against float64.
+    for name, mk, depth, d, seed, xs, centre, spread in (
+            ("cube3_big", lambda: Cube3().get_nnet_model(), 6, 54, 2028, 13, 25.0, 4.0),
+            ("cube3_big", lambda: Cube3().get_nnet_model(), 6, 54, 2029, 14, 25.0, 4.0),
+            ("cube3_big", lambda: Cube3().get_nnet_model(), 6, 54, 2030, 15, 25.0, 4.0),
+            ("puzzle48_big", lambda: NPuzzle(7).get_nnet_model(), 49, 49, 2031, 16, 200.0, 100.0)):
+        net = mk()
+        det_weights(net, seed)
+        net.eval()
+        x = synth_states(512 if d == 54 else 256, d, xs)
+        if d == 54:
+            x = (x // 9).astype(np.uint8)
+        with torch.no_grad():
+            y0 = net(torch.tensor(x)).numpy()[:, 0]
+        s = np.float32(spread / max(float(np.abs(y0 - y0.mean()).max()), 1e-6))
+        t = np.float32(centre)
+        with torch.no_grad():
+            net.fc_out.weight.mul_(float(s))
+            net.fc_out.bias.mul_(float(s)).add_(float(t) - float(s) * float(y0.mean()))
+            y32 = net(torch.tensor(x)).numpy()[:, 0]
+        y64 = forward_fp64({k: v.numpy() for k, v in net.state_dict().items()}, x, depth)
+        print("%s seed %d: y32 range" % (name, seed), y32.min(), y32.max(),
+              " reference fp32 vs its own fp64 evaluation: max abs", np.abs(y32.astype(np.float64) - y64).max(),
+              " relative to |h|", (np.abs(y32.astype(np.float64) - y64) / np.abs(y64)).max())
+        key = "%s_seed%d" % (name, seed)
+        out[key + "_x"] = x
+        out[key + "_y32"] = y32.astype(np.float32)
+        out[key + "_y64"] = y64.astype(np.float64)
+        out[key + "_out_scale"] = np.array(s, np.float32)
+        out[key + "_out_shift"] = np.array(np.float32(float(t) - float(s) * float(y0.mean())), np.float32)
     np.savez_compressed(os.path.join(OUT, "nets.npz"), **out)
     print("wrote", os.path.join(OUT, "nets.npz"))
 

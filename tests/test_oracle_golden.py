@@ -341,13 +341,27 @@ def test_resnet_restatement_puzzle_nets_and_trained_magnitudes():
         w = no.resnet_det_weights(no.resnet_shapes(D, D, 5000, 1000, 4), seed)
         y = no.resnet_forward(w, nets["%s_resnet_seed%d_x" % (name, seed)], D, 4, np.float64)
         assert np.max(np.abs(y - nets["%s_resnet_seed%d_y" % (name, seed)])) < 1e-5
-    w = no.resnet_det_weights(no.resnet_shapes(54, 6, 5000, 1000, 4), 2028)
-    s, t = np.float64(nets["cube3_big_seed2028_out_scale"]), np.float64(nets["cube3_big_seed2028_out_shift"])
+    for seed in (2028, 2029, 2030):
+        key = "cube3_big_seed%d" % seed
+        w = no.resnet_det_weights(no.resnet_shapes(54, 6, 5000, 1000, 4), seed)
+        s, t = np.float64(nets[key + "_out_scale"]), np.float64(nets[key + "_out_shift"])
+        w["fc_out.weight"] = (w["fc_out.weight"] * np.float32(s)).astype(np.float32)
+        w["fc_out.bias"] = (w["fc_out.bias"] * np.float32(s) + np.float32(t)).astype(np.float32)
+        y64 = no.resnet_forward(w, nets[key + "_x"], 6, 4, np.float64)
+        assert 20.0 < y64.min() and y64.max() < 30.0
+        # the oracle's fp64 evaluation IS the fixture's fp64 yardstick (same weights, same arithmetic) ...
+        assert np.max(np.abs(y64 - nets[key + "_y64"])) < 1e-9
+        # ... and the reference's own fp32 forward sits within the north star's 1e-5 of it even at this magnitude
+        assert np.max(np.abs(nets[key + "_y32"] - y64)) < 1e-5
+    # puzzle48 at ITS trained magnitudes (|h| 100-280): the reference's fp32 forward is NOT within 1e-5 absolute of float64
+    # there (one fp32 ulp is 0.8e-5 .. 3e-5) — it is within 1e-5 * |h|, which is the tolerance the GPU test holds the product to
+    key = "puzzle48_big_seed2031"
+    w = no.resnet_det_weights(no.resnet_shapes(49, 49, 5000, 1000, 4), 2031)
+    s, t = np.float64(nets[key + "_out_scale"]), np.float64(nets[key + "_out_shift"])
     w["fc_out.weight"] = (w["fc_out.weight"] * np.float32(s)).astype(np.float32)
     w["fc_out.bias"] = (w["fc_out.bias"] * np.float32(s) + np.float32(t)).astype(np.float32)
-    y64 = no.resnet_forward(w, nets["cube3_big_seed2028_x"], 6, 4, np.float64)
-    assert 20.0 < y64.min() and y64.max() < 30.0
-    # the oracle's fp64 evaluation IS the fixture's fp64 yardstick (same weights, same arithmetic) ...
-    assert np.max(np.abs(y64 - nets["cube3_big_seed2028_y64"])) < 1e-9
-    # ... and the reference's own fp32 forward sits within the north star's 1e-5 of it even at this magnitude
-    assert np.max(np.abs(nets["cube3_big_seed2028_y32"] - y64)) < 1e-5
+    y64 = no.resnet_forward(w, nets[key + "_x"], 49, 4, np.float64)
+    assert 99.0 < y64.min() and y64.max() < 300.0
+    assert np.max(np.abs(y64 - nets[key + "_y64"]) / np.abs(y64)) < 1e-11
+    d = np.abs(nets[key + "_y32"] - y64)
+    assert d.max() > 1e-5 and (d / np.abs(y64)).max() < 1e-5

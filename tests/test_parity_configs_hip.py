@@ -189,23 +189,31 @@ def test_avi_update_one_million_puzzle48_states(L, co):
 
 
 # ------------------------------------------------------------------------------------------------ (d) trained magnitudes
-@torch.no_grad()
-def test_heuristic_tolerance_at_trained_network_magnitudes(L, nets):
-    """|h| = 21..29: one float32 ulp is 1.9e-6, the reference's own fp32 forward is 6.3e-6 away from the float64
-    evaluation of its weights.  Every device path must stay within the north star's 1e-5 of that float64 yardstick
-    (absolute); the CLI-default path is ALSO within 1e-5 absolute of the reference's fp32 values (the tolerance block below
-    states what each path is held to)."""
-    from deepcubea_amd.utils.pytorch_models import FastResnet, ResnetModel, fold_batchnorm
-    from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
-    net = ResnetModel(54, 6, 5000, 1000, 4, 1, True)
-    load_synthetic_weights(net, 2028)
+def _rescaled(net, nets, key):
+    """fc_out rescaled exactly as make_golden_nets.py did for the reference's module (float32 arithmetic on both sides)."""
     with torch.no_grad():
-        s, t = float(nets["cube3_big_seed2028_out_scale"]), float(nets["cube3_big_seed2028_out_shift"])
+        s, t = float(nets[key + "_out_scale"]), float(nets[key + "_out_shift"])
         net.fc_out.weight.copy_((net.fc_out.weight * np.float32(s)).float())
         net.fc_out.bias.copy_((net.fc_out.bias * np.float32(s) + np.float32(t)).float())
-    net.eval()
-    x = torch.tensor(nets["cube3_big_seed2028_x"]).cuda()
-    y32, y64 = nets["cube3_big_seed2028_y32"].astype(np.float64), nets["cube3_big_seed2028_y64"]
+    return net.eval()
+
+
+@pytest.mark.parametrize("seed", [2028, 2029, 2030])
+@torch.no_grad()
+def test_heuristic_tolerance_at_trained_network_magnitudes(L, nets, seed):
+    """|h| = 21..29, THREE weight seeds (one seed at 9.54e-6 under a 1e-5 assert is one data point): one
+    float32 ulp is 1.9e-6, the reference's own fp32 forward is 6.0e-6 .. 7.2e-6 away from the float64 evaluation of its
+    weights (printed by make_golden_nets.py).  Every device path must stay within the north star's 1e-5 of that float64
+    yardstick (absolute); the CLI-default path is ALSO within 1e-5 absolute of the reference's fp32 values (the tolerance block
+    below states what each path is held to).  Each seed's measured errors are printed."""
+    from deepcubea_amd.utils.pytorch_models import FastResnet, ResnetModel, fold_batchnorm
+    from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
+    key = "cube3_big_seed%d" % seed
+    net = ResnetModel(54, 6, 5000, 1000, 4, 1, True)
+    load_synthetic_weights(net, seed)
+    net = _rescaled(net, nets, key)
+    x = torch.tensor(nets[key + "_x"]).cuda()
+    y32, y64 = nets[key + "_y32"].astype(np.float64), nets[key + "_y64"]
     assert 20.0 < y64.min() and y64.max() < 30.0
     ref_err = float(np.max(np.abs(y32 - y64)))
     assert ref_err < 1e-5
@@ -219,18 +227,19 @@ def test_heuristic_tolerance_at_trained_network_magnitudes(L, nets):
     for name, m in paths.items():
         y = m(x)[:, 0].double().cpu().numpy()
         errs[name] = (float(np.max(np.abs(y - y64))), float(np.max(np.abs(y - y32))))
-    print("max abs error vs float64 / vs reference fp32 (reference fp32 vs float64: %.2e):" % ref_err, errs)
+    print("seed %d: max abs error vs float64 / vs reference fp32 (reference fp32 vs float64: %.2e):" % (seed, ref_err), errs)
     # measured on the MI355X (r02): module 1.02e-5, folded 1.15e-5, FastResnet native fp32 1.37e-5 — the library's fp32 GEMMs
     # themselves sit AT the 1e-5 line at this magnitude — and the f16x3 parity mode 8.3e-6: the CLI default is the path
     # held to the north star's 1e-5 here; the plain fp32 paths get the fp32 noise floor of |h| = 29 (2e-5)
     # THE TOLERANCE, stated once (also in DESIGN §2 and in `--nnet_dtype`'s help):
     #   * the CLI-default path (f16x3 parity mode) is within the north star's 1e-5 ABSOLUTE of the REFERENCE's fp32 values
-    #     even at trained magnitudes |h| = 21..29 (measured on the MI355X, r05: 9.54e-6; one fp32 ulp of 25 is 1.9e-6), and
-    #     within 1e-5 absolute of the float64 yardstick (8.92e-6);
+    #     even at trained cube3 magnitudes |h| = 21..29 (one fp32 ulp of 25 is 1.9e-6) and within 1e-5 absolute of the
+    #     float64 yardstick — for each of the three seeds (the measured values are in DESIGN §2);
     #   * the plain fp32-GEMM paths (the reference's own module on the device, BN-folded, FastResnet split=False — none of
     #     them the default) are held to 1e-5 * max(1, |h|) relative-to-magnitude, with a 2e-5 absolute regression guard:
     #     the library's fp32 GEMMs sit AT the 1e-5 line here (1.14e-5 .. 1.34e-5 vs the reference's fp32 values; the
-    #     reference's own fp32 forward is 6.3e-6 from float64, so two correct fp32 evaluations can be 1.3e-5 apart).
+    #     reference's own fp32 forward is 6-7e-6 from float64, so two correct fp32 evaluations can be 1.3e-5 apart);
+    #   * beyond |h| ~ 40 an absolute 1e-5 is below fp32's own resolution: see the puzzle48 test below.
     hmax = float(np.max(np.abs(y32)))
     tol_ref = 1e-5 * max(1.0, hmax)
     for name, (e64, e32) in errs.items():
@@ -252,6 +261,48 @@ def test_heuristic_tolerance_at_trained_network_magnitudes(L, nets):
     xp[:rows] = x
     hp = hfn(xp)[:rows].double().cpu().numpy().reshape(-1)
     e64p, e32p = float(np.max(np.abs(hp - y64))), float(np.max(np.abs(hp - y32)))
-    print("engine packed path (rows padded to %d): vs float64 %.3e, vs reference fp32 %.3e (tolerance 1e-5 absolute)" % (pad, e64p, e32p))
+    print("seed %d: engine packed path (rows padded to %d): vs float64 %.3e, vs reference fp32 %.3e (tolerance 1e-5 absolute)"
+          % (seed, pad, e64p, e32p))
     assert e64p <= 1e-5 and e32p <= 1e-5
     assert np.array_equal(hp, f(x)[:, 0].double().cpu().numpy())  # bit-identical to the unpadded evaluation
+
+
+@torch.no_grad()
+def test_heuristic_tolerance_at_puzzle48_magnitudes(L, nets):
+    """configs[4] is puzzle48, whose trained cost-to-go is O(100-300).  One float32 ulp is 7.6e-6 at 100 and 3.1e-5 at 280:
+    the reference's own fp32 forward is 2.5e-4 away from the float64 evaluation of its weights there (1.6e-6 * |h|, recorded by
+    make_golden_nets.py), so NO fp32 result can be within 1e-5 ABSOLUTE of another.  The tolerance of the parity mode at
+    these magnitudes is therefore 1e-5 * max(1, |h|) per state — against the reference's fp32 values and against float64 —
+    which is what this test asserts (and what DESIGN §2 and `--nnet_dtype`'s help say); the f16x3 path is also required to be
+    no further from float64 than 2x the reference's own fp32 forward is."""
+    from deepcubea_amd.utils import nnet_utils
+    from deepcubea_amd.utils.pytorch_models import FastResnet
+    key = "puzzle48_big_seed2031"
+    net = _rescaled(_puzzle_net(7, 2031), nets, key)
+    x = torch.tensor(nets[key + "_x"]).cuda()
+    y32, y64 = nets[key + "_y32"].astype(np.float64), nets[key + "_y64"]
+    assert 99.0 < y64.min() and y64.max() < 300.0
+    ref_rel = float(np.max(np.abs(y32 - y64) / np.abs(y64)))
+    ref_abs = float(np.max(np.abs(y32 - y64)))
+    assert ref_abs > 1e-5 and ref_rel < 1e-5   # the reference itself: outside 1e-5 absolute, inside 1e-5 * |h|
+    fast = FastResnet(net).cuda()
+    assert fast.split
+    paths = {"module_fp32": net.cuda(), "fast_native_fp32": FastResnet(net, split=False).cuda(), "fast_f16x3 (CLI default)": fast}
+    for name, m in paths.items():
+        y = m(x)[:, 0].double().cpu().numpy()
+        r64 = float(np.max(np.abs(y - y64) / np.maximum(1.0, np.abs(y64))))
+        r32 = float(np.max(np.abs(y - y32) / np.maximum(1.0, np.abs(y32))))
+        a64 = float(np.max(np.abs(y - y64)))
+        print("puzzle48 |h| 100-280, %s: vs float64 %.3e abs = %.3e * |h|; vs reference fp32 %.3e * |h| "
+              "(reference fp32 vs float64: %.3e abs = %.3e * |h|)" % (name, a64, r64, r32, ref_abs, ref_rel))
+        assert r64 <= 1e-5 and r32 <= 1e-5, (name, r64, r32)
+        if "f16x3" in name:
+            assert a64 <= 2.0 * ref_abs, (a64, ref_abs)
+    assert fast.split_fallbacks == 0
+    # through the heuristic closure on padded uint8 rows, as the engine calls it: same bits
+    hfn = nnet_utils.get_heuristic_fn_dev(fast, clip_zero=False, batch_size=1 << 17)
+    xp = torch.zeros((2048, 49), dtype=torch.uint8, device="cuda")
+    xp[:] = torch.arange(49, dtype=torch.uint8, device="cuda")
+    xp[:x.shape[0]] = x
+    hp = hfn(xp)[:x.shape[0]].double().cpu().numpy().reshape(-1)
+    assert np.array_equal(hp, fast(x)[:, 0].double().cpu().numpy())
