@@ -95,12 +95,14 @@ def dist_setup(backend: str = "nccl"):
             if ndev:
                 torch.cuda.set_device(local % ndev)
             dist.init_process_group("gloo", rank=rank, world_size=world)
-            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-            if ndev and local_world > ndev:
-                # ranks share a GPU (a test box): the grid-wide refinement of giant tie bins needs every workgroup of a
-                # launch resident, which two processes on one device cannot promise each other
+            if ndev:
+                # ranks sharing a GPU (a test box) are COUNTED over the process group by physical device identity, like the
+                # CLI does: the grid-wide refinement of giant tie bins needs every workgroup of a launch resident, which two
+                # processes on one device cannot promise each other, and node pools take 1/sharers of the HBM
                 from deepcubea_amd import _lib
-                _lib.check(_lib.lib().dca_debug_tune(5, 1), "dca_debug_tune")
+                from deepcubea_amd.search_methods import sharding
+                if sharding.count_sharers(world) > 1:
+                    _lib.check(_lib.lib().dca_debug_tune(5, 1), "dca_debug_tune")
     elif ndev:
         torch.cuda.set_device(0)
     return world, rank, local
@@ -399,7 +401,8 @@ def run_sharded_queue(args, world, rank):
     from deepcubea_amd.search_methods.engine import BwasEngine
     env, B, w, hid = "puzzle15", 10000, 0.8, _lib.HEUR_MANHATTAN
     n_states = args.queue_states * world
-    eng = BwasEngine(env, w, B, max_nodes=1 << 27)
+    # (a pool of 2^27 ids — or this rank's share of the device when ranks share a GPU)
+    eng = BwasEngine(env, w, B, max_nodes=min(1 << 27, BwasEngine.auto_max_nodes(env, B, 1, sharers=sharding.ranks_on_my_device())))
     queue = sharding.WorkQueue(n_states, world, rank, key="dca_bench_queue")
     barrier(world)
     t0 = time.perf_counter()
@@ -863,6 +866,9 @@ def main():
         "data": "synthetic",
         "config": res["config"],
     }
+    if world > 1 and torch.cuda.is_available():
+        from deepcubea_amd.search_methods import sharding
+        line["ranks_sharing_gpu"] = [int(v) for v in gather_ranks(float(sharding.ranks_on_my_device()), world)]
     for k in ("roofline", "roofline_iteration", "per_rank_value", "engine_onehot_f32", "concurrent_instances", "sharded_queue",
               "expand_1M"):
         if k in res:

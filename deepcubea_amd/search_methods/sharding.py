@@ -81,6 +81,12 @@ def _device_identity() -> tuple:
             os.environ.get("HIP_VISIBLE_DEVICES", ""), os.environ.get("CUDA_VISIBLE_DEVICES", ""))
 
 
+def count_sharers(world: int) -> int:
+    """Public form of the count for drivers that set up their own process group (bench.py)."""
+    _count_sharers(world)
+    return ranks_on_my_device()
+
+
 def _count_sharers(world: int) -> None:
     """After the rendezvous: every rank says which device of which host it uses; the ranks whose answer equals mine share
     my GPU.  Independent of the launcher's environment variables (torch.distributed.run, srun, mpirun)."""
