@@ -34,6 +34,7 @@ scrambles, no collective on the data path; only the timing barrier / reductions 
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -731,6 +732,21 @@ def run_expand(args, world, rank, onehot=None, steps=None, warmup=None):
     total_exp = reduce_ranks(float(n * steps), world, "sum")
     alg = 54 + 12 * 54 + 12 * 324 * esz  # 16 254 B (f32 one-hot) / 8 478 B (16-bit)
     achieved = alg * n / (kern_ms * 1e-3) / 1e9
+    # the store-only yardstick in the SAME process, on the same buffer, right after the kernel (the "96 % of
+    # the achievable write bandwidth" of round 1 compared numbers from two boxes): the kernel's output bytes written by
+    # k_write_ceiling — plain 16-byte stores, one contiguous MiB per workgroup, nothing gathered
+    ceil_bytes = out["onehot"].numel() * esz // 16 * 16
+    cev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(5, steps // 2))]
+    for i in range(2 + len(cev)):
+        if i >= 2:
+            cev[i - 2][0].record()
+        _lib.check(_lib.lib().dca_debug_write_ceiling(C.c_void_p(out["onehot"].data_ptr()), C.c_int64(ceil_bytes),
+                                                      C.c_int64(1 << 20), _lib.stream_ptr()), "dca_debug_write_ceiling")
+        if i >= 2:
+            cev[i - 2][1].record()
+    torch.cuda.synchronize()
+    ceil_ms = float(np.mean([a.elapsed_time(b) for a, b in cev]))
+    write_ceiling = ceil_bytes / (ceil_ms * 1e-3) / 1e9
     del out, S
     torch.cuda.empty_cache()
     return {
@@ -744,7 +760,11 @@ def run_expand(args, world, rank, onehot=None, steps=None, warmup=None):
                      "traffic": expand_pmc_traffic(onehot, n),
                      "traffic_source": PMC_SOURCE.get("expand_fused_kernel<cube3,%s>" % onehot),
                      "bytes_per_launch": alg * n, "kernel_ms": kern_ms,
-                     "timing": "HIP events around each of the %d launches on the launch stream" % steps},
+                     "timing": "HIP events around each of the %d launches on the launch stream" % steps,
+                     "write_ceiling_GBs": write_ceiling, "frac_of_write_ceiling": achieved / write_ceiling,
+                     "write_ceiling_how": "same process, same buffer, right after the timed launches: %d bytes (the kernel's "
+                                          "one-hot output) by plain 16-byte stores, one contiguous MiB per workgroup "
+                                          "(dca_debug_write_ceiling), %.3f ms per launch" % (ceil_bytes, ceil_ms)},
     }
 
 

@@ -44,7 +44,7 @@ ABI_SYMBOLS = [
     "dca_head_gemv", "dca_engine_packed_state", "dca_engine_info", "dca_gemm8_mx", "dca_l1_onehot_gemm_mx",
     "dca_cube4_perm_table", "dca_cube4_next_state", "dca_cube4_prev_state", "dca_cube4_expand_fused",
     "dca_engine_set_weight_instance", "dca_engine_set_weights", "dca_engine_park_instance", "dca_engine_last_popped",
-    "dca_engine_reset_many", "dca_engine_root_commit_many", "dca_engine_set_weights_dev",
+    "dca_engine_reset_many", "dca_engine_root_commit_many", "dca_engine_set_weights_dev", "dca_debug_write_ceiling",
 ]
 
 

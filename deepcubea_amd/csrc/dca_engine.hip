@@ -2513,6 +2513,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
     uint8_t* lst = smem + TL::LDS_BYTES;  // child rows of the tile, laid out exactly like their HBM destination
     __shared__ uint32_t l_pid[kEngTile], l_g[kEngTile];
     __shared__ uint32_t l_qn, l_qcc[PROBE ? kThreads : 1], l_qrep[PROBE ? kThreads : 1], l_qres[PROBE ? kThreads : 1];
+    __shared__ uint32_t l_ohq;  // one-hot rows: next 1 KiB piece (one wave-wide 16-byte store) nobody has claimed yet
     static_assert((EV::D + 3) / 4 < 16, "no spare lane per row for the parent's path cost");
     // batch geometry: every workgroup derives it from the state the previous iteration left (S[iters & 1]) and the
     // pop that k_rank just finished; workgroup 0 also records it for the rest of the iteration (close_pop)
@@ -2539,6 +2540,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
     }
     if (r0 >= npop) return;
     const uint32_t np = min((uint32_t)kTileParents, npop - r0);
+    if (OH != 0 && threadIdx.x == 0) l_ohq = 0;
     {
         // gather the popped rows by node id.  One lane per (parent, 4-byte word): 16 lanes cover a row, so
         // a 256-thread block fetches 16 rows per round and the 4 rounds are issued back to back.
@@ -2575,6 +2577,84 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
     TL t{lpar, ltab};
     const uint32_t nchild = np * EV::A;
     const uint32_t j0 = r0 * EV::A;  // first child index of the tile within the batch
+
+    // One-hot rows of the tile's children (pytorch_models.py:49-52), from the child rows staged in `lst`.  The rows of a tile are
+    // one contiguous run of the batch's one-hot buffer; it is cut into 1 KiB pieces — one wave-wide 16-byte store each — which
+    // the waves CLAIM from an LDS counter, so that whichever wave has nothing else to do stores: the wave(s) of the per-child
+    // round that hold no child (192 children on 256 lanes for cube3: wave 3) start as soon as the rows are staged and their
+    // stores drain under the CLOSED probe's load -> compare-and-swap -> row-compare chains of the other waves; everybody joins
+    // at the end.  (Until round 6 all one-hot stores came after the probe: every workgroup of the launch probed at the same time,
+    // then every workgroup stored — 102 us for a launch whose stores alone take 63 and whose probe alone takes 28.)
+    auto oh_emit = [&](uint32_t max_pieces) {
+        if constexpr (OH != 0) {
+            constexpr uint32_t ROW = EV::D * EV::DEPTH;
+            constexpr uint32_t EPC = 16 / OH;
+            const uint32_t te = nchild * ROW;
+            const uint32_t one16 = E.oh_dtype == DCA_DT_F16 ? 0x3C00u : 0x3F80u;
+            uint8_t* goh = E.onehot + (size_t)j0 * ROW * OH;
+            const uint32_t nch = (te + EPC - 1) / EPC;
+            // (one read of the staged row per position; a lane that runs one row past the tile reads the slack behind it — its
+            // chunk is never stored)
+            auto staged_nnet = [&](uint32_t i) -> uint32_t {
+                const uint32_t b = lst[i];
+                return ENV == DCA_ENV_CUBE3 ? (b * 57u) >> 9 : b;
+            };
+            for (uint32_t n = 0; n < max_pieces; n++) {
+                uint32_t piece = 0;
+                if ((threadIdx.x & 63u) == 0) piece = atomicAdd(&l_ohq, 1u);
+                piece = (uint32_t)__builtin_amdgcn_readfirstlane((int)piece);
+                if (piece * 64u >= nch) break;
+                const uint32_t q = piece * 64u + (threadIdx.x & 63u);
+                if (q >= nch) continue;
+                uint32_t e0 = q * EPC;
+                if constexpr (ENV == DCA_ENV_CUBE3 && OH == 2) {
+                    if (e0 + EPC <= te) {  // two stickers and a lookup per chunk (dca_tile.h: cube3_onehot16_chunk)
+                        const uint32_t P0 = (q << 2) / 3u, phase = (q << 2) - 3u * P0;
+                        uint32_t w[4];
+                        cube3_onehot16_chunk(phase, staged_nnet(P0), staged_nnet(P0 + 1u), one16, w);
+                        store16(goh + (size_t)e0 * OH, w, true);
+                        continue;
+                    }
+                }
+                uint32_t cch = e0 / ROW, e = e0 - cch * ROW;
+                uint32_t pos = e / EV::DEPTH, col = e - pos * EV::DEPTH;
+                uint32_t r = cch / EV::A, a = cch - r * EV::A;
+                uint32_t nb = staged_nnet(cch * EV::D + pos);
+                uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (uint32_t k = 0; k < EPC; k++) {
+                    bool hot = (nb == col) && (e0 + k < te);
+                    if constexpr (OH == 4)
+                        w[k] = hot ? 0x3F800000u : 0u;
+                    else
+                        w[k >> 1] |= (hot ? one16 : 0u) << (16 * (k & 1));
+                    if (++col == EV::DEPTH) {
+                        col = 0;
+                        if (++pos == EV::D) {
+                            pos = 0;
+                            if (++a == EV::A) {
+                                a = 0;
+                                ++r;
+                            }
+                        }
+                        nb = staged_nnet((r * EV::A + a) * EV::D + pos);
+                    }
+                }
+                uint8_t* dst = goh + (size_t)e0 * OH;
+                if (e0 + EPC <= te) {
+                    store16(dst, w, true);
+                } else {
+                    for (uint32_t k = 0; e0 + k < te; k++) {
+                        if constexpr (OH == 4)
+                            reinterpret_cast<uint32_t*>(dst)[k] = w[k];
+                        else
+                            reinterpret_cast<uint16_t*>(dst)[k] = (uint16_t)(w[k >> 1] >> (16 * (k & 1)));
+                    }
+                }
+            }
+        }
+    };
+    const int oh_mode = OH != 0 ? g_tune[14] : 1;  // (knob 14, A/B: 0 = overlapped — shipped —, 1 = every store after the probe, 2 = no piece limit under the probe)
 
     // per child: hash, is_solved, node fields, built-in heuristic (rounds of 256 children; uniform: the probe below
     // synchronises the workgroup inside a round)
@@ -2641,6 +2721,16 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
             bool active = cvalid, inserted = false, paused = false;
             uint32_t slot = (uint32_t)h & E.tab_mask, v0 = GINF, rep_id = 0, probes = 0, qi = 0;
             __syncthreads();  // the round's rows are staged (lst) — and l_qn is zero
+            if constexpr (OH != 0) {
+                // a wave without a child in this round (it can only be the LAST round: every row of the tile is staged): its
+                // one-hot stores drain under the other waves' probe.  Half of the tile's pieces at most before it joins the
+                // barrier below — the others wait for it there with their chain hooks still to do.
+                if (oh_mode != 1 && cc0 + (threadIdx.x & ~63u) >= nchild) {
+                    constexpr uint32_t ROWB = EV::D * EV::DEPTH * OH;
+                    const uint32_t pieces = (nchild * ROWB + 1023u) >> 10;
+                    oh_emit(oh_mode == 2 ? pieces : (pieces + 1u) / 2u);
+                }
+            }
             for (;;) {
                 if (active && !paused) {
                     for (;;) {
@@ -2800,59 +2890,8 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
         }
     }
 
-    // optional one-hot rows of the batch (pytorch_models.py:49-52) for the heuristic network
-    if constexpr (OH != 0) {
-        constexpr uint32_t ROW = EV::D * EV::DEPTH;
-        constexpr uint32_t EPC = 16 / OH;
-        const uint32_t te = nchild * ROW;
-        const uint32_t one16 = E.oh_dtype == DCA_DT_F16 ? 0x3C00u : 0x3F80u;
-        uint8_t* goh = E.onehot + (size_t)j0 * ROW * OH;
-        const uint32_t nch = (te + EPC - 1) / EPC;
-        // (the child rows are already staged in LDS: one read per position instead of the two-step gather through the move
-        // table; a lane that runs one row past the tile reads the slack behind it — its chunk is never stored)
-        auto staged_nnet = [&](uint32_t i) -> uint32_t {
-            const uint32_t b = lst[i];
-            return ENV == DCA_ENV_CUBE3 ? (b * 57u) >> 9 : b;
-        };
-        for (uint32_t q = threadIdx.x; q < nch; q += kThreads) {
-            uint32_t e0 = q * EPC;
-            uint32_t cch = e0 / ROW, e = e0 - cch * ROW;
-            uint32_t pos = e / EV::DEPTH, col = e - pos * EV::DEPTH;
-            uint32_t r = cch / EV::A, a = cch - r * EV::A;
-            uint32_t nb = staged_nnet(cch * EV::D + pos);
-            uint32_t w[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (uint32_t k = 0; k < EPC; k++) {
-                bool hot = (nb == col) && (e0 + k < te);
-                if constexpr (OH == 4)
-                    w[k] = hot ? 0x3F800000u : 0u;
-                else
-                    w[k >> 1] |= (hot ? one16 : 0u) << (16 * (k & 1));
-                if (++col == EV::DEPTH) {
-                    col = 0;
-                    if (++pos == EV::D) {
-                        pos = 0;
-                        if (++a == EV::A) {
-                            a = 0;
-                            ++r;
-                        }
-                    }
-                    nb = staged_nnet((r * EV::A + a) * EV::D + pos);
-                }
-            }
-            uint8_t* dst = goh + (size_t)e0 * OH;
-            if (e0 + EPC <= te) {
-                store16(dst, w, true);
-            } else {
-                for (uint32_t k = 0; e0 + k < te; k++) {
-                    if constexpr (OH == 4)
-                        reinterpret_cast<uint32_t*>(dst)[k] = w[k];
-                    else
-                        reinterpret_cast<uint16_t*>(dst)[k] = (uint16_t)(w[k >> 1] >> (16 * (k & 1)));
-                }
-            }
-        }
-    }
+    // the one-hot pieces nobody has claimed yet (all of them when no wave was idle under the probe)
+    oh_emit(~0u);
 }
 
 // ---------------------------------------------------------------------------------------------

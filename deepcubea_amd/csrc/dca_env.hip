@@ -139,6 +139,28 @@ __global__ __launch_bounds__(kThreads) void expand_fused_kernel(
         const bool al = (align_mask & 8) != 0;
         for (uint32_t q = threadIdx.x; q < nch; q += kThreads) {
             uint32_t e0 = q * EPC;
+            if constexpr (ENV == DCA_ENV_CUBE3 && OH == 2) {
+                // 16-bit elements: half the bytes per gathered sticker of the f32 rows, so the generic element loop below (a
+                // compare / select / shift / or chain per element) made this variant instruction-bound (0.51 of the HBM peak
+                // against 0.66 for f32, round 5).  Two stickers and a lookup per chunk instead (cube3_onehot16_chunk).
+                if (e0 + EPC <= te) {
+                    const uint32_t P0 = (q << 2) / 3u, phase = (q << 2) - 3u * P0;  // 8 q = 6 P0 + 2 phase
+                    const uint32_t c0p = P0 / (uint32_t)E::D, p0 = P0 - c0p * (uint32_t)E::D;
+                    const uint32_t r0p = c0p / (uint32_t)E::A, a0p = c0p - r0p * (uint32_t)E::A;
+                    uint32_t p1 = p0 + 1u, a1p = a0p, r1p = r0p;  // (one position past the tile on its very last chunk: inside the
+                    if (p1 == (uint32_t)E::D) {                    //  LDS allocation, and that chunk only uses W(v1, .) where valid)
+                        p1 = 0;
+                        if (++a1p == (uint32_t)E::A) {
+                            a1p = 0;
+                            ++r1p;
+                        }
+                    }
+                    uint32_t w[4];
+                    cube3_onehot16_chunk(phase, t.nnet_byte(r0p, a0p, p0), t.nnet_byte(r1p, a1p, p1), one16, w);
+                    store16(onehot + (ge + e0) * OH, w, al);
+                    continue;
+                }
+            }
             uint32_t c = e0 / ROW, e = e0 - c * ROW;
             uint32_t pos = e / E::DEPTH, col = e - pos * E::DEPTH;
             uint32_t r = c / E::A, a = c - r * E::A;
@@ -323,6 +345,16 @@ static int launch_next(const uint8_t* in, int64_t n, int action, uint8_t* out, h
     return launch_check("next_state_kernel");
 }
 
+// Store-only yardstick for the gather kernel (dca_debug_write_ceiling; the stand-alone tools/hbm_write_ceiling.hip found this
+// pattern the best on the chip): every workgroup fills its own contiguous region with plain 16-byte stores, 1 KiB per wave
+// instruction — what expand_fused_kernel's output phase does, minus everything that produces the bytes.
+__global__ __launch_bounds__(kThreads) void k_write_ceiling(uint4* __restrict__ p, uint64_t chunks_per_block, uint64_t chunks) {
+    const uint64_t c0 = (uint64_t)blockIdx.x * chunks_per_block;
+    const uint64_t c1 = c0 + chunks_per_block < chunks ? c0 + chunks_per_block : chunks;
+    const uint4 v = make_uint4(blockIdx.x, 1u, 2u, 3u);
+    for (uint64_t i = c0 + threadIdx.x; i < c1; i += kThreads) p[i] = v;
+}
+
 // internal entry points used by the engine (dca_engine.hip)
 int expand_dispatch(int env, int dim, const uint8_t* parents, int64_t n, uint8_t* children, uint8_t* nnet_in,
                     void* onehot, int onehot_dtype, uint8_t* solved, uint64_t* hash, hipStream_t s) {
@@ -386,6 +418,15 @@ int dca_npuzzle_next_state(const uint8_t* in, int64_t n, int dim, int action, ui
 int dca_npuzzle_prev_state(const uint8_t* in, int64_t n, int dim, int action, uint8_t* out, void* stream) {
     DCA_ARG(action >= 0 && action < 4);  // moves_rev = D,U,R,L (n_puzzle.py:29)
     return dca_npuzzle_next_state(in, n, dim, action ^ 1, out, stream);
+}
+
+int dca_debug_write_ceiling(void* buf, int64_t bytes, int64_t bytes_per_block, void* stream) {
+    DCA_ARG(buf != nullptr && bytes >= 16 && bytes_per_block >= 16 && (reinterpret_cast<uintptr_t>(buf) & 15) == 0);
+    const uint64_t chunks = (uint64_t)bytes / 16, cpb = (uint64_t)bytes_per_block / 16;
+    const uint64_t blocks = (chunks + cpb - 1) / cpb;
+    DCA_ARG(blocks < (1ull << 31));
+    hipLaunchKernelGGL(k_write_ceiling, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, (uint4*)buf, cpb, chunks);
+    return launch_check("k_write_ceiling");
 }
 
 const uint8_t* dca_cube4_perm_table(void) { return &kCube4Perm.p[0][0]; }

@@ -102,6 +102,22 @@ __device__ __forceinline__ void stage_tables(uint8_t* tab, const uint8_t* par, u
     }
 }
 
+// cube3 one-hot rows with 16-bit elements (pytorch_models.py:49-52: index = position * 6 + colour), one 16-byte chunk = 8
+// elements.  8 q mod 6 only takes the values 0 / 2 / 4 (q mod 3 = 0 / 1 / 2), so chunk q always starts at column 0, 2 or 4 of
+// position P0 = 4 q / 3 and ends inside position P0 + 1: its four words are a window of the SIX words {W(v0,0..2), W(v1,0..2)},
+// W(v, k) = the pair of columns 2k, 2k+1 of a position whose colour is v = `one` in the half that is hot, else 0 — a lookup on
+// (v >> 1, v & 1) instead of eight compare / select / shift / or chains with a running (column, position, move, parent) counter.
+__device__ __forceinline__ void cube3_onehot16_chunk(uint32_t phase, uint32_t v0, uint32_t v1, uint32_t one16, uint32_t (&w)[4]) {
+    const uint32_t s0 = (v0 & 1u) ? (one16 << 16) : one16, k0 = v0 >> 1;
+    const uint32_t s1 = (v1 & 1u) ? (one16 << 16) : one16, k1 = v1 >> 1;
+    const uint32_t a0 = k0 == 0u ? s0 : 0u, a1 = k0 == 1u ? s0 : 0u, a2 = k0 == 2u ? s0 : 0u;
+    const uint32_t b0 = k1 == 0u ? s1 : 0u, b1 = k1 == 1u ? s1 : 0u, b2 = k1 == 2u ? s1 : 0u;
+    w[0] = phase == 0u ? a0 : phase == 1u ? a1 : a2;
+    w[1] = phase == 0u ? a1 : phase == 1u ? a2 : b0;
+    w[2] = phase == 0u ? a2 : phase == 1u ? b0 : b1;
+    w[3] = phase == 0u ? b0 : phase == 1u ? b1 : b2;
+}
+
 // store 16 assembled bytes
 __device__ __forceinline__ void store16(uint8_t* dst, const uint32_t (&w)[4], bool aligned) {
     if (aligned) {

@@ -43,6 +43,12 @@ int dca_engine_debug(dca_engine* e, double* out /*host [16]*/, void* stream);
  * set before the engine is created / first stepped); 9: largest bin k_rank orders a thread per entry; 0-15 accepted.      */
 int dca_debug_tune(int knob, int value);
 
+/* ---- environment kernels ------------------------------------------------------------------------------------------- */
+/* Store-only yardstick of the gather kernel's roofline (bench.py times it in the same process, right after the kernel itself):
+ * fills buf[0, bytes) with plain 16-byte stores, one contiguous region of bytes_per_block per workgroup (1 MiB: the pattern
+ * tools/hbm_write_ceiling.hip found best on an MI355X).  buf 16-byte aligned; bytes and bytes_per_block multiples of 16. */
+int dca_debug_write_ceiling(void* buf, int64_t bytes, int64_t bytes_per_block, void* stream);
+
 /* ---- dense-layer kernels: schedule selectors (the race screens compare the default schedule with a plain one) --------- */
 /* dca_f16x3_gemm */
 /* test hook: 3 (default) = 256 x 256 tiles filled by LDS-DMA on the ping-pong / half-tile schedule (two wave groups one barrier
