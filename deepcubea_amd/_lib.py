@@ -45,6 +45,7 @@ ABI_SYMBOLS = [
     "dca_cube4_perm_table", "dca_cube4_next_state", "dca_cube4_prev_state", "dca_cube4_expand_fused",
     "dca_engine_set_weight_instance", "dca_engine_set_weights", "dca_engine_park_instance", "dca_engine_last_popped",
     "dca_engine_reset_many", "dca_engine_root_commit_many", "dca_engine_set_weights_dev", "dca_debug_write_ceiling",
+    "dca_l1_supported8", "dca_l1_kpad8", "dca_l1_onehot_gemm8",
 ]
 
 
@@ -75,13 +76,14 @@ def lib() -> C.CDLL:
         for name in ABI_SYMBOLS:
             fn = getattr(_lib, name)  # AttributeError here = stale build of libdca_hip.so
             if name not in ("dca_last_error", "dca_cube3_perm_table", "dca_cube4_perm_table", "dca_engine_destroy", "dca_bn_workspace_bytes",
-                            "dca_l1_kpad"):
+                            "dca_l1_kpad", "dca_l1_kpad8"):
                 fn.restype = C.c_int
         _lib.dca_l1_kpad.restype = C.c_int64
+        _lib.dca_l1_kpad8.restype = C.c_int64
         _lib.dca_bn_workspace_bytes.restype = C.c_int64
         _lib.dca_bn_workspace_bytes.argtypes = [C.c_int64]
         _lib.dca_engine_destroy.restype = None
-        if _lib.dca_abi_version() != 3:
+        if _lib.dca_abi_version() != 4:
             raise DcaError("libdca_hip.so ABI version mismatch")
     return _lib
 
@@ -450,6 +452,28 @@ def l1_onehot_gemm(states_nnet: torch.Tensor, depth: int, w_tiles: torch.Tensor,
         code = _TORCH_DT[out_dtype]
     check(lib().dca_l1_onehot_gemm(ptr(x), C.c_int64(m), int(d), int(depth), ptr(w_tiles), int(planes), C.c_int64(n_pad),
                                    ptr(bias), int(relu), ptr(out), code, ptr(overflow), stream_ptr()), "dca_l1_onehot_gemm")
+    return out
+
+
+def l1_supported8(state_dim: int, depth: int) -> bool:
+    return bool(lib().dca_l1_supported8(int(state_dim), int(depth)))
+
+
+def l1_kpad8(state_dim: int, depth: int) -> int:
+    return int(lib().dca_l1_kpad8(int(state_dim), int(depth)))
+
+
+def l1_onehot_gemm8(states_nnet: torch.Tensor, depth: int, w_tiles8: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor,
+                    relu: bool) -> torch.Tensor:
+    """Layer 1 of the fp8 mode on the f8f6f4 pipe (dca_l1_onehot_gemm8): e4m3(sat(relu?((onehot(s) . w8^T) * scale + bias))),
+    [m, n_pad] e4m3, from the uint8 rows; w_tiles8 from pytorch_models.l1_weight_tiles8."""
+    x = _u8(states_nnet)
+    m, d = x.shape
+    n_pad = bias.numel()
+    assert scale.dtype == torch.float32 and bias.dtype == torch.float32 and scale.numel() == n_pad and n_pad % 128 == 0
+    out = torch.empty((m, n_pad), dtype=E4M3, device=x.device)
+    check(lib().dca_l1_onehot_gemm8(ptr(x), C.c_int64(m), int(d), int(depth), ptr(w_tiles8), C.c_int64(n_pad), ptr(scale),
+                                    ptr(bias), int(relu), ptr(out), stream_ptr()), "dca_l1_onehot_gemm8")
     return out
 
 

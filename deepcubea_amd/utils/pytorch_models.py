@@ -147,6 +147,16 @@ def l1_weight_tiles(w: torch.Tensor, planes: int, k_pad: int) -> torch.Tensor:
     return t
 
 
+def l1_weight_tiles8(w8: torch.Tensor, k_pad: int) -> torch.Tensor:
+    """e4m3 weight matrix [n_pad, K] (out, in; already divided by its per-unit scales) -> the byte tiles `dca_l1_onehot_gemm8`
+    stages into LDS: K zero padded to k_pad (a multiple of 64), laid out [n_pad/128][k_pad/16][128][16]."""
+    n_pad, k = w8.shape
+    assert n_pad % 128 == 0 and k_pad % 64 == 0 and k_pad >= k and w8.dtype == torch.float8_e4m3fn
+    r = torch.zeros((n_pad, k_pad), dtype=torch.uint8)
+    r[:, :k] = w8.detach().cpu().view(torch.uint8)
+    return r.view(n_pad // 128, 128, k_pad // 16, 16).permute(0, 2, 1, 3).contiguous()
+
+
 def _pow2_scale(w: torch.Tensor) -> torch.Tensor:
     """Per output unit (row of w) the power of two that brings max|row| to ~1024, so that the fp16 low halves of the
     scaled weights stay normal numbers whatever the spread of magnitudes ACROSS units (BatchNorm folding can make it large)."""
@@ -440,8 +450,11 @@ class Fp8Resnet(_Fp8BlockMixin, nn.Module):
     HEADROOM = 1.25
     MIN_CALIB_ROWS = 1024
 
-    def __init__(self, model: ResnetModel, scaling: str = "tensor"):
-        """scaling="tensor" (default, `--nnet_dtype fp8`): one static scale per activation tensor, calibrated on the first
+    def __init__(self, model: ResnetModel, scaling: str = "tensor", l1: str = "auto"):
+        """l1: "fp8" = layer 1 on the f8f6f4 pipe with e4m3 weights (dca_l1_onehot_gemm8; per-tensor scaling only), "bf16" = the
+        round-5 arrangement (one bf16 weight plane on the bf16 pipe, output rounded to e4m3), "auto" = fp8 where the geometry is
+        instantiated (dca_l1_supported8) and the scaling is per tensor.
+        scaling="tensor" (default, `--nnet_dtype fp8`): one static scale per activation tensor, calibrated on the first
         batch of >= 1024 REAL rows (see `forward`).  scaling="block" (`--nnet_dtype fp8mx`): activations carry one E8M0
         scale per row and 64 elements, computed in the epilogue that produces them and applied by the scaled MFMA
         (dca_gemm8_mx / dca_l1_onehot_gemm_mx) — nothing is calibrated, nothing is frozen, nothing saturates, whatever depth
@@ -478,6 +491,13 @@ class Fp8Resnet(_Fp8BlockMixin, nn.Module):
         self._b1 = B[0].contiguous()
         self.l1_tiles8 = None
         self.l1_bias8 = None
+        assert l1 in ("auto", "fp8", "bf16")
+        can8 = scaling == "tensor" and _lib.l1_supported8(self.state_dim, self.one_hot_depth) and self._w1.shape[0] % 128 == 0
+        if l1 == "fp8" and not can8:
+            raise ValueError("Fp8Resnet(l1='fp8') needs per-tensor scaling and a geometry dca_l1_supported8 instantiates")
+        self.l1_fp8 = can8 and l1 != "bf16"
+        self.l1_w8_tiles = None   # l1_fp8: e4m3 weight tiles, and scale[n] = w_scale[n] / act_scale[0] for the kernel's epilogue
+        self.l1_scale8 = None
         self.act_scale: List[float] = []  # [h1, x after fc2, then (h, x) per residual block]
         self.layer_scale = None           # per dense layer: activation scale of its input x w_scale, on the device
 
@@ -515,9 +535,16 @@ class Fp8Resnet(_Fp8BlockMixin, nn.Module):
         dev = states_nnet.device
         kpad = _lib.l1_kpad(self.state_dim, self.one_hot_depth)
         inv1 = 1.0 / self.act_scale[0]
-        w1 = (self._w1 * inv1).to(torch.bfloat16).float()
-        self.l1_tiles8 = l1_weight_tiles(w1, 1, kpad).to(dev)
-        self.l1_bias8 = (self._b1 * inv1).to(dev)
+        if self.l1_fp8:
+            # one scale per output unit like every other e4m3 layer; the activation scale of h1 rides in the epilogue's factors
+            sw = (self._w1.abs().amax(dim=1) / self.E4M3_MAX).clamp_min(1e-30)
+            w8 = (self._w1 / sw[:, None]).to(_lib.E4M3)
+            self.l1_w8_tiles = l1_weight_tiles8(w8, _lib.l1_kpad8(self.state_dim, self.one_hot_depth)).to(dev)
+            self.l1_scale8 = (sw * inv1).float().contiguous().to(dev)
+        else:
+            w1 = (self._w1 * inv1).to(torch.bfloat16).float()
+            self.l1_tiles8 = l1_weight_tiles(w1, 1, kpad).to(dev)
+        self.l1_bias8 = (self._b1 * inv1).float().contiguous().to(dev)
         # input scale of dense layer j (0 = fc2): h1, then inside block i: x_i for the first Linear, h_i for the second
         s_in = [self.act_scale[0]]
         for i in range((len(self.w8) - 1) // 2):
@@ -541,7 +568,10 @@ class Fp8Resnet(_Fp8BlockMixin, nn.Module):
                 return self.base(states_nnet)
             self.calibrate(states_nnet[:real])
         s = self.act_scale
-        h8 = _lib.l1_onehot_gemm(states_nnet, self.one_hot_depth, self.l1_tiles8, 1, self.l1_bias8, True, _lib.E4M3)
+        if self.l1_fp8:
+            h8 = _lib.l1_onehot_gemm8(states_nnet, self.one_hot_depth, self.l1_w8_tiles, self.l1_scale8, self.l1_bias8, True)
+        else:
+            h8 = _lib.l1_onehot_gemm(states_nnet, self.one_hot_depth, self.l1_tiles8, 1, self.l1_bias8, True, _lib.E4M3)
         x16, x8 = _lib.gemm8(h8, self.w8[0], self.layer_scale[0], self.bias[0], None, True, True, 1.0 / s[1])
         nblk = (len(self.w8) - 1) // 2
         for i in range(nblk):

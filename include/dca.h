@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DCA_ABI_VERSION 3
+#define DCA_ABI_VERSION 4
 
 /* library error codes (negative; positive values are hipError_t) */
 #define DCA_E_BADARG (-1)
@@ -332,6 +332,21 @@ int64_t dca_l1_kpad(int state_dim, int depth);
 int dca_l1_onehot_gemm(const uint8_t* nnet_in /*[m, state_dim]*/, int64_t m, int state_dim, int depth, const void* w_tiles,
                        int planes, int64_t n_pad, const float* bias /*[n_pad]*/, int relu, void* out, int out_dtype,
                        int* overflow /*device flag, set to 1 if a DCA_DT_F16X3 value exceeds fp16; or NULL*/, void* stream);
+
+/* The same layer in the NON-parity fp8 mode, on gfx950's f8f6f4 matrix pipe (csrc/dca_mlp8.hip): a one-hot row is exact in
+ * OCP e4m3, so with the layer's weights as e4m3 bytes + one fp32 scale per output unit (what every other fp8 layer carries)
+ *   out8[r, n] = e4m3(sat( relu?( (onehot(s_r) . w8[n, :]) * scale[n] + bias[n] ) ))
+ * runs on v_mfma_f32_32x32x64_f8f6f4 — twice the rate of the bf16 pipe dca_l1_onehot_gemm(..., DCA_DT_E4M3) multiplies the same
+ * exact 0 / 1 rows on.  The caller folds the activation scale of the output tensor into scale[] and bias[].
+ * w_tiles: [n_pad/128][k_pad/16][128][16] e4m3 bytes, k_pad = dca_l1_kpad8(state_dim, depth) (K zero padded to a multiple of 64;
+ * deepcubea_amd/utils/pytorch_models.py:l1_weight_tiles8 builds it); n_pad % 128 == 0; nnet_in and out8 16-byte aligned;
+ * out8: [m, n_pad] bytes.  Instantiated where the 128-column weight tile fits LDS: dca_l1_supported8() != 0 (cube3,
+ * puzzle15, puzzle24, lightsout7); other geometries keep the bf16-pipe kernel. */
+int dca_l1_supported8(int state_dim, int depth);
+int64_t dca_l1_kpad8(int state_dim, int depth);
+int dca_l1_onehot_gemm8(const uint8_t* nnet_in /*[m, state_dim]*/, int64_t m, int state_dim, int depth, const void* w_tiles,
+                        int64_t n_pad, const float* scale /*[n_pad]*/, const float* bias /*[n_pad]*/, int relu, void* out8,
+                        void* stream);
 
 /* Glue of the fp32-accurate "f16x3" dense layers (csrc/dca_mlp.hip): v = relu?(y*alpha*col_scale + bias (+ skip)) over the row-major
  * fp32 GEMM output y [m, n]; writes the next layer's A operand a3 [m, 3n] fp16, a3[3k..3k+2] = (vh, vl, vh) with

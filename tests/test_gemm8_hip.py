@@ -124,6 +124,77 @@ def test_layer1_kernel_e4m3_output_is_the_rounded_accumulator():
     assert torch.equal(y8.cpu().view(torch.uint8), _q(y32.cpu()).view(torch.uint8))
 
 
+@pytest.mark.parametrize("D,depth,n_pad,m", [(54, 6, 256, 1500), (54, 6, 5120, 777), (16, 16, 128, 513), (25, 25, 256, 64),
+                                             (49, 6, 128, 1000)])
+def test_layer1_fp8_pipe_kernel_against_float64(D, depth, n_pad, m):
+    """dca_l1_onehot_gemm8 (layer 1 on the f8f6f4 pipe): the one-hot row is exact in e4m3 and the weights ARE e4m3 numbers, so
+    the accumulator must equal the float64 sum of the D selected weights up to fp32 accumulation — the output is that sum times
+    scale[n] plus bias[n], ReLU, saturated, rounded to e4m3: compared byte for byte with the host's rounding of the float64
+    value wherever that value is not within an fp32 rounding error of a tie between two e4m3 neighbours.  Rows are ragged
+    (m not a multiple of 64 / 512), weights asymmetric in K and n (a transposed or permuted operand cannot pass), and the
+    saturation branch is exercised."""
+    from deepcubea_amd import _lib
+    from deepcubea_amd.utils.pytorch_models import l1_weight_tiles8
+    _lib.require_gpu()
+    assert _lib.l1_supported8(D, depth) and _lib.l1_kpad8(D, depth) % 64 == 0
+    g = torch.Generator().manual_seed(100 + D)
+    K = D * depth
+    w8 = (torch.randn(n_pad, K, generator=g) * 40.0 + torch.arange(K)[None, :] * 0.05 + torch.arange(n_pad)[:, None] * 0.01).to(E4M3)
+    scale = (torch.rand(n_pad, generator=g) * 0.2 + 0.05).float()
+    bias = (torch.randn(n_pad, generator=g) * 30.0).float()
+    tiles = l1_weight_tiles8(w8, _lib.l1_kpad8(D, depth)).cuda()
+    x = torch.randint(0, depth, (m, D), dtype=torch.uint8, generator=g)
+    y8 = _lib.l1_onehot_gemm8(x.cuda(), depth, tiles, scale.cuda(), bias.cuda(), True).cpu()
+    idx = (torch.arange(D)[None, :] * depth + x.long())                        # [m, D] one-hot columns
+    acc = w8.double().t()[idx].sum(dim=1)                                       # [m, n_pad] exact in float64
+    v = torch.clamp(acc * scale.double()[None, :] + bias.double()[None, :], min=0.0)
+    assert float(v.max()) > 448.0 and float((v > 0).float().mean()) > 0.2      # saturation and both ReLU branches are exercised
+    want = _q(v.float())
+    got, wnt = y8.view(torch.uint8), want.view(torch.uint8)
+    same = got == wnt
+    # where the bytes differ the float64 value must sit (within fp32 rounding of the fma) on the midpoint between the two
+    # neighbouring e4m3 numbers: |got - v| and |want - v| are then equal to ~1e-6 relative
+    if not bool(same.all()):
+        dg = (y8.double() - v.clamp(max=448.0)).abs()[~same]
+        dw = (want.double() - v.clamp(max=448.0)).abs()[~same]
+        assert float(((dg - dw).abs() / (dw + 1e-30)).max()) < 1e-3, "a byte differs where the value is not at a rounding tie"
+        assert int((~same).sum()) < 1e-4 * same.numel()
+    # no ReLU: negative values saturate at -448
+    y8n = _lib.l1_onehot_gemm8(x.cuda(), depth, tiles, scale.cuda(), bias.cuda(), False).cpu()
+    vn = (acc * scale.double()[None, :] + bias.double()[None, :]).float()
+    bad = y8n.view(torch.uint8) != _q(vn).view(torch.uint8)
+    assert float(vn.min()) < -448.0 and int(bad.sum()) < 1e-4 * bad.numel()
+    # repeated launches are bit-identical (the race screen: wave-private LDS slices, no workgroup barrier in the row loop)
+    for _ in range(3):
+        assert torch.equal(_lib.l1_onehot_gemm8(x.cuda(), depth, tiles, scale.cuda(), bias.cuda(), True).cpu().view(torch.uint8), got)
+
+
+@torch.no_grad()
+def test_fp8_layer1_on_the_fp8_pipe_costs_no_accuracy_that_matters():
+    """Fp8Resnet with layer 1 on the f8f6f4 pipe (e4m3 weights; the default since round 6) against the round-5 arrangement
+    (bf16 weights on the bf16 pipe, output rounded to e4m3): deviation of both from the fp32 parity-mode network on the same
+    states, printed; the new arrangement may not be worse by more than a tenth of the format's own deviation."""
+    from deepcubea_amd import _lib
+    from deepcubea_amd.utils.pytorch_models import FastResnet, Fp8Resnet, ResnetModel
+    from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
+    _lib.require_gpu()
+    net = ResnetModel(54, 6, 5000, 1000, 4, 1, True)
+    load_synthetic_weights(net, 2024)
+    net.eval()
+    x = torch.randint(0, 6, (6000, 54), dtype=torch.uint8, generator=torch.Generator().manual_seed(3)).cuda()
+    y32 = FastResnet(net).cuda()(x)[:, 0]
+    f_new, f_old = Fp8Resnet(net, l1="fp8").cuda(), Fp8Resnet(net, l1="bf16").cuda()
+    assert f_new.l1_fp8 and not f_old.l1_fp8 and Fp8Resnet(net).l1_fp8
+    scale = float(y32.abs().max())
+    out = {}
+    for name, f in (("l1 fp8 pipe", f_new), ("l1 bf16 pipe", f_old)):
+        y = f(x)[:, 0]
+        out[name] = (float((y - y32).abs().max()) / scale, float((y - y32).pow(2).mean().sqrt()) / scale)
+    print("fp8 network vs fp32 network, deviation / max|h| (max, rms):", out)
+    assert out["l1 fp8 pipe"][1] <= out["l1 bf16 pipe"][1] * 1.10 + 1e-3
+    assert out["l1 fp8 pipe"][0] < 0.25
+
+
 @torch.no_grad()
 def test_fp8_network_deviation_from_the_fp32_network_is_stated():
     """Whole cube3 network at fp8 operand precision (layer 1 -> e4m3, nine dca_gemm8 layers, bf16 residual stream) against the

@@ -149,3 +149,24 @@ for n, k in ((1024, 1024), (1024, 5120)) if only in ("", "e4m3") else ():
     print(json.dumps(row))
     del x8, w8, skip, out
     torch.cuda.empty_cache()
+
+# ---- layer 1 of the fp8 mode (cube3, 324 -> 5120 from the uint8 rows, e4m3 out): the bf16-pipe kernel that only ROUNDS to
+# e4m3 (round 5) vs the f8f6f4-pipe kernel with e4m3 weights (round 6)
+if only in ("", "l1"):
+    from deepcubea_amd.utils.pytorch_models import l1_weight_tiles, l1_weight_tiles8  # noqa: E402
+    D, depth, n_pad = 54, 6, 5120
+    g = torch.Generator().manual_seed(7)
+    x = torch.randint(0, depth, (m, D), dtype=torch.uint8, generator=g).cuda()
+    w1 = torch.randn(n_pad, D * depth, generator=g) * 8.0
+    b1 = torch.randn(n_pad, generator=g).cuda()
+    t16 = l1_weight_tiles(w1.to(torch.bfloat16).float(), 1, _lib.l1_kpad(D, depth)).cuda()
+    sw = (w1.abs().amax(dim=1) / 448.0)
+    t8 = l1_weight_tiles8((w1 / sw[:, None]).to(E4M3), _lib.l1_kpad8(D, depth)).cuda()
+    swc = sw.float().cuda()
+    res = interleaved([("bf16_pipe_e4m3_out", lambda: _lib.l1_onehot_gemm(x, depth, t16, 1, b1, True, _lib.E4M3)),
+                       ("f8f6f4_pipe_e4m3_out", lambda: _lib.l1_onehot_gemm8(x, depth, t8, swc, b1, True)),
+                       ("bf16_pipe_bf16_out", lambda: _lib.l1_onehot_gemm(x, depth, t16, 1, b1, True, torch.bfloat16))])
+    row = {"layer": "l1 cube3 one-hot 324 -> 5120", "m": m}
+    for name, ms in res.items():
+        row[name + "_ms"] = round(ms, 4)
+    print(json.dumps(row))
