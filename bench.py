@@ -374,11 +374,13 @@ def run_astar(args, world, rank):
         from deepcubea_amd import _lib
         sem = _lib.SEM_CPP if args.semantics == "cpp" else _lib.SEM_PY
         sweep = {}
-        for k in [int(x) for x in args.concurrent.split(",") if int(x) > 1]:
-            sweep[str(k)] = run_astar_concurrent(args, world, rank, sem, _lib.HEUR_HASHU01, k)
+        ks = [int(x) for x in args.concurrent.split(",") if int(x) > 1]
+        for k in ks:  # (the device-side launch profile rides on the largest K: the leg the CLI's `auto` picks)
+            sweep[str(k)] = run_astar_concurrent(args, world, rank, sem, _lib.HEUR_HASHU01, k, profile=(k == max(ks)))
         if sweep:
             best = max(sweep, key=lambda k: sweep[k]["value"])
-            res["concurrent_instances"] = dict(sweep[best], sweep={k: {"value": v["value"], "ms_per_step": v["ms_per_step"]}
+            res["concurrent_instances"] = dict(sweep[best], sweep={k: {"value": v["value"], "ms_per_step": v["ms_per_step"],
+                                                                       "roofline_frac": v["roofline_iteration"]["frac"]}
                                                                    for k, v in sweep.items()},
                                                note="K searches share every launch (grid.y = instance): the CLI's "
                                                     "--instances_per_gpu auto picks K from this kind of sweep "
@@ -432,7 +434,7 @@ def run_sharded_queue(args, world, rank):
                    "refills, tie groups included)"}
 
 
-def run_astar_concurrent(args, world, rank, sem, hid, k):
+def run_astar_concurrent(args, world, rank, sem, hid, k, profile=False):
     """k independent search instances per GPU stepped together by ONE engine (grid.y = instance; finer per-instance
     sharding, like the reference's AStar stepping a list of instances): a batch-20 000 iteration is launch/latency
     bound and leaves most of the chip idle.  Reported next to the single-instance `value`, never instead of it."""
@@ -464,11 +466,38 @@ def run_astar_concurrent(args, world, rank, sem, hid, k):
         episodes += 1
         if wall_sum >= MIN_TIMED_S / 2 or episodes >= 100:
             break
+    ms_step = wall_sum / (steps * episodes) * 1e3
+    out = {"instances_per_gpu": k, "value": total / wall_sum, "unit": "nodes expanded/s",
+           "ms_per_step": ms_step, "episodes": episodes, "steps_per_episode": steps,
+           "how": "one engine, every kernel launched once for all instances (grid.y = instance)"}
+    # the same yardstick as the single-search headline ("so that 4.4e8 has a fraction next to it"):
+    # SURVEY §8(d) bytes per expansion x batch x K / ms_per_step, and — one more episode of the timed shape with the device
+    # stamps on, every instance's workgroups stamping — the launches' envelopes against their algorithmic bytes x K
+    alg = engine_bytes("cube3", B, 0)
+    itb = alg["per_expansion_8d"] * B * k
+    out["roofline_iteration"] = {"bound": "hbm", "bytes_per_step": itb, "achieved": itb / (ms_step * 1e-3) / 1e9,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": itb / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if profile and args.profile_iters > 0:
+        for i in range(k):
+            root = test_root((rank + world * episodes) * k + i)
+            eng.reset(root, i)
+            if sem == _lib.SEM_PY:
+                eng.root_commit(_lib.heuristic_builtin(hid, torch.from_numpy(root[None].copy()).cuda()), i)
+        eng.run_builtin(hid, warm, use_graph=not args.no_graph)
+        prof = eng.profile_builtin(hid, steps, use_graph=not args.no_graph)
+        span = prof["span_ms"]
+        alg_k = {"expand": (alg["expand"] + alg["probe"] - B * 12 * (54 + 16)) * k, "commit": alg["commit"] * k}
+        out["launch_span_ms"] = {kk: round(v, 5) for kk, v in span.items()}
+        out["launch_gap_ms"] = {kk: round(v, 5) for kk, v in prof["gap_ms"].items()}
+        out["launch_rooflines"] = {"k_" + kk: {"bytes_per_launch": alg_k[kk], "kernel_ms": round(span[kk], 5),
+                                                "achieved_GBs": round(alg_k[kk] / (span[kk] * 1e-3) / 1e9, 1),
+                                                "frac": round(alg_k[kk] / (span[kk] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                "traffic": (lambda t: None if t is None else t * k)(pmc_traffic("k_" + kk, "cube3", B)),
+                                                "traffic_how": "the single-instance launch's PMC traffic x K (same per-instance work)"}
+                                   for kk in alg_k if kk in span and span[kk] > 0}
     eng.close()
     torch.cuda.empty_cache()
-    return {"instances_per_gpu": k, "value": total / wall_sum, "unit": "nodes expanded/s",
-            "ms_per_step": wall_sum / (steps * episodes) * 1e3, "episodes": episodes, "steps_per_episode": steps,
-            "how": "one engine, every kernel launched once for all instances (grid.y = instance)"}
+    return out
 
 
 def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool = False, gemm16: str = "hip"):

@@ -273,11 +273,12 @@ __device__ __forceinline__ void fresh_binning(const Ctl* c, uint32_t buf, uint64
 // Device-side profile: thread 0 of every workgroup (instance 0 only) folds its wall-clock start / end into the
 // launch's slot, so the host can read each launch's busy span and the gap to the next one INSIDE a replayed hipGraph.
 // Off (prof == nullptr) it costs one scalar compare.
+// (every instance's workgroups stamp into the same slots: with K instances sharing a launch the span is the launch's envelope)
 struct Stamp {
     unsigned long long* p;
     unsigned long long t0;
     __device__ __forceinline__ Stamp(const Eng& E, int kid) : p(nullptr), t0(0) {
-        if (E.prof != nullptr && threadIdx.x == 0 && blockIdx.y == 0) {
+        if (E.prof != nullptr && threadIdx.x == 0) {
             p = E.prof + ((size_t)kid * kProfSlots + (blockIdx.x & (kProfSlots - 1))) * 2;
             t0 = wall_clock64();
         }
@@ -292,11 +293,11 @@ struct Stamp {
 
 // phase marks inside a launch (same slots; profile only)
 __device__ __forceinline__ void prof_begin(const Eng& E, int kid) {
-    if (E.prof != nullptr && threadIdx.x == 0 && blockIdx.y == 0)
+    if (E.prof != nullptr && threadIdx.x == 0)
         atomicMin(E.prof + ((size_t)kid * kProfSlots + (blockIdx.x & (kProfSlots - 1))) * 2, (unsigned long long)wall_clock64());
 }
 __device__ __forceinline__ void prof_end(const Eng& E, int kid) {
-    if (E.prof != nullptr && threadIdx.x == 0 && blockIdx.y == 0)
+    if (E.prof != nullptr && threadIdx.x == 0)
         atomicMax(E.prof + ((size_t)kid * kProfSlots + (blockIdx.x & (kProfSlots - 1))) * 2 + 1, (unsigned long long)wall_clock64());
 }
 
