@@ -598,7 +598,12 @@ __device__ __forceinline__ void gemm16_tail_full(const Gemm16Args& p, uint8_t* t
     rows32(std::integral_constant<int, 3>{});
 }
 
-template <bool BF16, bool SKIP, bool BIAS>
+// LDSPROBE (dca_gemm16_variant 4 / 5, tools/gemm16_probe.py — WRONG RESULTS, timing only): the same kernel issuing 16 / 12
+// fragment reads per K-tile and wave instead of 24 (0.5 / 0.375 ds_read_b128 per MFMA instead of 0.75: what a 128 x 128 wave tile
+// would read), the skipped fragments replaced by ones already in registers — same MFMAs on random data, same DMA stream, same
+// tail.  The experiment behind round 6's decision on the one-wave-per-SIMD layout: if the K loop's deficit against the library on
+// random operands (it is level on all-zero ones) is the energy of its LDS reads, this must close it.
+template <bool BF16, bool SKIP, bool BIAS, int LDSPROBE = 0>
 __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16s(const Gemm16Args p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     using frag_t = typename std::conditional<BF16, b16x8, h16x8>::type;
@@ -645,12 +650,23 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16s(const Gemm16Args p) {
     frag_t av[2][4], wv0[4], wv1[4];
     auto read_a = [&](const uint8_t* base, int u) {
 #pragma unroll
-        for (int ii = 0; ii < 2; ii++)
+        for (int ii = 0; ii < (LDSPROBE ? 1 : 2); ii++)
 #pragma unroll
             for (int s = 0; s < 4; s++)
                 av[ii][s] = *reinterpret_cast<const frag_t*>(base + u * PSLOT + a_row0 + ii * 4096 + foff[s]);
+        if constexpr (LDSPROBE != 0) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) av[1][s] = av[0][(s + 1) & 3];  // (a fragment already in registers stands in)
+        }
     };
     auto read_b = [&](const uint8_t* base, int u, frag_t (&wv)[4]) {
+        if constexpr (LDSPROBE == 2) {
+            if (u == PS_B1) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) wv[s] = wv0[(s + 1) & 3];
+                return;
+            }
+        }
 #pragma unroll
         for (int s = 0; s < 4; s++) wv[s] = *reinterpret_cast<const frag_t*>(base + u * PSLOT + b_row0 + foff[s]);
     };
@@ -771,7 +787,7 @@ extern "C" {
  * 8-phase ping-pong schedule with the general tail (what ragged strips and other layer forms always run on); 3 (default) = the
  * same schedule with operand roles swapped and the lean tail for the network's layer forms */
 int dca_gemm16_variant(int v) {
-    DCA_ARG(v >= 1 && v <= 3);
+    DCA_ARG(v >= 1 && v <= 5);  // (4, 5: the LDS-read probes of k_gemm16s — timing only, WRONG results; bf16 bias form)
     g_gemm16_variant = v;
     return 0;
 }
@@ -842,6 +858,16 @@ int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int 
     if (g_gemm16_variant < 3) {
         if (int rc = launch_generic(p, g_gemm16_variant)) return rc;
         return launch_check("k_gemm16");
+    }
+    if (g_gemm16_variant > 3) {  // LDS-read probe: whole tiles, bf16, relu(a . w^T + bias) only
+        DCA_ARG(dtype == DCA_DT_BF16 && bias && !skip && relu && m % QBM == 0 && n % QBN == 0 && ldo % 8 == 0);
+        const void* kern = g_gemm16_variant == 4 ? reinterpret_cast<const void*>(k_gemm16s<true, false, true, 1>)
+                                                 : reinterpret_cast<const void*>(k_gemm16s<true, false, true, 2>);
+        DCA_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
+        const int64_t blocks = ((m / QBM + 7) / 8) * 8 * (n / QBN);
+        void* kargs[] = {&p};
+        DCA_HIP(hipLaunchKernel(kern, dim3((unsigned)blocks), dim3(QTHREADS), kargs, QLDS, s));
+        return launch_check("k_gemm16s (LDS-read probe)");
     }
     // Variant 3 — the lean-tail kernel — serves the network's own layer forms, relu(a . w^T (+ bias) (+ skip)), on whole tiles
     // with 16-byte aligned rows; any other form goes to variant 2, and so do the ragged right and bottom strips of a layer

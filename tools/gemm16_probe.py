@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 from deepcubea_amd import _lib  # noqa: E402
 
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 204800
-variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["2", "3"])]
+variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["3", "4", "5"])]  # 4 / 5: LDS-read probes (wrong results)
 dt = torch.bfloat16
 
 
@@ -49,7 +49,7 @@ def hip(v, x, w, b):
 
 
 n = 1024
-for k in (64, 256, 1024, 2048, 5120):
+for k in [int(v) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["1024", "5120"])]:
     for fill in ("random", "zeros"):
         g = torch.Generator().manual_seed(k)
         if fill == "random":
