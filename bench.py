@@ -149,7 +149,7 @@ def pmc_traffic(kernel: str, env: str, B: int):
     """HBM bytes per launch from the rocprofv3 PMC passes of THIS command (`tools/pmc_summary.py` writes
     profiles/r03_pmc_traffic.json from `rocprofv3 --pmc ... -- python bench.py`): counters cannot be read from inside
     the process, so the entry is matched on kernel, environment and batch size and otherwise left null."""
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
@@ -801,7 +801,7 @@ def expand_pmc_traffic(onehot: str, n: int):
     """HBM bytes per launch of the gather kernel from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of
     `bench.py --workload expand` (tools/profile_expand.sh -> profiles/rNN_expand_pmc_traffic.json), matched on the one-hot
     type and the number of states; null when no pass at this shape is committed."""
-    for name in ("r05_expand_pmc_traffic.json",):
+    for name in ("r06_expand_pmc_traffic.json", "r05_expand_pmc_traffic.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):

@@ -2515,6 +2515,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
     __shared__ uint32_t l_pid[kEngTile], l_g[kEngTile];
     __shared__ uint32_t l_qn, l_qcc[PROBE ? kThreads : 1], l_qrep[PROBE ? kThreads : 1], l_qres[PROBE ? kThreads : 1];
     __shared__ uint32_t l_ohq;  // one-hot rows: next 1 KiB piece (one wave-wide 16-byte store) nobody has claimed yet
+    __shared__ uint32_t l_pdone;  // waves of the per-child round whose probes are through (what a storing idle wave polls)
     static_assert((EV::D + 3) / 4 < 16, "no spare lane per row for the parent's path cost");
     // batch geometry: every workgroup derives it from the state the previous iteration left (S[iters & 1]) and the
     // pop that k_rank just finished; workgroup 0 also records it for the rest of the iteration (close_pop)
@@ -2541,7 +2542,10 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
     }
     if (r0 >= npop) return;
     const uint32_t np = min((uint32_t)kTileParents, npop - r0);
-    if (OH != 0 && threadIdx.x == 0) l_ohq = 0;
+    if (OH != 0 && threadIdx.x == 0) {
+        l_ohq = 0;
+        l_pdone = 0;
+    }
     {
         // gather the popped rows by node id.  One lane per (parent, 4-byte word): 16 lanes cover a row, so
         // a 256-thread block fetches 16 rows per round and the 4 rounds are issued back to back.
@@ -2581,12 +2585,15 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
 
     // One-hot rows of the tile's children (pytorch_models.py:49-52), from the child rows staged in `lst`.  The rows of a tile are
     // one contiguous run of the batch's one-hot buffer; it is cut into 1 KiB pieces — one wave-wide 16-byte store each — which
-    // the waves CLAIM from an LDS counter, so that whichever wave has nothing else to do stores: the wave(s) of the per-child
-    // round that hold no child (192 children on 256 lanes for cube3: wave 3) start as soon as the rows are staged and their
-    // stores drain under the CLOSED probe's load -> compare-and-swap -> row-compare chains of the other waves; everybody joins
-    // at the end.  (Until round 6 all one-hot stores came after the probe: every workgroup of the launch probed at the same time,
-    // then every workgroup stored — 102 us for a launch whose stores alone take 63 and whose probe alone takes 28.)
-    auto oh_emit = [&](uint32_t max_pieces) {
+    // the waves CLAIM from an LDS counter, so that whichever wave has nothing else to do can store.  Shipped order: every store
+    // after the probe (all workgroups of the launch are resident at once: they probe at the same time, then store at the same
+    // time).  Round 6 tried to put stores UNDER the probe — the wave of the per-child round that holds no child (192 children on
+    // 256 lanes for cube3: wave 3) storing while the others walk their load -> compare-and-swap -> row-compare chains:
+    //   * unpaced (half / all of the tile's pieces at once): 110 / 141 us instead of 98.6 — the probe's loads queue behind the
+    //     idle wave's stores in the CU's one memory pipe, three dependent round trips each a few microseconds longer;
+    //   * PACED (knob 14 = 2): at most `pace` stores of the idle wave in flight (s_waitcnt vmcnt after each), and it stops as
+    //     soon as the probing waves have signalled (l_pdone) — profiles/r06_engine_ab.txt has what that measured.
+    auto oh_emit = [&](uint32_t max_pieces, const int pace = 0, const uint32_t stop_at = 0u) {
         if constexpr (OH != 0) {
             constexpr uint32_t ROW = EV::D * EV::DEPTH;
             constexpr uint32_t EPC = 16 / OH;
@@ -2601,6 +2608,17 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
                 return ENV == DCA_ENV_CUBE3 ? (b * 57u) >> 9 : b;
             };
             for (uint32_t n = 0; n < max_pieces; n++) {
+                if (pace != 0) {  // (the idle wave under the probe: few stores in flight, and done as soon as the probers are)
+                    if (pace <= 1)
+                        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                    else if (pace <= 2)
+                        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else if (pace <= 4)
+                        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else
+                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    if (*reinterpret_cast<volatile uint32_t*>(&l_pdone) >= stop_at) break;
+                }
                 uint32_t piece = 0;
                 if ((threadIdx.x & 63u) == 0) piece = atomicAdd(&l_ohq, 1u);
                 piece = (uint32_t)__builtin_amdgcn_readfirstlane((int)piece);
@@ -2655,7 +2673,8 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
             }
         }
     };
-    const int oh_mode = OH != 0 ? g_tune[14] : 1;  // (knob 14, A/B: 0 = overlapped — shipped —, 1 = every store after the probe, 2 = no piece limit under the probe)
+    const int oh_mode = OH != 0 ? g_tune[14] : 0;  // (knob 14, A/B: 0 = every store after the probe — shipped —, 2 = paced stores of the idle wave under the probe)
+    const int oh_pace = g_tune[15] > 0 ? g_tune[15] : 2;
 
     // per child: hash, is_solved, node fields, built-in heuristic (rounds of 256 children; uniform: the probe below
     // synchronises the workgroup inside a round)
@@ -2721,18 +2740,13 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
             const uint64_t tag = h >> 32;
             bool active = cvalid, inserted = false, paused = false;
             uint32_t slot = (uint32_t)h & E.tab_mask, v0 = GINF, rep_id = 0, probes = 0, qi = 0;
-            __syncthreads();  // the round's rows are staged (lst) — and l_qn is zero
-            if constexpr (OH != 0) {
-                // a wave without a child in this round (it can only be the LAST round: every row of the tile is staged): its
-                // one-hot stores drain under the other waves' probe.  Half of the tile's pieces at most before it joins the
-                // barrier below — the others wait for it there with their chain hooks still to do.
-                if (oh_mode != 1 && cc0 + (threadIdx.x & ~63u) >= nchild) {
-                    constexpr uint32_t ROWB = EV::D * EV::DEPTH * OH;
-                    const uint32_t pieces = (nchild * ROWB + 1023u) >> 10;
-                    oh_emit(oh_mode == 2 ? pieces : (pieces + 1u) / 2u);
-                }
-            }
+            __syncthreads();  // the round's rows are staged (lst) — and l_qn, l_pdone are zero
+            // (knob 14 = 2) a wave without a child in this round — it can only be the LAST round: every row of the tile is staged
+            const bool oh_idle_wave = OH != 0 && oh_mode == 2 && cc0 + (threadIdx.x & ~63u) >= nchild;
+            const uint32_t oh_probers = (min(nchild - cc0, (uint32_t)kThreads) + 63u) >> 6;  // waves of this round that hold children
+            bool oh_first = OH != 0 && oh_mode == 2;
             for (;;) {
+                if (oh_first && oh_idle_wave) oh_emit(~0u, oh_pace, oh_probers);  // until the probing waves have signalled
                 if (active && !paused) {
                     for (;;) {
                         // look first, claim second; one 16-byte load fetches the entry with its value (see k_probe)
@@ -2786,6 +2800,8 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
                         }
                     }
                 }
+                if (oh_first && !oh_idle_wave && (threadIdx.x & 63u) == 0) atomicAdd(&l_pdone, 1u);  // this wave's probes are through
+                oh_first = false;
                 __syncthreads();
                 const uint32_t nq = l_qn;
                 if (nq == 0) break;
@@ -2891,7 +2907,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
         }
     }
 
-    // the one-hot pieces nobody has claimed yet (all of them when no wave was idle under the probe)
+    // the one-hot pieces nobody has claimed yet (all of them, unless an idle wave stored under the probe)
     oh_emit(~0u);
 }
 

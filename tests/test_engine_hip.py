@@ -431,7 +431,7 @@ def test_device_set_weights_survive_a_host_upload(L, co):
     import torch
     from deepcubea_amd.search_methods.engine import BwasEngine
     roots = [scramble(co, "cube3", [3, 8, 1, 10, 6]), scramble(co, "cube3", [11, 2, 6, 9, 0])]
-    eng = BwasEngine("cube3", 1.0, 100, max_nodes=1 << 21, num_instances=2)
+    eng = BwasEngine("cube3", 1.0, 100, max_nodes=1 << 23, num_instances=2)  # (weight 0.2 generates 3.7 M nodes on the first root)
     eng.set_weights_dev(torch.tensor([0.2, 0.6], dtype=torch.float64, device="cuda"))
     eng.set_tiers(3200, 9600)          # upload_engs: must carry the device's weights, not the creation-time 1.0
     eng.set_weight(0.4, instance=1)    # host setter for ONE instance: the other keeps its device-set weight
