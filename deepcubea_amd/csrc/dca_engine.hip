@@ -2499,12 +2499,14 @@ constexpr int kEngTile = 16;  // parents per workgroup: a 20 000-parent batch th
 // row in HBM yet.  It needs none: its id says which popped parent and which move made it (id = base + rank * A + move),
 // and the parent's row was written an iteration ago — the tile rebuilds the representative from it (16 lanes per pending
 // comparison) and compares exactly.
-template <int ENV, int DIM, int OH, bool PROBE>
+// TP: parents per workgroup.  16 everywhere (a 20 000-parent batch = 1250 workgroups); 32 / 64 exist for the launches that also
+// write one-hot rows (knob 8, A/B: a workgroup's one-hot output is then one contiguous 0.5 / 1 MB run instead of 249 KB).
+template <int ENV, int DIM, int OH, bool PROBE, int TP = kEngTile>
 __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ engs, int heur_id, int write_nn) {
     const Eng& E = engs[blockIdx.y];
     using EV = EnvT<ENV, DIM>;
-    using TL = Tile<ENV, DIM, kEngTile>;
-    constexpr int kTileParents = kEngTile;  // shadows the stand-alone kernels' 64
+    using TL = Tile<ENV, DIM, TP>;
+    constexpr int kTileParents = TP;  // shadows the stand-alone kernels' 64
     Ctl* c = E.ctl;
     if (c->done) return;
     Stamp stamp(E, P_EXPAND);
@@ -2512,7 +2514,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
     uint8_t* lpar = smem;
     uint8_t* ltab = smem + TL::PAR_BYTES;
     uint8_t* lst = smem + TL::LDS_BYTES;  // child rows of the tile, laid out exactly like their HBM destination
-    __shared__ uint32_t l_pid[kEngTile], l_g[kEngTile];
+    __shared__ uint32_t l_pid[TP], l_g[TP];
     __shared__ uint32_t l_qn, l_qcc[PROBE ? kThreads : 1], l_qrep[PROBE ? kThreads : 1], l_qres[PROBE ? kThreads : 1];
     __shared__ uint32_t l_ohq;  // one-hot rows: next 1 KiB piece (one wave-wide 16-byte store) nobody has claimed yet
     __shared__ uint32_t l_pdone;  // waves of the per-child round whose probes are through (what a storing idle wave polls)
@@ -2551,9 +2553,11 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
         // a 256-thread block fetches 16 rows per round and the 4 rounds are issued back to back.
         constexpr int WPR = (EV::D + 3) / 4;  // words per row (<= 14)
         static_assert(WPR <= 16, "row wider than 64 bytes");
-        const uint32_t w = threadIdx.x & 15, r = threadIdx.x >> 4;  // 16 lanes per row, 16 rows
+        const uint32_t w = threadIdx.x & 15;  // 16 lanes per row, 16 rows per round
         // (a spare lane of every row fetches the parent's path cost in the same round trip as the row itself: the
         // per-child loop below used to wait for it — a dependent random access — before it could write anything)
+#pragma unroll
+        for (uint32_t r = threadIdx.x >> 4; r < (uint32_t)TP; r += 16) {
         if (r < np && w == WPR) {
             const uint32_t pid = E.pop_id[r0 + r] & ID_MASK;
             l_pid[r] = pid;
@@ -2571,6 +2575,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
 #pragma unroll
             for (int b = 0; b < 4; b++)
                 if (4 * w + b < EV::D) lpar[r * EV::D + 4 * w + b] = (uint8_t)(v >> (8 * b));
+        }
         }
     }
     if constexpr (ENV == DCA_ENV_CUBE3) stage_tables<ENV, DIM>(ltab, lpar, np);
@@ -3532,6 +3537,29 @@ int launch_expand_env(const dca_engine* e, int heur_id, bool want_oh, bool want_
     const size_t lds = TL::LDS_BYTES + ((kEngTile * EnvT<ENV, DIM>::A * EnvT<ENV, DIM>::D + 15) / 16) * 16 + 64;  // (+ slack: the one-hot loop peeks one byte past the tile)
     const bool fuse = fuse_probe();
     const int wnn = ((want_nn && heur_id < 0) || h_tune[12] != 0) ? 1 : 0;  // (knob 12: always write them, the round-4 behaviour, for A/B runs)
+    if constexpr (ENV == DCA_ENV_CUBE3 || ENV == DCA_ENV_NPUZZLE) {
+        // (knob 8, A/B: 32 or 64 parents per workgroup for the launches that write one-hot rows)
+        if (E.onehot != nullptr && want_oh && fuse && (h_tune[8] == 32 || h_tune[8] == 64)) {
+            const int tp = h_tune[8];
+            using TL2 = Tile<ENV, DIM, 64>;
+            const size_t lds2 = TL2::LDS_BYTES + ((size_t)(tp * EnvT<ENV, DIM>::A * EnvT<ENV, DIM>::D + 15) / 16) * 16 + 64;
+            const dim3 g2 = gxy((E.B + tp - 1) / tp, e);
+            const bool f32 = E.oh_dtype == DCA_DT_F32;
+#define DCA_EXP_TP(OHV, TPV)                                                                                            \
+    do {                                                                                                                \
+        auto kern = k_expand<ENV, DIM, OHV, true, TPV>;                                                                 \
+        DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
+        hipLaunchKernelGGL(kern, g2, b, lds2, s, e->d_engs, heur_id, wnn);                                              \
+    } while (0)
+            if (tp == 32) {
+                if (f32) DCA_EXP_TP(4, 32); else DCA_EXP_TP(2, 32);
+            } else {
+                if (f32) DCA_EXP_TP(4, 64); else DCA_EXP_TP(2, 64);
+            }
+#undef DCA_EXP_TP
+            return launch_check("k_expand");
+        }
+    }
     if (E.onehot == nullptr || !want_oh) {
         if (fuse)
             hipLaunchKernelGGL((k_expand<ENV, DIM, 0, true>), g, b, lds, s, e->d_engs, heur_id, wnn);
