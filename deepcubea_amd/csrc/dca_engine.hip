@@ -2631,6 +2631,15 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
                 const uint32_t q = piece * 64u + (threadIdx.x & 63u);
                 if (q >= nch) continue;
                 uint32_t e0 = q * EPC;
+                if constexpr (ENV == DCA_ENV_CUBE3 && OH == 4) {
+                    if (e0 + EPC <= te) {  // one or two stickers and four compares per chunk (dca_tile.h: cube3_onehot32_chunk)
+                        const uint32_t P0 = (q << 1) / 3u, phase = (q << 1) - 3u * P0;
+                        uint32_t w[4];
+                        cube3_onehot32_chunk(phase, staged_nnet(P0), phase == 2u ? staged_nnet(P0 + 1u) : 0u, w);
+                        store16(goh + (size_t)e0 * OH, w, true);
+                        continue;
+                    }
+                }
                 if constexpr (ENV == DCA_ENV_CUBE3 && OH == 2) {
                     if (e0 + EPC <= te) {  // two stickers and a lookup per chunk (dca_tile.h: cube3_onehot16_chunk)
                         const uint32_t P0 = (q << 2) / 3u, phase = (q << 2) - 3u * P0;

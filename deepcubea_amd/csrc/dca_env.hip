@@ -161,6 +161,28 @@ __global__ __launch_bounds__(kThreads) void expand_fused_kernel(
                     continue;
                 }
             }
+            if constexpr (ENV == DCA_ENV_CUBE3 && OH == 4) {
+                // fp32 rows the same way (round 6): one or two stickers and four compares per chunk instead of the element loop's
+                // running (column, position, move, parent) counters
+                if (e0 + EPC <= te) {
+                    const uint32_t P0 = (q << 1) / 3u, phase = (q << 1) - 3u * P0;  // 4 q = 6 P0 + 2 phase
+                    const uint32_t c0p = P0 / (uint32_t)E::D, p0 = P0 - c0p * (uint32_t)E::D;
+                    const uint32_t r0p = c0p / (uint32_t)E::A, a0p = c0p - r0p * (uint32_t)E::A;
+                    uint32_t p1 = p0 + 1u, a1p = a0p, r1p = r0p;
+                    if (p1 == (uint32_t)E::D) {
+                        p1 = 0;
+                        if (++a1p == (uint32_t)E::A) {
+                            a1p = 0;
+                            ++r1p;
+                        }
+                    }
+                    uint32_t w[4];
+                    // (position P0 + 1 is only looked at by the chunks that reach into it; one past the tile: LDS slack, unused)
+                    cube3_onehot32_chunk(phase, t.nnet_byte(r0p, a0p, p0), phase == 2u ? t.nnet_byte(r1p, a1p, p1) : 0u, w);
+                    store16(onehot + (ge + e0) * OH, w, al);
+                    continue;
+                }
+            }
             uint32_t c = e0 / ROW, e = e0 - c * ROW;
             uint32_t pos = e / E::DEPTH, col = e - pos * E::DEPTH;
             uint32_t r = c / E::A, a = c - r * E::A;

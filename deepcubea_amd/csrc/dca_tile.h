@@ -118,6 +118,19 @@ __device__ __forceinline__ void cube3_onehot16_chunk(uint32_t phase, uint32_t v0
     w[3] = phase == 0u ? b0 : phase == 1u ? b1 : b2;
 }
 
+// The same for fp32 elements (one 16-byte chunk = 4 elements): 4 q mod 6 only takes 0 / 4 / 2, so chunk q starts at column
+// c0 = 0, 2 or 4 (phase = 2 q - 3 P0 = 0, 1, 2; c0 = 2 * phase) of position P0 = 2 q / 3 and its words are
+//   c0 = 0: v0 == 0, 1, 2, 3      c0 = 2: v0 == 2, 3, 4, 5      c0 = 4: v0 == 4, 5, then v1 == 0, 1   (v1 = colour of position P0 + 1)
+// i.e. words 0, 1 test v0 - c0 against 0 / 1 and words 2, 3 test (phase == 2 ? v1 : v0 - c0 - 2) against 0 / 1.
+__device__ __forceinline__ void cube3_onehot32_chunk(uint32_t phase, uint32_t v0, uint32_t v1, uint32_t (&w)[4]) {
+    const uint32_t a = v0 - 2u * phase;
+    const uint32_t b = phase == 2u ? v1 : a - 2u;
+    w[0] = a == 0u ? 0x3F800000u : 0u;
+    w[1] = a == 1u ? 0x3F800000u : 0u;
+    w[2] = b == 0u ? 0x3F800000u : 0u;
+    w[3] = b == 1u ? 0x3F800000u : 0u;
+}
+
 // store 16 assembled bytes
 __device__ __forceinline__ void store16(uint8_t* dst, const uint32_t (&w)[4], bool aligned) {
     if (aligned) {
