@@ -425,28 +425,34 @@ def test_back_squeeze_without_a_refill_keeps_exactness(L, co):
 def test_device_set_weights_survive_a_host_upload(L, co):
     """dca_engine_set_weights_dev writes the DEVICE copy of the instance table only; every later call that uploads
     the host's copy (set_tiers, the host weight setters, the profile calls) used to revert it silently.  Two instances created
-    with weight 1.0, set to (0.2, 0.6) from a device array; then set_tiers (an upload) and a host-side change of instance 1
-    ALONE — instance 0 must still search with 0.2 (and instance 1 with the host's 0.4), node for node against the oracle; a
+    with weight 1.0, set to (0.8, 0.6) from a device array; then set_tiers (an upload) and a host-side change of instance 1
+    ALONE — instance 0 must still search with 0.8 (and instance 1 with the host's 0.7), node for node against the oracle; a
     negative / NaN device weight is clamped to 0 (the host setters refuse it)."""
     import torch
     from deepcubea_amd.search_methods.engine import BwasEngine
+    hid = L.HEUR_KNUTH3
     roots = [scramble(co, "cube3", [3, 8, 1, 10, 6]), scramble(co, "cube3", [11, 2, 6, 9, 0])]
-    eng = BwasEngine("cube3", 1.0, 100, max_nodes=1 << 23, num_instances=2)  # (weight 0.2 generates 3.7 M nodes on the first root)
-    eng.set_weights_dev(torch.tensor([0.2, 0.6], dtype=torch.float64, device="cuda"))
+    eng = BwasEngine("cube3", 1.0, 100, max_nodes=1 << 22, num_instances=2)
+    eng.set_weights_dev(torch.tensor([0.8, 0.6], dtype=torch.float64, device="cuda"))
     eng.set_tiers(3200, 9600)          # upload_engs: must carry the device's weights, not the creation-time 1.0
-    eng.set_weight(0.4, instance=1)    # host setter for ONE instance: the other keeps its device-set weight
-    out = eng.solve_many_builtin(roots, L.HEUR_MOD97)
-    for r, root, w in zip(out, roots, (0.2, 0.4)):
-        ref = co.astar("cube3", root, w, 100, co.SEM_PY, heur_builtin_id=0)
+    eng.set_weight(0.7, instance=1)    # host setter for ONE instance: the other keeps its device-set weight
+    out = eng.solve_many_builtin(roots, hid)
+    for r, root, w in zip(out, roots, (0.8, 0.7)):
+        ref = co.astar("cube3", root, w, 100, co.SEM_PY, heur_builtin_id=hid)
         assert r["solved"] and r["moves"] == ref["moves"] and r["nodes_generated"] == ref["nodes_generated"], (w, r, ref)
-    one = co.astar("cube3", roots[0], 1.0, 100, co.SEM_PY, heur_builtin_id=0)
+    one = co.astar("cube3", roots[0], 1.0, 100, co.SEM_PY, heur_builtin_id=hid)
     assert one["nodes_generated"] != out[0]["nodes_generated"]  # (the test can tell the weights apart)
+    # a negative / NaN weight from the device is clamped to 0: 25 iterations of both searches equal the oracle's at weight 0
     eng.set_weights_dev(torch.tensor([-1.0, float("nan")], dtype=torch.float64, device="cuda"))
     eng.set_tiers(3200, 9600)
-    out = eng.solve_many_builtin(roots, L.HEUR_MOD97)
-    for r, root in zip(out, roots):
-        ref = co.astar("cube3", root, 0.0, 100, co.SEM_PY, heur_builtin_id=0)
-        assert r["solved"] and r["moves"] == ref["moves"] and r["nodes_generated"] == ref["nodes_generated"]
+    for i, root in enumerate(roots):
+        eng.reset(root, i)
+        eng.root_commit(L.heuristic_builtin(hid, torch.from_numpy(root[None].copy()).cuda()), i)
+    eng.run_builtin(hid, 25)
+    for i, root in enumerate(roots):
+        ref = co.astar("cube3", root, 0.0, 100, co.SEM_PY, heur_builtin_id=hid, max_iters=25, trace_cap=25, stop_on_goal=False)
+        st = eng.status(i)
+        assert (st["open_size"], st["closed_size"], st["nodes_generated"]) == tuple(int(v) for v in ref["trace"][24]), (i, st, ref["trace"][24])
     eng.close()
 
 
