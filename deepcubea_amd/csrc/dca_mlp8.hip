@@ -20,7 +20,8 @@
 //   * a wave's 64 state rows (64 x D contiguous bytes, 16-byte aligned) come in by 16-byte loads through a wave-private LDS slice;
 //     lane (j, h) builds the K-bit one-hot mask of ONE row (row j for h = 0, row 32 + j for h = 1) and one v_permlane32_swap
 //     per K step hands each lane the 32 mask bits it feeds the instruction with for both of its rows (word 2 s + h of each);
-//     a mask nibble becomes four e4m3 bytes with two multiplies (bit i -> byte i: * 0x00204081 & 0x01010101, * 0x38);
+//     a mask byte becomes eight e4m3 bytes through a 256-entry table in LDS; the rows of the NEXT chunk are prefetched into
+//     registers under the K loop;
 //   * tail: scale / bias from LDS, ReLU + saturation as one v_med3, v_cvt_pk_fp8_f32, 8-byte pieces exchanged inside the wave
 //     through 4 KB of LDS so that 8 lanes store one 128-byte row segment (full lines).
 #include "dca_common.h"
@@ -43,7 +44,9 @@ struct L8Geo {
     static constexpr int MW = KPAD / 32;  // one-hot mask words per row
     static constexpr int W_BYTES = KPAD * kL8Cols;
     static constexpr int ROW_BYTES = ((64 * D + 15) / 16) * 16 + 16;  // a wave's 64 rows (+ slack for the last 16-byte piece)
-    static constexpr int LDS = W_BYTES + 2 * kL8Cols * 4 + (kL8Threads / 64) * (4096 + ROW_BYTES);
+    static constexpr int MISC_BYTES = 2 * kL8Cols * 4 + 256 * 8;  // scale, bias, the byte -> eight e4m3 bytes table
+    static constexpr int NPRE = (64 * D + 1023) / 1024;              // 16-byte row pieces per lane of a wave's 64 rows
+    static constexpr int LDS = W_BYTES + MISC_BYTES + (kL8Threads / 64) * (4096 + ROW_BYTES);
 };
 
 template <int D, int DEPTH>
@@ -56,11 +59,36 @@ __global__ __launch_bounds__(kL8Threads) void k_l1_onehot_gemm8(const uint8_t* _
     uint8_t* lw = l8;
     float* lsc = reinterpret_cast<float*>(l8 + G::W_BYTES);
     float* lbi = lsc + kL8Cols;
+    uint2* lut = reinterpret_cast<uint2*>(lbi + kL8Cols);  // mask byte -> its eight e4m3 bytes (1.0 = 0x38 where the bit is set)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    uint8_t* lx = l8 + G::W_BYTES + 2 * kL8Cols * 4 + wv * (4096 + G::ROW_BYTES);  // the wave's exchange slice ...
-    uint8_t* lr = lx + 4096;                                                        // ... and its staged state rows
+    uint8_t* lx = l8 + G::W_BYTES + G::MISC_BYTES + wv * (4096 + G::ROW_BYTES);  // the wave's exchange slice ...
+    uint8_t* lr = lx + 4096;                                                      // ... and its staged state rows
     const int64_t n0 = (int64_t)blockIdx.x * kL8Cols;
+    // The wave's 64 rows of a chunk (64 x D contiguous bytes; rw is a multiple of 64, so rw * D is a multiple of 16) are
+    // PREFETCHED into registers one chunk ahead: with two waves per SIMD nothing else hides the HBM round trip of the rows,
+    // which is as long as the chunk's whole K loop (the first cut waited for it at the top of every chunk: 31 % MFMA-busy).
+    uint4 pre[G::NPRE];
+    auto prefetch = [&](int64_t chunk_n) {
+        const int64_t rwn = chunk_n * kL8Threads + wv * 64;
+#pragma unroll
+        for (int j = 0; j < G::NPRE; j++) pre[j] = make_uint4(0u, 0u, 0u, 0u);
+        if (rwn >= m) return;
+        const int nb = (int)((m - rwn) < 64 ? (m - rwn) : 64) * D;
+        const uint8_t* g = nn + rwn * D;
+#pragma unroll
+        for (int j = 0; j < G::NPRE; j++) {
+            const int q = lane + 64 * j;
+            if (q * 16 + 16 <= nb) {
+                pre[j] = *reinterpret_cast<const uint4*>(g + q * 16);
+            } else if (q * 16 < nb) {  // the last, partial piece of the matrix: byte by byte (nothing is read past its end)
+                uint32_t t[4] = {0u, 0u, 0u, 0u};
+                for (int b = q * 16; b < nb; b++) t[(b & 15) >> 2] |= (uint32_t)g[b] << (8 * (b & 3));
+                pre[j] = make_uint4(t[0], t[1], t[2], t[3]);
+            }
+        }
+    };
+    prefetch(blockIdx.y);
     {
         const uint4* src = reinterpret_cast<const uint4*>(wt) + (size_t)blockIdx.x * (G::W_BYTES / 16);
         uint4* dst = reinterpret_cast<uint4*>(lw);
@@ -69,6 +97,10 @@ __global__ __launch_bounds__(kL8Threads) void k_l1_onehot_gemm8(const uint8_t* _
             lsc[threadIdx.x] = scale[n0 + threadIdx.x];
             lbi[threadIdx.x] = bias[n0 + threadIdx.x];
         }
+        if (threadIdx.x < 256) {  // bit i of a nibble -> byte i: * 0x00204081 & 0x01010101; 1.0 in e4m3 = 0x38
+            const uint32_t b = threadIdx.x;
+            lut[b] = make_uint2((((b & 0xFu) * 0x00204081u) & 0x01010101u) * 0x38u, (((b >> 4) * 0x00204081u) & 0x01010101u) * 0x38u);
+        }
     }
     __syncthreads();
     const int wcol = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
@@ -76,18 +108,14 @@ __global__ __launch_bounds__(kL8Threads) void k_l1_onehot_gemm8(const uint8_t* _
         const int64_t rw = chunk * kL8Threads + wv * 64;  // first row of this wave (no workgroup barrier below: waves run free)
         if (rw >= m) continue;
         const int nrows = (int)((m - rw) < 64 ? (m - rw) : 64);
-        // ---- the wave's rows -> LDS (rw is a multiple of 64, so rw * D is a multiple of 16)
+        // ---- the wave's rows (prefetched) -> LDS
         {
-            const uint8_t* g = nn + rw * D;
-            const int nbytes = nrows * D;
-            for (int q = lane; q * 16 < nbytes; q += 64) {
-                if (q * 16 + 16 <= nbytes) {
-                    *reinterpret_cast<uint4*>(lr + q * 16) = *reinterpret_cast<const uint4*>(g + q * 16);
-                } else {
-                    for (int b = q * 16; b < nbytes; b++) lr[b] = g[b];
-                }
+#pragma unroll
+            for (int j = 0; j < G::NPRE; j++) {
+                const int q = lane + 64 * j;
+                if (q * 16 < G::ROW_BYTES - 16) *reinterpret_cast<uint4*>(lr + q * 16) = pre[j];
             }
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
         // ---- one-hot mask of ONE row per lane (row l31 for h = 0, row 32 + l31 for h = 1): bit pos * DEPTH + value
@@ -133,6 +161,8 @@ __global__ __launch_bounds__(kL8Threads) void k_l1_onehot_gemm8(const uint8_t* _
             mk[0][s] = r[0];
             mk[1][s] = r[1];
         }
+        __builtin_amdgcn_wave_barrier();  // (every lane has read its row: the slice may be rewritten by the next chunk)
+        prefetch(chunk + gridDim.y);      // the next chunk's rows fly under this chunk's K loop and tail
         l8_f32x16 acc[2][4];
 #pragma unroll
         for (int i = 0; i < 2; i++)
@@ -146,8 +176,11 @@ __global__ __launch_bounds__(kL8Threads) void k_l1_onehot_gemm8(const uint8_t* _
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
-                for (int d = 0; d < 8; d++)  // mask bits 4 d .. 4 d + 3 -> four e4m3 bytes (1.0 = 0x38)
-                    bf[i][d] = (int)(((((mk[i][s] >> (4 * d)) & 0xFu) * 0x00204081u) & 0x01010101u) * 0x38u);
+                for (int d = 0; d < 4; d++) {  // mask byte d -> eight e4m3 bytes: one 8-byte LDS read (the arithmetic form — two
+                    const uint2 t = lut[(mk[i][s] >> (8 * d)) & 0xFFu];  // multiplies and two masks per four bytes — was a third of the kernel's VALU work)
+                    bf[i][2 * d] = (int)t.x;
+                    bf[i][2 * d + 1] = (int)t.y;
+                }
 #pragma unroll
             for (int jn = 0; jn < 4; jn++) {
                 const uint8_t* p = lw + ((size_t)((s * 4 + h * 2) * kL8Cols + jn * 32 + wcol)) * 16;
