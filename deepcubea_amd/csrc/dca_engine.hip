@@ -2499,14 +2499,14 @@ constexpr int kEngTile = 16;  // parents per workgroup: a 20 000-parent batch th
 // row in HBM yet.  It needs none: its id says which popped parent and which move made it (id = base + rank * A + move),
 // and the parent's row was written an iteration ago — the tile rebuilds the representative from it (16 lanes per pending
 // comparison) and compares exactly.
-// TP: parents per workgroup.  16 everywhere (a 20 000-parent batch = 1250 workgroups); 32 / 64 exist for the launches that also
-// write one-hot rows (knob 8, A/B: a workgroup's one-hot output is then one contiguous 0.5 / 1 MB run instead of 249 KB).
-template <int ENV, int DIM, int OH, bool PROBE, int TP = kEngTile>
+template <int ENV, int DIM, int OH, bool PROBE>
 __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ engs, int heur_id, int write_nn) {
     const Eng& E = engs[blockIdx.y];
     using EV = EnvT<ENV, DIM>;
-    using TL = Tile<ENV, DIM, TP>;
-    constexpr int kTileParents = TP;  // shadows the stand-alone kernels' 64
+    using TL = Tile<ENV, DIM, kEngTile>;
+    constexpr int kTileParents = kEngTile;  // shadows the stand-alone kernels' 64 (32 / 64 parents per workgroup measured SLOWER
+                                            // also for the launches that write one-hot rows: profiles/r06_engine_ab.txt)
+    constexpr int TP = kEngTile;
     Ctl* c = E.ctl;
     if (c->done) return;
     Stamp stamp(E, P_EXPAND);
@@ -2517,7 +2517,6 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
     __shared__ uint32_t l_pid[TP], l_g[TP];
     __shared__ uint32_t l_qn, l_qcc[PROBE ? kThreads : 1], l_qrep[PROBE ? kThreads : 1], l_qres[PROBE ? kThreads : 1];
     __shared__ uint32_t l_ohq;  // one-hot rows: next 1 KiB piece (one wave-wide 16-byte store) nobody has claimed yet
-    __shared__ uint32_t l_pdone;  // waves of the per-child round whose probes are through (what a storing idle wave polls)
     static_assert((EV::D + 3) / 4 < 16, "no spare lane per row for the parent's path cost");
     // batch geometry: every workgroup derives it from the state the previous iteration left (S[iters & 1]) and the
     // pop that k_rank just finished; workgroup 0 also records it for the rest of the iteration (close_pop)
@@ -2544,10 +2543,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
     }
     if (r0 >= npop) return;
     const uint32_t np = min((uint32_t)kTileParents, npop - r0);
-    if (OH != 0 && threadIdx.x == 0) {
-        l_ohq = 0;
-        l_pdone = 0;
-    }
+    if (OH != 0 && threadIdx.x == 0) l_ohq = 0;
     {
         // gather the popped rows by node id.  One lane per (parent, 4-byte word): 16 lanes cover a row, so
         // a 256-thread block fetches 16 rows per round and the 4 rounds are issued back to back.
@@ -2590,15 +2586,12 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
 
     // One-hot rows of the tile's children (pytorch_models.py:49-52), from the child rows staged in `lst`.  The rows of a tile are
     // one contiguous run of the batch's one-hot buffer; it is cut into 1 KiB pieces — one wave-wide 16-byte store each — which
-    // the waves CLAIM from an LDS counter, so that whichever wave has nothing else to do can store.  Shipped order: every store
-    // after the probe (all workgroups of the launch are resident at once: they probe at the same time, then store at the same
-    // time).  Round 6 tried to put stores UNDER the probe — the wave of the per-child round that holds no child (192 children on
-    // 256 lanes for cube3: wave 3) storing while the others walk their load -> compare-and-swap -> row-compare chains:
-    //   * unpaced (half / all of the tile's pieces at once): 110 / 141 us instead of 98.6 — the probe's loads queue behind the
-    //     idle wave's stores in the CU's one memory pipe, three dependent round trips each a few microseconds longer;
-    //   * PACED (knob 14 = 2): at most `pace` stores of the idle wave in flight (s_waitcnt vmcnt after each), and it stops as
-    //     soon as the probing waves have signalled (l_pdone) — profiles/r06_engine_ab.txt has what that measured.
-    auto oh_emit = [&](uint32_t max_pieces, const int pace = 0, const uint32_t stop_at = 0u) {
+    // the waves CLAIM from an LDS counter.  Every store comes after the probe: all workgroups of the launch are resident at
+    // once, they probe at the same time and then store at the same time, and the launch takes its stores (57-63 us for fp32
+    // rows at B = 20 000) PLUS its probe (~28 us).  Round 6 tried to overlap the two — the wave of the per-child round that holds
+    // no child storing under the others' probe, unpaced (110-141 us instead of 97: the probe's loads queue behind the stores in
+    // the CU's one memory pipe) and paced (level) — and larger tiles (32 / 64 parents: 108 / 145 us); profiles/r06_engine_ab.txt.
+    auto oh_emit = [&]() {
         if constexpr (OH != 0) {
             constexpr uint32_t ROW = EV::D * EV::DEPTH;
             constexpr uint32_t EPC = 16 / OH;
@@ -2612,18 +2605,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
                 const uint32_t b = lst[i];
                 return ENV == DCA_ENV_CUBE3 ? (b * 57u) >> 9 : b;
             };
-            for (uint32_t n = 0; n < max_pieces; n++) {
-                if (pace != 0) {  // (the idle wave under the probe: few stores in flight, and done as soon as the probers are)
-                    if (pace <= 1)
-                        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-                    else if (pace <= 2)
-                        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                    else if (pace <= 4)
-                        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    else
-                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    if (*reinterpret_cast<volatile uint32_t*>(&l_pdone) >= stop_at) break;
-                }
+            for (;;) {
                 uint32_t piece = 0;
                 if ((threadIdx.x & 63u) == 0) piece = atomicAdd(&l_ohq, 1u);
                 piece = (uint32_t)__builtin_amdgcn_readfirstlane((int)piece);
@@ -2687,8 +2669,6 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
             }
         }
     };
-    const int oh_mode = OH != 0 ? g_tune[14] : 0;  // (knob 14, A/B: 0 = every store after the probe — shipped —, 2 = paced stores of the idle wave under the probe)
-    const int oh_pace = g_tune[15] > 0 ? g_tune[15] : 2;
 
     // per child: hash, is_solved, node fields, built-in heuristic (rounds of 256 children; uniform: the probe below
     // synchronises the workgroup inside a round)
@@ -2754,13 +2734,8 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
             const uint64_t tag = h >> 32;
             bool active = cvalid, inserted = false, paused = false;
             uint32_t slot = (uint32_t)h & E.tab_mask, v0 = GINF, rep_id = 0, probes = 0, qi = 0;
-            __syncthreads();  // the round's rows are staged (lst) — and l_qn, l_pdone are zero
-            // (knob 14 = 2) a wave without a child in this round — it can only be the LAST round: every row of the tile is staged
-            const bool oh_idle_wave = OH != 0 && oh_mode == 2 && cc0 + (threadIdx.x & ~63u) >= nchild;
-            const uint32_t oh_probers = (min(nchild - cc0, (uint32_t)kThreads) + 63u) >> 6;  // waves of this round that hold children
-            bool oh_first = OH != 0 && oh_mode == 2;
+            __syncthreads();  // the round's rows are staged (lst) — and l_qn is zero
             for (;;) {
-                if (oh_first && oh_idle_wave) oh_emit(~0u, oh_pace, oh_probers);  // until the probing waves have signalled
                 if (active && !paused) {
                     for (;;) {
                         // look first, claim second; one 16-byte load fetches the entry with its value (see k_probe)
@@ -2814,8 +2789,6 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
                         }
                     }
                 }
-                if (oh_first && !oh_idle_wave && (threadIdx.x & 63u) == 0) atomicAdd(&l_pdone, 1u);  // this wave's probes are through
-                oh_first = false;
                 __syncthreads();
                 const uint32_t nq = l_qn;
                 if (nq == 0) break;
@@ -2921,8 +2894,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(const Eng* __restrict__ eng
         }
     }
 
-    // the one-hot pieces nobody has claimed yet (all of them, unless an idle wave stored under the probe)
-    oh_emit(~0u);
+    oh_emit();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3546,29 +3518,6 @@ int launch_expand_env(const dca_engine* e, int heur_id, bool want_oh, bool want_
     const size_t lds = TL::LDS_BYTES + ((kEngTile * EnvT<ENV, DIM>::A * EnvT<ENV, DIM>::D + 15) / 16) * 16 + 64;  // (+ slack: the one-hot loop peeks one byte past the tile)
     const bool fuse = fuse_probe();
     const int wnn = ((want_nn && heur_id < 0) || h_tune[12] != 0) ? 1 : 0;  // (knob 12: always write them, the round-4 behaviour, for A/B runs)
-    if constexpr (ENV == DCA_ENV_CUBE3 || ENV == DCA_ENV_NPUZZLE) {
-        // (knob 8, A/B: 32 or 64 parents per workgroup for the launches that write one-hot rows)
-        if (E.onehot != nullptr && want_oh && fuse && (h_tune[8] == 32 || h_tune[8] == 64)) {
-            const int tp = h_tune[8];
-            using TL2 = Tile<ENV, DIM, 64>;
-            const size_t lds2 = TL2::LDS_BYTES + ((size_t)(tp * EnvT<ENV, DIM>::A * EnvT<ENV, DIM>::D + 15) / 16) * 16 + 64;
-            const dim3 g2 = gxy((E.B + tp - 1) / tp, e);
-            const bool f32 = E.oh_dtype == DCA_DT_F32;
-#define DCA_EXP_TP(OHV, TPV)                                                                                            \
-    do {                                                                                                                \
-        auto kern = k_expand<ENV, DIM, OHV, true, TPV>;                                                                 \
-        DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
-        hipLaunchKernelGGL(kern, g2, b, lds2, s, e->d_engs, heur_id, wnn);                                              \
-    } while (0)
-            if (tp == 32) {
-                if (f32) DCA_EXP_TP(4, 32); else DCA_EXP_TP(2, 32);
-            } else {
-                if (f32) DCA_EXP_TP(4, 64); else DCA_EXP_TP(2, 64);
-            }
-#undef DCA_EXP_TP
-            return launch_check("k_expand");
-        }
-    }
     if (E.onehot == nullptr || !want_oh) {
         if (fuse)
             hipLaunchKernelGGL((k_expand<ENV, DIM, 0, true>), g, b, lds, s, e->d_engs, heur_id, wnn);

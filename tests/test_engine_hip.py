@@ -456,43 +456,37 @@ def test_device_set_weights_survive_a_host_upload(L, co):
     eng.close()
 
 
-@pytest.mark.parametrize("knobs", [{8: 32}, {8: 64}, {14: 2}, {14: 2, 15: 1}, {8: 64, 14: 2}], ids=lambda k: ",".join("%d=%d" % kv for kv in k.items()))
-@pytest.mark.parametrize("env,dt", [("cube3", torch.float32), ("cube3", torch.bfloat16), ("puzzle15", torch.float32)])
-def test_onehot_launch_variants_write_the_same_rows_and_search(L, co, knobs, env, dt):
-    """The A/B forms of the expansion launch that also writes one-hot rows (knob 8: 32 / 64 parents per workgroup — several
-    per-child rounds per tile —, knob 14 = 2: the idle wave stores paced under the CLOSED probe): the same one-hot rows, the
-    same network-input rows, the same search as the oracle, batch sizes that leave the last tile ragged."""
+@pytest.mark.parametrize("env,dt", [("cube3", torch.float32), ("cube3", torch.bfloat16), ("cube3", torch.float16), ("puzzle15", torch.float32),
+                                    ("puzzle15", torch.bfloat16)])
+def test_onehot_rows_written_by_the_expansion_launch(L, co, env, dt):
+    """The north star's "one-hot encoding fused into the same launch", inside the search: the expansion launch's one-hot rows
+    (claimed 1 KiB pieces; cube3 rows assembled chunk-wise from one or two stickers, dca_tile.h) equal the one-hot of the
+    children it generated — fp32, bf16 and fp16 rows, batches that leave the last tile ragged — and the search equals the oracle's."""
     from deepcubea_amd.search_methods.engine import BwasEngine
     from oracle import np_oracle as no
     depth = 6 if env == "cube3" else 16
     root = scramble(co, env, [3, 8, 1, 10, 6] if env == "cube3" else [0, 2, 0, 2, 1, 3, 0, 0, 2, 1])
     B = 150
     ref = co.astar(env, root, 0.8, B, co.SEM_PY, heur_builtin_id=1, trace_cap=10000)
-    try:
-        for k, v in knobs.items():
-            L.check(L.lib().dca_debug_tune(k, v), "dca_debug_tune")
-        eng = BwasEngine(env, 0.8, B, max_nodes=1 << 19, onehot_dtype=dt)
-        eng.reset(root)
-        eng.root_commit(L.heuristic_builtin(1, torch.from_numpy(root[None].copy()).cuda()))
-        it = 0
-        while True:
-            nn, oh = eng.pop_expand()
-            ch = eng.last_children()
-            m = ch.shape[0]
-            h = torch.zeros(eng.m_capacity, dtype=torch.float32, device="cuda")
-            h[:m] = L.heuristic_builtin(1, ch.contiguous())
-            if it < 6 or it % 7 == 0:
-                chn = ch.cpu().numpy()
-                want_nn = chn // 9 if env == "cube3" else chn
-                assert np.array_equal(nn[:m].cpu().numpy(), want_nn)
-                assert np.array_equal(oh[:m].float().cpu().numpy(), no.onehot(want_nn, depth))
-            eng.commit(h)
-            it += 1
-            if eng.status()["done"]:
-                break
-        res = eng._result()
-        assert res["moves"] == ref["moves"] and res["nodes_generated"] == ref["nodes_generated"] and res["iterations"] == ref["iterations"]
-        eng.close()
-    finally:
-        for k in knobs:
-            L.check(L.lib().dca_debug_tune(k, 0), "dca_debug_tune")
+    eng = BwasEngine(env, 0.8, B, max_nodes=1 << 19, onehot_dtype=dt)
+    eng.reset(root)
+    eng.root_commit(L.heuristic_builtin(1, torch.from_numpy(root[None].copy()).cuda()))
+    it = 0
+    while True:
+        nn, oh = eng.pop_expand()
+        ch = eng.last_children()
+        m = ch.shape[0]
+        h = torch.zeros(eng.m_capacity, dtype=torch.float32, device="cuda")
+        h[:m] = L.heuristic_builtin(1, ch.contiguous())
+        if it < 6 or it % 7 == 0:
+            chn = ch.cpu().numpy()
+            want_nn = chn // 9 if env == "cube3" else chn
+            assert np.array_equal(nn[:m].cpu().numpy(), want_nn)
+            assert np.array_equal(oh[:m].float().cpu().numpy(), no.onehot(want_nn, depth))
+        eng.commit(h)
+        it += 1
+        if eng.status()["done"]:
+            break
+    res = eng._result()
+    assert res["moves"] == ref["moves"] and res["nodes_generated"] == ref["nodes_generated"] and res["iterations"] == ref["iterations"]
+    eng.close()

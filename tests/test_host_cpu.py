@@ -529,11 +529,13 @@ def test_sharers_are_counted_by_physical_device_not_by_index(monkeypatch):
 
 def test_bench_reads_the_committed_pmc_traffic_of_this_round():
     """bench.py's `roofline.traffic` figures come from the rocprofv3 PMC passes committed under profiles/ (counters cannot be read
-    inside the timed process): the engine kernels' and the gather kernel's entries of round 5 are there and name their source."""
+    inside the timed process): the engine kernels' and the gather kernel's entries of THIS round (6) are there and name their source."""
     import importlib
     bench = importlib.import_module("bench")
     t = bench.pmc_traffic("k_expand", "cube3", 20000)
-    assert t is not None and 3e7 < t < 1.2e8 and bench.PMC_SOURCE["k_expand"].startswith("profiles/r05_pmc_traffic.json")
+    assert t is not None and 3e7 < t < 1.2e8 and bench.PMC_SOURCE["k_expand"].startswith("profiles/r06_pmc_traffic.json")
+    bench.expand_pmc_traffic("f32", 1_000_000)
+    assert bench.PMC_SOURCE["expand_fused_kernel<cube3,f32>"].startswith("profiles/r06_expand_pmc_traffic.json")
     for oh, alg in (("f32", 16_254_000_000), ("bf16", 8_478_000_000)):
         b = bench.expand_pmc_traffic(oh, 1_000_000)
         assert b is not None and alg <= b <= 1.03 * alg, (oh, b)  # no re-reads: measured traffic = algorithmic bytes (+ hash / solved)
