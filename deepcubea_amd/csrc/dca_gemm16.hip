@@ -29,7 +29,25 @@ namespace dca {
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// The matrix instruction of all three kernels is v_mfma_f32_16x16x32_{bf16,f16} (round 6; it was 32x32x16 until then).  Both
+// shapes peak at the same rate, but on RANDOM operands the chip runs at its power limit and the 32x32x16 form draws more per
+// flop: MFMAs alone, from registers, 8 waves per CU, sustain 1780 TFLOP/s with 32x32x16 and 2030 with 16x16x32 (2466 for both on
+// all-zero operands; tools/mfma_power_probe.hip, profiles/r06_mfma_power_probe.txt) — hipBLASLt's gfx950 kernels are built on
+// 16x16 too ("MI16x16x1" in their names), which is why they lost 7 % to random data where these kernels lost 26 %.
+// Fragment of a 16-row block for the K step t (32 deep) of a 64-deep K-tile: lane (g = lane >> 4, j = lane & 15) holds row j,
+// 16-byte chunk 4 t + g of the 128-byte row — the same LDS image, DMA map and swizzle as before (the four lane groups of a
+// ds_read_b128 still meet 16 different (row parity, slot) pairs: conflict-free).  D = A . B: lane (g, j) holds
+// D[4 g + r][j], r = 0..3.
+template <bool BF16, typename F>
+__device__ __forceinline__ f32x4 mma16(const F& a, const F& b, const f32x4& c) {
+    if constexpr (BF16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
 
 constexpr int QBM = 256, QBN = 256, QBK = 64, QTHREADS = 512;
 constexpr int QIMG = 256 * QBK * 2;  // bytes of one operand image (32 KB)
@@ -75,21 +93,23 @@ __device__ __forceinline__ float from_f16(uint16_t b) {
     return (float)h;
 }
 
-// Layer tail, shared by both schedules.  Accumulator layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+// Layer tail, shared by both schedules.  Accumulator layout (activations = A operand): acc[ib][jb][r] = row ib * 16 + 4 g + r,
+// column jb * 16 + j of the wave's 128 x 64 (g = lane >> 4, j = lane & 15).  NJ counts the wave's 32-column groups.
 template <bool BF16, int NJ>
-__device__ __forceinline__ void gemm16_epilogue(const Gemm16Args& p, uint8_t* lds, f32x16 (&acc)[4][NJ], int64_t m0, int n0, int w,
+__device__ __forceinline__ void gemm16_epilogue(const Gemm16Args& p, uint8_t* lds, f32x4 (&acc)[8][2 * NJ], int64_t m0, int n0, int w,
                                                 int wm, int wn, int lane, int l31, int h) {
+    const int g4 = lane >> 4, j16 = lane & 15;
     // Each wave transposes its tile (4 x NJ blocks of 32 x 32) through its own NJ * 8 KB of the (now idle) LDS, 32 rows at a
     // time, and leaves with 8-byte accesses: a lane owns 4 consecutive columns of a row (one 8-byte skip load, one 8-byte
     // store; 16 lanes = 128 contiguous bytes).
     constexpr int CW = NJ * 32, LPR = CW / 4, RPP = 64 / LPR, NP = 32 / RPP;  // columns per wave, lanes per row, rows per pass, passes
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the operand stages
     float* sl = reinterpret_cast<float*>(lds + w * (CW * 32 * 4));
-    float bv[NJ];
+    float bv[2 * NJ];
 #pragma unroll
-    for (int jn = 0; jn < NJ; jn++) {
-        const int col = n0 + wn * CW + jn * 32 + l31;
-        bv[jn] = (col < p.n && p.bias) ? p.bias[col] : 0.f;
+    for (int jb = 0; jb < 2 * NJ; jb++) {
+        const int col = n0 + wn * CW + jb * 16 + j16;
+        bv[jb] = (col < p.n && p.bias) ? p.bias[col] : 0.f;
     }
     const int c4 = (lane % LPR) * 4;  // this lane's 4 columns inside the wave's CW
     const int colg = n0 + wn * CW + c4;
@@ -101,10 +121,11 @@ __device__ __forceinline__ void gemm16_epilogue(const Gemm16Args& p, uint8_t* ld
     auto rows32 = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
 #pragma unroll
-        for (int jn = 0; jn < NJ; jn++)
+        for (int b = 0; b < 2; b++)
 #pragma unroll
-            for (int reg = 0; reg < 16; reg++)
-                sl[((reg & 3) + 8 * (reg >> 2) + 4 * h) * CW + jn * 32 + l31] = acc[i][jn][reg] + bv[jn];
+            for (int jb = 0; jb < 2 * NJ; jb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) sl[(16 * b + 4 * g4 + r) * CW + jb * 16 + j16] = acc[2 * i + b][jb][r] + bv[jb];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private slice: no barrier, just the wave's own writes
         const int64_t rbase = m0 + wm * 128 + i * 32;
         uint2 sk[NP];
@@ -202,13 +223,14 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16(const Gemm16Args p) {
         }
     };
 
-    f32x16 acc[4][2];
+    f32x4 acc[8][4];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 8; i++)
 #pragma unroll
-        for (int jn = 0; jn < 2; jn++)
+        for (int jn = 0; jn < 4; jn++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][jn][e] = 0.f;
+            for (int e = 0; e < 4; e++) acc[i][jn][e] = 0.f;
+    const int g4 = lane >> 4, j16 = lane & 15;
 
     const int nk = p.k / QBK;
     issue(0, 0);
@@ -219,26 +241,21 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16(const Gemm16Args p) {
         if (kt + 1 < nk) issue((kt + 1) & 1, (kt + 1) * QBK);
         const uint8_t* base = lds + (kt & 1) * QSTAGE;
 #pragma unroll
-        for (int s = 0; s < QBK / 16; s++) {
-            const uint32_t c = 2u * s + (uint32_t)h;
+        for (int s = 0; s < QBK / 32; s++) {
+            const uint32_t c = 4u * s + (uint32_t)g4;
             // (typed vector loads, not HIP's uint4 struct: the compiler orders a fragment read behind the LDS-DMA in flight
             // — s_waitcnt vmcnt(0) in front of the first ds_read, no overlap at all — unless type-based alias
             // information tells it the two cannot meet)
-            frag_t av[4], wv[2];
+            frag_t av[8], wv[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) av[i] = *reinterpret_cast<const frag_t*>(base + swz128((uint32_t)(wm * 128 + i * 32 + l31), c));
+            for (int i = 0; i < 8; i++) av[i] = *reinterpret_cast<const frag_t*>(base + swz128((uint32_t)(wm * 128 + i * 16 + j16), c));
 #pragma unroll
-            for (int jn = 0; jn < 2; jn++)
-                wv[jn] = *reinterpret_cast<const frag_t*>(base + QIMG + swz128((uint32_t)(wn * 64 + jn * 32 + l31), c));
+            for (int jn = 0; jn < 4; jn++)
+                wv[jn] = *reinterpret_cast<const frag_t*>(base + QIMG + swz128((uint32_t)(wn * 64 + jn * 16 + j16), c));
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < 8; i++)
 #pragma unroll
-                for (int jn = 0; jn < 2; jn++) {
-                    if constexpr (BF16)
-                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], wv[jn], acc[i][jn], 0, 0, 0);
-                    else
-                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], wv[jn], acc[i][jn], 0, 0, 0);
-                }
+                for (int jn = 0; jn < 4; jn++) acc[i][jn] = mma16<BF16>(av[i], wv[jn], acc[i][jn]);
         }
     }
 
@@ -328,43 +345,45 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16p(const Gemm16Args p) {
         }
     };
 
-    f32x16 acc[4][2];
+    f32x4 acc[8][4];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 8; i++)
 #pragma unroll
-        for (int jn = 0; jn < 2; jn++)
+        for (int jn = 0; jn < 4; jn++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][jn][e] = 0.f;
+            for (int e = 0; e < 4; e++) acc[i][jn][e] = 0.f;
 
-    // fragment addresses inside a slot: local row = (wave's block) * 32 + l31, logical chunk 2 s + h
-    uint32_t foff[4];
+    // fragment addresses inside a slot: local row = (wave's 16-row block) * 16 + j, logical chunk 4 t + g (K step t = 0, 1)
+    const int g4 = lane >> 4, j16 = lane & 15;
+    uint32_t foff[2];
 #pragma unroll
-    for (int s = 0; s < 4; s++) foff[s] = swz128((uint32_t)l31, 2u * s + (uint32_t)h);
-    const uint32_t a_row0 = (uint32_t)wm * 64u * 128u;  // A slots: this wave row's 64 local rows
-    const uint32_t b_row0 = (uint32_t)wn * 32u * 128u;  // B slots: this wave column's 32 local rows
+    for (int s = 0; s < 2; s++) foff[s] = swz128((uint32_t)j16, 4u * s + (uint32_t)g4);
+    const uint32_t a_row0 = (uint32_t)wm * 64u * 128u;  // A slots: this wave row's 64 local rows (four 16-row blocks)
+    const uint32_t b_row0 = (uint32_t)wn * 32u * 128u;  // B slots: this wave column's 32 local rows (two 16-row blocks)
 
-    frag_t av[2][4], wv0[4], wv1[4];
+    frag_t av[4][2], wv0[2][2], wv1[2][2];
     auto read_a = [&](const uint8_t* base, int u) {
 #pragma unroll
-        for (int ii = 0; ii < 2; ii++)
+        for (int ii = 0; ii < 4; ii++)
 #pragma unroll
-            for (int s = 0; s < 4; s++)
-                av[ii][s] = *reinterpret_cast<const frag_t*>(base + u * PSLOT + a_row0 + ii * 4096 + foff[s]);
+            for (int s = 0; s < 2; s++)
+                av[ii][s] = *reinterpret_cast<const frag_t*>(base + u * PSLOT + a_row0 + ii * 2048 + foff[s]);
     };
-    auto read_b = [&](const uint8_t* base, int u, frag_t (&wv)[4]) {
+    auto read_b = [&](const uint8_t* base, int u, frag_t (&wv)[2][2]) {
 #pragma unroll
-        for (int s = 0; s < 4; s++) wv[s] = *reinterpret_cast<const frag_t*>(base + u * PSLOT + b_row0 + foff[s]);
+        for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+            for (int s = 0; s < 2; s++) wv[jj][s] = *reinterpret_cast<const frag_t*>(base + u * PSLOT + b_row0 + jj * 2048 + foff[s]);
     };
+    // one phase: (I0 / 2)-th half of the wave's rows (four 16-row blocks) x JN-th half of its columns (two 16-column blocks) x
+    // both K steps = 16 MFMAs; every accumulator takes step 0 before step 1, like the two-stage loop
 #define DCA_MMA8(I0, JN, WV)                                                                                          \
     do {                                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
         __builtin_amdgcn_s_setprio(1);                                                                                \
-        _Pragma("unroll") for (int s = 0; s < 4; s++) _Pragma("unroll") for (int ii = 0; ii < 2; ii++) {              \
-            if constexpr (BF16)                                                                                       \
-                acc[(I0) + ii][JN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ii][s], WV[s], acc[(I0) + ii][JN], 0, 0, 0); \
-            else                                                                                                      \
-                acc[(I0) + ii][JN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[ii][s], WV[s], acc[(I0) + ii][JN], 0, 0, 0);  \
-        }                                                                                                             \
+        _Pragma("unroll") for (int s = 0; s < 2; s++) _Pragma("unroll") for (int ii = 0; ii < 4; ii++)                \
+            _Pragma("unroll") for (int jj = 0; jj < 2; jj++)                                                          \
+                acc[2 * (I0) + ii][2 * (JN) + jj] = mma16<BF16>(av[ii][s], WV[jj][s], acc[2 * (I0) + ii][2 * (JN) + jj]); \
         __builtin_amdgcn_s_setprio(0);                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
     } while (0)
@@ -484,11 +503,11 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16p(const Gemm16Args p) {
 // active — the tail got 7.4 us long instead of disappearing — and the K loop itself runs at that same fetch rate (64 KB per
 // K-tile in ~1.75 us), not at the matrix pipe's.
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int sigma16(int jn, int i) {
-    // MFMA row i = r + 8 q + 4 h (r = reg & 3, q = reg >> 2, h = lane half)  ->  column inside the wave's 64:
-    // (jn * 2 + (q >> 1)) * 16 + h * 8 + (q & 1) * 4 + r
-    const int r = i & 3, hh = (i >> 2) & 1, q = i >> 3;
-    return (jn * 2 + (q >> 1)) * 16 + hh * 8 + (q & 1) * 4 + r;
+__device__ __forceinline__ int sigma16(int jb, int i) {
+    // 16 x 16 blocks: MFMA row i = 4 g + r of weight block jb (g = lane >> 4 of the lane that will hold it, r = its register)
+    //   ->  column inside the wave's 64: (jb >> 1) * 32 + g * 8 + (jb & 1) * 4 + r,
+    // so that lane (g, j) finds columns (jb >> 1) * 32 + g * 8 + 0..7 of ITS activation row in acc[.][2 p][0..3], acc[.][2 p + 1][0..3]
+    return (jb >> 1) * 32 + (i >> 2) * 8 + (jb & 1) * 4 + (i & 3);
 }
 
 
@@ -515,27 +534,33 @@ __device__ __forceinline__ float hi16(uint32_t v) {
 }
 
 // Tail of a FULL tile.  tl: this wave's 4 KB exchange slice; rows cm0 + wm*128 .. +128, columns cn0 + wn*64 .. +64.
+// Lane (g = lane >> 4, j = lane & 15) holds, of the 32-row group i: rows 16 b + j (b = 0, 1: accumulator blocks 2 i + b), of each
+// the two 16-byte pieces c16 = 4 p + g (p = 0, 1: columns p * 32 + g * 8 .. + 8 = acc[2 i + b][2 p][0..3], acc[2 i + b][2 p + 1][0..3]).
 template <bool BF16, bool SKIP, bool RELU, bool BIAS>
-__device__ __forceinline__ void gemm16_tail_full(const Gemm16Args& p, uint8_t* tl, f32x16 (&acc)[4][2], int64_t cm0, int cn0, int wm,
+__device__ __forceinline__ void gemm16_tail_full(const Gemm16Args& p, uint8_t* tl, f32x4 (&acc)[8][4], int64_t cm0, int cn0, int wm,
                                                  int wn, int l31, int h) {
     const int tg = l31 >> 2, tx = l31 & 3;
-    const uint32_t a_own = (uint32_t)l31 * 128u;  // + ((c16 ^ (row & 7)) << 4)
-    auto own_addr = [&](int X) { return tl + a_own + ((uint32_t)(((X * 2 + h) ^ (l31 & 7))) << 4); };
+    const int lane_ = h * 32 + l31, g4 = lane_ >> 4, j16 = lane_ & 15;
+    // piece X = 2 b + p of the lane's four: row 16 b + j, c16 = 4 p + g
+    auto own_addr = [&](int X) {
+        const int row = 16 * (X >> 1) + j16, c16 = 4 * (X & 1) + g4;
+        return tl + row * 128 + ((uint32_t)((c16 ^ (row & 7))) << 4);
+    };
     auto quad_addr = [&](int j) {
         const int row = 4 * tg + j;
         return tl + row * 128 + ((uint32_t)(((tx * 2 + h) ^ (row & 7))) << 4);
     };
     const int colw = cn0 + wn * 64;
-    if constexpr (BIAS) {  // bias of this lane's 4 x 8 columns, added in place
-        const float* bp = p.bias + colw + h * 8;
+    if constexpr (BIAS) {  // bias of this lane's 2 x 8 columns, added in place
+        const float* bp = p.bias + colw + g4 * 8;
 #pragma unroll
-        for (int X = 0; X < 4; X++) {
-            const float4 b0 = *reinterpret_cast<const float4*>(bp + X * 16), b1 = *reinterpret_cast<const float4*>(bp + X * 16 + 4);
+        for (int pp = 0; pp < 2; pp++) {
+            const float4 b0 = *reinterpret_cast<const float4*>(bp + pp * 32), b1 = *reinterpret_cast<const float4*>(bp + pp * 32 + 4);
             const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int ib = 0; ib < 8; ib++)
 #pragma unroll
-                for (int e = 0; e < 8; e++) acc[i][X >> 1][8 * (X & 1) + e] += bb[e];
+                for (int e = 0; e < 8; e++) acc[ib][2 * pp + (e >> 2)][e & 3] += bb[e];
             __builtin_amdgcn_sched_barrier(0);  // (left alone, the scheduler hoists every load of the tail to its top and spills)
         }
     }
@@ -564,9 +589,9 @@ __device__ __forceinline__ void gemm16_tail_full(const Gemm16Args& p, uint8_t* t
 #pragma unroll
             for (int X = 0; X < 4; X++)
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    acc[i][X >> 1][8 * (X & 1) + 2 * e] += lo16<BF16>(mine[X][e]);
-                    acc[i][X >> 1][8 * (X & 1) + 2 * e + 1] += hi16<BF16>(mine[X][e]);
+                for (int e = 0; e < 4; e++) {  // values 2 e, 2 e + 1 of the piece's eight: accumulator 2 p + (e >> 1), registers 2 (e & 1), + 1
+                    acc[2 * i + (X >> 1)][2 * (X & 1) + (e >> 1)][2 * (e & 1)] += lo16<BF16>(mine[X][e]);
+                    acc[2 * i + (X >> 1)][2 * (X & 1) + (e >> 1)][2 * (e & 1) + 1] += hi16<BF16>(mine[X][e]);
                 }
         }
 #pragma unroll
@@ -574,7 +599,8 @@ __device__ __forceinline__ void gemm16_tail_full(const Gemm16Args& p, uint8_t* t
             u32x4 ov;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                float a = acc[i][X >> 1][8 * (X & 1) + 2 * e], b = acc[i][X >> 1][8 * (X & 1) + 2 * e + 1];
+                float a = acc[2 * i + (X >> 1)][2 * (X & 1) + (e >> 1)][2 * (e & 1)],
+                      b = acc[2 * i + (X >> 1)][2 * (X & 1) + (e >> 1)][2 * (e & 1) + 1];
                 if constexpr (RELU) {
                     a = fmaxf(a, 0.f);
                     b = fmaxf(b, 0.f);
@@ -598,12 +624,10 @@ __device__ __forceinline__ void gemm16_tail_full(const Gemm16Args& p, uint8_t* t
     rows32(std::integral_constant<int, 3>{});
 }
 
-// LDSPROBE (dca_gemm16_variant 4 / 5, tools/gemm16_probe.py — WRONG RESULTS, timing only): the same kernel issuing 16 / 12
-// fragment reads per K-tile and wave instead of 24 (0.5 / 0.375 ds_read_b128 per MFMA instead of 0.75: what a 128 x 128 wave tile
-// would read), the skipped fragments replaced by ones already in registers — same MFMAs on random data, same DMA stream, same
-// tail.  The experiment behind round 6's decision on the one-wave-per-SIMD layout: if the K loop's deficit against the library on
-// random operands (it is level on all-zero ones) is the energy of its LDS reads, this must close it.
-template <bool BF16, bool SKIP, bool BIAS, int LDSPROBE = 0>
+// (Round 6 ran this kernel with 16 / 12 fragment reads per K-tile instead of 24 — registers standing in for the skipped fragments,
+// timing only — to price the one-wave-per-SIMD layout's only advantage: 2.5 % of the K loop, profiles/r06_gemm16_probe.txt.  The
+// probe variants were removed when the kernels moved to the 16x16x32 instruction.)
+template <bool BF16, bool SKIP, bool BIAS>
 __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16s(const Gemm16Args p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     using frag_t = typename std::conditional<BF16, b16x8, h16x8>::type;
@@ -628,7 +652,7 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16s(const Gemm16Args p) {
                 const int64_t gr = m0 + (r >> 6) * 128 + (u == PS_A23 ? 64 : 0) + (r & 63);
                 src[u][q] = p.a + gr * p.lda + c * 8;
             } else {
-                const int gn = n0 + (int)(r >> 5) * 64 + sigma16(u == PS_B1 ? 1 : 0, (int)(r & 31));
+                const int gn = n0 + (int)(r >> 5) * 64 + sigma16((u == PS_B1 ? 2 : 0) + (int)((r >> 4) & 1), (int)(r & 15));
                 src[u][q] = p.w + (int64_t)gn * p.ldw + c * 8;
             }
         }
@@ -640,47 +664,36 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16s(const Gemm16Args p) {
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
-    uint32_t foff[4];
+    const int g4 = lane >> 4, j16 = lane & 15;
+    uint32_t foff[2];
 #pragma unroll
-    for (int s = 0; s < 4; s++) foff[s] = swz128((uint32_t)l31, 2u * s + (uint32_t)h);
+    for (int s = 0; s < 2; s++) foff[s] = swz128((uint32_t)j16, 4u * s + (uint32_t)g4);
     const uint32_t a_row0 = (uint32_t)wm * 64u * 128u;
     const uint32_t b_row0 = (uint32_t)wn * 32u * 128u;
 
-    f32x16 acc[4][2];
-    frag_t av[2][4], wv0[4], wv1[4];
+    f32x4 acc[8][4];
+    frag_t av[4][2], wv0[2][2], wv1[2][2];
     auto read_a = [&](const uint8_t* base, int u) {
 #pragma unroll
-        for (int ii = 0; ii < (LDSPROBE ? 1 : 2); ii++)
+        for (int ii = 0; ii < 4; ii++)
 #pragma unroll
-            for (int s = 0; s < 4; s++)
-                av[ii][s] = *reinterpret_cast<const frag_t*>(base + u * PSLOT + a_row0 + ii * 4096 + foff[s]);
-        if constexpr (LDSPROBE != 0) {
-#pragma unroll
-            for (int s = 0; s < 4; s++) av[1][s] = av[0][(s + 1) & 3];  // (a fragment already in registers stands in)
-        }
+            for (int s = 0; s < 2; s++)
+                av[ii][s] = *reinterpret_cast<const frag_t*>(base + u * PSLOT + a_row0 + ii * 2048 + foff[s]);
     };
-    auto read_b = [&](const uint8_t* base, int u, frag_t (&wv)[4]) {
-        if constexpr (LDSPROBE == 2) {
-            if (u == PS_B1) {
+    auto read_b = [&](const uint8_t* base, int u, frag_t (&wv)[2][2]) {
 #pragma unroll
-                for (int s = 0; s < 4; s++) wv[s] = wv0[(s + 1) & 3];
-                return;
-            }
-        }
+        for (int jj = 0; jj < 2; jj++)
 #pragma unroll
-        for (int s = 0; s < 4; s++) wv[s] = *reinterpret_cast<const frag_t*>(base + u * PSLOT + b_row0 + foff[s]);
+            for (int s = 0; s < 2; s++) wv[jj][s] = *reinterpret_cast<const frag_t*>(base + u * PSLOT + b_row0 + jj * 2048 + foff[s]);
     };
     // (weight fragment = A operand, activation fragment = B operand: see the header)
 #define DCA_MMA8(I0, JN, WV)                                                                                          \
     do {                                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
         __builtin_amdgcn_s_setprio(1);                                                                                \
-        _Pragma("unroll") for (int s = 0; s < 4; s++) _Pragma("unroll") for (int ii = 0; ii < 2; ii++) {              \
-            if constexpr (BF16)                                                                                       \
-                acc[(I0) + ii][JN] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WV[s], av[ii][s], acc[(I0) + ii][JN], 0, 0, 0); \
-            else                                                                                                      \
-                acc[(I0) + ii][JN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WV[s], av[ii][s], acc[(I0) + ii][JN], 0, 0, 0);  \
-        }                                                                                                             \
+        _Pragma("unroll") for (int s = 0; s < 2; s++) _Pragma("unroll") for (int ii = 0; ii < 4; ii++)                \
+            _Pragma("unroll") for (int jj = 0; jj < 2; jj++)                                                          \
+                acc[2 * (I0) + ii][2 * (JN) + jj] = mma16<BF16>(WV[jj][s], av[ii][s], acc[2 * (I0) + ii][2 * (JN) + jj]); \
         __builtin_amdgcn_s_setprio(0);                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
     } while (0)
@@ -729,11 +742,11 @@ __global__ __launch_bounds__(QTHREADS, 2) void k_gemm16s(const Gemm16Args p) {
     };
 
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 8; i++)
 #pragma unroll
-        for (int jn = 0; jn < 2; jn++)
+        for (int jn = 0; jn < 4; jn++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][jn][e] = 0.f;
+            for (int e = 0; e < 4; e++) acc[i][jn][e] = 0.f;
     issue(PS_A01, 0, 0);
     issue(PS_B0, 0, 0);
     issue(PS_B1, 0, 0);
@@ -787,7 +800,7 @@ extern "C" {
  * 8-phase ping-pong schedule with the general tail (what ragged strips and other layer forms always run on); 3 (default) = the
  * same schedule with operand roles swapped and the lean tail for the network's layer forms */
 int dca_gemm16_variant(int v) {
-    DCA_ARG(v >= 1 && v <= 5);  // (4, 5: the LDS-read probes of k_gemm16s — timing only, WRONG results; bf16 bias form)
+    DCA_ARG(v >= 1 && v <= 3);
     g_gemm16_variant = v;
     return 0;
 }
@@ -858,16 +871,6 @@ int dca_gemm16(const void* a, int64_t m, int k, int64_t lda, const void* w, int 
     if (g_gemm16_variant < 3) {
         if (int rc = launch_generic(p, g_gemm16_variant)) return rc;
         return launch_check("k_gemm16");
-    }
-    if (g_gemm16_variant > 3) {  // LDS-read probe: whole tiles, bf16, relu(a . w^T + bias) only
-        DCA_ARG(dtype == DCA_DT_BF16 && bias && !skip && relu && m % QBM == 0 && n % QBN == 0 && ldo % 8 == 0);
-        const void* kern = g_gemm16_variant == 4 ? reinterpret_cast<const void*>(k_gemm16s<true, false, true, 1>)
-                                                 : reinterpret_cast<const void*>(k_gemm16s<true, false, true, 2>);
-        DCA_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
-        const int64_t blocks = ((m / QBM + 7) / 8) * 8 * (n / QBN);
-        void* kargs[] = {&p};
-        DCA_HIP(hipLaunchKernel(kern, dim3((unsigned)blocks), dim3(QTHREADS), kargs, QLDS, s));
-        return launch_check("k_gemm16s (LDS-read probe)");
     }
     // Variant 3 — the lean-tail kernel — serves the network's own layer forms, relu(a . w^T (+ bias) (+ skip)), on whole tiles
     // with 16-byte aligned rows; any other form goes to variant 2, and so do the ragged right and bottom strips of a layer

@@ -62,10 +62,7 @@ int dca_f16x3_gemm_variant(int variant);
  * drained) with the MFMA operand roles swapped and a lean tail compiled per layer form — relu(a . w^T + bias (+ skip)) on whole
  * 256 x 256 tiles with 16-byte aligned rows; other forms and the ragged strips of a layer run on 2 = the same schedule with the
  * general tail; 1 = two whole K-step stages with one drain + barrier per K-step (the plain reference of the race screens).
- * Bit-identical results (same products, same accumulation order).
- * 4 / 5 = TIMING PROBES with WRONG results (tools/gemm16_probe.py): variant 3's kernel issuing 16 / 12 fragment reads per K-tile
- * and wave instead of 24, registers standing in for the skipped fragments — what a 128 x 128 wave tile would read from LDS per
- * MFMA; bf16, whole tiles, relu(a . w^T + bias) only. */
+ * Bit-identical results (same products, same accumulation order). */
 int dca_gemm16_variant(int variant);
 
 #ifdef __cplusplus
