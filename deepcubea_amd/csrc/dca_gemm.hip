@@ -29,6 +29,7 @@ namespace dca {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GBK = 64;  // K granularity of the planes (operands are padded to it)
 
@@ -67,7 +68,18 @@ constexpr int HIMG = 256 * HBK * 2;   // bytes of one operand image (16 KB)
 constexpr int HSTAGE = 4 * HIMG;      // A high, A low, W high, W low
 constexpr int HLDS = 2 * HSTAGE;      // two stages: 128 KB
 
-__device__ __forceinline__ uint32_t swz64(uint32_t row, uint32_t chunk) { return row * 64u + ((chunk ^ ((row >> 2) & 3u)) << 4); }
+// Round 6: the matrix instruction is v_mfma_f32_16x16x32_f16 (it was 32x32x16).  Same peak rate, less power per flop on random
+// operands — MFMAs alone sustain 2030 instead of 1780 TFLOP/s at the chip's power limit (tools/mfma_power_probe.hip; csrc/
+// dca_gemm16.hip has the story) — and these kernels run AT that limit.  A fragment of a 16-row block for one 32-deep K-step:
+// lane (g = lane >> 4, j = lane & 15) holds row j, 16-byte chunk g of the 64-byte row; D = A . B: lane (g, j) holds D[4 g + r][j].
+// The chunk swizzle of a 64-byte row is chunk ^ f((row >> 2) & 3) with f = (0, 2, 3, 1) (it was the identity for the 32-row
+// fragments): the four lane groups of a ds_read_b128 — {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and their upper twins — then
+// meet 16 different (row & 3, slot) pairs, i.e. every bank group once.
+__device__ __forceinline__ uint32_t swz64_key(uint32_t row) { return (0x78u >> (((row >> 2) & 3u) * 2u)) & 3u; }
+__device__ __forceinline__ uint32_t swz64(uint32_t row, uint32_t chunk) { return row * 64u + ((chunk ^ swz64_key(row)) << 4); }
+__device__ __forceinline__ f32x4 mma16h(const f16x8& a, const f16x8& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
 
 // Layer tail of the 256 x 256 kernels (shared by the two-stage and the ping-pong schedule).
 // MODE < 0: any shape, any form, every option tested at run time.  MODE >= 0 (bit 0 skip, bit 1 fp32 output, bit 2 planes): the
@@ -75,8 +87,10 @@ __device__ __forceinline__ uint32_t swz64(uint32_t row, uint32_t chunk) { return
 // no per-row / per-element tests left (round 5: the general tail is ~7400 instructions per wave, most of them branches around
 // cases the network's own shapes never take; csrc/dca_gemm16.hip has the measurements that led here).
 template <int MODE>
-__device__ __forceinline__ void f16x3_epilogue_as(const GemmArgs& p, uint8_t* lds, const f32x16 (&acc)[4][2], int64_t m0, int n0, int w,
+__device__ __forceinline__ void f16x3_epilogue_as(const GemmArgs& p, uint8_t* lds, const f32x4 (&acc)[8][4], int64_t m0, int n0, int w,
                                                   int wm, int wn, int lane, int l31, int h) {
+    // accumulator layout: acc[ib][jb][r] = row ib * 16 + 4 g + r, column jb * 16 + j of the wave's 128 x 64 (g = lane >> 4, j = lane & 15)
+    const int g4 = lane >> 4, j16 = lane & 15;
     // The accumulator layout (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) would make
     // every store a 4-byte (fp32) or 2-byte (planes) column access — measured 1.8 ms per layer, more than the K loop.  So
     // each wave transposes its tile through its own 16 KB of the (now idle) LDS, 32 rows at a time, and leaves with
@@ -89,10 +103,10 @@ __device__ __forceinline__ void f16x3_epilogue_as(const GemmArgs& p, uint8_t* ld
     const bool relu = G ? p.relu != 0 : true;
     float* sl = reinterpret_cast<float*>(lds + w * 16384);
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    float cs[2], bv[2];
+    float cs[4], bv[4];
 #pragma unroll
-    for (int jn = 0; jn < 2; jn++) {
-        const int col = n0 + wn * 64 + jn * 32 + l31;
+    for (int jn = 0; jn < 4; jn++) {
+        const int col = n0 + wn * 64 + jn * 16 + j16;
         const bool cv = G ? col < p.n : true;
         cs[jn] = cv ? ((G ? p.col_scale != nullptr : true) ? p.alpha * p.col_scale[col] : p.alpha) : 0.f;
         bv[jn] = (cv && (G ? p.bias != nullptr : true)) ? p.bias[col] : 0.f;
@@ -104,10 +118,11 @@ __device__ __forceinline__ void f16x3_epilogue_as(const GemmArgs& p, uint8_t* ld
 #pragma unroll
     for (int i = 0; i < 4; i++) {
 #pragma unroll
-        for (int jn = 0; jn < 2; jn++)
+        for (int b = 0; b < 2; b++)
 #pragma unroll
-            for (int reg = 0; reg < 16; reg++)
-                sl[((reg & 3) + 8 * (reg >> 2) + 4 * h) * 64 + jn * 32 + l31] = acc[i][jn][reg] * cs[jn] + bv[jn];
+            for (int jb = 0; jb < 4; jb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) sl[(16 * b + 4 * g4 + r) * 64 + jb * 16 + j16] = acc[2 * i + b][jb][r] * cs[jb] + bv[jb];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private slice: no barrier, just the wave's own writes
         const int64_t rbase = m0 + wm * 128 + i * 32;
         float4 sk[8];
@@ -158,7 +173,7 @@ __device__ __forceinline__ void f16x3_epilogue_as(const GemmArgs& p, uint8_t* ld
     if (ovf && has_planes && p.overflow) *p.overflow = 1;
 }
 
-__device__ __forceinline__ void f16x3_epilogue(const GemmArgs& p, uint8_t* lds, f32x16 (&acc)[4][2], int64_t m0, int n0, int w, int wm,
+__device__ __forceinline__ void f16x3_epilogue(const GemmArgs& p, uint8_t* lds, f32x4 (&acc)[8][4], int64_t m0, int n0, int w, int wm,
                                                int wn, int lane, int l31, int h) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the operand stages
     // the network's own layer forms on a tile inside the matrix (uniform over the workgroup) take a tail compiled for them
@@ -195,7 +210,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v2(const GemmArgs p)
     for (int q = 0; q < 8; q++) {
         const int img = q >> 1;
         const uint32_t r = (uint32_t)(((q & 1) * 8 + w) * 16 + (lane >> 2));
-        const uint32_t c = (uint32_t)(lane & 3) ^ ((r >> 2) & 3u);
+        const uint32_t c = (uint32_t)(lane & 3) ^ swz64_key(r);
         if (img < 2) {
             int64_t gr = m0 + r;
             gr = gr < p.m ? gr : p.m - 1;
@@ -215,13 +230,14 @@ __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v2(const GemmArgs p)
         }
     };
 
-    f32x16 acc[4][2];
+    f32x4 acc[8][4];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 8; i++)
 #pragma unroll
-        for (int jn = 0; jn < 2; jn++)
+        for (int jn = 0; jn < 4; jn++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][jn][e] = 0.f;
+            for (int e = 0; e < 4; e++) acc[i][jn][e] = 0.f;
+    const int g4 = lane >> 4, j16 = lane & 15;
 
     const int nk = p.k / HBK;
     issue(0, 0);
@@ -233,29 +249,28 @@ __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v2(const GemmArgs p)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (kt + 1 < nk) issue((kt + 1) & 1, (kt + 1) * HBK);
         const uint8_t* base = lds + (kt & 1) * HSTAGE;
+        {  // one 32-deep step = one instruction deep
+            const uint32_t c = (uint32_t)g4;
+            f16x8 ah[8], al[8], wh[4], wl[4];
 #pragma unroll
-        for (int s = 0; s < HBK / 16; s++) {
-            const uint32_t c = 2u * s + (uint32_t)h;
-            f16x8 ah[4], al[4], wh[2], wl[2];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t off = swz64((uint32_t)(wm * 128 + i * 32 + l31), c);
+            for (int i = 0; i < 8; i++) {
+                const uint32_t off = swz64((uint32_t)(wm * 128 + i * 16 + j16), c);
                 ah[i] = *reinterpret_cast<const f16x8*>(base + off);
                 al[i] = *reinterpret_cast<const f16x8*>(base + HIMG + off);
             }
 #pragma unroll
-            for (int jn = 0; jn < 2; jn++) {
-                const uint32_t off = swz64((uint32_t)(wn * 64 + jn * 32 + l31), c);
+            for (int jn = 0; jn < 4; jn++) {
+                const uint32_t off = swz64((uint32_t)(wn * 64 + jn * 16 + j16), c);
                 wh[jn] = *reinterpret_cast<const f16x8*>(base + 2 * HIMG + off);
                 wl[jn] = *reinterpret_cast<const f16x8*>(base + 3 * HIMG + off);
             }
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < 8; i++)
 #pragma unroll
-                for (int jn = 0; jn < 2; jn++) {
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[jn], acc[i][jn], 0, 0, 0);
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[jn], acc[i][jn], 0, 0, 0);
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[jn], acc[i][jn], 0, 0, 0);
+                for (int jn = 0; jn < 4; jn++) {
+                    acc[i][jn] = mma16h(al[i], wh[jn], acc[i][jn]);
+                    acc[i][jn] = mma16h(ah[i], wl[jn], acc[i][jn]);
+                    acc[i][jn] = mma16h(ah[i], wh[jn], acc[i][jn]);
                 }
         }
     }
@@ -300,7 +315,7 @@ __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v3(const GemmArgs p)
     const _Float16* src[4][2];
     {
         const uint32_t r = (uint32_t)(w * 16 + (lane >> 2));
-        const uint32_t c = (uint32_t)(lane & 3) ^ ((r >> 2) & 3u);
+        const uint32_t c = (uint32_t)(lane & 3) ^ swz64_key(r);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             if (u < 2) {
@@ -325,52 +340,47 @@ __global__ __launch_bounds__(HTHREADS, 2) void k_f16x3_gemm_v3(const GemmArgs p)
         }
     };
 
-    f32x16 acc[4][2];
+    f32x4 acc[8][4];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 8; i++)
 #pragma unroll
-        for (int jn = 0; jn < 2; jn++)
+        for (int jn = 0; jn < 4; jn++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][jn][e] = 0.f;
+            for (int e = 0; e < 4; e++) acc[i][jn][e] = 0.f;
 
-    // fragment addresses inside a plane of a slot: local row = (wave's block) * 32 + l31, logical chunk 2 s + h
-    uint32_t foff[2];
-#pragma unroll
-    for (int s = 0; s < 2; s++) foff[s] = swz64((uint32_t)l31, 2u * s + (uint32_t)h);
-    const uint32_t a_row0 = (uint32_t)wm * 64u * 64u;  // A slots: this wave row's 64 local rows
-    const uint32_t b_row0 = (uint32_t)wn * 32u * 64u;  // B slots: this wave column's 32 local rows
+    // fragment address inside a plane of a slot: local row = (wave's 16-row block) * 16 + j, logical chunk g
+    const int g4 = lane >> 4, j16 = lane & 15;
+    const uint32_t foff = swz64((uint32_t)j16, (uint32_t)g4);
+    const uint32_t a_row0 = (uint32_t)wm * 64u * 64u;  // A slots: this wave row's 64 local rows (four 16-row blocks)
+    const uint32_t b_row0 = (uint32_t)wn * 32u * 64u;  // B slots: this wave column's 32 local rows (two 16-row blocks)
 
-    f16x8 avh[2][2], avl[2][2], wh0[2], wl0[2], wh1[2], wl1[2];
+    f16x8 avh[4], avl[4], wh0[2], wl0[2], wh1[2], wl1[2];
     auto read_a = [&](const uint8_t* base, int u) {
 #pragma unroll
-        for (int ii = 0; ii < 2; ii++)
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                avh[ii][s] = *reinterpret_cast<const f16x8*>(base + u * PSLOT3 + a_row0 + ii * 2048 + foff[s]);
-                avl[ii][s] = *reinterpret_cast<const f16x8*>(base + u * PSLOT3 + 8192 + a_row0 + ii * 2048 + foff[s]);
-            }
+        for (int ii = 0; ii < 4; ii++) {
+            avh[ii] = *reinterpret_cast<const f16x8*>(base + u * PSLOT3 + a_row0 + ii * 1024 + foff);
+            avl[ii] = *reinterpret_cast<const f16x8*>(base + u * PSLOT3 + 8192 + a_row0 + ii * 1024 + foff);
+        }
     };
     auto read_b = [&](const uint8_t* base, int u, f16x8 (&wh)[2], f16x8 (&wl)[2]) {
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            wh[s] = *reinterpret_cast<const f16x8*>(base + u * PSLOT3 + b_row0 + foff[s]);
-            wl[s] = *reinterpret_cast<const f16x8*>(base + u * PSLOT3 + 8192 + b_row0 + foff[s]);
+        for (int jj = 0; jj < 2; jj++) {
+            wh[jj] = *reinterpret_cast<const f16x8*>(base + u * PSLOT3 + b_row0 + jj * 1024 + foff);
+            wl[jj] = *reinterpret_cast<const f16x8*>(base + u * PSLOT3 + 8192 + b_row0 + jj * 1024 + foff);
         }
     };
-    // 12 MFMAs: per accumulator the order of v2 (low x high, high x low, high x high, K ascending), the two accumulators
-    // of the phase interleaved so that no MFMA waits on the one before it
+    // 24 MFMAs: per accumulator the order of v2 (low x high, high x low, high x high), the eight accumulators of the phase
+    // interleaved so that no MFMA waits on the one before it
 #define DCA_MMA12(I0, JN, WH, WL)                                                                                       \
     do {                                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
         __builtin_amdgcn_s_setprio(1);                                                                                  \
-        _Pragma("unroll") for (int s = 0; s < 2; s++) {                                                                 \
-            _Pragma("unroll") for (int ii = 0; ii < 2; ii++)                                                            \
-                acc[(I0) + ii][JN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl[ii][s], WH[s], acc[(I0) + ii][JN], 0, 0, 0); \
-            _Pragma("unroll") for (int ii = 0; ii < 2; ii++)                                                            \
-                acc[(I0) + ii][JN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[ii][s], WL[s], acc[(I0) + ii][JN], 0, 0, 0); \
-            _Pragma("unroll") for (int ii = 0; ii < 2; ii++)                                                            \
-                acc[(I0) + ii][JN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[ii][s], WH[s], acc[(I0) + ii][JN], 0, 0, 0); \
-        }                                                                                                               \
+        _Pragma("unroll") for (int ii = 0; ii < 4; ii++) _Pragma("unroll") for (int jj = 0; jj < 2; jj++)               \
+            acc[2 * (I0) + ii][2 * (JN) + jj] = mma16h(avl[ii], WH[jj], acc[2 * (I0) + ii][2 * (JN) + jj]);             \
+        _Pragma("unroll") for (int ii = 0; ii < 4; ii++) _Pragma("unroll") for (int jj = 0; jj < 2; jj++)               \
+            acc[2 * (I0) + ii][2 * (JN) + jj] = mma16h(avh[ii], WL[jj], acc[2 * (I0) + ii][2 * (JN) + jj]);             \
+        _Pragma("unroll") for (int ii = 0; ii < 4; ii++) _Pragma("unroll") for (int jj = 0; jj < 2; jj++)               \
+            acc[2 * (I0) + ii][2 * (JN) + jj] = mma16h(avh[ii], WH[jj], acc[2 * (I0) + ii][2 * (JN) + jj]);             \
         __builtin_amdgcn_s_setprio(0);                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
     } while (0)
