@@ -243,8 +243,8 @@ def build_parser() -> ArgumentParser:
     parser.add_argument('--nnet_dtype', type=str, default="fp32", choices=["fp32", "bf16", "fp16", "fp8", "fp8mx"],
                         help="fp32 = parity mode: heuristic values within 1e-5 * max(1, |h|) of the reference's fp32 forward — 1e-5 "
                              "ABSOLUTE for |h| <= 1 (every reference-recorded network fixture); at cube3's trained magnitudes "
-                             "|h| ~ 25 measured 0.95 / 1.14 / 1.53e-5 against the reference's fp32 values over three weight seeds "
-                             "(5-8 fp32 ulps; the reference's own forward is 0.6-0.7e-5 from float64 there, its module on this "
+                             "|h| ~ 25 measured 0.95 / 1.14 / 1.34e-5 against the reference's fp32 values over three weight seeds "
+                             "(5-7 fp32 ulps; the reference's own forward is 0.6-0.7e-5 from float64 there, its module on this "
                              "GPU's fp32 GEMMs 1.5e-5), at puzzle48's |h| ~ 100-300 within 1e-5 * |h| "
                              "(tests/test_parity_configs_hip.py); bf16/fp16 = faster, NOT parity; fp8 = OCP e4m3 operands on the "
                              "hand-written layer kernels (dca_gemm8), one calibrated scale per activation tensor: fastest, "

@@ -207,8 +207,8 @@ def test_heuristic_tolerance_at_trained_network_magnitudes(L, nets, seed):
 
     THE FINDING of round 6, measured on the MI355X and NOT tuned away: the north star's 1e-5 ABSOLUTE holds at these magnitudes
     for one seed of three.  CLI-default path (f16x3 parity mode), max |error| vs float64 / vs the reference's fp32 values:
-        seed 2028  8.9e-6 / 9.5e-6      seed 2029  1.08e-5 / 1.53e-5      seed 2030  8.9e-6 / 1.14e-5
-    (1.53e-5 = 8 fp32 ulps of 29).  The reference's own module run on this GPU's fp32 GEMMs is FURTHER from float64 than that
+        seed 2028  9.5e-6 / 9.5e-6      seed 2029  1.06e-5 / 1.34e-5      seed 2030  9.5e-6 / 1.14e-5
+    (1.34e-5 = 7 fp32 ulps of 29; on the 32x32x16 form of the kernels, earlier in the round: 8.9e-6 / 9.5e-6, 1.08e-5 / 1.53e-5, 8.9e-6 / 1.14e-5).  The reference's own module run on this GPU's fp32 GEMMs is FURTHER from float64 than that
     (1.48e-5 .. 1.59e-5): two correct fp32 evaluations of this network differ by up to ~1.5e-5 at |h| ~ 25 whatever computes
     them, because each is 0.6 - 1.6e-5 from exact arithmetic.  The tolerance this repo states for the parity mode is therefore
     1e-5 * max(1, |h|) per state (`--nnet_dtype` help) — which is 1e-5 absolute wherever |h| <= 1, the regime of
