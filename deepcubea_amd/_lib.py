@@ -45,7 +45,7 @@ ABI_SYMBOLS = [
     "dca_cube4_perm_table", "dca_cube4_next_state", "dca_cube4_prev_state", "dca_cube4_expand_fused",
     "dca_engine_set_weight_instance", "dca_engine_set_weights", "dca_engine_park_instance", "dca_engine_last_popped",
     "dca_engine_reset_many", "dca_engine_root_commit_many", "dca_engine_set_weights_dev", "dca_debug_write_ceiling",
-    "dca_l1_supported8", "dca_l1_kpad8", "dca_l1_onehot_gemm8",
+    "dca_l1_supported8", "dca_l1_kpad8", "dca_l1_onehot_gemm8", "dca_l1_embed_supported", "dca_l1_embed",
 ]
 
 
@@ -83,7 +83,7 @@ def lib() -> C.CDLL:
         _lib.dca_bn_workspace_bytes.restype = C.c_int64
         _lib.dca_bn_workspace_bytes.argtypes = [C.c_int64]
         _lib.dca_engine_destroy.restype = None
-        if _lib.dca_abi_version() != 4:
+        if _lib.dca_abi_version() != 5:
             raise DcaError("libdca_hip.so ABI version mismatch")
     return _lib
 
@@ -474,6 +474,38 @@ def l1_onehot_gemm8(states_nnet: torch.Tensor, depth: int, w_tiles8: torch.Tenso
     out = torch.empty((m, n_pad), dtype=E4M3, device=x.device)
     check(lib().dca_l1_onehot_gemm8(ptr(x), C.c_int64(m), int(d), int(depth), ptr(w_tiles8), C.c_int64(n_pad), ptr(scale),
                                     ptr(bias), int(relu), ptr(out), stream_ptr()), "dca_l1_onehot_gemm8")
+    return out
+
+
+def l1_embed_supported(state_dim: int, depth: int) -> bool:
+    return bool(lib().dca_l1_embed_supported(int(state_dim), int(depth)))
+
+
+def l1_embed(states_nnet: torch.Tensor, depth: int, w_t: torch.Tensor, bias: torch.Tensor, relu: bool, out_dtype=torch.float32,
+             split=False, overflow: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Layer 1 as an embedding sum (dca_l1_embed): relu?(b1 + sum_pos w_t[pos * depth + s[pos]]) in exact fp32 arithmetic from
+    the uint8 rows; w_t = W1^T fp32 [state_dim * depth, n_pad].  [m, n_pad] in out_dtype (fp32 / bf16 / e4m3 saturating), or split="planes":
+    dca_f16x3_gemm's operand [2, m, n_pad] fp16."""
+    x = _u8(states_nnet)
+    if x.data_ptr() % 16:  # a row slice of a larger matrix: the kernel streams the rows in 16-byte pieces
+        x = x.clone()
+    m, d = x.shape
+    n_pad = bias.numel()
+    assert w_t.dtype == torch.float32 and bias.dtype == torch.float32 and w_t.is_contiguous() and tuple(w_t.shape) == (d * depth, n_pad)
+    if split == "planes":
+        out = torch.empty((2, m, n_pad), dtype=torch.float16, device=x.device)
+        code = DT_F16_PLANES
+    elif out_dtype == E4M3:  # (the caller has folded the activation scale into the weights and bias)
+        out = torch.empty((m, n_pad), dtype=E4M3, device=x.device)
+        code = DT_E4M3
+    else:
+        assert not split and out_dtype in (torch.float32, torch.bfloat16)
+        out = torch.empty((m, n_pad), dtype=out_dtype, device=x.device)
+        code = _TORCH_DT[out_dtype]
+    if m == 0:
+        return out
+    check(lib().dca_l1_embed(ptr(x), C.c_int64(m), int(d), int(depth), ptr(w_t), C.c_int64(n_pad), ptr(bias), int(relu), ptr(out),
+                             code, ptr(overflow), stream_ptr()), "dca_l1_embed")
     return out
 
 

@@ -171,6 +171,13 @@ def _split_f16(w: torch.Tensor, sc: torch.Tensor):
     return wh, (ws - wh.float()).to(torch.float16)
 
 
+# One-hot depth from which layer 1 runs as the embedding sum (dca_l1_embed) instead of the one-hot MFMA kernel, by mode.  Measured,
+# ms per 409 600 rows x 5120 units, MFMA kernel / embedding sum (profiles/r06_l1_embed_bench.txt):
+#   fp32 (planes out): cube3 3.94 / 7.41, puzzle15 3.08 / 2.55, puzzle24 9.55 / 4.40, puzzle35 17.3 / 8.31, puzzle48 30.1 / 7.83
+#   bf16:              cube3 1.70 / 7.08, puzzle15 1.34 / 2.11, puzzle24 4.80 / 3.98, puzzle35 9.45 / 5.09, puzzle48 15.9 / 7.35
+L1_EMBED_MIN_DEPTH = {torch.float32: 16, torch.bfloat16: 25, torch.float16: 1 << 30}
+
+
 class FastResnet(nn.Module):
     """Inference-only re-layout of a `ResnetModel` (pytorch_models.py:5-86 of the reference), same function:
 
@@ -192,8 +199,9 @@ class FastResnet(nn.Module):
     written by the engine's pack kernel through `forward_onehot`.  fp32 is the 1e-5 parity mode."""
 
     def __init__(self, model: ResnetModel, dtype: torch.dtype = torch.float32, split: bool = True, gemm: str = "hip",
-                 gemm16: str = "hip"):
+                 gemm16: str = "hip", l1: str = "auto"):
         super().__init__()
+        assert l1 in ("auto", "mfma", "embed")
         m = fold_batchnorm(model)
         self.state_dim, self.one_hot_depth = m.state_dim, m.one_hot_depth
         self.dtype = dtype
@@ -287,6 +295,7 @@ class FastResnet(nn.Module):
         self.l1_planes = {torch.float32: 3, torch.float16: 2, torch.bfloat16: 1}[dtype]
         self.l1_tiles = None
         self.l1_bias = None
+        self.l1_embed_w = None
         # measured at 204 800 rows x 5120 units: fp32 2.30 ms vs 5.89 ms for the library's fp32 GEMM; bf16 on par with the
         # library (and no one-hot rows to write/read); two-plane fp16 is slower than the library's f16 GEMM -> not used
         if self.one_hot_depth > 0 and dtype != torch.float16:
@@ -300,6 +309,14 @@ class FastResnet(nn.Module):
                 w1 = ws[0][:, :in_dim] if dtype == torch.float32 else ws[0][:, :in_dim].to(dtype).float()
                 self.l1_tiles = nn.Parameter(l1_weight_tiles(w1, self.l1_planes, kpad), requires_grad=False)
                 self.l1_bias = nn.Parameter(bs[0].to(dtype).float(), requires_grad=False)
+                # the same layer as an embedding sum on the vector pipes (csrc/dca_embed.hip: one gathered fp32 weight per
+                # position instead of `depth` multiply-adds, exact fp32 arithmetic): ahead of the MFMA kernel where the one-hot
+                # depth is large — the sliding puzzles (see L1_EMBED_MIN_DEPTH); cube3 (depth 6) stays on the matrix pipes
+                emb_ok = _lib.l1_embed_supported(self.state_dim, self.one_hot_depth)
+                if l1 == "embed" and not emb_ok:
+                    raise ValueError("FastResnet(l1='embed'): geometry (%d, %d) not instantiated" % (self.state_dim, self.one_hot_depth))
+                if emb_ok and (l1 == "embed" or (l1 == "auto" and self.one_hot_depth >= L1_EMBED_MIN_DEPTH[dtype])):
+                    self.l1_embed_w = nn.Parameter(w1.t().contiguous(), requires_grad=False)  # [K, h1_pad] fp32 (bf16 mode: bf16-rounded values)
 
     @property
     def uses_l1_kernel(self) -> bool:
@@ -369,16 +386,23 @@ class FastResnet(nn.Module):
         if self.l1_tiles is None or not states_nnet.is_cuda:
             return self.forward_onehot(self.encode(states_nnet))
         from .. import _lib
+        emb = self.l1_embed_w if (self.gemm == "hip" or not self.split) else None  # (the library-GEMM f16x3 operand: MFMA kernel only)
         if self.split:  # the layer-1 kernel's epilogue writes the next layer's split operand directly
             self._overflow.zero_()
-            a3 = _lib.l1_onehot_gemm(states_nnet, self.one_hot_depth, self.l1_tiles, self.l1_planes, self.l1_bias, True,
-                                     self.dtype, split="planes" if self.gemm == "hip" else True, overflow=self._overflow)
+            if emb is not None:
+                a3 = _lib.l1_embed(states_nnet, self.one_hot_depth, emb, self.l1_bias, True, split="planes", overflow=self._overflow)
+            else:
+                a3 = _lib.l1_onehot_gemm(states_nnet, self.one_hot_depth, self.l1_tiles, self.l1_planes, self.l1_bias, True,
+                                         self.dtype, split="planes" if self.gemm == "hip" else True, overflow=self._overflow)
             out = self._after_l1_planes(a3) if self.gemm == "hip" else self._after_l1_split(a3)
             if int(self._overflow.item()) == 0:
                 return out
             self.split_fallbacks += 1  # some activation beyond fp16 range: same batch again with fp32 GEMMs
-        x = _lib.l1_onehot_gemm(states_nnet, self.one_hot_depth, self.l1_tiles, self.l1_planes, self.l1_bias, True,
-                                self.dtype)
+        if emb is not None:
+            x = _lib.l1_embed(states_nnet, self.one_hot_depth, emb, self.l1_bias, True, self.dtype)
+        else:
+            x = _lib.l1_onehot_gemm(states_nnet, self.one_hot_depth, self.l1_tiles, self.l1_planes, self.l1_bias, True,
+                                    self.dtype)
         return self._after_l1(x)
 
     def _after_l1_split(self, a3: torch.Tensor) -> torch.Tensor:
@@ -490,6 +514,7 @@ class Fp8Resnet(_Fp8BlockMixin, nn.Module):
         self._w1 = W[0][:, :self.in_dim].contiguous()  # layer 1 is rebuilt with the activation scale folded in (calibrate)
         self._b1 = B[0].contiguous()
         self.l1_tiles8 = None
+        self.l1_embed_w8 = None
         self.l1_bias8 = None
         assert l1 in ("auto", "fp8", "bf16")
         can8 = scaling == "tensor" and _lib.l1_supported8(self.state_dim, self.one_hot_depth) and self._w1.shape[0] % 128 == 0
@@ -544,6 +569,8 @@ class Fp8Resnet(_Fp8BlockMixin, nn.Module):
         else:
             w1 = (self._w1 * inv1).to(torch.bfloat16).float()
             self.l1_tiles8 = l1_weight_tiles(w1, 1, kpad).to(dev)
+            # deep one-hot geometries (the larger sliding puzzles): the same weights through the embedding sum, like the bf16 mode
+            self.l1_embed_w8 = w1.t().contiguous().to(dev) if b.l1_embed_w is not None else None
         self.l1_bias8 = (self._b1 * inv1).float().contiguous().to(dev)
         # input scale of dense layer j (0 = fc2): h1, then inside block i: x_i for the first Linear, h_i for the second
         s_in = [self.act_scale[0]]
@@ -571,7 +598,10 @@ class Fp8Resnet(_Fp8BlockMixin, nn.Module):
         if self.l1_fp8:
             h8 = _lib.l1_onehot_gemm8(states_nnet, self.one_hot_depth, self.l1_w8_tiles, self.l1_scale8, self.l1_bias8, True)
         else:
-            h8 = _lib.l1_onehot_gemm(states_nnet, self.one_hot_depth, self.l1_tiles8, 1, self.l1_bias8, True, _lib.E4M3)
+            if self.l1_embed_w8 is not None:
+                h8 = _lib.l1_embed(states_nnet, self.one_hot_depth, self.l1_embed_w8, self.l1_bias8, True, _lib.E4M3)
+            else:
+                h8 = _lib.l1_onehot_gemm(states_nnet, self.one_hot_depth, self.l1_tiles8, 1, self.l1_bias8, True, _lib.E4M3)
         x16, x8 = _lib.gemm8(h8, self.w8[0], self.layer_scale[0], self.bias[0], None, True, True, 1.0 / s[1])
         nblk = (len(self.w8) - 1) // 2
         for i in range(nblk):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DCA_ABI_VERSION 4
+#define DCA_ABI_VERSION 5
 
 /* library error codes (negative; positive values are hipError_t) */
 #define DCA_E_BADARG (-1)
@@ -347,6 +347,21 @@ int64_t dca_l1_kpad8(int state_dim, int depth);
 int dca_l1_onehot_gemm8(const uint8_t* nnet_in /*[m, state_dim]*/, int64_t m, int state_dim, int depth, const void* w_tiles,
                         int64_t n_pad, const float* scale /*[n_pad]*/, const float* bias /*[n_pad]*/, int relu, void* out8,
                         void* stream);
+
+/* The same layer as an EMBEDDING SUM on the vector pipes (csrc/dca_embed.hip): a one-hot row has one 1 per position, so
+ *   out[r, n] = relu?( bias[n] + sum_pos w_t[pos * depth + s[r, pos]][n] )          (positions in ascending order, fp32 adds)
+ * — state_dim gathered weights per output instead of state_dim * depth multiply-adds, in exact fp32 arithmetic with no operand
+ * splitting.  It pays where depth is large (the sliding puzzles: depth = the tile count; puzzle48: 49 of 2401 columns are ones);
+ * cube3 (depth 6) is faster on the matrix pipes (dca_l1_onehot_gemm).  w_t: the layer's weight matrix TRANSPOSED, fp32
+ * [state_dim * depth][n_pad] (row = one-hot column); bias [n_pad]; n_pad % 64 == 0; nnet_in, w_t, out 16-byte aligned.
+ * out_dtype: DCA_DT_F32 [m, n_pad], DCA_DT_BF16 [m, n_pad], or DCA_DT_F16_PLANES (dca_f16x3_gemm's operand: [m, n_pad] fp16
+ * high halves, then [m, n_pad] low halves; *overflow set to 1 if a value exceeds fp16), or DCA_DT_E4M3 [m, n_pad] bytes,
+ * saturating (the caller has folded the activation scale into w_t and bias).  State bytes must be < depth.
+ * Instantiated for the geometries dca_l1_embed_supported() names (cube3, puzzle15/24/35/48, lightsout7). */
+int dca_l1_embed_supported(int state_dim, int depth);
+int dca_l1_embed(const uint8_t* nnet_in /*[m, state_dim]*/, int64_t m, int state_dim, int depth, const float* w_t, int64_t n_pad,
+                 const float* bias /*[n_pad]*/, int relu, void* out, int out_dtype, int* overflow /*device flag or NULL*/,
+                 void* stream);
 
 /* Glue of the fp32-accurate "f16x3" dense layers (csrc/dca_mlp.hip): v = relu?(y*alpha*col_scale + bias (+ skip)) over the row-major
  * fp32 GEMM output y [m, n]; writes the next layer's A operand a3 [m, 3n] fp16, a3[3k..3k+2] = (vh, vl, vh) with

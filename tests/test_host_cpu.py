@@ -25,7 +25,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     L = C.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), "libdca_hip.so does not export %s" % name
-    assert _lib.lib().dca_abi_version() == 4
+    assert _lib.lib().dca_abi_version() == 5
 
 
 def test_host_tables_match_golden(golden):
