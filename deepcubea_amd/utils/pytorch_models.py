@@ -173,8 +173,8 @@ def _split_f16(w: torch.Tensor, sc: torch.Tensor):
 
 # One-hot depth from which layer 1 runs as the embedding sum (dca_l1_embed) instead of the one-hot MFMA kernel, by mode.  Measured,
 # ms per 409 600 rows x 5120 units, MFMA kernel / embedding sum (profiles/r06_l1_embed_bench.txt):
-#   fp32 (planes out): cube3 3.94 / 7.41, puzzle15 3.08 / 2.55, puzzle24 9.55 / 4.40, puzzle35 17.3 / 8.31, puzzle48 30.1 / 7.83
-#   bf16:              cube3 1.70 / 7.08, puzzle15 1.34 / 2.11, puzzle24 4.80 / 3.98, puzzle35 9.45 / 5.09, puzzle48 15.9 / 7.35
+#   fp32 (planes out): cube3 3.98 / 6.86, puzzle15 3.10 / 2.48, puzzle24 9.44 / 4.09, puzzle35 17.3 / 5.22, puzzle48 30.1 / 6.54
+#   bf16:              cube3 1.73 / 6.32, puzzle15 1.35 / 2.05, puzzle24 4.80 / 3.44, puzzle35 9.43 / 4.68, puzzle48 16.0 / 6.38
 L1_EMBED_MIN_DEPTH = {torch.float32: 16, torch.bfloat16: 25, torch.float16: 1 << 30}
 
 
