@@ -7,7 +7,7 @@
 #include <cstdlib>
 
 typedef float f2 __attribute__((ext_vector_type(2)));
-constexpr int ITERS = 4096;
+constexpr int ITERS = 65536;
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(float* out, long long* cyc, float seed) {
