@@ -2,12 +2,16 @@
 """update -> train -> search, end to end on one MI355X, with the repo's own heuristic: the reference's
 checkpoints are not in the mount, so the parity half of the metric ("solution lengths matching results/<env>/") has never had a
 network-driven datum.  This runs `ctg_approx/avi.py` (GBFS updates on the device, `train_nnet`, target hand-over) on puzzle15
-for a fixed wall-time budget, then `search_methods/astar.py --language hip --weight 0.8 --batch_size 20000` (train.sh:21) on
-the first N shipped `data/puzzle15/test` states with the network that came out, and prints the reference's compare_solutions
+(or cube3) for a fixed wall-time budget, then `search_methods/astar.py --language hip` with the reference's own search settings
+(train.sh:21 / train.sh:9) on the first N shipped `data/<env>/test` states with the network that came out, and prints the reference's compare_solutions
 report against (a) the optimal lengths shipped with the test set and (b) the published per-state results of the
 reference's fully trained network (results/puzzle15/output.txt, kept as a fixture).
 
-    python tools/avi_e2e.py [train_seconds] [n_states] [states_per_update] [save_dir] [epochs_per_update]
+    python tools/avi_e2e.py [train_seconds] [n_states] [states_per_update] [save_dir] [epochs_per_update] [env]
+
+env = puzzle15 (default; train.sh:18,21: loss threshold 0.1, back_max 500, search weight 0.8, batch 20 000) or cube3
+(train.sh:4,9: loss threshold 0.06, back_max 30, search weight 0.6, batch 10 000 — the north star's own configuration; the
+reference trained it for 1.2 M iterations, saved_models/cube3/output.txt).
 
 Seeds are fixed (torch / numpy / random / the device state generator), so a rerun on the same build repeats the schedule up to
 the order of floating-point atomics."""
@@ -25,12 +29,16 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from deepcubea_amd.ctg_approx import avi  # noqa: E402
+from deepcubea_amd.environments.cube3 import Cube3State  # noqa: E402
 from deepcubea_amd.environments.n_puzzle import NPuzzleState  # noqa: E402
 from deepcubea_amd.search_methods import astar  # noqa: E402
 from deepcubea_amd.utils import compare_solutions as cs  # noqa: E402
 from deepcubea_amd.utils import data_utils  # noqa: E402
 
-env = "puzzle15"
+env = sys.argv[6] if len(sys.argv) > 6 else "puzzle15"
+LOSS_THRESH, BACK_MAX, WEIGHT, SEARCH_B, StateCls = {"puzzle15": ("0.1", "500", "0.8", "20000", NPuzzleState),
+                                                     "cube3": ("0.06", "30", "0.6", "10000", Cube3State)}[env]
+WEIGHT = os.environ.get("DCA_E2E_WEIGHT", WEIGHT)  # (a search-only rerun of an exported network at another path-cost weight)
 train_s = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 spu = int(sys.argv[3]) if len(sys.argv) > 3 else 3_000_000
@@ -44,9 +52,28 @@ t0 = time.time()
 # the reference's own line (train.sh:18: 50 M states per update, 5000 steps of 10 000) scaled to the budget: `spu` states and
 # spu / 10 000 steps per update — value iteration moves the cost-to-go frontier about one move per update, so the number of
 # updates is what the budget has to buy (the reference ran ~200)
-avi.main(["--env", env, "--states_per_update", str(spu), "--batch_size", str(B), "--nnet_name", env, "--max_itrs", "100000000",
-          "--loss_thresh", "0.1", "--back_max", "500", "--num_test", "1000", "--save_dir", save, "--max_seconds", str(train_s),
+IMPORT, EXPORT = os.environ.get("DCA_E2E_IMPORT"), os.environ.get("DCA_E2E_EXPORT")
+if IMPORT:  # a network exported by an earlier run (fp16 copy of the state dict): search only, or train on from it
+    cur = os.path.join(save, env, "current")
+    os.makedirs(cur, exist_ok=True)
+    blob = torch.load(IMPORT, map_location="cpu")
+    torch.save({k: (v.float() if v.is_floating_point() else v) for k, v in blob["state_dict"].items()}, os.path.join(cur, "model_state_dict.pt"))
+    pickle.dump(int(blob["train_itr"]), open(os.path.join(cur, "train_itr.pkl"), "wb"), protocol=-1)
+    pickle.dump(int(blob["update_num"]), open(os.path.join(cur, "update_num.pkl"), "wb"), protocol=-1)
+    print("imported %s: %d iterations, %d target updates" % (IMPORT, blob["train_itr"], blob["update_num"]))
+    if train_s > 0:  # training on: the imported network is also the target (the reference's manual `cp current/* target/`, train.sh:5)
+        import shutil
+        shutil.copytree(cur, os.path.join(save, env, "target"), dirs_exist_ok=True)
+if train_s > 0:
+  avi.main(["--env", env, "--states_per_update", str(spu), "--batch_size", str(B), "--nnet_name", env, "--max_itrs", "100000000",
+          "--loss_thresh", LOSS_THRESH, "--back_max", BACK_MAX, "--num_test", "1000", "--save_dir", save, "--max_seconds", str(train_s),
           "--update_nnet_batch_size", "100000", "--epochs_per_update", str(epochs), "--seed", "0", "--debug"])
+if EXPORT:
+    cur = os.path.join(save, env, "current")
+    sd = torch.load(os.path.join(cur, "model_state_dict.pt"), map_location="cpu")
+    torch.save({"state_dict": {k: (v.half() if v.is_floating_point() else v) for k, v in sd.items()},
+                "train_itr": pickle.load(open(os.path.join(cur, "train_itr.pkl"), "rb")),
+                "update_num": pickle.load(open(os.path.join(cur, "update_num.pkl"), "rb"))}, EXPORT)
 train_wall = time.time() - t0
 itr = pickle.load(open(os.path.join(save, env, "current", "train_itr.pkl"), "rb"))
 upd = pickle.load(open(os.path.join(save, env, "current", "update_num.pkl"), "rb"))
@@ -61,15 +88,15 @@ pub = {"lens": g["published_%s_len" % env][:n].astype(np.int64), "times": g["pub
        "num_nodes_generated": g["published_%s_nodes" % env][:n].astype(np.float64)}
 tmp = tempfile.mkdtemp()
 spath = os.path.join(tmp, "data_0.pkl")
-pickle.dump({"states": [NPuzzleState(s.copy()) for s in states]}, open(spath, "wb"))
+pickle.dump({"states": [StateCls(s.copy()) for s in states]}, open(spath, "wb"))
 rdir = os.path.join(tmp, "res")
 t1 = time.time()
 MAXN = os.environ.get("DCA_E2E_MAX_NODES", "300000000")  # ids per search: a heuristic too weak for a state fails it instead of running on
 
 
 def search(path, out):
-    astar.main(["--states", path, "--model_dir", os.path.join(save, env, "current"), "--env", env, "--weight", "0.8", "--batch_size",
-                "20000", "--results_dir", out, "--language", "hip", "--nnet_batch_size", "10000", "--max_nodes", MAXN, "--debug"])
+    astar.main(["--states", path, "--model_dir", os.path.join(save, env, "current"), "--env", env, "--weight", WEIGHT, "--batch_size",
+                SEARCH_B, "--results_dir", out, "--language", "hip", "--nnet_batch_size", "10000", "--max_nodes", MAXN, "--debug"])
     return data_utils.load_pickle(os.path.join(out, "results.pkl"))
 
 
@@ -82,7 +109,7 @@ except Exception as e:  # noqa: BLE001 - a state the network cannot solve inside
     solved_idx = []
     for i in range(n):
         sp_i = os.path.join(tmp, "one_%d.pkl" % i)
-        pickle.dump({"states": [NPuzzleState(states[i].copy())]}, open(sp_i, "wb"))
+        pickle.dump({"states": [StateCls(states[i].copy())]}, open(sp_i, "wb"))
         try:
             r = search(sp_i, os.path.join(tmp, "res_%d" % i))
         except Exception as e2:  # noqa: BLE001
@@ -101,13 +128,13 @@ except Exception as e:  # noqa: BLE001 - a state the network cannot solve inside
 search_wall = time.time() - t1
 mine = {"lens": np.array([len(s) for s in res["solutions"]]), "times": np.array(res["times"], np.float64),
         "num_nodes_generated": np.array(res["num_nodes_generated"], np.float64)}
-print("\nSEARCH %s" % json.dumps({"states": n, "weight": 0.8, "batch_size": 20000, "wall_seconds": round(search_wall, 2),
+print("\nSEARCH %s" % json.dumps({"states": n, "weight": float(WEIGHT), "batch_size": int(SEARCH_B), "wall_seconds": round(search_wall, 2),
                                  "mean_len": float(mine["lens"].mean()), "mean_nodes": float(mine["num_nodes_generated"].mean()),
                                  "mean_seconds_per_state": float(mine["times"].mean())}))
-print("\n==== vs the OPTIMAL lengths shipped with data/puzzle15/test (soln1 = optimal, soln2 = this run)")
+print("\n==== vs the OPTIMAL lengths shipped with data/%s/test (soln1 = optimal, soln2 = this run)" % env)
 print(cs.format_report(cs.compare({"lens": opt, "times": np.ones(n), "num_nodes_generated": np.ones(n)}, mine)))
 print("optimal on %d of %d states, mean excess %.3f moves, none shorter than optimal: %s"
       % (int((mine["lens"] == opt).sum()), n, float((mine["lens"] - opt).mean()), bool((mine["lens"] >= opt).all())))
-print("\n==== vs the PUBLISHED results of the reference's fully trained network (results/puzzle15/output.txt; soln1 = published)")
+print("\n==== vs the PUBLISHED results of the reference's fully trained network (results/%s/output.txt; soln1 = published)" % env)
 print(cs.format_report(cs.compare(pub, mine)))
 print("published: optimal on %d of %d, mean excess %.3f moves" % (int((pub["lens"] == opt).sum()), n, float((pub["lens"] - opt).mean())))
