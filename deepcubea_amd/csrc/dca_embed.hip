@@ -109,64 +109,64 @@ __global__ __launch_bounds__(WAVES * 64) void k_l1_embed(const uint8_t* __restri
         pre1 = pre2;
         pre2 = prefetch(g + 3 * gstride);
         for (int j = 0; j < T; j++) {  // the lane's T states of this step (state j * 64 / LPS + sl of the step)
-        // the state's D bytes from the image: aligned dwords, shifted into place
-        const int sj = j * (64 / G::LPS) + sl;
-        const uint32_t boff = (uint32_t)((g * (G::SPW * D)) & 15) + (uint32_t)sj * D, sh = boff & 3u;
-        const uint32_t* wsrc = reinterpret_cast<const uint32_t*>(ls + (boff & ~3u));
-        uint32_t w[G::NW];
+            // the state's D bytes from the image: aligned dwords, shifted into place
+            const int sj = j * (64 / G::LPS) + sl;
+            const uint32_t boff = (uint32_t)((g * (G::SPW * D)) & 15) + (uint32_t)sj * D, sh = boff & 3u;
+            const uint32_t* wsrc = reinterpret_cast<const uint32_t*>(ls + (boff & ~3u));
+            uint32_t w[G::NW];
 #pragma unroll
-        for (int i = 0; i < G::NW; i++) w[i] = wsrc[i];
-        uint32_t v[G::NW - 1];
+            for (int i = 0; i < G::NW; i++) w[i] = wsrc[i];
+            uint32_t v[G::NW - 1];
 #pragma unroll
-        for (int i = 0; i < G::NW - 1; i++) v[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh);
-        float4 acc = *reinterpret_cast<const float4*>(lb + 4 * cp);
+            for (int i = 0; i < G::NW - 1; i++) v[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh);
+            float4 acc = *reinterpret_cast<const float4*>(lb + 4 * cp);
 #pragma unroll
-        for (int pos = 0; pos < D; pos++) {
-            const uint32_t s = (v[pos >> 2] >> (8 * (pos & 3))) & 0xFFu;
-            const float4 gw = *reinterpret_cast<const float4*>(wcol + (s + (uint32_t)(pos * DEPTH)) * (uint32_t)(NT * 4));
-            acc.x += gw.x;
-            acc.y += gw.y;
-            acc.z += gw.z;
-            acc.w += gw.w;
-        }
-        float u[4] = {acc.x, acc.y, acc.z, acc.w};
-        if (relu) {
-#pragma unroll
-            for (int e = 0; e < 4; e++) u[e] = fmaxf(u[e], 0.f);
-        }
-        const int64_t r = g * G::SPW + sj;
-        if (r < m) {
-            const int64_t o = r * n_pad + n0 + 4 * cp;
-            if constexpr (OUT == 0) {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + o) = make_float4(u[0], u[1], u[2], u[3]);
-            } else if constexpr (OUT == 2) {
-                typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-                typedef float f2 __attribute__((ext_vector_type(2)));
-                const f2 a = {u[0], u[1]}, b = {u[2], u[3]};
-                const bf2 pa = __builtin_convertvector(a, bf2), pb = __builtin_convertvector(b, bf2);
-                uint2 q;
-                __builtin_memcpy(&q.x, &pa, 4);
-                __builtin_memcpy(&q.y, &pb, 4);
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + o) = q;
-            } else if constexpr (OUT == 5) {  // e4m3fn has no infinity: saturate at +-448
-                auto sat = [](float f) { return fminf(fmaxf(f, -448.f), 448.f); };
-                uint32_t q = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(sat(u[0]), sat(u[1]), 0, false);
-                q = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(sat(u[2]), sat(u[3]), (int)q, true);
-                *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(out) + o) = q;
-            } else {
-                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-                h4 hi, lo;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    ovf |= !(fabsf(u[e]) <= 60000.0f);
-                    hi[e] = (_Float16)u[e];
-                    lo[e] = (_Float16)(u[e] - (float)hi[e]);
-                }
-                _Float16* q = reinterpret_cast<_Float16*>(out) + o;
-                *reinterpret_cast<h4*>(q) = hi;
-                *reinterpret_cast<h4*>(q + m * n_pad) = lo;
+            for (int pos = 0; pos < D; pos++) {
+                const uint32_t s = (v[pos >> 2] >> (8 * (pos & 3))) & 0xFFu;
+                const float4 gw = *reinterpret_cast<const float4*>(wcol + (s + (uint32_t)(pos * DEPTH)) * (uint32_t)(NT * 4));
+                acc.x += gw.x;
+                acc.y += gw.y;
+                acc.z += gw.z;
+                acc.w += gw.w;
             }
-        }
+            float u[4] = {acc.x, acc.y, acc.z, acc.w};
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) u[e] = fmaxf(u[e], 0.f);
+            }
+            const int64_t r = g * G::SPW + sj;
+            if (r < m) {
+                const int64_t o = r * n_pad + n0 + 4 * cp;
+                if constexpr (OUT == 0) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + o) = make_float4(u[0], u[1], u[2], u[3]);
+                } else if constexpr (OUT == 2) {
+                    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    const f2 a = {u[0], u[1]}, b = {u[2], u[3]};
+                    const bf2 pa = __builtin_convertvector(a, bf2), pb = __builtin_convertvector(b, bf2);
+                    uint2 q;
+                    __builtin_memcpy(&q.x, &pa, 4);
+                    __builtin_memcpy(&q.y, &pb, 4);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + o) = q;
+                } else if constexpr (OUT == 5) {  // e4m3fn has no infinity: saturate at +-448
+                    auto sat = [](float f) { return fminf(fmaxf(f, -448.f), 448.f); };
+                    uint32_t q = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(sat(u[0]), sat(u[1]), 0, false);
+                    q = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(sat(u[2]), sat(u[3]), (int)q, true);
+                    *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(out) + o) = q;
+                } else {
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    h4 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        ovf |= !(fabsf(u[e]) <= 60000.0f);
+                        hi[e] = (_Float16)u[e];
+                        lo[e] = (_Float16)(u[e] - (float)hi[e]);
+                    }
+                    _Float16* q = reinterpret_cast<_Float16*>(out) + o;
+                    *reinterpret_cast<h4*>(q) = hi;
+                    *reinterpret_cast<h4*>(q + m * n_pad) = lo;
+                }
+            }
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();  // (every lane has read its rows: the slice may be rewritten by the next step)

@@ -303,24 +303,27 @@ class FastResnet(nn.Module):
                 from .. import _lib
                 ok = _lib.l1_supported(self.state_dim, self.one_hot_depth)
                 kpad = _lib.l1_kpad(self.state_dim, self.one_hot_depth) if ok else 0
-            except Exception:  # library not built (host-only use of the module)
-                ok = False
-            if ok:
-                w1 = ws[0][:, :in_dim] if dtype == torch.float32 else ws[0][:, :in_dim].to(dtype).float()
-                self.l1_tiles = nn.Parameter(l1_weight_tiles(w1, self.l1_planes, kpad), requires_grad=False)
-                self.l1_bias = nn.Parameter(bs[0].to(dtype).float(), requires_grad=False)
-                # the same layer as an embedding sum on the vector pipes (csrc/dca_embed.hip: one gathered fp32 weight per
-                # position instead of `depth` multiply-adds, exact fp32 arithmetic): ahead of the MFMA kernel where the one-hot
-                # depth is large — the sliding puzzles (see L1_EMBED_MIN_DEPTH); cube3 (depth 6) stays on the matrix pipes
                 emb_ok = _lib.l1_embed_supported(self.state_dim, self.one_hot_depth)
-                if l1 == "embed" and not emb_ok:
-                    raise ValueError("FastResnet(l1='embed'): geometry (%d, %d) not instantiated" % (self.state_dim, self.one_hot_depth))
-                if emb_ok and (l1 == "embed" or (l1 == "auto" and self.one_hot_depth >= L1_EMBED_MIN_DEPTH[dtype])):
-                    self.l1_embed_w = nn.Parameter(w1.t().contiguous(), requires_grad=False)  # [K, h1_pad] fp32 (bf16 mode: bf16-rounded values)
+            except Exception:  # library not built (host-only use of the module)
+                ok = emb_ok = False
+            # the same layer as an embedding sum on the vector pipes (csrc/dca_embed.hip: one gathered fp32 weight per position
+            # instead of `depth` multiply-adds, exact fp32 arithmetic): ahead of the MFMA kernel where the one-hot depth is
+            # large — the sliding puzzles (see L1_EMBED_MIN_DEPTH); cube3 (depth 6) stays on the matrix pipes
+            if l1 == "embed" and not emb_ok:
+                raise ValueError("FastResnet(l1='embed'): dca_l1_embed is not available for geometry (%d, %d)"
+                                 % (self.state_dim, self.one_hot_depth))
+            use_emb = emb_ok and (l1 == "embed" or (l1 == "auto" and ok and self.one_hot_depth >= L1_EMBED_MIN_DEPTH[dtype]))
+            if ok or use_emb:
+                w1 = ws[0][:, :in_dim] if dtype == torch.float32 else ws[0][:, :in_dim].to(dtype).float()
+                self.l1_bias = nn.Parameter(bs[0].to(dtype).float(), requires_grad=False)
+            if ok:
+                self.l1_tiles = nn.Parameter(l1_weight_tiles(w1, self.l1_planes, kpad), requires_grad=False)
+            if use_emb:
+                self.l1_embed_w = nn.Parameter(w1.t().contiguous(), requires_grad=False)  # [K, h1_pad] fp32 (bf16 mode: bf16-rounded values)
 
     @property
     def uses_l1_kernel(self) -> bool:
-        return self.l1_tiles is not None
+        return self.l1_tiles is not None or self.l1_embed_w is not None
 
     def _head(self, x: torch.Tensor) -> torch.Tensor:
         """fc_out (pytorch_models.py:83-86 of the reference): [M, res_pad] -> [M, out_dim] float32.  On the device: the
@@ -383,10 +386,10 @@ class FastResnet(nn.Module):
     @torch.no_grad()
     def forward(self, states_nnet: torch.Tensor) -> torch.Tensor:
         """uint8 network inputs [M, state_dim] -> [M, out_dim] float32."""
-        if self.l1_tiles is None or not states_nnet.is_cuda:
+        emb = self.l1_embed_w if (self.gemm == "hip" or not self.split) else None  # (the library-GEMM f16x3 operand: MFMA kernel only)
+        if (self.l1_tiles is None and emb is None) or not states_nnet.is_cuda:
             return self.forward_onehot(self.encode(states_nnet))
         from .. import _lib
-        emb = self.l1_embed_w if (self.gemm == "hip" or not self.split) else None  # (the library-GEMM f16x3 operand: MFMA kernel only)
         if self.split:  # the layer-1 kernel's epilogue writes the next layer's split operand directly
             self._overflow.zero_()
             if emb is not None:

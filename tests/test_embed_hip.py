@@ -151,3 +151,24 @@ def test_network_with_the_embedding_layer_matches_the_mfma_layer_and_is_batch_in
     assert (auto.l1_embed_w is not None) == (16 >= L1_EMBED_MIN_DEPTH[torch.float32])
     cube = ResnetModel(54, 6, 5000, 1000, 4, 1, True)
     assert FastResnet(cube.eval()).l1_embed_w is None
+
+
+@torch.no_grad()
+def test_lightsout_geometry_has_only_the_embedding_kernel():
+    """(49, 6) — lightsout7 — has no one-hot MFMA instantiation in the fp32 / bf16 modes: by default its first layer runs on
+    materialised one-hot rows; `l1="embed"` feeds the uint8 rows to dca_l1_embed instead.  Same network, within 1e-5."""
+    from deepcubea_amd import _lib
+    from deepcubea_amd.utils.pytorch_models import FastResnet, ResnetModel
+    from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
+    _lib.require_gpu()
+    assert not _lib.l1_supported(49, 6) and _lib.l1_embed_supported(49, 6)
+    net = ResnetModel(49, 6, 5000, 1000, 4, 1, True)  # lights_out.py:80-83
+    load_synthetic_weights(net, 7)
+    net = net.eval()
+    x = torch.randint(0, 2, (3001, 49), generator=torch.Generator().manual_seed(1)).to(torch.uint8).cuda()
+    dflt, emb = FastResnet(net).cuda(), FastResnet(net, l1="embed").cuda()
+    assert not dflt.uses_l1_kernel and emb.uses_l1_kernel and emb.l1_tiles is None
+    yd, ye = dflt(x)[:, 0], emb(x)[:, 0]
+    assert emb.split_fallbacks == 0
+    assert float((yd - ye).abs().max()) < 1e-5 * max(1.0, float(yd.abs().max()))
+    assert torch.equal(emb(x[77:1500].contiguous())[:, 0], ye[77:1500])

@@ -214,6 +214,39 @@ def test_network_weight_layouts_for_the_mfma_paths():
         assert torch.allclose(f.forward_onehot(oh), m.forward_onehot(oh[:, :324]), atol=1e-5)
 
 
+def test_layer1_kernel_choice_by_geometry_and_mode():
+    """`FastResnet(l1="auto")`: the embedding sum (dca_l1_embed) where the one-hot depth makes it the faster kernel — the
+    sliding puzzles in the fp32 parity mode, the larger ones in bf16 too — the one-hot MFMA kernel for cube3; the table handed
+    to the kernel is the folded first-layer weight matrix, transposed (bf16 mode: its bf16-rounded values)."""
+    from deepcubea_amd import _lib
+    from deepcubea_amd.utils.pytorch_models import FastResnet, ResnetModel, fold_batchnorm, L1_EMBED_MIN_DEPTH
+    assert L1_EMBED_MIN_DEPTH[torch.float32] == 16 and L1_EMBED_MIN_DEPTH[torch.bfloat16] == 25
+    for d, depth in ((54, 6), (16, 16), (25, 25), (36, 36), (49, 49), (49, 6)):
+        assert _lib.l1_embed_supported(d, depth)
+    assert not _lib.l1_embed_supported(54, 7)
+
+    def net(d, depth):
+        m = ResnetModel(d, depth, 130, 64, 1, 1, True).eval()
+        with torch.no_grad():
+            m.bn1.running_mean.uniform_(-1, 1), m.bn1.running_var.uniform_(0.5, 2.0)
+        return m
+
+    cube, p15, p24 = net(54, 6), net(16, 16), net(25, 25)
+    assert FastResnet(cube).l1_embed_w is None and FastResnet(cube, torch.bfloat16).l1_embed_w is None
+    assert FastResnet(cube, l1="embed").l1_embed_w is not None  # on request (slower there: csrc/dca_embed.hip)
+    f15 = FastResnet(p15)
+    assert f15.l1_embed_w is not None and f15.uses_l1_kernel and FastResnet(p15, torch.bfloat16).l1_embed_w is None
+    assert FastResnet(p15, l1="mfma").l1_embed_w is None
+    f24 = FastResnet(p24, torch.bfloat16)
+    assert FastResnet(p24).l1_embed_w is not None and f24.l1_embed_w is not None
+    w1 = fold_batchnorm(p15).fc1.weight.detach()
+    assert f15.l1_embed_w.shape == (256, 192) and torch.equal(f15.l1_embed_w[:, :130], w1.t()) and torch.all(f15.l1_embed_w[:, 130:] == 0)
+    w1 = fold_batchnorm(p24).fc1.weight.detach()
+    assert torch.equal(f24.l1_embed_w[:, :130], w1.t().to(torch.bfloat16).float())
+    with pytest.raises(ValueError):
+        FastResnet(ResnetModel(20, 5, 130, 64, 1, 1, True).eval(), l1="embed")
+
+
 def test_make_batches_drops_the_tail_like_the_reference():
     from deepcubea_amd.utils import nnet_utils
     np.random.seed(0)

@@ -65,9 +65,9 @@ if IMPORT:  # a network exported by an earlier run (fp16 copy of the state dict)
         import shutil
         shutil.copytree(cur, os.path.join(save, env, "target"), dirs_exist_ok=True)
 if train_s > 0:
-  avi.main(["--env", env, "--states_per_update", str(spu), "--batch_size", str(B), "--nnet_name", env, "--max_itrs", "100000000",
-          "--loss_thresh", LOSS_THRESH, "--back_max", BACK_MAX, "--num_test", "1000", "--save_dir", save, "--max_seconds", str(train_s),
-          "--update_nnet_batch_size", "100000", "--epochs_per_update", str(epochs), "--seed", "0", "--debug"])
+    avi.main(["--env", env, "--states_per_update", str(spu), "--batch_size", str(B), "--nnet_name", env, "--max_itrs", "100000000",
+              "--loss_thresh", LOSS_THRESH, "--back_max", BACK_MAX, "--num_test", "1000", "--save_dir", save, "--max_seconds",
+              str(train_s), "--update_nnet_batch_size", "100000", "--epochs_per_update", str(epochs), "--seed", "0", "--debug"])
 if EXPORT:
     cur = os.path.join(save, env, "current")
     sd = torch.load(os.path.join(cur, "model_state_dict.pt"), map_location="cpu")
