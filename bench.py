@@ -569,6 +569,11 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
     expanded = st1["nodes_expanded"] - st0["nodes_expanded"]
     rows = (eng.rows_evaluated - rows0) / steps
     total_exp = reduce_ranks(float(expanded), world, "sum")
+    # layer 1 as an embedding sum (dca_l1_embed: the sliding puzzles) issues no MFMA flops: the roofline below counts the dense layers only
+    l1_embed = (not eval_all_children) and (getattr(fast, "l1_embed_w", None) is not None
+                                            or getattr(fast, "l1_embed_w8", None) is not None)
+    if l1_embed:
+        macs -= model.fc1.in_features * model.fc1.out_features
     flops = 2.0 * macs * rows
     eng.close()
     torch.cuda.empty_cache()
@@ -578,7 +583,7 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
             "what": "MFMA flops ISSUED per second over the whole iteration (engine launches and host hand-over included): "
                     "2 x MACs x network rows%s / ms_per_step, against the dense peak of the pipe the layers run on"
                     % (" x 3 (f16x3: three f16 products per fp32-accurate one)" if dtype_name == "fp32" and not eval_all_children else ""),
-            "mfma_busy_profile": {"fp32": "profiles/r05_nnet_fp32_pmc_mfma.txt", "fp8": "profiles/r05_nnet_fp8_pmc_mfma.txt"}.get(
+            "mfma_busy_profile": {"fp32": "profiles/r06_nnet_fp32_pmc_mfma.txt", "fp8": "profiles/r06_nnet_fp8_pmc_mfma.txt"}.get(
                 dtype_name if not eval_all_children else "", None),
             "clock_note": "the dense layers run power-limited on random operands (1.3-1.7 GHz shader clock inside their K loops, 2.4 GHz "
                           "nominal: profiles/r04_gemm_timeline.txt) and fetch-bound on the L2 -> LDS operand stream "
@@ -588,6 +593,8 @@ def run_astar_nnet(args, world, rank, dtype_name: str, eval_all_children: bool =
             "steps": steps, "timed_s": wall, "heuristic_dtype": dtype_name + (" (block-scaled, MX-64)" if dtype_name == "fp8" and fp8_scaling == "block" else ""), "weights": "synthetic (numpy PCG64 seed 2024, BN folded)",
             "order": "eval_all_children (reference order)" if eval_all_children else "dedup_first (CLI default)",
             "layer1": "library GEMM on one-hot rows" if eval_all_children or not fast.uses_l1_kernel
+            else "dca_l1_embed (embedding sum on the vector pipes: one gathered fp32 weight per position, exact fp32; not in the MFMA flop count)" if l1_embed
+            else "dca_l1_onehot_gemm8 (hand-written f8f6f4 MFMA, e4m3 weights)" if getattr(fast, "l1_fp8", False)
             else "dca_l1_onehot_gemm (hand-written MFMA, %d bf16 plane(s)%s)" % ((1, ", e4m3 output" + (" with E8M0 block scales" if fp8_scaling == "block" else "")) if dtype_name == "fp8"
                                                                                 else (fast.l1_planes, "")),
             "dense_layers": ("library fp32 GEMMs" if eval_all_children else "dca_f16x3_gemm (hand-written MFMA, epilogue-fused)")
@@ -667,6 +674,8 @@ def run_avi(args, world, rank):
     barrier(world)
     wall = reduce_ranks(time.perf_counter() - t0, world, "max")
     total = reduce_ranks(float(tot), world, "sum")
+    if fast.l1_embed_w is not None:  # layer 1 as an embedding sum (dca_l1_embed): no multiply-adds issued for it
+        macs -= model.fc1.in_features * model.fc1.out_features
     flops = 2.0 * macs * A * (tot / args.steps)
     published = {"cube3": "1.55e5 states/s on 3 GPUs + 30 CPU procs (saved_models/cube3/output.txt)",
                  "puzzle48": "9.4e4 states/s on 4 GPUs + 30 CPU procs (50M states in 528-530 s, saved_models/puzzle48/output.txt)"}
@@ -678,6 +687,8 @@ def run_avi(args, world, rank):
                    "states_per_step_per_gpu": n, "back_max": back_max, "gbfs_steps": 1, "nnet_dtype": args.nnet_dtype,
                    "parallelism": "state shards per GPU x%d" % world,
                    "heuristic_tflops_per_gpu": flops / (wall / args.steps) / 1e12,
+                   "layer1": "dca_l1_embed (embedding sum, not in the flop count)" if fast.l1_embed_w is not None
+                   else ("dca_l1_onehot_gemm (one-hot MFMA kernel)" if fast.uses_l1_kernel else "library GEMM on one-hot rows"),
                    "reference_published": published.get(args.env)},
     }
 
