@@ -28,6 +28,8 @@
 // read peak).  Per 409 600 rows x 5120 units (profiles/r06_l1_embed_bench.txt), one-hot MFMA kernel -> this kernel, fp16 planes out:
 // puzzle15 3.10 -> 2.48 ms, puzzle24 9.44 -> 4.09, puzzle35 17.3 -> 5.22, puzzle48 30.1 -> 6.54; cube3 3.98 -> 6.86 (stays on MFMA).
 #include "dca_common.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace dca {
 
@@ -44,7 +46,83 @@ struct EmbGeo {
     static_assert(NPIECE <= 64, "one 16-byte piece per lane");
 };
 
-template <int D, int DEPTH, int NT, int WAVES, int T, int OUT /*0 fp32, 2 bf16, 4 two fp16 planes (high, then low at + m * ldo), 5 e4m3 (saturating)*/>
+// relu, conversion and store of one lane's 4 consecutive columns of row r (OUT: 0 fp32, 2 bf16, 4 two fp16 planes — high, then low at
+// + m * n_pad —, 5 e4m3 saturating); returns whether a value left the fp16 range (planes only)
+template <int OUT>
+__device__ __forceinline__ bool emb_store(const float4& acc, int relu, int64_t r, int64_t m, int64_t n_pad, int64_t col, void* __restrict__ out) {
+    float u[4] = {acc.x, acc.y, acc.z, acc.w};
+    if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) u[e] = fmaxf(u[e], 0.f);
+    }
+    bool ovf = false;
+    if (r < m) {
+        const int64_t o = r * n_pad + col;
+        if constexpr (OUT == 0) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + o) = make_float4(u[0], u[1], u[2], u[3]);
+        } else if constexpr (OUT == 2) {
+            typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 a = {u[0], u[1]}, b = {u[2], u[3]};
+            const bf2 pa = __builtin_convertvector(a, bf2), pb = __builtin_convertvector(b, bf2);
+            uint2 q;
+            __builtin_memcpy(&q.x, &pa, 4);
+            __builtin_memcpy(&q.y, &pb, 4);
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + o) = q;
+        } else if constexpr (OUT == 5) {  // e4m3fn has no infinity: saturate at +-448
+            auto sat = [](float f) { return fminf(fmaxf(f, -448.f), 448.f); };
+            uint32_t q = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(sat(u[0]), sat(u[1]), 0, false);
+            q = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(sat(u[2]), sat(u[3]), (int)q, true);
+            *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(out) + o) = q;
+        } else {
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            h4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                ovf |= !(fabsf(u[e]) <= 60000.0f);
+                hi[e] = (_Float16)u[e];
+                lo[e] = (_Float16)(u[e] - (float)hi[e]);
+            }
+            _Float16* q = reinterpret_cast<_Float16*>(out) + o;
+            *reinterpret_cast<h4*>(q) = hi;
+            *reinterpret_cast<h4*>(q + m * n_pad) = lo;
+        }
+    }
+    return ovf;
+}
+
+// byte 1 of `a` <- byte B of `w`, the other bytes of `a` kept: with 256-byte table rows (NT = 64) `a` = lane offset (byte 0) | window
+// (bytes 2-3) becomes the row address of state byte s in ONE vector instruction (v_bfe + v_lshl_add otherwise)
+template <int B>
+__device__ __forceinline__ void put_byte1(uint32_t& a, uint32_t w) {
+    if constexpr (B == 0) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(a) : "v"(w));
+    if constexpr (B == 1) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(a) : "v"(w));
+    if constexpr (B == 2) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(a) : "v"(w));
+    if constexpr (B == 3) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3" : "+v"(a) : "v"(w));
+}
+
+template <int D, int DEPTH, int NT, int WAVES, int T, int POS, int N>
+struct EmbSum {  // positions POS .. N - 1 of one state, unrolled at compile time (the byte selector is an instruction field)
+    template <int NWIN, int NV>
+    static __device__ __forceinline__ void run(float4& acc, uint32_t (&ab)[NWIN][4], const uint32_t (&v)[NV]) {
+        if constexpr (POS < N) {
+            constexpr int row0 = POS * DEPTH, win = row0 >> 8, r = row0 & 255;
+            uint32_t& a = ab[win][POS & 3];
+            put_byte1<POS & 3>(a, v[POS >> 2]);
+            // `a` is the LDS address itself (the table starts at LDS offset 0: checked at kernel entry)
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const f4v gw = *reinterpret_cast<const __attribute__((address_space(3))) f4v*>((uintptr_t)(a + (uint32_t)(r * 256)));
+            acc.x += gw.x;
+            acc.y += gw.y;
+            acc.z += gw.z;
+            acc.w += gw.w;
+            EmbSum<D, DEPTH, NT, WAVES, T, POS + 1, N>::run(acc, ab, v);
+        }
+    }
+};
+
+template <int D, int DEPTH, int NT, int WAVES, int T, int OUT /*0 fp32, 2 bf16, 4 two fp16 planes (high, then low at + m * ldo), 5 e4m3 (saturating)*/,
+          bool SD = false /*row addresses by SDWA byte moves (NT = 64)*/>
 __global__ __launch_bounds__(WAVES * 64) void k_l1_embed(const uint8_t* __restrict__ nn, int64_t m, const float* __restrict__ wt /*[K][n_pad]*/,
                                                          int64_t n_pad, const float* __restrict__ bias, int relu, void* __restrict__ out,
                                                          int* __restrict__ overflow) {
@@ -53,6 +131,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_l1_embed(const uint8_t* __restri
     float* lw = reinterpret_cast<float*>(le);
     float* lb = lw + G::K * NT;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    if constexpr (SD) {  // the SDWA row addresses are absolute LDS addresses: the weight table must start at LDS offset 0
+        if ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint8_t*)le) != 0u) __builtin_trap();
+    }
     uint8_t* ls = le + G::W_BYTES + NT * 4 + wave * G::SLICE;  // this wave's slice: no other wave touches it, no workgroup barrier in the loop
     // workgroups go to the 8 XCDs round-robin in launch order: hand each XCD a run of CONSECUTIVE column tiles of one row slice, so
     // that the pieces of an output line written by neighbouring tiles meet in one L2 instead of reaching memory one by one
@@ -120,53 +201,27 @@ __global__ __launch_bounds__(WAVES * 64) void k_l1_embed(const uint8_t* __restri
 #pragma unroll
             for (int i = 0; i < G::NW - 1; i++) v[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh);
             float4 acc = *reinterpret_cast<const float4*>(lb + 4 * cp);
+            if constexpr (SD) {
+                static_assert(NT == 64, "SDWA row addresses need 256-byte rows");
+                constexpr int NWIN = (((D - 1) * DEPTH) >> 8) + 1;
+                uint32_t ab[NWIN][4];
 #pragma unroll
-            for (int pos = 0; pos < D; pos++) {
-                const uint32_t s = (v[pos >> 2] >> (8 * (pos & 3))) & 0xFFu;
-                const float4 gw = *reinterpret_cast<const float4*>(wcol + (s + (uint32_t)(pos * DEPTH)) * (uint32_t)(NT * 4));
-                acc.x += gw.x;
-                acc.y += gw.y;
-                acc.z += gw.z;
-                acc.w += gw.w;
-            }
-            float u[4] = {acc.x, acc.y, acc.z, acc.w};
-            if (relu) {
+                for (int wi = 0; wi < NWIN; wi++)
 #pragma unroll
-                for (int e = 0; e < 4; e++) u[e] = fmaxf(u[e], 0.f);
-            }
-            const int64_t r = g * G::SPW + sj;
-            if (r < m) {
-                const int64_t o = r * n_pad + n0 + 4 * cp;
-                if constexpr (OUT == 0) {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + o) = make_float4(u[0], u[1], u[2], u[3]);
-                } else if constexpr (OUT == 2) {
-                    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-                    typedef float f2 __attribute__((ext_vector_type(2)));
-                    const f2 a = {u[0], u[1]}, b = {u[2], u[3]};
-                    const bf2 pa = __builtin_convertvector(a, bf2), pb = __builtin_convertvector(b, bf2);
-                    uint2 q;
-                    __builtin_memcpy(&q.x, &pa, 4);
-                    __builtin_memcpy(&q.y, &pb, 4);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + o) = q;
-                } else if constexpr (OUT == 5) {  // e4m3fn has no infinity: saturate at +-448
-                    auto sat = [](float f) { return fminf(fmaxf(f, -448.f), 448.f); };
-                    uint32_t q = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(sat(u[0]), sat(u[1]), 0, false);
-                    q = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(sat(u[2]), sat(u[3]), (int)q, true);
-                    *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(out) + o) = q;
-                } else {
-                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-                    h4 hi, lo;
+                    for (int k = 0; k < 4; k++) ab[wi][k] = (uint32_t)cp * 16u + (uint32_t)wi * 65536u;
+                EmbSum<D, DEPTH, NT, WAVES, T, 0, D>::run(acc, ab, v);
+            } else {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        ovf |= !(fabsf(u[e]) <= 60000.0f);
-                        hi[e] = (_Float16)u[e];
-                        lo[e] = (_Float16)(u[e] - (float)hi[e]);
-                    }
-                    _Float16* q = reinterpret_cast<_Float16*>(out) + o;
-                    *reinterpret_cast<h4*>(q) = hi;
-                    *reinterpret_cast<h4*>(q + m * n_pad) = lo;
+                for (int pos = 0; pos < D; pos++) {
+                    const uint32_t s = (v[pos >> 2] >> (8 * (pos & 3))) & 0xFFu;
+                    const float4 gw = *reinterpret_cast<const float4*>(wcol + (s + (uint32_t)(pos * DEPTH)) * (uint32_t)(NT * 4));
+                    acc.x += gw.x;
+                    acc.y += gw.y;
+                    acc.z += gw.z;
+                    acc.w += gw.w;
                 }
             }
+            ovf |= emb_store<OUT>(acc, relu, g * G::SPW + sj, m, n_pad, n0 + 4 * cp, out);
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();  // (every lane has read its rows: the slice may be rewritten by the next step)
@@ -174,7 +229,152 @@ __global__ __launch_bounds__(WAVES * 64) void k_l1_embed(const uint8_t* __restri
     if (OUT == 4 && ovf && overflow) *overflow = 1;
 }
 
-template <int D, int DEPTH, int NT, int WAVES, int T>
+// ---------------------------------------------------------------------------------------------------------------------------
+// Position-group form, for the tables that do not fit LDS at 64 columns (puzzle35: 1296 rows, puzzle48: 2401): the workgroup
+// keeps the ACCUMULATORS of 1024 states in registers (a lane: SPL states x 4 columns) and streams the table past them in NG
+// slices of PG positions (puzzle48: 5 x 122 KB), each brought in by LDS-DMA between two barriers.  64-column tiles give 256-byte
+// rows: the 16 lanes of a state cover all 64 banks (no conflicts, against 46 % conflict cycles at 16 columns), and a row address
+// is one SDWA byte move.  A state's sum still runs bias, position 0, 1, ... in fp32 — the same bits as k_l1_embed.  The price
+// is the restaging: 614 KB of table per 1024 states and tile (puzzle48), ~1/5 of the gather time — so the form is used from a
+// few thousand rows up (dca_l1_embed picks), where the whole chip has workgroups to run.
+template <int D, int DEPTH, int PG>
+struct PgGeo {
+    static constexpr int NG = (D + PG - 1) / PG;
+    static constexpr int PGL = D - (NG - 1) * PG;             // positions of the last group
+    static constexpr int QUADS = (PG * DEPTH + 3) / 4;        // a slice is staged in 1 KB pieces (4 table rows)
+    static constexpr int W_BYTES = QUADS * 1024;
+    static constexpr int LDS = W_BYTES + 256;                 // + the tile's bias
+    static constexpr int NWIN = (((PG - 1) * DEPTH) >> 8) + 1;
+    static constexpr int NWD = (PG + 3) / 4 + 1;              // aligned dwords covering a group's bytes of one state at any offset
+};
+
+template <int NWD>
+struct PgBytes {
+    uint32_t w[NWD], sh;
+};
+
+template <int D, int DEPTH, int PG, int WAVES, int SPL, int OUT>
+__global__ __launch_bounds__(WAVES * 64) void k_l1_embed_pg(const uint8_t* __restrict__ nn, int64_t m, const float* __restrict__ wt, int64_t n_pad,
+                                                            const float* __restrict__ bias, int relu, void* __restrict__ out,
+                                                            int* __restrict__ overflow) {
+    using G = PgGeo<D, DEPTH, PG>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t le[];
+    if ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint8_t*)le) != 0u) __builtin_trap();  // SDWA addresses are absolute
+    float* lb = reinterpret_cast<float*>(le + G::W_BYTES);
+    const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, sl = lane >> 4, cp = lane & 15;
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    {  // (the XCD-aware tile map of k_l1_embed)
+        const uint32_t nwg = gridDim.x * gridDim.y, lin = blockIdx.x + blockIdx.y * gridDim.x;
+        if ((nwg & 7u) == 0) {
+            const uint32_t v = (lin & 7u) * (nwg >> 3) + (lin >> 3);
+            by = v / gridDim.x;
+            bx = v - by * gridDim.x;
+        }
+    }
+    const int64_t n0 = (int64_t)bx * 64, total = m * D;
+    constexpr int SS = WAVES * 4 * SPL;  // states of a superstep
+    const int64_t nss = (m + SS - 1) / SS;
+    if (t < 64) lb[t] = bias[n0 + t];
+    uint32_t ab[G::NWIN][4];
+#pragma unroll
+    for (int wi = 0; wi < G::NWIN; wi++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) ab[wi][k] = (uint32_t)cp * 16u + (uint32_t)wi * 65536u;
+
+    // the PG bytes of group g of this lane's j-th state: aligned dwords from the matrix (the 16 lanes of a state load the same
+    // addresses).  Dwords past the one that holds the matrix's last byte are not touched (their address is clamped to it: the
+    // group's own bytes never lie there)
+    // (32-bit offsets: the launcher sends matrices of 2 GB and more to k_l1_embed)
+    const uint32_t lastd = ((uint32_t)total - 1u) & ~3u, mlast = (uint32_t)m - 1u;
+    auto load_bytes = [&](uint32_t st0, int g, int j) {
+        PgBytes<G::NWD> b;
+        uint32_t st = st0 + (uint32_t)j * (WAVES * 4);
+        st = st < mlast ? st : mlast;
+        const uint32_t o = st * D + (uint32_t)(g * PG), oa = o & ~3u;
+        const int room = (int)(lastd - oa), dmax = room < 4 * (G::NWD - 1) ? room : 4 * (G::NWD - 1);
+        b.sh = o & 3u;
+#pragma unroll
+        for (int i = 0; i < G::NWD; i++) b.w[i] = *reinterpret_cast<const uint32_t*>(nn + (oa + (uint32_t)(4 * i < dmax ? 4 * i : dmax)));
+        return b;
+    };
+    float4 acc[SPL];
+    bool ovf = false;
+    for (int64_t ss = by; ss < nss; ss += gridDim.y) {
+        const uint32_t st0 = (uint32_t)ss * SS + (uint32_t)(wave * 4 + sl);
+        for (int g = 0; g < G::NG; g++) {
+            uint32_t st0g = st0;
+            asm volatile("" : "+v"(st0g));  // (opaque per group: otherwise every state's row offset is hoisted out of this loop and spilled)
+            PgBytes<G::NWD> cur = load_bytes(st0g, g, 0);  // flies under the staging
+            __syncthreads();                             // every wave is done with the previous slice
+            const int rows = (g < G::NG - 1 ? PG : G::PGL) * DEPTH;
+            for (int rq = wave; rq * 4 < rows; rq += WAVES) {
+                int rr = rq * 4 + (lane >> 4);
+                rr = rr < rows ? rr : rows - 1;
+                const float* src = wt + ((int64_t)g * (PG * DEPTH) + rr) * n_pad + n0 + (lane & 15) * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(le + rq * 1024), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (g == 0) {
+                const float4 b4 = *reinterpret_cast<const float4*>(lb + 4 * cp);
+#pragma unroll
+                for (int j = 0; j < SPL; j++) acc[j] = b4;
+            }
+            auto body = [&](auto npos) {
+                constexpr int N = decltype(npos)::value;
+#pragma unroll
+                for (int j = 0; j < SPL; j++) {
+                    asm volatile("" ::: "memory");  // (keeps the scheduler from hoisting every state's loads to the top: one state ahead)
+                    PgBytes<G::NWD> nxt;
+                    if (j + 1 < SPL) nxt = load_bytes(st0g, g, j + 1);
+                    uint32_t v[G::NWD - 1];
+#pragma unroll
+                    for (int i = 0; i < G::NWD - 1; i++) v[i] = __builtin_amdgcn_alignbyte(cur.w[i + 1], cur.w[i], cur.sh);
+                    EmbSum<D, DEPTH, 64, 0, 0, 0, N>::run(acc[j], ab, v);
+                    if (j + 1 < SPL) cur = nxt;
+                }
+            };
+            if (g < G::NG - 1)
+                body(std::integral_constant<int, PG>{});
+            else
+                body(std::integral_constant<int, G::PGL>{});
+        }
+#pragma unroll
+        for (int j = 0; j < SPL; j++)
+            ovf |= emb_store<OUT>(acc[j], relu, (int64_t)(st0 + (uint32_t)j * (WAVES * 4)), m, n_pad, n0 + 4 * cp, out);
+    }
+    if (OUT == 4 && ovf && overflow) *overflow = 1;
+}
+
+template <int D, int DEPTH, int PG, int WAVES, int SPL>
+int launch_embed_pg(const uint8_t* nn, int64_t m, const float* wt, int64_t n_pad, const float* bias, int relu, void* out, int out_dtype,
+                    int* overflow, hipStream_t s) {
+    using G = PgGeo<D, DEPTH, PG>;
+    static_assert(G::LDS <= 160 * 1024, "table slice does not fit LDS");
+    const int64_t nss = (m + WAVES * 4 * SPL - 1) / (WAVES * 4 * SPL), tiles = n_pad / 64;
+    int64_t gy = (1024 + tiles - 1) / tiles;
+    if (gy > nss) gy = nss;
+    const dim3 grid((unsigned)tiles, (unsigned)gy), block(WAVES * 64);
+#define DCA_EMB_LAUNCH(OUTV)                                                                                            \
+    do {                                                                                                                \
+        auto kern = k_l1_embed_pg<D, DEPTH, PG, WAVES, SPL, OUTV>;                                                      \
+        DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS)); \
+        hipLaunchKernelGGL(kern, grid, block, G::LDS, s, nn, m, wt, n_pad, bias, relu, out, overflow);                  \
+    } while (0)
+    if (out_dtype == DCA_DT_F32)
+        DCA_EMB_LAUNCH(0);
+    else if (out_dtype == DCA_DT_BF16)
+        DCA_EMB_LAUNCH(2);
+    else if (out_dtype == DCA_DT_E4M3)
+        DCA_EMB_LAUNCH(5);
+    else
+        DCA_EMB_LAUNCH(4);
+#undef DCA_EMB_LAUNCH
+    return launch_check("k_l1_embed_pg");
+}
+
+template <int D, int DEPTH, int NT, int WAVES, int T, bool SD = false>
 int launch_embed(const uint8_t* nn, int64_t m, const float* wt, int64_t n_pad, const float* bias, int relu, void* out, int out_dtype,
                  int* overflow, hipStream_t s) {
     using G = EmbGeo<D, DEPTH, NT, WAVES, T>;
@@ -191,7 +391,7 @@ int launch_embed(const uint8_t* nn, int64_t m, const float* wt, int64_t n_pad, c
     const dim3 grid((unsigned)tiles, (unsigned)gy), block(WAVES * 64);
 #define DCA_EMB_LAUNCH(OUTV)                                                                                            \
     do {                                                                                                                \
-        auto kern = k_l1_embed<D, DEPTH, NT, WAVES, T, OUTV>;                                                           \
+        auto kern = k_l1_embed<D, DEPTH, NT, WAVES, T, OUTV, SD>;                                                       \
         DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS)); \
         hipLaunchKernelGGL(kern, grid, block, G::LDS, s, nn, m, wt, n_pad, bias, relu, out, overflow);                  \
     } while (0)
@@ -229,12 +429,29 @@ int dca_l1_embed(const uint8_t* nnet_in, int64_t m, int state_dim, int depth, co
     }
     if (m == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (state_dim == 54) return launch_embed<54, 6, 64, 16, 4>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
-    if (state_dim == 16) return launch_embed<16, 16, 64, 16, 8>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
-    if (state_dim == 25) return launch_embed<25, 25, 32, 16, 2>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
+    static const bool sd = getenv("DCA_EMBED_SDWA") != nullptr;     // EXPERIMENT (removed after measuring)
+    static const bool nt64 = getenv("DCA_EMBED_P24_NT64") != nullptr;  // EXPERIMENT
+#define DCA_EMB_GEO(...) (sd ? launch_embed<__VA_ARGS__, true>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s) \
+                             : launch_embed<__VA_ARGS__, false>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s))
+    if (state_dim == 54) return DCA_EMB_GEO(54, 6, 64, 16, 4);
+    if (state_dim == 16) return DCA_EMB_GEO(16, 16, 64, 16, 8);
+    if (state_dim == 25) {
+        if (nt64) return DCA_EMB_GEO(25, 25, 64, 12, 2);
+        return launch_embed<25, 25, 32, 16, 2>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
+    }
+    static const bool pgf = getenv("DCA_EMBED_PG") != nullptr;  // EXPERIMENT
+    if (pgf && m >= 8192 && m * state_dim < ((int64_t)1 << 31)) {
+        static const int pgv = atoi(getenv("DCA_EMBED_PG"));
+        if (state_dim == 36) return launch_embed_pg<36, 36, 12, 8, 32>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
+        if (depth == 49 && pgv == 1) return launch_embed_pg<49, 49, 10, 8, 32>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
+        if (depth == 49 && pgv == 2) return launch_embed_pg<49, 49, 10, 12, 20>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
+        if (depth == 49 && pgv == 3) return launch_embed_pg<49, 49, 10, 16, 12>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
+        if (depth == 49 && pgv == 4) return launch_embed_pg<49, 49, 10, 16, 10>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
+    }
     if (state_dim == 36) return launch_embed<36, 36, 16, 16, 1>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
     if (depth == 49) return launch_embed<49, 49, 16, 12, 1>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
-    return launch_embed<49, 6, 64, 16, 4>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
+    return DCA_EMB_GEO(49, 6, 64, 16, 4);
+#undef DCA_EMB_GEO
 }
 
 }  // extern "C"

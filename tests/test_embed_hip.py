@@ -61,6 +61,31 @@ def test_embed_equals_the_same_fp32_additions_on_the_host(D, depth, m):
     assert torch.equal(pl[0].view(torch.int16), hi.view(torch.int16)) and torch.equal(pl[1].view(torch.int16), lo.view(torch.int16))
 
 
+@pytest.mark.parametrize("D,depth", [(49, 49), (36, 36), (25, 25)])
+def test_embed_large_batches_same_bits_as_the_host_sum(D, depth):
+    """From a few thousand rows up the large puzzles run the position-group form of the kernel (table slices streamed past
+    register-resident accumulators): same additions in the same order, so the same bits — checked against the host sum at 20 003
+    rows (a ragged last superstep), every output form, and against the small-batch kernel on a slice of the same rows."""
+    from deepcubea_amd import _lib
+    _lib.require_gpu()
+    m, n_pad = 20003, 128
+    w, b, x = _case(D, depth, m, n_pad, 4242 + D)
+    wt, bc, xc = w.t().contiguous().cuda(), b.cuda(), x.cuda()
+    want = _host_sum(w, b, x, depth, True)
+    got = _lib.l1_embed(xc, depth, wt, bc, True)
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert torch.equal(_lib.l1_embed(xc[4096:4096 + 1000].contiguous(), depth, wt, bc, True), got[4096:4096 + 1000])
+    wantt = torch.from_numpy(want)
+    assert torch.equal(_lib.l1_embed(xc, depth, wt, bc, True, torch.bfloat16).cpu().view(torch.int16), wantt.to(torch.bfloat16).view(torch.int16))
+    ovf = torch.zeros(1, dtype=torch.int32, device="cuda")
+    pl = _lib.l1_embed(xc, depth, wt, bc, True, split="planes", overflow=ovf).cpu()
+    hi = wantt.to(torch.float16)
+    assert int(ovf.item()) == 0 and torch.equal(pl[0].view(torch.int16), hi.view(torch.int16))
+    assert torch.equal(pl[1].view(torch.int16), (wantt - hi.float()).to(torch.float16).view(torch.int16))
+    nr = _lib.l1_embed(xc, depth, wt, bc, False).cpu().numpy()
+    assert np.array_equal(nr.view(np.uint32), _host_sum(w, b, x, depth, False).view(np.uint32))
+
+
 def test_embed_overflow_flag_and_wide_layer():
     """A value beyond fp16 raises the planes' overflow flag (FastResnet then redoes the batch in fp32); the network's real
     width (5120 columns: 80 column tiles, every workgroup walking several row chunks)."""
