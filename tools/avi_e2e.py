@@ -71,7 +71,8 @@ if train_s > 0:
 if EXPORT:
     cur = os.path.join(save, env, "current")
     sd = torch.load(os.path.join(cur, "model_state_dict.pt"), map_location="cpu")
-    torch.save({"state_dict": {k: (v.half() if v.is_floating_point() else v) for k, v in sd.items()},
+    keep32 = os.environ.get("DCA_E2E_EXPORT_FP32") is not None  # (59 MB for the cube3 network; fp16: 29 MB, weights rounded)
+    torch.save({"state_dict": {k: (v.half() if v.is_floating_point() and not keep32 else v) for k, v in sd.items()},
                 "train_itr": pickle.load(open(os.path.join(cur, "train_itr.pkl"), "rb")),
                 "update_num": pickle.load(open(os.path.join(cur, "update_num.pkl"), "rb"))}, EXPORT)
 train_wall = time.time() - t0
@@ -100,16 +101,45 @@ def search(path, out):
     return data_utils.load_pickle(os.path.join(out, "results.pkl"))
 
 
-try:
-    res = search(spath, rdir)
-    solved_idx = list(range(n))
-except Exception as e:  # noqa: BLE001 - a state the network cannot solve inside MAXN nodes: go state by state and keep what solves
-    print("search of all %d states stopped (%s): state by state" % (n, str(e)[:200]))
-    res = {"solutions": [], "times": [], "num_nodes_generated": []}
-    solved_idx = []
-    for i in range(n):
+# chunks of CHUNK states per CLI call (searched side by side as engine instances); a chunk with a state the network cannot solve
+# inside MAXN nodes is redone state by state and keeps what solves.  DCA_E2E_DEADLINE (seconds since the tool started) stops
+# the search between calls: what was searched by then is what is reported.
+CHUNK = int(os.environ.get("DCA_E2E_CHUNK", "20"))
+DEADLINE = float(os.environ.get("DCA_E2E_DEADLINE", "0"))
+res = {"solutions": [], "times": [], "num_nodes_generated": []}
+solved_idx, tried = [], 0
+
+
+def out_of_time():
+    return DEADLINE > 0 and time.time() - t0 > DEADLINE
+
+
+def dump(idx, path):
+    pickle.dump({"states": [StateCls(states[i].copy()) for i in idx]}, open(path, "wb"))
+
+
+for c0 in range(0, n, CHUNK):
+    if out_of_time():
+        print("deadline reached after %d of %d states" % (tried, n))
+        break
+    idx = list(range(c0, min(c0 + CHUNK, n)))
+    cp_path = os.path.join(tmp, "chunk_%d.pkl" % c0)
+    dump(idx, cp_path)
+    try:
+        r = search(cp_path, os.path.join(tmp, "res_chunk_%d" % c0))
+        solved_idx += idx
+        tried += len(idx)
+        for k in res:
+            res[k] += list(r[k])
+        continue
+    except Exception as e:  # noqa: BLE001
+        print("chunk %d-%d stopped (%s): state by state" % (idx[0], idx[-1], str(e)[:160]))
+    for i in idx:
+        if out_of_time():
+            break
         sp_i = os.path.join(tmp, "one_%d.pkl" % i)
-        pickle.dump({"states": [StateCls(states[i].copy())]}, open(sp_i, "wb"))
+        dump([i], sp_i)
+        tried += 1
         try:
             r = search(sp_i, os.path.join(tmp, "res_%d" % i))
         except Exception as e2:  # noqa: BLE001
@@ -118,13 +148,13 @@ except Exception as e:  # noqa: BLE001 - a state the network cannot solve inside
         solved_idx.append(i)
         for k in res:
             res[k] += list(r[k])
-    print("solved %d of %d states: %s" % (len(solved_idx), n, solved_idx))
-    if not solved_idx:
-        print("NO shipped state solved inside the node budget: the GBFS test lines above (Back Steps / %Solved) say how deep the network solves")
-        sys.exit(0)
-    opt = opt[solved_idx]
-    pub = {k: v[solved_idx] for k, v in pub.items()}
-    n = len(solved_idx)
+print("solved %d of the %d states tried (of %d): %s" % (len(solved_idx), tried, n, solved_idx))
+if not solved_idx:
+    print("NO shipped state solved inside the node budget: the GBFS test lines above (Back Steps / %Solved) say how deep the network solves")
+    sys.exit(0)
+opt = opt[solved_idx]
+pub = {k: v[solved_idx] for k, v in pub.items()}
+n = len(solved_idx)
 search_wall = time.time() - t1
 mine = {"lens": np.array([len(s) for s in res["solutions"]]), "times": np.array(res["times"], np.float64),
         "num_nodes_generated": np.array(res["num_nodes_generated"], np.float64)}
