@@ -10,26 +10,30 @@
 // network's flops, 29 ms of the parity mode's 56 ms per 409 600 rows.  As a sum of 49 gathered rows it is 1/49 of the work, in
 // EXACT fp32 arithmetic (no operand splitting), and LDS-bandwidth bound:
 //
-//   * a workgroup (16 waves; 12 for puzzle48, whose weights leave no room for more) owns NT output columns; their fp32 weights,
-//     transposed — [K][NT], one 4 * NT-byte row per one-hot column — sit in LDS for the workgroup's whole life (NT = 64 for cube3:
-//     83 KB; 16 for puzzle48: 154 KB); after staging them the workgroup never meets at a barrier again;
+//   * a workgroup (16 waves; 12 where the weights leave no room for more) owns NT output columns; their fp32 weights, transposed
+//     — [K][NT], one 4 * NT-byte row per one-hot column — sit in LDS for the workgroup's whole life (NT = 64: cube3 83 KB, puzzle15
+//     66 KB, puzzle24 160 KB; NT = 16: puzzle35 83 KB, puzzle48 154 KB); after staging them the workgroup never meets at a barrier again;
 //   * each WAVE walks over steps of 64 / (NT / 4) * T states on its own: the step's state bytes come in as one 16-byte load per lane
 //     (issued three steps ahead) into a wave-private LDS slice; a lane owns (state, 4 consecutive columns): it pulls its state's
-//     bytes out of the slice as aligned dwords + v_alignbyte, then per position one byte extract, one row address, one
-//     ds_read_b128 and four adds — positions in ascending order, so a state's value has the same bits in any batch;
+//     bytes out of the slice as aligned dwords + v_alignbyte, then per position one row address, one ds_read_b128 and four adds —
+//     positions in ascending order, so a state's value has the same bits in any batch;
+//   * with NT = 64 a table row is 256 bytes, so the row address of state byte s is `lane offset | s << 8` — ONE SDWA byte move
+//     (v_mov_b32_sdwa dst_sel:BYTE_1) into a register that keeps the lane offset, instead of v_bfe + v_lshl_add: 3 vector
+//     instructions per position instead of 4.4 (puzzle15 2.44 -> 2.11 ms, puzzle24 3.97 -> 3.68);
 //   * the NT / 4 lanes of a state read 4 * NT contiguous bytes of one LDS row: for NT = 64 the lane groups of a ds_read_b128
 //     touch disjoint banks (SQ_LDS_BANK_CONFLICT = 0); for NT = 16 four states share a lane group and their random rows collide
 //     (46 % of the LDS cycles, profiles/r06_l1_embed_pmc.txt) — the price of the 2401-row table;
 //   * the tail stores 2 * NT contiguous bytes per state and plane (fp16 planes for the f16x3 layers, bf16, fp32, or e4m3 bytes
 //     for the fp8 layers); the blockIdx -> (column tile, row slice) map hands each XCD consecutive column tiles of one row slice,
 //     so the pieces of an output line meet in one L2 (puzzle35 planes 8.2 -> 5.1 ms).
-// What bounds it: the LDS array and the vector ALU TOGETHER — per position and wave 4 LDS cycles (1 KB at 256 B/clk) and ~4.4
-// vector instructions (two v_pk_add_f32, the address); measured both ~50 % busy (cube3 geometry: 69 TB/s of the ~150 TB/s LDS
-// read peak).  Per 409 600 rows x 5120 units (profiles/r06_l1_embed_bench.txt), one-hot MFMA kernel -> this kernel, fp16 planes out:
-// puzzle15 3.10 -> 2.48 ms, puzzle24 9.44 -> 4.09, puzzle35 17.3 -> 5.22, puzzle48 30.1 -> 6.54; cube3 3.98 -> 6.86 (stays on MFMA).
+// What bounds it (rocprofv3 PMC, tools/valu_rate_probe.hip): with NT = 64 the vector ALU (two v_pk_add_f32 of ~4.9 cycles and the
+// address per position) with the LDS array half busy; with NT = 16 the LDS array, 84 % busy, 46 % of it conflict cycles.
+// Built, measured, removed (profiles/r06_l1_embed_experiments.txt): a "position-group" form for puzzle35 / 48 — 64-column tiles,
+// the accumulators of 640-1024 states in registers, the table streamed past them in LDS-DMA slices between barriers: no bank
+// conflicts, but the restaging and the per-slice state loads made it 1.5-2.2x SLOWER (puzzle48 9.5-14.2 ms against 6.5).
+// Per 409 600 rows x 5120 units (profiles/r06_l1_embed_bench.txt), one-hot MFMA kernel -> this kernel, fp16 planes out:
+// puzzle15 3.0 -> 2.1 ms, puzzle24 9.2 -> 3.7, puzzle35 17.3 -> 5.2, puzzle48 30.1 -> 6.5; cube3 3.9 -> 6.0 (stays on MFMA).
 #include "dca_common.h"
-#include <cstdlib>
-#include <type_traits>
 
 namespace dca {
 
@@ -122,7 +126,7 @@ struct EmbSum {  // positions POS .. N - 1 of one state, unrolled at compile tim
 };
 
 template <int D, int DEPTH, int NT, int WAVES, int T, int OUT /*0 fp32, 2 bf16, 4 two fp16 planes (high, then low at + m * ldo), 5 e4m3 (saturating)*/,
-          bool SD = false /*row addresses by SDWA byte moves (NT = 64)*/>
+          bool SD = false /*row addresses by SDWA byte moves (256-byte table rows: NT = 64)*/>
 __global__ __launch_bounds__(WAVES * 64) void k_l1_embed(const uint8_t* __restrict__ nn, int64_t m, const float* __restrict__ wt /*[K][n_pad]*/,
                                                          int64_t n_pad, const float* __restrict__ bias, int relu, void* __restrict__ out,
                                                          int* __restrict__ overflow) {
@@ -229,152 +233,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_l1_embed(const uint8_t* __restri
     if (OUT == 4 && ovf && overflow) *overflow = 1;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Position-group form, for the tables that do not fit LDS at 64 columns (puzzle35: 1296 rows, puzzle48: 2401): the workgroup
-// keeps the ACCUMULATORS of 1024 states in registers (a lane: SPL states x 4 columns) and streams the table past them in NG
-// slices of PG positions (puzzle48: 5 x 122 KB), each brought in by LDS-DMA between two barriers.  64-column tiles give 256-byte
-// rows: the 16 lanes of a state cover all 64 banks (no conflicts, against 46 % conflict cycles at 16 columns), and a row address
-// is one SDWA byte move.  A state's sum still runs bias, position 0, 1, ... in fp32 — the same bits as k_l1_embed.  The price
-// is the restaging: 614 KB of table per 1024 states and tile (puzzle48), ~1/5 of the gather time — so the form is used from a
-// few thousand rows up (dca_l1_embed picks), where the whole chip has workgroups to run.
-template <int D, int DEPTH, int PG>
-struct PgGeo {
-    static constexpr int NG = (D + PG - 1) / PG;
-    static constexpr int PGL = D - (NG - 1) * PG;             // positions of the last group
-    static constexpr int QUADS = (PG * DEPTH + 3) / 4;        // a slice is staged in 1 KB pieces (4 table rows)
-    static constexpr int W_BYTES = QUADS * 1024;
-    static constexpr int LDS = W_BYTES + 256;                 // + the tile's bias
-    static constexpr int NWIN = (((PG - 1) * DEPTH) >> 8) + 1;
-    static constexpr int NWD = (PG + 3) / 4 + 1;              // aligned dwords covering a group's bytes of one state at any offset
-};
-
-template <int NWD>
-struct PgBytes {
-    uint32_t w[NWD], sh;
-};
-
-template <int D, int DEPTH, int PG, int WAVES, int SPL, int OUT>
-__global__ __launch_bounds__(WAVES * 64) void k_l1_embed_pg(const uint8_t* __restrict__ nn, int64_t m, const float* __restrict__ wt, int64_t n_pad,
-                                                            const float* __restrict__ bias, int relu, void* __restrict__ out,
-                                                            int* __restrict__ overflow) {
-    using G = PgGeo<D, DEPTH, PG>;
-    extern __shared__ __attribute__((aligned(16))) uint8_t le[];
-    if ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint8_t*)le) != 0u) __builtin_trap();  // SDWA addresses are absolute
-    float* lb = reinterpret_cast<float*>(le + G::W_BYTES);
-    const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, sl = lane >> 4, cp = lane & 15;
-    uint32_t bx = blockIdx.x, by = blockIdx.y;
-    {  // (the XCD-aware tile map of k_l1_embed)
-        const uint32_t nwg = gridDim.x * gridDim.y, lin = blockIdx.x + blockIdx.y * gridDim.x;
-        if ((nwg & 7u) == 0) {
-            const uint32_t v = (lin & 7u) * (nwg >> 3) + (lin >> 3);
-            by = v / gridDim.x;
-            bx = v - by * gridDim.x;
-        }
-    }
-    const int64_t n0 = (int64_t)bx * 64, total = m * D;
-    constexpr int SS = WAVES * 4 * SPL;  // states of a superstep
-    const int64_t nss = (m + SS - 1) / SS;
-    if (t < 64) lb[t] = bias[n0 + t];
-    uint32_t ab[G::NWIN][4];
-#pragma unroll
-    for (int wi = 0; wi < G::NWIN; wi++)
-#pragma unroll
-        for (int k = 0; k < 4; k++) ab[wi][k] = (uint32_t)cp * 16u + (uint32_t)wi * 65536u;
-
-    // the PG bytes of group g of this lane's j-th state: aligned dwords from the matrix (the 16 lanes of a state load the same
-    // addresses).  Dwords past the one that holds the matrix's last byte are not touched (their address is clamped to it: the
-    // group's own bytes never lie there)
-    // (32-bit offsets: the launcher sends matrices of 2 GB and more to k_l1_embed)
-    const uint32_t lastd = ((uint32_t)total - 1u) & ~3u, mlast = (uint32_t)m - 1u;
-    auto load_bytes = [&](uint32_t st0, int g, int j) {
-        PgBytes<G::NWD> b;
-        uint32_t st = st0 + (uint32_t)j * (WAVES * 4);
-        st = st < mlast ? st : mlast;
-        const uint32_t o = st * D + (uint32_t)(g * PG), oa = o & ~3u;
-        const int room = (int)(lastd - oa), dmax = room < 4 * (G::NWD - 1) ? room : 4 * (G::NWD - 1);
-        b.sh = o & 3u;
-#pragma unroll
-        for (int i = 0; i < G::NWD; i++) b.w[i] = *reinterpret_cast<const uint32_t*>(nn + (oa + (uint32_t)(4 * i < dmax ? 4 * i : dmax)));
-        return b;
-    };
-    float4 acc[SPL];
-    bool ovf = false;
-    for (int64_t ss = by; ss < nss; ss += gridDim.y) {
-        const uint32_t st0 = (uint32_t)ss * SS + (uint32_t)(wave * 4 + sl);
-        for (int g = 0; g < G::NG; g++) {
-            uint32_t st0g = st0;
-            asm volatile("" : "+v"(st0g));  // (opaque per group: otherwise every state's row offset is hoisted out of this loop and spilled)
-            PgBytes<G::NWD> cur = load_bytes(st0g, g, 0);  // flies under the staging
-            __syncthreads();                             // every wave is done with the previous slice
-            const int rows = (g < G::NG - 1 ? PG : G::PGL) * DEPTH;
-            for (int rq = wave; rq * 4 < rows; rq += WAVES) {
-                int rr = rq * 4 + (lane >> 4);
-                rr = rr < rows ? rr : rows - 1;
-                const float* src = wt + ((int64_t)g * (PG * DEPTH) + rr) * n_pad + n0 + (lane & 15) * 4;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(le + rq * 1024), 16, 0, 0);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (g == 0) {
-                const float4 b4 = *reinterpret_cast<const float4*>(lb + 4 * cp);
-#pragma unroll
-                for (int j = 0; j < SPL; j++) acc[j] = b4;
-            }
-            auto body = [&](auto npos) {
-                constexpr int N = decltype(npos)::value;
-#pragma unroll
-                for (int j = 0; j < SPL; j++) {
-                    asm volatile("" ::: "memory");  // (keeps the scheduler from hoisting every state's loads to the top: one state ahead)
-                    PgBytes<G::NWD> nxt;
-                    if (j + 1 < SPL) nxt = load_bytes(st0g, g, j + 1);
-                    uint32_t v[G::NWD - 1];
-#pragma unroll
-                    for (int i = 0; i < G::NWD - 1; i++) v[i] = __builtin_amdgcn_alignbyte(cur.w[i + 1], cur.w[i], cur.sh);
-                    EmbSum<D, DEPTH, 64, 0, 0, 0, N>::run(acc[j], ab, v);
-                    if (j + 1 < SPL) cur = nxt;
-                }
-            };
-            if (g < G::NG - 1)
-                body(std::integral_constant<int, PG>{});
-            else
-                body(std::integral_constant<int, G::PGL>{});
-        }
-#pragma unroll
-        for (int j = 0; j < SPL; j++)
-            ovf |= emb_store<OUT>(acc[j], relu, (int64_t)(st0 + (uint32_t)j * (WAVES * 4)), m, n_pad, n0 + 4 * cp, out);
-    }
-    if (OUT == 4 && ovf && overflow) *overflow = 1;
-}
-
-template <int D, int DEPTH, int PG, int WAVES, int SPL>
-int launch_embed_pg(const uint8_t* nn, int64_t m, const float* wt, int64_t n_pad, const float* bias, int relu, void* out, int out_dtype,
-                    int* overflow, hipStream_t s) {
-    using G = PgGeo<D, DEPTH, PG>;
-    static_assert(G::LDS <= 160 * 1024, "table slice does not fit LDS");
-    const int64_t nss = (m + WAVES * 4 * SPL - 1) / (WAVES * 4 * SPL), tiles = n_pad / 64;
-    int64_t gy = (1024 + tiles - 1) / tiles;
-    if (gy > nss) gy = nss;
-    const dim3 grid((unsigned)tiles, (unsigned)gy), block(WAVES * 64);
-#define DCA_EMB_LAUNCH(OUTV)                                                                                            \
-    do {                                                                                                                \
-        auto kern = k_l1_embed_pg<D, DEPTH, PG, WAVES, SPL, OUTV>;                                                      \
-        DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS)); \
-        hipLaunchKernelGGL(kern, grid, block, G::LDS, s, nn, m, wt, n_pad, bias, relu, out, overflow);                  \
-    } while (0)
-    if (out_dtype == DCA_DT_F32)
-        DCA_EMB_LAUNCH(0);
-    else if (out_dtype == DCA_DT_BF16)
-        DCA_EMB_LAUNCH(2);
-    else if (out_dtype == DCA_DT_E4M3)
-        DCA_EMB_LAUNCH(5);
-    else
-        DCA_EMB_LAUNCH(4);
-#undef DCA_EMB_LAUNCH
-    return launch_check("k_l1_embed_pg");
-}
-
-template <int D, int DEPTH, int NT, int WAVES, int T, bool SD = false>
+template <int D, int DEPTH, int NT, int WAVES, int T>
 int launch_embed(const uint8_t* nn, int64_t m, const float* wt, int64_t n_pad, const float* bias, int relu, void* out, int out_dtype,
                  int* overflow, hipStream_t s) {
     using G = EmbGeo<D, DEPTH, NT, WAVES, T>;
@@ -391,7 +250,7 @@ int launch_embed(const uint8_t* nn, int64_t m, const float* wt, int64_t n_pad, c
     const dim3 grid((unsigned)tiles, (unsigned)gy), block(WAVES * 64);
 #define DCA_EMB_LAUNCH(OUTV)                                                                                            \
     do {                                                                                                                \
-        auto kern = k_l1_embed<D, DEPTH, NT, WAVES, T, OUTV, SD>;                                                       \
+        auto kern = k_l1_embed<D, DEPTH, NT, WAVES, T, OUTV, NT == 64>;                                                 \
         DCA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS)); \
         hipLaunchKernelGGL(kern, grid, block, G::LDS, s, nn, m, wt, n_pad, bias, relu, out, overflow);                  \
     } while (0)
@@ -429,29 +288,12 @@ int dca_l1_embed(const uint8_t* nnet_in, int64_t m, int state_dim, int depth, co
     }
     if (m == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    static const bool sd = getenv("DCA_EMBED_SDWA") != nullptr;     // EXPERIMENT (removed after measuring)
-    static const bool nt64 = getenv("DCA_EMBED_P24_NT64") != nullptr;  // EXPERIMENT
-#define DCA_EMB_GEO(...) (sd ? launch_embed<__VA_ARGS__, true>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s) \
-                             : launch_embed<__VA_ARGS__, false>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s))
-    if (state_dim == 54) return DCA_EMB_GEO(54, 6, 64, 16, 4);
-    if (state_dim == 16) return DCA_EMB_GEO(16, 16, 64, 16, 8);
-    if (state_dim == 25) {
-        if (nt64) return DCA_EMB_GEO(25, 25, 64, 12, 2);
-        return launch_embed<25, 25, 32, 16, 2>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
-    }
-    static const bool pgf = getenv("DCA_EMBED_PG") != nullptr;  // EXPERIMENT
-    if (pgf && m >= 8192 && m * state_dim < ((int64_t)1 << 31)) {
-        static const int pgv = atoi(getenv("DCA_EMBED_PG"));
-        if (state_dim == 36) return launch_embed_pg<36, 36, 12, 8, 32>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
-        if (depth == 49 && pgv == 1) return launch_embed_pg<49, 49, 10, 8, 32>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
-        if (depth == 49 && pgv == 2) return launch_embed_pg<49, 49, 10, 12, 20>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
-        if (depth == 49 && pgv == 3) return launch_embed_pg<49, 49, 10, 16, 12>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
-        if (depth == 49 && pgv == 4) return launch_embed_pg<49, 49, 10, 16, 10>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
-    }
+    if (state_dim == 54) return launch_embed<54, 6, 64, 16, 4>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
+    if (state_dim == 16) return launch_embed<16, 16, 64, 16, 8>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
+    if (state_dim == 25) return launch_embed<25, 25, 64, 12, 2>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
     if (state_dim == 36) return launch_embed<36, 36, 16, 16, 1>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
     if (depth == 49) return launch_embed<49, 49, 16, 12, 1>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
-    return DCA_EMB_GEO(49, 6, 64, 16, 4);
-#undef DCA_EMB_GEO
+    return launch_embed<49, 6, 64, 16, 4>(nnet_in, m, w_t, n_pad, bias, relu, out, out_dtype, overflow, s);
 }
 
 }  // extern "C"

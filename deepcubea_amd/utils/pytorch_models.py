@@ -173,8 +173,8 @@ def _split_f16(w: torch.Tensor, sc: torch.Tensor):
 
 # One-hot depth from which layer 1 runs as the embedding sum (dca_l1_embed) instead of the one-hot MFMA kernel, by mode.  Measured,
 # ms per 409 600 rows x 5120 units, MFMA kernel / embedding sum (profiles/r06_l1_embed_bench.txt):
-#   fp32 (planes out): cube3 3.98 / 6.86, puzzle15 3.10 / 2.48, puzzle24 9.44 / 4.09, puzzle35 17.3 / 5.22, puzzle48 30.1 / 6.54
-#   bf16:              cube3 1.73 / 6.32, puzzle15 1.35 / 2.05, puzzle24 4.80 / 3.44, puzzle35 9.43 / 4.68, puzzle48 16.0 / 6.38
+#   fp32 (planes out): cube3 4.0 / 6.0, puzzle15 3.0 / 2.1, puzzle24 9.2 / 3.7, puzzle35 17.3 / 5.2, puzzle48 30.1 / 6.5
+#   bf16:              cube3 1.7 / 5.5, puzzle15 1.3 / 1.8, puzzle24 4.8 / 3.1, puzzle35 9.4 / 4.7, puzzle48 16.0 / 6.4
 L1_EMBED_MIN_DEPTH = {torch.float32: 16, torch.bfloat16: 25, torch.float16: 1 << 30}
 
 

@@ -63,9 +63,9 @@ def test_embed_equals_the_same_fp32_additions_on_the_host(D, depth, m):
 
 @pytest.mark.parametrize("D,depth", [(49, 49), (36, 36), (25, 25)])
 def test_embed_large_batches_same_bits_as_the_host_sum(D, depth):
-    """From a few thousand rows up the large puzzles run the position-group form of the kernel (table slices streamed past
-    register-resident accumulators): same additions in the same order, so the same bits — checked against the host sum at 20 003
-    rows (a ragged last superstep), every output form, and against the small-batch kernel on a slice of the same rows."""
+    """Engine-sized batches: every wave walks many steps, workgroups wrap around the row slices, the last step is ragged — the
+    same additions in the same order as for one row, so the same bits: checked against the host sum at 20 003 rows, every output
+    form, and against a separate launch on a slice of the same rows."""
     from deepcubea_amd import _lib
     _lib.require_gpu()
     m, n_pad = 20003, 128

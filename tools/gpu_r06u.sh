@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round 6, GPU visit U: dca_l1_embed experiments — row addresses by SDWA byte moves (NT = 64 geometries) and puzzle24 on 64-column
+# Round 6, GPU visit U (the switches below existed only for this visit; what won is the default now, the rest was removed):
+# dca_l1_embed experiments — row addresses by SDWA byte moves (NT = 64 geometries) and puzzle24 on 64-column
 # tiles (12 waves) — tests with the switches on, then the per-geometry timing three ways.
 out=gpurun_out/r06u
 mkdir -p $out
