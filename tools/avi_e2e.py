@@ -13,6 +13,10 @@ env = puzzle15 (default; train.sh:18,21: loss threshold 0.1, back_max 500, searc
 (train.sh:4,9: loss threshold 0.06, back_max 30, search weight 0.6, batch 10 000 — the north star's own configuration; the
 reference trained it for 1.2 M iterations, saved_models/cube3/output.txt).
 
+Environment switches: DCA_E2E_MAX_NODES (node ids per search), DCA_E2E_CHUNK (states per CLI call, 20), DCA_E2E_DEADLINE (seconds
+since the start after which no further search call is made), DCA_E2E_EXPORT=path (+ DCA_E2E_EXPORT_FP32) / DCA_E2E_IMPORT=path
+(carry the trained network out of / into a GPU-box visit: `train_seconds` 0 + an import = search only), DCA_E2E_WEIGHT.
+
 Seeds are fixed (torch / numpy / random / the device state generator), so a rerun on the same build repeats the schedule up to
 the order of floating-point atomics."""
 import json
