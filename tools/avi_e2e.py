@@ -15,7 +15,8 @@ reference trained it for 1.2 M iterations, saved_models/cube3/output.txt).
 
 Environment switches: DCA_E2E_MAX_NODES (node ids per search), DCA_E2E_CHUNK (states per CLI call, 20), DCA_E2E_DEADLINE (seconds
 since the start after which no further search call is made), DCA_E2E_EXPORT=path (+ DCA_E2E_EXPORT_FP32) / DCA_E2E_IMPORT=path
-(carry the trained network out of / into a GPU-box visit: `train_seconds` 0 + an import = search only), DCA_E2E_WEIGHT.
+(carry the trained network out of / into a GPU-box visit: `train_seconds` 0 + an import = search only), DCA_E2E_WEIGHT,
+DCA_E2E_STATES=i,j,... (explicit test-set indices).
 
 Seeds are fixed (torch / numpy / random / the device state generator), so a rerun on the same build repeats the schedule up to
 the order of floating-point atomics."""
@@ -87,10 +88,15 @@ print("\nTRAINED %s" % json.dumps({"seconds": round(train_wall, 1), "train_itera
                                   "adam_steps_per_update": epochs * -(-spu // B), "batch_size": B}))
 
 g = np.load(os.path.join(ROOT, "tests", "golden", "golden.npz"))
-states = g[env + "_test_states"][:n]
-opt = g[env + "_test_opt_len"][:n].astype(np.int64)
-pub = {"lens": g["published_%s_len" % env][:n].astype(np.int64), "times": g["published_%s_time" % env][:n].astype(np.float64),
-       "num_nodes_generated": g["published_%s_nodes" % env][:n].astype(np.float64)}
+sel = np.arange(n)
+if os.environ.get("DCA_E2E_STATES"):  # explicit test-set indices instead of the first n (e.g. a state an earlier run left unsolved)
+    sel = np.array([int(v) for v in os.environ["DCA_E2E_STATES"].split(",")])
+    n = len(sel)
+    print("test-set states %s" % sel.tolist())
+states = g[env + "_test_states"][sel]
+opt = g[env + "_test_opt_len"][sel].astype(np.int64)
+pub = {"lens": g["published_%s_len" % env][sel].astype(np.int64), "times": g["published_%s_time" % env][sel].astype(np.float64),
+       "num_nodes_generated": g["published_%s_nodes" % env][sel].astype(np.float64)}
 tmp = tempfile.mkdtemp()
 spath = os.path.join(tmp, "data_0.pkl")
 pickle.dump({"states": [StateCls(s.copy()) for s in states]}, open(spath, "wb"))
