@@ -205,6 +205,32 @@ def test_resnet_forward_restatement(tiny_resnet, golden):
     assert np.max(np.abs(yf - ref)) < 1e-5 * max(1.0, np.abs(ref).max())
 
 
+def test_first_layer_as_an_embedding_sum_reproduces_the_reference_outputs(tiny_resnet, golden):
+    """The identity dca_l1_embed rests on (SURVEY 8(f)-2's "embedding-sum layer 1"): onehot(s) . W1^T = the sum of one gathered
+    weight column per position.  The oracle's restatement of it (BatchNorm folded, positions in ascending order) gives the
+    reference-recorded network outputs — float64 and float32 — for cube3 and for the puzzle geometries it is used on."""
+    w = {k[2:]: tiny_resnet[k] for k in tiny_resnet.files if k.startswith("w:")}
+    for dt in (np.float64, np.float32):
+        y = no.resnet_forward(w, tiny_resnet["x"], 6, 2, dt, l1="embed")
+        assert np.max(np.abs(y - tiny_resnet["y"])) < 1e-5
+    a = no.l1_embedding_sum(w, tiny_resnet["x"], 6, np.float64)
+    x = no.onehot(tiny_resnet["x"], 6, np.float64)
+    g = w["bn1.weight"] / np.sqrt(w["bn1.running_var"].astype(np.float64) + 1e-5)
+    ref = np.maximum((x @ w["fc1.weight"].astype(np.float64).T + w["fc1.bias"] - w["bn1.running_mean"]) * g + w["bn1.bias"], 0)
+    assert np.max(np.abs(a - ref)) < 1e-12
+    wf = no.resnet_det_weights(no.resnet_shapes(54, 6, 5000, 1000, 4), 2024)
+    yf = no.resnet_forward(wf, golden["cube3_resnet_seed2024_x"], 6, 4, np.float64, l1="embed")
+    assert np.max(np.abs(yf - golden["cube3_resnet_seed2024_y"])) < 1e-5
+    nets = np.load(os.path.join(os.path.dirname(__file__), "golden", "nets.npz"))
+    for name, dim, seed in (("puzzle48", 7, 2026), ("puzzle24", 5, 2027)):
+        D = dim * dim
+        wp = no.resnet_det_weights(no.resnet_shapes(D, D, 5000, 1000, 4), seed)
+        xk = nets["%s_resnet_seed%d_x" % (name, seed)]
+        y = no.resnet_forward(wp, xk, D, 4, np.float64, l1="embed")
+        assert np.max(np.abs(y - nets["%s_resnet_seed%d_y" % (name, seed)])) < 1e-5
+        assert np.max(np.abs(y - no.resnet_forward(wp, xk, D, 4, np.float64))) < 1e-9
+
+
 # ------------------------------------------------------------------ BWAS, python semantics
 def _py_cases(golden):
     return [str(k) for k in golden["astar_py_cases"]]
