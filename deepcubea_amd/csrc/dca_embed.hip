@@ -105,7 +105,7 @@ __device__ __forceinline__ void put_byte1(uint32_t& a, uint32_t w) {
     if constexpr (B == 3) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3" : "+v"(a) : "v"(w));
 }
 
-template <int D, int DEPTH, int NT, int WAVES, int T, int POS, int N>
+template <int DEPTH, int POS, int N>
 struct EmbSum {  // positions POS .. N - 1 of one state, unrolled at compile time (the byte selector is an instruction field)
     template <int NWIN, int NV>
     static __device__ __forceinline__ void run(float4& acc, uint32_t (&ab)[NWIN][4], const uint32_t (&v)[NV]) {
@@ -120,7 +120,7 @@ struct EmbSum {  // positions POS .. N - 1 of one state, unrolled at compile tim
             acc.y += gw.y;
             acc.z += gw.z;
             acc.w += gw.w;
-            EmbSum<D, DEPTH, NT, WAVES, T, POS + 1, N>::run(acc, ab, v);
+            EmbSum<DEPTH, POS + 1, N>::run(acc, ab, v);
         }
     }
 };
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_l1_embed(const uint8_t* __restri
                 for (int wi = 0; wi < NWIN; wi++)
 #pragma unroll
                     for (int k = 0; k < 4; k++) ab[wi][k] = (uint32_t)cp * 16u + (uint32_t)wi * 65536u;
-                EmbSum<D, DEPTH, NT, WAVES, T, 0, D>::run(acc, ab, v);
+                EmbSum<DEPTH, 0, D>::run(acc, ab, v);
             } else {
 #pragma unroll
                 for (int pos = 0; pos < D; pos++) {
