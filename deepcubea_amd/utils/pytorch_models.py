@@ -312,7 +312,10 @@ class FastResnet(nn.Module):
             if l1 == "embed" and not emb_ok:
                 raise ValueError("FastResnet(l1='embed'): dca_l1_embed is not available for geometry (%d, %d)"
                                  % (self.state_dim, self.one_hot_depth))
-            use_emb = emb_ok and (l1 == "embed" or (l1 == "auto" and ok and self.one_hot_depth >= L1_EMBED_MIN_DEPTH[dtype]))
+            # (lightsout7 has no one-hot MFMA instantiation in these modes: its fp32 forward is faster with the embedding sum than
+            # with layer 1 on materialised one-hot rows — 31.7 vs 38.6 ms per 409 600 rows —, its bf16 forward is not: 15.2 vs 12.0)
+            use_emb = emb_ok and (l1 == "embed" or (l1 == "auto" and (
+                (ok and self.one_hot_depth >= L1_EMBED_MIN_DEPTH[dtype]) or (not ok and dtype == torch.float32))))
             if ok or use_emb:
                 w1 = ws[0][:, :in_dim] if dtype == torch.float32 else ws[0][:, :in_dim].to(dtype).float()
                 self.l1_bias = nn.Parameter(bs[0].to(dtype).float(), requires_grad=False)

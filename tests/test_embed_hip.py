@@ -180,8 +180,9 @@ def test_network_with_the_embedding_layer_matches_the_mfma_layer_and_is_batch_in
 
 @torch.no_grad()
 def test_lightsout_geometry_has_only_the_embedding_kernel():
-    """(49, 6) — lightsout7 — has no one-hot MFMA instantiation in the fp32 / bf16 modes: by default its first layer runs on
-    materialised one-hot rows; `l1="embed"` feeds the uint8 rows to dca_l1_embed instead.  Same network, within 1e-5."""
+    """(49, 6) — lightsout7 — has no one-hot MFMA instantiation in the fp32 / bf16 modes: its first layer ran on materialised
+    one-hot rows; in the fp32 parity mode `l1="auto"` now feeds the uint8 rows to dca_l1_embed instead (18 % off the forward).
+    Same network, within 1e-5; and the engine's packed uint8 rows drive it to the same values as the kept children directly."""
     from deepcubea_amd import _lib
     from deepcubea_amd.utils.pytorch_models import FastResnet, ResnetModel
     from deepcubea_amd.utils.synthetic_weights import load_synthetic_weights
@@ -191,9 +192,29 @@ def test_lightsout_geometry_has_only_the_embedding_kernel():
     load_synthetic_weights(net, 7)
     net = net.eval()
     x = torch.randint(0, 2, (3001, 49), generator=torch.Generator().manual_seed(1)).to(torch.uint8).cuda()
-    dflt, emb = FastResnet(net).cuda(), FastResnet(net, l1="embed").cuda()
+    dflt, emb = FastResnet(net, l1="mfma").cuda(), FastResnet(net).cuda()  # ("mfma": no embedding sum -> layer 1 on one-hot rows)
     assert not dflt.uses_l1_kernel and emb.uses_l1_kernel and emb.l1_tiles is None
+    assert FastResnet(net, torch.bfloat16).l1_embed_w is None  # bf16: the one-hot rows + library GEMM are faster there
     yd, ye = dflt(x)[:, 0], emb(x)[:, 0]
     assert emb.split_fallbacks == 0
     assert float((yd - ye).abs().max()) < 1e-5 * max(1.0, float(yd.abs().max()))
     assert torch.equal(emb(x[77:1500].contiguous())[:, 0], ye[77:1500])
+    # the engine's dedup-first stepping hands the network its packed uint8 rows (lights_out.py state bytes)
+    from deepcubea_amd.search_methods.engine import BwasEngine
+    from deepcubea_amd.utils import nnet_utils
+    hfn = nnet_utils.get_heuristic_fn_dev(emb, clip_zero=False, batch_size=1 << 17)
+    eng = BwasEngine("lightsout7", 0.8, 256, max_nodes=1 << 20, packed=True)
+    root = torch.zeros(49, dtype=torch.uint8)
+    root[[3, 10, 11, 24, 30, 41]] = 1
+    eng.reset(root.numpy())
+    eng.root_commit(hfn(eng.root_nnet_in()))
+    for it in range(4):
+        nn, oh, src, rows = eng.pop_expand_packed()
+        assert oh is None and rows > 0
+        kept = eng.last_children()[src[:rows].long()].contiguous()
+        n = (rows + 1023) // 1024 * 1024
+        h = hfn(nn[:n])
+        assert float((h[:rows] - emb(kept)[:, 0]).abs().max()) < 1e-5
+        assert float((h[:rows] - dflt(kept)[:, 0]).abs().max()) < 1e-5 * max(1.0, float(h[:rows].abs().max()))
+        eng.commit_packed(h.float().contiguous())
+    eng.close()

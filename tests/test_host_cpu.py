@@ -245,6 +245,10 @@ def test_layer1_kernel_choice_by_geometry_and_mode():
     assert torch.equal(f24.l1_embed_w[:, :130], w1.t().to(torch.bfloat16).float())
     with pytest.raises(ValueError):
         FastResnet(ResnetModel(20, 5, 130, 64, 1, 1, True).eval(), l1="embed")
+    lo = net(49, 6)  # lightsout7: only the embedding kernel exists for it; taken in the fp32 mode, not in bf16
+    assert FastResnet(lo).l1_embed_w is not None and FastResnet(lo).l1_tiles is None and FastResnet(lo).uses_l1_kernel
+    assert FastResnet(lo, torch.bfloat16).l1_embed_w is None and not FastResnet(lo, torch.bfloat16).uses_l1_kernel
+    assert FastResnet(lo, l1="mfma").l1_embed_w is None
 
 
 def test_make_batches_drops_the_tail_like_the_reference():
